@@ -1,0 +1,904 @@
+/*
+ * wg_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, never shipped, never on the product path).
+ *
+ * A literal CPU restatement of the reference's differentiable Gaussian-splat rasterizer
+ * (Mip-Splatting variant + GOF abs-gradient + WildGaussians accumulation):
+ *
+ *   submodules/diff-gaussian-rasterization/cuda_rasterizer/forward.cu   (K1 preprocess, K8 render)
+ *   submodules/diff-gaussian-rasterization/cuda_rasterizer/backward.cu  (K9 render bwd, K10, K11)
+ *   submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer_impl.cu (binning order)
+ *   submodules/diff-gaussian-rasterization/cuda_rasterizer/auxiliary.h  (helpers, constants)
+ *
+ * Each function cites the reference file:line it follows.  Arithmetic is done in `real`
+ * (float in the f32 build, double in the -DWGO_F64 arbitration build); the places where the
+ * reference silently promotes to double (un-suffixed literals such as 1e-6, 1.0, 0.5) are kept
+ * in `double` here so the f32 build reproduces the reference's operation order and precision.
+ * Build with -ffp-contract=off: no fused multiply-adds are introduced by the compiler.
+ *
+ * PARITY STATUS: "parity unpinned" by the reference's own tests -- the reference ships no tests,
+ * golden vectors or CPU path for this code.  The oracle is pinned only
+ * indirectly, against golden vectors generated from the reference's own in-repo duplicate
+ * formulas (wildgaussians/method.py eval_sh / build_rotation / projection helpers; see
+ * tests/golden/make_golden.py) and against float64 finite differences (tests/test_oracle.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef WGO_F64
+typedef double real;
+#define R_SQRT sqrt
+#define R_EXP exp
+#define R_CEIL ceil
+#define R_FABS fabs
+#else
+typedef float real;
+#define R_SQRT sqrtf
+#define R_EXP expf
+#define R_CEIL ceilf
+#define R_FABS fabsf
+#endif
+
+#define WGO_API __attribute__((visibility("default")))
+
+/* config.h:14-16 */
+#define NUM_CHANNELS 3
+#define BLOCK_X 16
+#define BLOCK_Y 16
+#define BLOCK_SIZE (BLOCK_X * BLOCK_Y)
+
+/* auxiliary.h:22-39 */
+static const real SH_C0 = (real)0.28209479177387814;
+static const real SH_C1 = (real)0.4886025119029199;
+static const real SH_C2[5] = {(real)1.0925484305920792, (real)-1.0925484305920792, (real)0.31539156525252005,
+                              (real)-1.0925484305920792, (real)0.5462742152960396};
+static const real SH_C3[7] = {(real)-0.5900435899266435, (real)2.890611442640554,  (real)-0.4570457994644658,
+                              (real)0.3731763325901154,  (real)-0.4570457994644658, (real)1.445305721320277,
+                              (real)-0.5900435899266435};
+
+static inline real rmin(real a, real b) { return a < b ? a : b; }
+static inline real rmax(real a, real b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline double dmax(double a, double b) { return a > b ? a : b; }
+
+/* ---- column-major 3x3 with the vendored glm evaluation order (third_party/glm/glm/detail/
+ *      type_mat3x3.inl:486-519): R[c][r] = A[0][r]*B[c][0] + A[1][r]*B[c][1] + A[2][r]*B[c][2] ---- */
+typedef struct { real m[3][3]; } m3; /* m[col][row] */
+
+static inline m3 m3_set(real x0, real y0, real z0, real x1, real y1, real z1, real x2, real y2, real z2) {
+    m3 r;
+    r.m[0][0] = x0; r.m[0][1] = y0; r.m[0][2] = z0;
+    r.m[1][0] = x1; r.m[1][1] = y1; r.m[1][2] = z1;
+    r.m[2][0] = x2; r.m[2][1] = y2; r.m[2][2] = z2;
+    return r;
+}
+static inline m3 m3_mul(m3 a, m3 b) {
+    m3 r;
+    for (int c = 0; c < 3; c++)
+        for (int w = 0; w < 3; w++)
+            r.m[c][w] = a.m[0][w] * b.m[c][0] + a.m[1][w] * b.m[c][1] + a.m[2][w] * b.m[c][2];
+    return r;
+}
+static inline m3 m3_transpose(m3 a) {
+    m3 r;
+    for (int c = 0; c < 3; c++)
+        for (int w = 0; w < 3; w++) r.m[c][w] = a.m[w][c];
+    return r;
+}
+
+typedef struct { real x, y, z; } v3;
+typedef struct { real x, y, z, w; } v4;
+
+/* auxiliary.h:58-66 */
+static inline v3 transformPoint4x3(v3 p, const real* M) {
+    v3 t;
+    t.x = M[0] * p.x + M[4] * p.y + M[8] * p.z + M[12];
+    t.y = M[1] * p.x + M[5] * p.y + M[9] * p.z + M[13];
+    t.z = M[2] * p.x + M[6] * p.y + M[10] * p.z + M[14];
+    return t;
+}
+/* auxiliary.h:68-77 */
+static inline v4 transformPoint4x4(v3 p, const real* M) {
+    v4 t;
+    t.x = M[0] * p.x + M[4] * p.y + M[8] * p.z + M[12];
+    t.y = M[1] * p.x + M[5] * p.y + M[9] * p.z + M[13];
+    t.z = M[2] * p.x + M[6] * p.y + M[10] * p.z + M[14];
+    t.w = M[3] * p.x + M[7] * p.y + M[11] * p.z + M[15];
+    return t;
+}
+/* auxiliary.h:89-97 */
+static inline v3 transformVec4x3Transpose(v3 p, const real* M) {
+    v3 t;
+    t.x = M[0] * p.x + M[1] * p.y + M[2] * p.z;
+    t.y = M[4] * p.x + M[5] * p.y + M[6] * p.z;
+    t.z = M[8] * p.x + M[9] * p.y + M[10] * p.z;
+    return t;
+}
+/* auxiliary.h:41-44 -- the un-suffixed literals make this double arithmetic */
+static inline real ndc2Pix(real v, int S) { return (real)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
+
+/* auxiliary.h:46-56 -- max_radius arrives as int (float->int conversion at the call site) */
+static inline void getRect(real px, real py, int max_radius, int gx, int gy, int* rmin_x, int* rmin_y, int* rmax_x,
+                           int* rmax_y) {
+    *rmin_x = imin(gx, imax(0, (int)((px - (real)max_radius) / (real)BLOCK_X)));
+    *rmin_y = imin(gy, imax(0, (int)((py - (real)max_radius) / (real)BLOCK_Y)));
+    *rmax_x = imin(gx, imax(0, (int)((px + (real)max_radius + (real)(BLOCK_X - 1)) / (real)BLOCK_X)));
+    *rmax_y = imin(gy, imax(0, (int)((py + (real)max_radius + (real)(BLOCK_Y - 1)) / (real)BLOCK_Y)));
+}
+
+/* auxiliary.h:107-117 */
+static inline v3 dnormvdv(v3 v, v3 dv) {
+    real sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    real invsum32 = (real)1.0 / R_SQRT(sum2 * sum2 * sum2);
+    v3 r;
+    r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+    r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+    r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+typedef struct wgo_ctx {
+    int P, D, M, W, H, R, gx, gy;
+    int has_sh, has_cov_precomp;
+    /* GeometryState (rasterizer_impl.h:33-47) */
+    real* depths;
+    uint8_t* clamped;
+    int* radii;
+    real* means2D;       /* [P,2] */
+    real* cov3D;         /* [P,6] */
+    real* conic_opacity; /* [P,4] */
+    real* rgb;           /* [P,3] */
+    uint32_t* tiles_touched;
+    uint32_t* point_offsets;
+    /* BinningState (rasterizer_impl.h:58-67) */
+    uint64_t* keys_unsorted;
+    uint32_t* vals_unsorted;
+    uint64_t* keys;
+    uint32_t* point_list;
+    /* ImageState (rasterizer_impl.h:49-56) */
+    real* final_T;
+    uint32_t* n_contrib;
+    uint32_t* ranges; /* [Tn,2] */
+} wgo_ctx;
+
+/* forward.cu:20-71 */
+static v3 computeColorFromSH_fwd(int idx, int deg, int max_coeffs, const real* means, const real* campos,
+                                 const real* shs, uint8_t* clamped) {
+    v3 pos = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
+    v3 dir = {pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]};
+    real len = R_SQRT(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+    dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
+
+    const real* sh = shs + (size_t)idx * max_coeffs * 3;
+    real res[3];
+    real x = dir.x, y = dir.y, z = dir.z;
+    for (int c = 0; c < 3; c++) {
+#define SH(k) sh[(k) * 3 + c]
+        real result = SH_C0 * SH(0);
+        if (deg > 0) {
+            result = result - SH_C1 * y * SH(1) + SH_C1 * z * SH(2) - SH_C1 * x * SH(3);
+            if (deg > 1) {
+                real xx = x * x, yy = y * y, zz = z * z;
+                real xy = x * y, yz = y * z, xz = x * z;
+                result = result + SH_C2[0] * xy * SH(4) + SH_C2[1] * yz * SH(5) +
+                         SH_C2[2] * ((real)2.0 * zz - xx - yy) * SH(6) + SH_C2[3] * xz * SH(7) +
+                         SH_C2[4] * (xx - yy) * SH(8);
+                if (deg > 2) {
+                    result = result + SH_C3[0] * y * ((real)3.0 * xx - yy) * SH(9) + SH_C3[1] * xy * z * SH(10) +
+                             SH_C3[2] * y * ((real)4.0 * zz - xx - yy) * SH(11) +
+                             SH_C3[3] * z * ((real)2.0 * zz - (real)3.0 * xx - (real)3.0 * yy) * SH(12) +
+                             SH_C3[4] * x * ((real)4.0 * zz - xx - yy) * SH(13) + SH_C3[5] * z * (xx - yy) * SH(14) +
+                             SH_C3[6] * x * (xx - (real)3.0 * yy) * SH(15);
+                }
+            }
+        }
+#undef SH
+        result += (real)0.5;
+        clamped[3 * idx + c] = (result < 0);
+        res[c] = rmax(result, (real)0.0);
+    }
+    v3 out = {res[0], res[1], res[2]};
+    return out;
+}
+
+/* forward.cu:74-124; returns (cov.x, cov.y, cov.z, coef) */
+static v4 computeCov2D_fwd(v3 mean, real focal_x, real focal_y, real tan_fovx, real tan_fovy, real kernel_size,
+                           const real* cov3D, const real* viewmatrix) {
+    v3 t = transformPoint4x3(mean, viewmatrix);
+    const real limx = (real)1.3 * tan_fovx;
+    const real limy = (real)1.3 * tan_fovy;
+    const real txtz = t.x / t.z;
+    const real tytz = t.y / t.z;
+    t.x = rmin(limx, rmax(-limx, txtz)) * t.z;
+    t.y = rmin(limy, rmax(-limy, tytz)) * t.z;
+
+    m3 J = m3_set(focal_x / t.z, 0, -(focal_x * t.x) / (t.z * t.z), 0, focal_y / t.z, -(focal_y * t.y) / (t.z * t.z),
+                  0, 0, 0);
+    m3 Wm = m3_set(viewmatrix[0], viewmatrix[4], viewmatrix[8], viewmatrix[1], viewmatrix[5], viewmatrix[9],
+                   viewmatrix[2], viewmatrix[6], viewmatrix[10]);
+    m3 T = m3_mul(Wm, J);
+    m3 Vrk = m3_set(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+    m3 cov = m3_mul(m3_mul(m3_transpose(T), m3_transpose(Vrk)), T);
+
+    /* forward.cu:112-118: max(1e-6, float) and the +1e-6 terms are double arithmetic */
+    const real det_0 = (real)dmax(1e-6, (double)(cov.m[0][0] * cov.m[1][1] - cov.m[0][1] * cov.m[0][1]));
+    const real det_1 = (real)dmax(
+        1e-6, (double)((cov.m[0][0] + kernel_size) * (cov.m[1][1] + kernel_size) - cov.m[0][1] * cov.m[0][1]));
+    real coef = (real)sqrt((double)det_0 / ((double)det_1 + 1e-6) + 1e-6);
+    if ((double)det_0 <= 1e-6 || (double)det_1 <= 1e-6) coef = (real)0.0;
+
+    cov.m[0][0] += kernel_size;
+    cov.m[1][1] += kernel_size;
+    v4 r = {cov.m[0][0], cov.m[0][1], cov.m[1][1], coef};
+    return r;
+}
+
+/* forward.cu:129-163 */
+static void computeCov3D_fwd(const real* scale, real mod, const real* rot, real* cov3D) {
+    m3 S = m3_set(1, 0, 0, 0, 1, 0, 0, 0, 1);
+    S.m[0][0] = mod * scale[0];
+    S.m[1][1] = mod * scale[1];
+    S.m[2][2] = mod * scale[2];
+    real r = rot[0], x = rot[1], y = rot[2], z = rot[3]; /* no normalisation, forward.cu:138 */
+    m3 Rm = m3_set((real)1.0 - (real)2.0 * (y * y + z * z), (real)2.0 * (x * y - r * z), (real)2.0 * (x * z + r * y),
+                   (real)2.0 * (x * y + r * z), (real)1.0 - (real)2.0 * (x * x + z * z), (real)2.0 * (y * z - r * x),
+                   (real)2.0 * (x * z - r * y), (real)2.0 * (y * z + r * x), (real)1.0 - (real)2.0 * (x * x + y * y));
+    m3 Mm = m3_mul(S, Rm);
+    m3 Sigma = m3_mul(m3_transpose(Mm), Mm);
+    cov3D[0] = Sigma.m[0][0];
+    cov3D[1] = Sigma.m[0][1];
+    cov3D[2] = Sigma.m[0][2];
+    cov3D[3] = Sigma.m[1][1];
+    cov3D[4] = Sigma.m[1][2];
+    cov3D[5] = Sigma.m[2][2];
+}
+
+/* rasterizer_impl.cu:35-50 */
+static uint32_t getHigherMsb(uint32_t n) {
+    uint32_t msb = sizeof(n) * 4;
+    uint32_t step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step;
+        else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+WGO_API uint32_t wgo_get_higher_msb(uint32_t n) { return getHigherMsb(n); }
+
+/* stable LSD radix sort of (u64 key, u32 value) on bits [0, end_bit) -- the contract of
+ * cub::DeviceRadixSort::SortPairs as called at rasterizer_impl.cu:306-311 */
+static void stable_sort_pairs(const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, size_t n,
+                              int end_bit) {
+    if (n == 0) return;
+    uint64_t* ka = (uint64_t*)malloc(n * sizeof(uint64_t));
+    uint64_t* kb = (uint64_t*)malloc(n * sizeof(uint64_t));
+    uint32_t* va = (uint32_t*)malloc(n * sizeof(uint32_t));
+    uint32_t* vb = (uint32_t*)malloc(n * sizeof(uint32_t));
+    memcpy(ka, kin, n * sizeof(uint64_t));
+    memcpy(va, vin, n * sizeof(uint32_t));
+    for (int shift = 0; shift < end_bit; shift += 8) {
+        int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+        uint64_t mask = ((uint64_t)1 << bits) - 1;
+        size_t count[257];
+        memset(count, 0, sizeof(count));
+        for (size_t i = 0; i < n; i++) count[((ka[i] >> shift) & mask) + 1]++;
+        for (int b = 0; b < 256; b++) count[b + 1] += count[b];
+        for (size_t i = 0; i < n; i++) {
+            size_t d = count[(ka[i] >> shift) & mask]++;
+            kb[d] = ka[i];
+            vb[d] = va[i];
+        }
+        uint64_t* tk = ka; ka = kb; kb = tk;
+        uint32_t* tv = va; va = vb; vb = tv;
+    }
+    memcpy(kout, ka, n * sizeof(uint64_t));
+    memcpy(vout, va, n * sizeof(uint32_t));
+    free(ka); free(kb); free(va); free(vb);
+}
+
+WGO_API void wgo_free(wgo_ctx* c) {
+    if (!c) return;
+    free(c->depths); free(c->clamped); free(c->radii); free(c->means2D); free(c->cov3D);
+    free(c->conic_opacity); free(c->rgb); free(c->tiles_touched); free(c->point_offsets);
+    free(c->keys_unsorted); free(c->vals_unsorted); free(c->keys); free(c->point_list);
+    free(c->final_T); free(c->n_contrib); free(c->ranges);
+    free(c);
+}
+
+/* Rasterizer::forward, rasterizer_impl.cu:198-340.  Returns a context holding every intermediate
+ * buffer (the reference returns them as three opaque byte tensors); out_color is [3,H,W],
+ * radii_out is [P].  Null pointers mean "absent" exactly as at the reference boundary. */
+WGO_API wgo_ctx* wgo_forward(int P, int D, int M, const real* background, int width, int height, const real* means3D,
+                             const real* shs, const real* colors_precomp, const real* opacities, const real* scales,
+                             real scale_modifier, const real* rotations, const real* cov3D_precomp,
+                             const real* viewmatrix, const real* projmatrix, const real* cam_pos, real tan_fovx,
+                             real tan_fovy, real kernel_size, const real* subpixel_offset, int prefiltered,
+                             real* out_color, int* radii_out) {
+    wgo_ctx* c = (wgo_ctx*)calloc(1, sizeof(wgo_ctx));
+    const int W = width, H = height;
+    const size_t N = (size_t)W * H;
+    c->P = P; c->D = D; c->M = M; c->W = W; c->H = H;
+    c->has_sh = (colors_precomp == NULL);
+    c->has_cov_precomp = (cov3D_precomp != NULL);
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
+    c->gx = gx; c->gy = gy;
+    const size_t Tn = (size_t)gx * gy;
+    const size_t Pa = P > 0 ? (size_t)P : 1;
+
+    /* rasterizer_impl.cu:224-225 */
+    const real focal_y = (real)height / ((real)2.0 * tan_fovy);
+    const real focal_x = (real)width / ((real)2.0 * tan_fovx);
+
+    c->depths = (real*)calloc(Pa, sizeof(real));
+    c->clamped = (uint8_t*)calloc(Pa * 3, 1);
+    c->radii = (int*)calloc(Pa, sizeof(int));
+    c->means2D = (real*)calloc(Pa * 2, sizeof(real));
+    c->cov3D = (real*)calloc(Pa * 6, sizeof(real));
+    c->conic_opacity = (real*)calloc(Pa * 4, sizeof(real));
+    c->rgb = (real*)calloc(Pa * 3, sizeof(real));
+    c->tiles_touched = (uint32_t*)calloc(Pa, sizeof(uint32_t));
+    c->point_offsets = (uint32_t*)calloc(Pa, sizeof(uint32_t));
+    c->final_T = (real*)calloc(N ? N : 1, sizeof(real));
+    c->n_contrib = (uint32_t*)calloc(N ? N : 1, sizeof(uint32_t));
+    c->ranges = (uint32_t*)calloc((Tn ? Tn : 1) * 2, sizeof(uint32_t));
+
+    /* K1: preprocessCUDA, forward.cu:167-268 */
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        c->radii[idx] = 0;
+        c->tiles_touched[idx] = 0;
+        /* in_frustum, auxiliary.h:139-164 */
+        v3 p_orig = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+        v3 p_view = transformPoint4x3(p_orig, viewmatrix);
+        if (p_view.z <= (real)0.2) continue; /* prefiltered would __trap() here; the oracle just culls */
+        (void)prefiltered;
+
+        v4 p_hom = transformPoint4x4(p_orig, projmatrix);
+        real p_w = (real)1.0 / (p_hom.w + (real)0.0000001);
+        real p_proj_x = p_hom.x * p_w, p_proj_y = p_hom.y * p_w;
+
+        const real* cov3D;
+        if (cov3D_precomp != NULL) {
+            cov3D = cov3D_precomp + (size_t)idx * 6;
+        } else {
+            computeCov3D_fwd(scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx,
+                             c->cov3D + 6 * (size_t)idx);
+            cov3D = c->cov3D + 6 * (size_t)idx;
+        }
+        v4 cov = computeCov2D_fwd(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, kernel_size, cov3D, viewmatrix);
+
+        real det = (cov.x * cov.z - cov.y * cov.y);
+        if (det == (real)0.0) continue;
+        real det_inv = (real)1.0 / det;
+        real conic_x = cov.z * det_inv, conic_y = -cov.y * det_inv, conic_z = cov.x * det_inv;
+
+        real mid = (real)0.5 * (cov.x + cov.z);
+        real lambda1 = mid + R_SQRT(rmax((real)0.1, mid * mid - det));
+        real lambda2 = mid - R_SQRT(rmax((real)0.1, mid * mid - det));
+        real my_radius = R_CEIL((real)3.0 * R_SQRT(rmax(lambda1, lambda2)));
+        real pix_x = ndc2Pix(p_proj_x, W), pix_y = ndc2Pix(p_proj_y, H);
+        int rminx, rminy, rmaxx, rmaxy;
+        getRect(pix_x, pix_y, (int)my_radius, gx, gy, &rminx, &rminy, &rmaxx, &rmaxy);
+        if ((rmaxx - rminx) * (rmaxy - rminy) == 0) continue;
+
+        if (colors_precomp == NULL) {
+            v3 col = computeColorFromSH_fwd(idx, D, M, means3D, cam_pos, shs, c->clamped);
+            c->rgb[3 * idx + 0] = col.x;
+            c->rgb[3 * idx + 1] = col.y;
+            c->rgb[3 * idx + 2] = col.z;
+        }
+        c->depths[idx] = p_view.z;
+        c->radii[idx] = (int)my_radius;
+        c->means2D[2 * idx] = pix_x;
+        c->means2D[2 * idx + 1] = pix_y;
+        c->conic_opacity[4 * idx + 0] = conic_x;
+        c->conic_opacity[4 * idx + 1] = conic_y;
+        c->conic_opacity[4 * idx + 2] = conic_z;
+        c->conic_opacity[4 * idx + 3] = opacities[idx] * cov.w;
+        c->tiles_touched[idx] = (uint32_t)((rmaxy - rminy) * (rmaxx - rminx));
+    }
+    if (radii_out) memcpy(radii_out, c->radii, (size_t)P * sizeof(int));
+
+    /* K2: InclusiveSum, rasterizer_impl.cu:280 */
+    uint32_t run = 0;
+    for (int i = 0; i < P; i++) {
+        run += c->tiles_touched[i];
+        c->point_offsets[i] = run;
+    }
+    const int R = (int)run; /* K3, rasterizer_impl.cu:283-284 */
+    c->R = R;
+    const size_t Ra = R > 0 ? (size_t)R : 1;
+    c->keys_unsorted = (uint64_t*)calloc(Ra, sizeof(uint64_t));
+    c->vals_unsorted = (uint32_t*)calloc(Ra, sizeof(uint32_t));
+    c->keys = (uint64_t*)calloc(Ra, sizeof(uint64_t));
+    c->point_list = (uint32_t*)calloc(Ra, sizeof(uint32_t));
+
+    /* K4: duplicateWithKeys, rasterizer_impl.cu:70-111 */
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        if (c->radii[idx] > 0) {
+            uint32_t off = (idx == 0) ? 0 : c->point_offsets[idx - 1];
+            int rminx, rminy, rmaxx, rmaxy;
+            getRect(c->means2D[2 * idx], c->means2D[2 * idx + 1], c->radii[idx], gx, gy, &rminx, &rminy, &rmaxx,
+                    &rmaxy);
+            float depth_f = (float)c->depths[idx];
+            uint32_t depth_bits;
+            memcpy(&depth_bits, &depth_f, 4);
+            for (int y = rminy; y < rmaxy; y++)
+                for (int x = rminx; x < rmaxx; x++) {
+                    uint64_t key = (uint64_t)(y * gx + x);
+                    key <<= 32;
+                    key |= depth_bits;
+                    c->keys_unsorted[off] = key;
+                    c->vals_unsorted[off] = (uint32_t)idx;
+                    off++;
+                }
+        }
+    }
+    /* K5: SortPairs on bits [0, 32+bit), rasterizer_impl.cu:303-311 */
+    int bit = (int)getHigherMsb((uint32_t)(gx * gy));
+    stable_sort_pairs(c->keys_unsorted, c->vals_unsorted, c->keys, c->point_list, (size_t)R, 32 + bit);
+
+    /* K6-K7: identifyTileRanges, rasterizer_impl.cu:116-138, 313-321 */
+    for (int idx = 0; idx < R; idx++) {
+        uint32_t currtile = (uint32_t)(c->keys[idx] >> 32);
+        if (idx == 0) c->ranges[2 * currtile] = 0;
+        else {
+            uint32_t prevtile = (uint32_t)(c->keys[idx - 1] >> 32);
+            if (currtile != prevtile) {
+                c->ranges[2 * prevtile + 1] = (uint32_t)idx;
+                c->ranges[2 * currtile] = (uint32_t)idx;
+            }
+        }
+        if (idx == R - 1) c->ranges[2 * currtile + 1] = (uint32_t)R;
+    }
+
+    /* K8: renderCUDA, forward.cu:273-395.  One "block" per tile; the per-pixel walk below is the
+     * per-thread program of the reference (the batch staging / block vote only changes when a
+     * thread stops looking, never what it accumulates). */
+    const real* features = colors_precomp != NULL ? colors_precomp : c->rgb;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < (int)Tn; tile++) {
+        const int tx = tile % gx, ty = tile / gx;
+        const uint32_t r0 = c->ranges[2 * tile], r1 = c->ranges[2 * tile + 1];
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                const int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                if (!(px < W && py < H)) continue;
+                const size_t pix_id = (size_t)W * py + px;
+                real pixf_x = (real)px, pixf_y = (real)py;
+                pixf_x += subpixel_offset[2 * pix_id];
+                pixf_y += subpixel_offset[2 * pix_id + 1];
+                real T = (real)1.0;
+                uint32_t contributor = 0, last_contributor = 0;
+                real C[NUM_CHANNELS] = {0, 0, 0};
+                for (uint32_t k = r0; k < r1; k++) {
+                    contributor++;
+                    const uint32_t g = c->point_list[k];
+                    real dx = c->means2D[2 * g] - pixf_x, dy = c->means2D[2 * g + 1] - pixf_y;
+                    const real* con_o = c->conic_opacity + 4 * (size_t)g;
+                    real power = (real)-0.5 * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
+                    if (power > (real)0.0) continue;
+                    real alpha = rmin((real)0.99, con_o[3] * R_EXP(power));
+                    if (alpha < (real)1.0 / (real)255.0) continue;
+                    real test_T = T * ((real)1.0 - alpha);
+                    if (test_T < (real)0.0001) break; /* done = true */
+                    for (int ch = 0; ch < NUM_CHANNELS; ch++) C[ch] += features[(size_t)g * NUM_CHANNELS + ch] * alpha * T;
+                    T = test_T;
+                    last_contributor = contributor;
+                }
+                c->final_T[pix_id] = T;
+                c->n_contrib[pix_id] = last_contributor;
+                for (int ch = 0; ch < NUM_CHANNELS; ch++) out_color[(size_t)ch * H * W + pix_id] = C[ch] + T * background[ch];
+            }
+    }
+    return c;
+}
+
+/* backward.cu:20-139 */
+static void computeColorFromSH_bwd(int idx, int deg, int max_coeffs, const real* means, const real* campos,
+                                   const real* shs, const uint8_t* clamped, const real* dL_dcolor, real* dL_dmeans,
+                                   real* dL_dshs) {
+    v3 pos = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
+    v3 dir_orig = {pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]};
+    real len = R_SQRT(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+    v3 dir = {dir_orig.x / len, dir_orig.y / len, dir_orig.z / len};
+    const real* sh = shs + (size_t)idx * max_coeffs * 3;
+    real* dL_dsh = dL_dshs + (size_t)idx * max_coeffs * 3;
+
+    real dL_dRGB[3];
+    for (int c = 0; c < 3; c++) dL_dRGB[c] = dL_dcolor[3 * idx + c] * (clamped[3 * idx + c] ? (real)0 : (real)1);
+
+    real x = dir.x, y = dir.y, z = dir.z;
+    real dRGBdx[3] = {0, 0, 0}, dRGBdy[3] = {0, 0, 0}, dRGBdz[3] = {0, 0, 0};
+#define SH(k) sh[(k) * 3 + c]
+#define DSH(k, v) for (int c = 0; c < 3; c++) dL_dsh[(k) * 3 + c] = (v) * dL_dRGB[c]
+    DSH(0, SH_C0);
+    if (deg > 0) {
+        real d1 = -SH_C1 * y, d2 = SH_C1 * z, d3 = -SH_C1 * x;
+        DSH(1, d1); DSH(2, d2); DSH(3, d3);
+        for (int c = 0; c < 3; c++) {
+            dRGBdx[c] = -SH_C1 * SH(3);
+            dRGBdy[c] = -SH_C1 * SH(1);
+            dRGBdz[c] = SH_C1 * SH(2);
+        }
+        if (deg > 1) {
+            real xx = x * x, yy = y * y, zz = z * z;
+            real xy = x * y, yz = y * z, xz = x * z;
+            real d4 = SH_C2[0] * xy, d5 = SH_C2[1] * yz, d6 = SH_C2[2] * ((real)2.0 * zz - xx - yy);
+            real d7 = SH_C2[3] * xz, d8 = SH_C2[4] * (xx - yy);
+            DSH(4, d4); DSH(5, d5); DSH(6, d6); DSH(7, d7); DSH(8, d8);
+            for (int c = 0; c < 3; c++) {
+                dRGBdx[c] += SH_C2[0] * y * SH(4) + SH_C2[2] * (real)2.0 * -x * SH(6) + SH_C2[3] * z * SH(7) +
+                             SH_C2[4] * (real)2.0 * x * SH(8);
+                dRGBdy[c] += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * (real)2.0 * -y * SH(6) +
+                             SH_C2[4] * (real)2.0 * -y * SH(8);
+                dRGBdz[c] += SH_C2[1] * y * SH(5) + SH_C2[2] * (real)2.0 * (real)2.0 * z * SH(6) + SH_C2[3] * x * SH(7);
+            }
+            if (deg > 2) {
+                real d9 = SH_C3[0] * y * ((real)3.0 * xx - yy);
+                real d10 = SH_C3[1] * xy * z;
+                real d11 = SH_C3[2] * y * ((real)4.0 * zz - xx - yy);
+                real d12 = SH_C3[3] * z * ((real)2.0 * zz - (real)3.0 * xx - (real)3.0 * yy);
+                real d13 = SH_C3[4] * x * ((real)4.0 * zz - xx - yy);
+                real d14 = SH_C3[5] * z * (xx - yy);
+                real d15 = SH_C3[6] * x * (xx - (real)3.0 * yy);
+                DSH(9, d9); DSH(10, d10); DSH(11, d11); DSH(12, d12); DSH(13, d13); DSH(14, d14); DSH(15, d15);
+                for (int c = 0; c < 3; c++) {
+                    dRGBdx[c] += (SH_C3[0] * SH(9) * (real)3.0 * (real)2.0 * xy + SH_C3[1] * SH(10) * yz +
+                                  SH_C3[2] * SH(11) * (real)-2.0 * xy + SH_C3[3] * SH(12) * (real)-3.0 * (real)2.0 * xz +
+                                  SH_C3[4] * SH(13) * ((real)-3.0 * xx + (real)4.0 * zz - yy) +
+                                  SH_C3[5] * SH(14) * (real)2.0 * xz + SH_C3[6] * SH(15) * (real)3.0 * (xx - yy));
+                    dRGBdy[c] += (SH_C3[0] * SH(9) * (real)3.0 * (xx - yy) + SH_C3[1] * SH(10) * xz +
+                                  SH_C3[2] * SH(11) * ((real)-3.0 * yy + (real)4.0 * zz - xx) +
+                                  SH_C3[3] * SH(12) * (real)-3.0 * (real)2.0 * yz + SH_C3[4] * SH(13) * (real)-2.0 * xy +
+                                  SH_C3[5] * SH(14) * (real)-2.0 * yz + SH_C3[6] * SH(15) * (real)-3.0 * (real)2.0 * xy);
+                    dRGBdz[c] += (SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * (real)4.0 * (real)2.0 * yz +
+                                  SH_C3[3] * SH(12) * (real)3.0 * ((real)2.0 * zz - xx - yy) +
+                                  SH_C3[4] * SH(13) * (real)4.0 * (real)2.0 * xz + SH_C3[5] * SH(14) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SH
+#undef DSH
+    /* glm::dot(a,b) = (a.x*b.x + a.y*b.y) + a.z*b.z */
+    v3 dL_ddir;
+    dL_ddir.x = dRGBdx[0] * dL_dRGB[0] + dRGBdx[1] * dL_dRGB[1] + dRGBdx[2] * dL_dRGB[2];
+    dL_ddir.y = dRGBdy[0] * dL_dRGB[0] + dRGBdy[1] * dL_dRGB[1] + dRGBdy[2] * dL_dRGB[2];
+    dL_ddir.z = dRGBdz[0] * dL_dRGB[0] + dRGBdz[1] * dL_dRGB[1] + dRGBdz[2] * dL_dRGB[2];
+    v3 dL_dmean = dnormvdv(dir_orig, dL_ddir);
+    dL_dmeans[3 * idx + 0] += dL_dmean.x;
+    dL_dmeans[3 * idx + 1] += dL_dmean.y;
+    dL_dmeans[3 * idx + 2] += dL_dmean.z;
+}
+
+/* backward.cu:144-310 */
+static void computeCov2D_bwd(int idx, const real* means, const real* cov3Ds, real h_x, real h_y, real tan_fovx,
+                             real tan_fovy, real kernel_size, const real* view_matrix, const real* dL_dconics,
+                             real* dL_dmeans, real* dL_dcov, const real* conic_opacity, real* dL_dopacity) {
+    const real* cov3D = cov3Ds + 6 * (size_t)idx;
+    v3 mean = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
+    real dL_dconic_x = dL_dconics[4 * idx], dL_dconic_y = dL_dconics[4 * idx + 1], dL_dconic_z = dL_dconics[4 * idx + 3];
+    const real combined_opacity = conic_opacity[4 * idx + 3];
+    v3 t = transformPoint4x3(mean, view_matrix);
+
+    const real limx = (real)1.3 * tan_fovx;
+    const real limy = (real)1.3 * tan_fovy;
+    const real txtz = t.x / t.z;
+    const real tytz = t.y / t.z;
+    t.x = rmin(limx, rmax(-limx, txtz)) * t.z;
+    t.y = rmin(limy, rmax(-limy, tytz)) * t.z;
+    const real x_grad_mul = (txtz < -limx || txtz > limx) ? (real)0 : (real)1;
+    const real y_grad_mul = (tytz < -limy || tytz > limy) ? (real)0 : (real)1;
+
+    m3 J = m3_set(h_x / t.z, 0, -(h_x * t.x) / (t.z * t.z), 0, h_y / t.z, -(h_y * t.y) / (t.z * t.z), 0, 0, 0);
+    m3 Wm = m3_set(view_matrix[0], view_matrix[4], view_matrix[8], view_matrix[1], view_matrix[5], view_matrix[9],
+                   view_matrix[2], view_matrix[6], view_matrix[10]);
+    m3 Vrk = m3_set(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+    m3 T = m3_mul(Wm, J);
+    m3 cov2D = m3_mul(m3_mul(m3_transpose(T), m3_transpose(Vrk)), T);
+
+    const real det_0 = (real)dmax(1e-6, (double)(cov2D.m[0][0] * cov2D.m[1][1] - cov2D.m[0][1] * cov2D.m[0][1]));
+    const real det_1 = (real)dmax(1e-6, (double)((cov2D.m[0][0] + kernel_size) * (cov2D.m[1][1] + kernel_size) -
+                                                 cov2D.m[0][1] * cov2D.m[0][1]));
+    const real coef = (real)sqrt((double)det_0 / ((double)det_1 + 1e-6) + 1e-6);
+
+    /* backward.cu:210-218 (double where the literals are un-suffixed) */
+    const real opacity = (real)((double)combined_opacity / ((double)coef + 1e-6));
+    const real dL_dcoef = dL_dopacity[idx] * opacity;
+    const real dL_dsqrtcoef = (real)((double)dL_dcoef * 0.5 * 1. / ((double)coef + 1e-6));
+    const real dL_ddet0 = (real)((double)dL_dsqrtcoef / ((double)det_1 + 1e-6));
+    const real dL_ddet1 = (real)((double)(dL_dsqrtcoef * det_0) * ((double)(real)-1.0 / ((double)(det_1 * det_1) + 1e-6)));
+    const real dcoef_da = dL_ddet0 * cov2D.m[1][1] + dL_ddet1 * (cov2D.m[1][1] + kernel_size);
+    const real dcoef_db = (real)((double)dL_ddet0 * (-2. * (double)cov2D.m[0][1]) + (double)dL_ddet1 * (-2. * (double)cov2D.m[0][1]));
+    const real dcoef_dc = dL_ddet0 * cov2D.m[0][0] + dL_ddet1 * (cov2D.m[0][0] + kernel_size);
+
+    real a = cov2D.m[0][0] += kernel_size;
+    real b = cov2D.m[0][1];
+    real cc = cov2D.m[1][1] += kernel_size;
+
+    real denom = a * cc - b * b;
+    real dL_da = 0, dL_db = 0, dL_dc = 0;
+    real denom2inv = (real)1.0 / ((denom * denom) + (real)0.0000001);
+
+    if (denom2inv != 0) {
+        dL_da = denom2inv * (-cc * cc * dL_dconic_x + 2 * b * cc * dL_dconic_y + (denom - a * cc) * dL_dconic_z);
+        dL_dc = denom2inv * (-a * a * dL_dconic_z + 2 * a * b * dL_dconic_y + (denom - a * cc) * dL_dconic_x);
+        dL_db = denom2inv * 2 * (b * cc * dL_dconic_x - (denom + 2 * b * b) * dL_dconic_y + a * b * dL_dconic_z);
+
+        if ((double)det_0 <= 1e-6 || (double)det_1 <= 1e-6) {
+            dL_dopacity[idx] = 0;
+        } else {
+            dL_da += dcoef_da;
+            dL_dc += dcoef_dc;
+            dL_db += dcoef_db;
+            dL_dopacity[idx] = dL_dopacity[idx] * coef;
+        }
+#define Tm(c_, r_) T.m[c_][r_]
+        dL_dcov[6 * idx + 0] = (Tm(0, 0) * Tm(0, 0) * dL_da + Tm(0, 0) * Tm(1, 0) * dL_db + Tm(1, 0) * Tm(1, 0) * dL_dc);
+        dL_dcov[6 * idx + 3] = (Tm(0, 1) * Tm(0, 1) * dL_da + Tm(0, 1) * Tm(1, 1) * dL_db + Tm(1, 1) * Tm(1, 1) * dL_dc);
+        dL_dcov[6 * idx + 5] = (Tm(0, 2) * Tm(0, 2) * dL_da + Tm(0, 2) * Tm(1, 2) * dL_db + Tm(1, 2) * Tm(1, 2) * dL_dc);
+        dL_dcov[6 * idx + 1] = 2 * Tm(0, 0) * Tm(0, 1) * dL_da + (Tm(0, 0) * Tm(1, 1) + Tm(0, 1) * Tm(1, 0)) * dL_db + 2 * Tm(1, 0) * Tm(1, 1) * dL_dc;
+        dL_dcov[6 * idx + 2] = 2 * Tm(0, 0) * Tm(0, 2) * dL_da + (Tm(0, 0) * Tm(1, 2) + Tm(0, 2) * Tm(1, 0)) * dL_db + 2 * Tm(1, 0) * Tm(1, 2) * dL_dc;
+        dL_dcov[6 * idx + 4] = 2 * Tm(0, 2) * Tm(0, 1) * dL_da + (Tm(0, 1) * Tm(1, 2) + Tm(0, 2) * Tm(1, 1)) * dL_db + 2 * Tm(1, 1) * Tm(1, 2) * dL_dc;
+    } else {
+        for (int i = 0; i < 6; i++) dL_dcov[6 * idx + i] = 0;
+    }
+#define Vm(c_, r_) Vrk.m[c_][r_]
+    real dL_dT00 = 2 * (Tm(0, 0) * Vm(0, 0) + Tm(0, 1) * Vm(0, 1) + Tm(0, 2) * Vm(0, 2)) * dL_da +
+                   (Tm(1, 0) * Vm(0, 0) + Tm(1, 1) * Vm(0, 1) + Tm(1, 2) * Vm(0, 2)) * dL_db;
+    real dL_dT01 = 2 * (Tm(0, 0) * Vm(1, 0) + Tm(0, 1) * Vm(1, 1) + Tm(0, 2) * Vm(1, 2)) * dL_da +
+                   (Tm(1, 0) * Vm(1, 0) + Tm(1, 1) * Vm(1, 1) + Tm(1, 2) * Vm(1, 2)) * dL_db;
+    real dL_dT02 = 2 * (Tm(0, 0) * Vm(2, 0) + Tm(0, 1) * Vm(2, 1) + Tm(0, 2) * Vm(2, 2)) * dL_da +
+                   (Tm(1, 0) * Vm(2, 0) + Tm(1, 1) * Vm(2, 1) + Tm(1, 2) * Vm(2, 2)) * dL_db;
+    real dL_dT10 = 2 * (Tm(1, 0) * Vm(0, 0) + Tm(1, 1) * Vm(0, 1) + Tm(1, 2) * Vm(0, 2)) * dL_dc +
+                   (Tm(0, 0) * Vm(0, 0) + Tm(0, 1) * Vm(0, 1) + Tm(0, 2) * Vm(0, 2)) * dL_db;
+    real dL_dT11 = 2 * (Tm(1, 0) * Vm(1, 0) + Tm(1, 1) * Vm(1, 1) + Tm(1, 2) * Vm(1, 2)) * dL_dc +
+                   (Tm(0, 0) * Vm(1, 0) + Tm(0, 1) * Vm(1, 1) + Tm(0, 2) * Vm(1, 2)) * dL_db;
+    real dL_dT12 = 2 * (Tm(1, 0) * Vm(2, 0) + Tm(1, 1) * Vm(2, 1) + Tm(1, 2) * Vm(2, 2)) * dL_dc +
+                   (Tm(0, 0) * Vm(2, 0) + Tm(0, 1) * Vm(2, 1) + Tm(0, 2) * Vm(2, 2)) * dL_db;
+#undef Vm
+#undef Tm
+    real dL_dJ00 = Wm.m[0][0] * dL_dT00 + Wm.m[0][1] * dL_dT01 + Wm.m[0][2] * dL_dT02;
+    real dL_dJ02 = Wm.m[2][0] * dL_dT00 + Wm.m[2][1] * dL_dT01 + Wm.m[2][2] * dL_dT02;
+    real dL_dJ11 = Wm.m[1][0] * dL_dT10 + Wm.m[1][1] * dL_dT11 + Wm.m[1][2] * dL_dT12;
+    real dL_dJ12 = Wm.m[2][0] * dL_dT10 + Wm.m[2][1] * dL_dT11 + Wm.m[2][2] * dL_dT12;
+
+    real tz = (real)1.0 / t.z;
+    real tz2 = tz * tz;
+    real tz3 = tz2 * tz;
+
+    real dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+    real dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+    real dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
+
+    v3 g = {dL_dtx, dL_dty, dL_dtz};
+    v3 dL_dmean = transformVec4x3Transpose(g, view_matrix);
+    dL_dmeans[3 * idx + 0] = dL_dmean.x; /* overwrite, backward.cu:309 */
+    dL_dmeans[3 * idx + 1] = dL_dmean.y;
+    dL_dmeans[3 * idx + 2] = dL_dmean.z;
+}
+
+/* backward.cu:314-377 */
+static void computeCov3D_bwd(int idx, const real* scale, real mod, const real* rot, const real* dL_dcov3Ds,
+                             real* dL_dscales, real* dL_drots) {
+    real r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    m3 Rm = m3_set((real)1.0 - (real)2.0 * (y * y + z * z), (real)2.0 * (x * y - r * z), (real)2.0 * (x * z + r * y),
+                   (real)2.0 * (x * y + r * z), (real)1.0 - (real)2.0 * (x * x + z * z), (real)2.0 * (y * z - r * x),
+                   (real)2.0 * (x * z - r * y), (real)2.0 * (y * z + r * x), (real)1.0 - (real)2.0 * (x * x + y * y));
+    m3 S = m3_set(1, 0, 0, 0, 1, 0, 0, 0, 1);
+    real sx = mod * scale[0], sy = mod * scale[1], sz = mod * scale[2];
+    S.m[0][0] = sx; S.m[1][1] = sy; S.m[2][2] = sz;
+    m3 Mm = m3_mul(S, Rm);
+    const real* d = dL_dcov3Ds + 6 * (size_t)idx;
+    m3 dL_dSigma = m3_set(d[0], (real)0.5 * d[1], (real)0.5 * d[2], (real)0.5 * d[1], d[3], (real)0.5 * d[4],
+                          (real)0.5 * d[2], (real)0.5 * d[4], d[5]);
+    /* dL_dM = 2.0f * M * dL_dSigma : (2.0f * M) first (scalar*mat), then mat*mat */
+    m3 M2;
+    for (int c = 0; c < 3; c++)
+        for (int w = 0; w < 3; w++) M2.m[c][w] = Mm.m[c][w] * (real)2.0;
+    m3 dL_dM = m3_mul(M2, dL_dSigma);
+    m3 Rt = m3_transpose(Rm);
+    m3 dL_dMt = m3_transpose(dL_dM);
+
+    real* dL_dscale = dL_dscales + 3 * (size_t)idx;
+    dL_dscale[0] = Rt.m[0][0] * dL_dMt.m[0][0] + Rt.m[0][1] * dL_dMt.m[0][1] + Rt.m[0][2] * dL_dMt.m[0][2];
+    dL_dscale[1] = Rt.m[1][0] * dL_dMt.m[1][0] + Rt.m[1][1] * dL_dMt.m[1][1] + Rt.m[1][2] * dL_dMt.m[1][2];
+    dL_dscale[2] = Rt.m[2][0] * dL_dMt.m[2][0] + Rt.m[2][1] * dL_dMt.m[2][1] + Rt.m[2][2] * dL_dMt.m[2][2];
+
+    for (int w = 0; w < 3; w++) {
+        dL_dMt.m[0][w] *= sx;
+        dL_dMt.m[1][w] *= sy;
+        dL_dMt.m[2][w] *= sz;
+    }
+#define D(c_, r_) dL_dMt.m[c_][r_]
+    real* q = dL_drots + 4 * (size_t)idx;
+    q[0] = 2 * z * (D(0, 1) - D(1, 0)) + 2 * y * (D(2, 0) - D(0, 2)) + 2 * x * (D(1, 2) - D(2, 1));
+    q[1] = 2 * y * (D(1, 0) + D(0, 1)) + 2 * z * (D(2, 0) + D(0, 2)) + 2 * r * (D(1, 2) - D(2, 1)) - 4 * x * (D(2, 2) + D(1, 1));
+    q[2] = 2 * x * (D(1, 0) + D(0, 1)) + 2 * r * (D(2, 0) - D(0, 2)) + 2 * z * (D(1, 2) + D(2, 1)) - 4 * y * (D(2, 2) + D(0, 0));
+    q[3] = 2 * r * (D(0, 1) - D(1, 0)) + 2 * x * (D(2, 0) + D(0, 2)) + 2 * y * (D(1, 2) + D(2, 1)) - 4 * z * (D(1, 1) + D(0, 0));
+#undef D
+}
+
+/* Rasterizer::backward, rasterizer_impl.cu:344-443.  All gradient outputs must be zero-filled by the
+ * caller (rasterize_points.cu:157-165).  dL_dconic is [P,2,2] (float4 per Gaussian), dL_dmean2D [P,3]. */
+WGO_API void wgo_backward(wgo_ctx* c, const real* background, const real* means3D, const real* shs,
+                          const real* colors_precomp, const real* scales, real scale_modifier, const real* rotations,
+                          const real* cov3D_precomp, const real* viewmatrix, const real* projmatrix, const real* campos,
+                          real tan_fovx, real tan_fovy, real kernel_size, const real* subpixel_offset,
+                          const real* dL_dpix, real* dL_dmean2D, real* dL_dconic, real* dL_dopacity, real* dL_dcolor,
+                          real* dL_dmean3D, real* dL_dcov3D, real* dL_dsh, real* dL_dscale, real* dL_drot) {
+    const int P = c->P, W = c->W, H = c->H, gx = c->gx, gy = c->gy, D = c->D, M = c->M;
+    const real focal_y = (real)H / ((real)2.0 * tan_fovy);
+    const real focal_x = (real)W / ((real)2.0 * tan_fovx);
+    const real* colors = (colors_precomp != NULL) ? colors_precomp : c->rgb;
+    const int Tn = gx * gy;
+
+    /* K9: renderCUDA backward, backward.cu:435-606.  The reference issues one float atomicAdd per
+     * (pixel, Gaussian, component) in arbitrary order; here each tile accumulates its pairs in pixel
+     * order into a tile-local buffer, and tiles are merged in tile order afterwards (one valid
+     * instance of the reference's unordered float summation, but deterministic). */
+    const real ddelx_dx = (real)(0.5 * W);
+    const real ddely_dy = (real)(0.5 * H);
+    real** tile_acc = (real**)calloc((size_t)(Tn ? Tn : 1), sizeof(real*));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < Tn; tile++) {
+        const int tx = tile % gx, ty = tile / gx;
+        const uint32_t r0 = c->ranges[2 * tile], r1 = c->ranges[2 * tile + 1];
+        const uint32_t len = r1 - r0;
+        if (len == 0) continue;
+        real* acc = (real*)calloc((size_t)len * 10, sizeof(real));
+        tile_acc[tile] = acc;
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                const int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                if (!(px < W && py < H)) continue;
+                const size_t pix_id = (size_t)W * py + px;
+                real pixf_x = (real)px + subpixel_offset[2 * pix_id];
+                real pixf_y = (real)py + subpixel_offset[2 * pix_id + 1];
+                const real T_final = c->final_T[pix_id];
+                real T = T_final;
+                uint32_t contributor = len;
+                const uint32_t last_contributor = c->n_contrib[pix_id];
+                real accum_rec[3] = {0, 0, 0};
+                real dL_dpixel[3];
+                for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpix[(size_t)i * H * W + pix_id];
+                real last_alpha = 0;
+                real last_color[3] = {0, 0, 0};
+                for (uint32_t k = r1; k-- > r0;) {
+                    contributor--;
+                    if (contributor >= last_contributor) continue;
+                    const uint32_t g = c->point_list[k];
+                    const real dx = c->means2D[2 * g] - pixf_x, dy = c->means2D[2 * g + 1] - pixf_y;
+                    const real* con_o = c->conic_opacity + 4 * (size_t)g;
+                    const real power = (real)-0.5 * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
+                    if (power > (real)0.0) continue;
+                    const real G = R_EXP(power);
+                    const real alpha = rmin((real)0.99, con_o[3] * G);
+                    if (alpha < (real)1.0 / (real)255.0) continue;
+
+                    T = T / ((real)1.0 - alpha);
+                    const real dchannel_dcolor = alpha * T;
+                    real* a = acc + (size_t)(k - r0) * 10;
+                    real dL_dalpha = 0;
+                    for (int ch = 0; ch < 3; ch++) {
+                        const real col = colors[(size_t)g * 3 + ch];
+                        accum_rec[ch] = last_alpha * last_color[ch] + ((real)1.0 - last_alpha) * accum_rec[ch];
+                        last_color[ch] = col;
+                        const real dL_dchannel = dL_dpixel[ch];
+                        dL_dalpha += (col - accum_rec[ch]) * dL_dchannel;
+                        a[ch] += dchannel_dcolor * dL_dchannel;
+                    }
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    real bg_dot_dpixel = 0;
+                    for (int i = 0; i < 3; i++) bg_dot_dpixel += background[i] * dL_dpixel[i];
+                    dL_dalpha += (-T_final / ((real)1.0 - alpha)) * bg_dot_dpixel;
+
+                    const real dL_dG = con_o[3] * dL_dalpha;
+                    const real gdx = G * dx;
+                    const real gdy = G * dy;
+                    const real dG_ddelx = -gdx * con_o[0] - gdy * con_o[1];
+                    const real dG_ddely = -gdy * con_o[2] - gdx * con_o[1];
+                    a[3] += dL_dG * dG_ddelx * ddelx_dx;
+                    a[4] += dL_dG * dG_ddely * ddely_dy;
+                    a[5] += R_FABS(dL_dG * dG_ddelx * ddelx_dx) + R_FABS(dL_dG * dG_ddely * ddely_dy);
+                    a[6] += (real)-0.5 * gdx * dx * dL_dG;
+                    a[7] += (real)-0.5 * gdx * dy * dL_dG;
+                    a[8] += (real)-0.5 * gdy * dy * dL_dG;
+                    a[9] += G * dL_dalpha;
+                }
+            }
+    }
+    for (int tile = 0; tile < Tn; tile++) {
+        real* acc = tile_acc[tile];
+        if (!acc) continue;
+        const uint32_t r0 = c->ranges[2 * tile], r1 = c->ranges[2 * tile + 1];
+        for (uint32_t k = r0; k < r1; k++) {
+            const uint32_t g = c->point_list[k];
+            const real* a = acc + (size_t)(k - r0) * 10;
+            dL_dcolor[3 * (size_t)g + 0] += a[0];
+            dL_dcolor[3 * (size_t)g + 1] += a[1];
+            dL_dcolor[3 * (size_t)g + 2] += a[2];
+            dL_dmean2D[3 * (size_t)g + 0] += a[3];
+            dL_dmean2D[3 * (size_t)g + 1] += a[4];
+            dL_dmean2D[3 * (size_t)g + 2] += a[5];
+            dL_dconic[4 * (size_t)g + 0] += a[6];
+            dL_dconic[4 * (size_t)g + 1] += a[7];
+            dL_dconic[4 * (size_t)g + 3] += a[8];
+            dL_dopacity[g] += a[9];
+        }
+        free(acc);
+    }
+    free(tile_acc);
+
+    /* K10: computeCov2DCUDA, backward.cu:144-310 (launch :639) */
+    const real* cov3D_ptr = (cov3D_precomp != NULL) ? cov3D_precomp : c->cov3D;
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        if (!(c->radii[idx] > 0)) continue;
+        computeCov2D_bwd(idx, means3D, cov3D_ptr, focal_x, focal_y, tan_fovx, tan_fovy, kernel_size, viewmatrix,
+                         dL_dconic, dL_dmean3D, dL_dcov3D, c->conic_opacity, dL_dopacity);
+    }
+    /* K11: preprocessCUDA backward, backward.cu:382-432 (launch :659) */
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++) {
+        if (!(c->radii[idx] > 0)) continue;
+        v3 m = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+        const real* proj = projmatrix;
+        v4 m_hom = transformPoint4x4(m, proj);
+        real m_w = (real)1.0 / (m_hom.w + (real)0.0000001);
+        real mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
+        real mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
+        const real gx2 = dL_dmean2D[3 * idx], gy2 = dL_dmean2D[3 * idx + 1];
+        real dmx = (proj[0] * m_w - proj[3] * mul1) * gx2 + (proj[1] * m_w - proj[3] * mul2) * gy2;
+        real dmy = (proj[4] * m_w - proj[7] * mul1) * gx2 + (proj[5] * m_w - proj[7] * mul2) * gy2;
+        real dmz = (proj[8] * m_w - proj[11] * mul1) * gx2 + (proj[9] * m_w - proj[11] * mul2) * gy2;
+        dL_dmean3D[3 * idx + 0] += dmx;
+        dL_dmean3D[3 * idx + 1] += dmy;
+        dL_dmean3D[3 * idx + 2] += dmz;
+        if (shs) computeColorFromSH_bwd(idx, D, M, means3D, campos, shs, c->clamped, dL_dcolor, dL_dmean3D, dL_dsh);
+        if (scales) computeCov3D_bwd(idx, scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, dL_dcov3D, dL_dscale, dL_drot);
+    }
+}
+
+/* Rasterizer::markVisible / checkFrustum, rasterizer_impl.cu:54-66,141-153 */
+WGO_API void wgo_mark_visible(int P, const real* means3D, const real* viewmatrix, const real* projmatrix, uint8_t* present) {
+    (void)projmatrix;
+    for (int idx = 0; idx < P; idx++) {
+        v3 p = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+        v3 pv = transformPoint4x3(p, viewmatrix);
+        present[idx] = !(pv.z <= (real)0.2);
+    }
+}
+
+/* ---- accessors for per-stage parity checks ---- */
+WGO_API int wgo_num_rendered(const wgo_ctx* c) { return c->R; }
+WGO_API int wgo_sizeof_real(void) { return (int)sizeof(real); }
+#define GETTER(name, type, field, count)                                  \
+    WGO_API void wgo_get_##name(const wgo_ctx* c, type* out) {            \
+        memcpy(out, c->field, (size_t)(count) * sizeof(type));            \
+    }
+GETTER(depths, real, depths, c->P)
+GETTER(clamped, uint8_t, clamped, 3 * (size_t)c->P)
+GETTER(radii, int, radii, c->P)
+GETTER(means2D, real, means2D, 2 * (size_t)c->P)
+GETTER(cov3D, real, cov3D, 6 * (size_t)c->P)
+GETTER(conic_opacity, real, conic_opacity, 4 * (size_t)c->P)
+GETTER(rgb, real, rgb, 3 * (size_t)c->P)
+GETTER(tiles_touched, uint32_t, tiles_touched, c->P)
+GETTER(point_offsets, uint32_t, point_offsets, c->P)
+GETTER(keys_unsorted, uint64_t, keys_unsorted, c->R)
+GETTER(keys, uint64_t, keys, c->R)
+GETTER(point_list, uint32_t, point_list, c->R)
+GETTER(final_T, real, final_T, (size_t)c->W * c->H)
+GETTER(n_contrib, uint32_t, n_contrib, (size_t)c->W * c->H)
+GETTER(ranges, uint32_t, ranges, 2 * (size_t)c->gx * c->gy)

@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native Gaussian-splat rasterizer.
+
+Metric (BASELINE.json): train iters/s + forward Mpix/s at 1M Gaussians @ 1920x1080, plus dL/dtheta max-rel-err vs the
+reference restatement (the CPU oracle).  A "step" is one pass of the hot path over one view: forward + backward of the
+rasterization operator (through the drop-in GaussianRasterizer autograd surface -> C-ABI -> HIP kernels) with a fixed
+cotangent, on synthetic data of SURVEY.md 8(d).  Inputs are resident in HBM before the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1 is view-parallel (one camera per GPU, Gaussians replicated, all-reduce of the scalar loss only): weak scaling.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "wild-gaussians_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def algorithmic_bytes(stage: str, P: int, V: int, R: int, N: int, tiles: int, M: int, sh: bool) -> float:
+    """ALGORITHMIC bytes per launch, SURVEY.md 8(d) formulas split per kernel (each compulsory datum counted once per
+    kernel boundary).  Stated again in DESIGN.md."""
+    c_in = 12 * M if sh else 12
+    table = {
+        "preprocess": P * (44 + c_in) + 8 * P + V * (4 + 48 + 8 + 24),  # attrs in; radii+tiles out; depth+record+rect+cov3D
+        "scan": 8 * P,
+        "duplicate_keys": 20 * P + 12 * R,
+        "sort": 24 * R * ((32 + int(np.ceil(np.log2(max(tiles, 2)))) + 7) // 8),
+        "tile_ranges": 8 * R + 8 * tiles,
+        "render_forward": R * (4 + 36) + 28 * N + 16 * tiles,
+        "render_backward": 28 * N + 12 * N + 40 * R + 40 * R,
+        "preprocess_backward": V * (100 + 40) + V * 90 + P * (12 + 12 + 16 + 4) + (24 * M * V if sh else 0),
+    }
+    return float(table[stage])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--colors", choices=["sh", "precomp"], default="sh")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (parity + CPU timing)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events in the timed region")
+    args = ap.parse_args()
+
+    import wg_scenes as S
+    import wg_viewparallel as VP
+    from diff_gaussian_rasterization import GaussianRasterizer, _C
+    from tests.wg_testlib import make_settings, to_dev, compare_forward, compare_grads
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the rasterizer has no CPU path")
+    rank, local_rank, world = VP.init()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    device = torch.device("cuda", local_rank)
+
+    W, H, P = args.width, args.height, args.gaussians
+    N = W * H
+    sh_degree = 3 if args.colors == "sh" else None
+    cloud = S.make_cloud(P, W, H, sh_degree=sh_degree, seed=0)
+    cam = VP.view_cameras(world, W, H)[rank]  # one camera per rank (config 4); rank 0 = the base camera
+    cot_np = S.make_cotangent(W, H)
+    deg = 3 if args.colors == "sh" else 0
+    M = 16 if args.colors == "sh" else 0
+
+    rs = make_settings(cam, deg, device=device)
+    rast = GaussianRasterizer(rs)
+    t = {k: to_dev(v, device).requires_grad_(True) for k, v in cloud.items()}
+    means2D = torch.zeros((P, 3), device=device, requires_grad=True)
+    cot = to_dev(cot_np, device)
+    cot_flat = cot.reshape(-1)
+    loss_buf = torch.zeros(1, device=device)
+
+    def call():
+        return rast(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t.get("shs"),
+                    colors_precomp=t.get("colors_precomp"), scales=t["scales"], rotations=t["rotations"])
+
+    def train_step():
+        for v in t.values():
+            v.grad = None
+        means2D.grad = None
+        color, radii, acc = call()
+        color.backward(cot)
+        loss = torch.dot(color.detach().reshape(-1), cot_flat).reshape(1)
+        VP.allreduce_loss(loss)  # the only collective: 4 bytes
+        return loss
+
+    def fwd_step():
+        with torch.no_grad():
+            return call()[0]
+
+    def timed(fn, steps):
+        VP.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(device)
+        VP.barrier()
+        return VP.max_over_ranks(time.perf_counter() - t0, device)
+
+    for _ in range(args.warmup):
+        train_step()
+    torch.cuda.synchronize(device)
+    profile = not args.no_profile
+    if profile:
+        _C.profile_reset()
+        _C.profile_enable(True)
+    t_train = timed(train_step, args.steps)
+    stages = {}
+    if profile:
+        stages = _C.profile_read()
+        _C.profile_enable(False)
+
+    for _ in range(max(1, args.warmup // 2)):
+        fwd_step()
+    t_fwd = timed(fwd_step, args.steps)
+
+    # workload statistics of this rank's view (needed for the algorithmic byte counts)
+    with torch.no_grad():
+        e = torch.Tensor([])
+        R, _c, radii, gb, bb, ib = _C.rasterize_gaussians(
+            rs.bg, t["means3D"], t["colors_precomp"] if "colors_precomp" in t else e, t["opacities"], t["scales"], t["rotations"], 1.0, e,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset, H, W,
+            t["shs"] if "shs" in t else e, deg, rs.campos, False, False)
+        V = int((radii > 0).sum().item())
+        tile_last = _C.view_image(ib, H, W)["tile_last"]
+        walked = int(tile_last.sum().item())
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+
+    iters_per_s = world * args.steps / t_train
+    fwd_fps = world * args.steps / t_fwd
+    out = {
+        "metric": "train_iters_per_s (fwd+bwd of the rasterizer, 1M Gaussians @1080p)",
+        "value": round(iters_per_s, 3),
+        "unit": "iter/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * t_train / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{P} Gaussians, {W}x{H}, {'SH deg 3' if args.colors == 'sh' else 'precomputed colours'}, "
+                               f"fwd+bwd, one view per GPU (view-parallel, loss all-reduce only)",
+                   "gaussians": P, "width": W, "height": H, "colors": args.colors, "views_per_step": world},
+        "forward_fps": round(fwd_fps, 2),
+        "forward_mpix_per_s": round(fwd_fps * N / 1e6, 1),
+        "forward_ms": round(1000.0 * t_fwd / args.steps, 4),
+        "workload_stats": {"P": P, "V": V, "R": int(R), "N": N, "tiles": tiles, "instances_walked": walked},
+    }
+
+    if stages:
+        per_stage = {k: (ms / n if n else 0.0) for k, (ms, n) in stages.items()}
+        out["stages_ms"] = {k: round(v, 4) for k, v in per_stage.items()}
+        dom = max(stages, key=lambda k: stages[k][0])
+        B = algorithmic_bytes(dom, P, V, int(R), N, tiles, M, args.colors == "sh")
+        ach = B / (per_stage[dom] * 1e-3) / 1e9 if per_stage[dom] > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "algorithmic_bytes_per_launch": B, "avg_launch_ms": round(per_stage[dom], 4)}
+        # whole forward / backward pipelines against the same roofline, for context
+        fwd_names = ["preprocess", "scan", "duplicate_keys", "sort", "tile_ranges", "render_forward"]
+        bwd_names = ["render_backward", "preprocess_backward"]
+        Bf = sum(algorithmic_bytes(k, P, V, int(R), N, tiles, M, args.colors == "sh") for k in fwd_names)
+        Bb = sum(algorithmic_bytes(k, P, V, int(R), N, tiles, M, args.colors == "sh") for k in bwd_names)
+        tf = sum(per_stage[k] for k in fwd_names)
+        tb = sum(per_stage[k] for k in bwd_names)
+        out["pipeline_roofline"] = {"forward_GBps": round(Bf / (tf * 1e-3) / 1e9, 1) if tf else None,
+                                    "backward_GBps": round(Bb / (tb * 1e-3) / 1e9, 1) if tb else None,
+                                    "forward_kernel_ms": round(tf, 4), "backward_kernel_ms": round(tb, 4)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU leg: the oracle (a CPU port of the reference's algorithm) on the same workload, timed on the host
+        # cores, and used as the checker for the parity part of the metric.  Never on the measured path.
+        from oracle import oracle
+        oracle.build()
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        o = oracle.run_scene(cloud, cam, sh_degree=deg, cotangent=cot_np)
+        t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(1.0 / t_cpu, 4), "unit": "iter/s", "cores": cores, "kind": "port",
+                               "sample": "1 full fwd+bwd step of the same workload (OpenMP over Gaussians/tiles)",
+                               "seconds": round(t_cpu, 2)}
+        train_step()
+        torch.cuda.synchronize(device)
+        grads = {"means3D": t["means3D"].grad, "means2D": means2D.grad, "opacities": t["opacities"].grad,
+                 "scales": t["scales"].grad, "rotations": t["rotations"].grad}
+        if "shs" in t:
+            grads["sh"] = t["shs"].grad
+        else:
+            grads["colors_precomp"] = t["colors_precomp"].grad
+        errs = compare_grads({k: v.detach().cpu().numpy() for k, v in grads.items()}, o["grads"])
+        cf = compare_forward(fwd_step().cpu().numpy(), o)
+        out["parity"] = {"grad_max_rel_err": {k: float(f"{v:.3e}") for k, v in errs.items()},
+                         "grad_max_rel_err_worst": float(f"{max(errs.values()):.3e}"),
+                         "fwd_max_abs_err_solid_pixels": float(f"{cf['max_err_solid']:.3e}"),
+                         "fwd_fragile_pixels": cf["n_fragile"], "fwd_fragile_over_1e-4": cf["n_over_in_fragile"],
+                         "radii_equal": bool((radii.cpu().numpy() == o["radii"]).all()),
+                         "num_rendered_equal": bool(int(R) == o["num_rendered"])}
+        out["speedup_vs_cpu_baseline"] = round(iters_per_s / (1.0 / t_cpu), 1)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

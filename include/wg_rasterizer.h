@@ -1,0 +1,184 @@
+/*
+ * wg_rasterizer.h -- C-ABI of the MI355X-native differentiable Gaussian-splat rasterizer.
+ *
+ * This is the drop-in boundary for the hot path of jkulhanek/wild-gaussians: it replaces the static
+ * C++ interface CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+ * (submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer.h:24-88), i.e. what the
+ * reference's torch binding (rasterize_points.cu:35-225) calls.  Differences from that interface,
+ * all forced by "plain C, no C++/torch types in the signature":
+ *
+ *   - std::function<char*(size_t)> allocators become (function pointer, void* user) pairs;
+ *   - every entry point takes the HIP stream to launch on (the reference uses the legacy default
+ *     stream, rasterizer_impl.cu:148,292,...); pass NULL for the default stream;
+ *   - errors are returned as negative wg_status codes instead of C++ exceptions
+ *     (std::runtime_error at rasterizer_impl.cu:244-247 and auxiliary.h:166-173);
+ *   - bool becomes int / unsigned char.
+ *
+ * All pointers are DEVICE pointers to contiguous float32 / int32 data unless stated otherwise.  A NULL
+ * pointer means "not provided" exactly as in the reference (shs vs colors_precomp, scales+rotations
+ * vs cov3D_precomp; forward.cu:217,253, backward.cu:426,430).  Matrices are the reference's layout:
+ * viewmatrix = W2C transposed, projmatrix = (P*W2C) transposed, row-major (auxiliary.h:58-77).
+ *
+ * The three scratch buffers (geometry / binning / image state) are opaque; their layout is private to
+ * this library (it differs from the reference's GeometryState/BinningState/ImageState).  The one
+ * documented property: the image-state buffer starts, at its first 256-byte-aligned address, with
+ * final_T as float[H*W] (the transmittance left at each pixel), so that
+ * accumulation = 1 - final_T can be read back by the caller like the reference's Python wrapper does
+ * (diff_gaussian_rasterization/__init__.py:101-113).
+ */
+#ifndef WG_RASTERIZER_H_INCLUDED
+#define WG_RASTERIZER_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WG_TILE_X 16 /* config.h:15 */
+#define WG_TILE_Y 16 /* config.h:16 */
+#define WG_NUM_CHANNELS 3 /* config.h:14 */
+
+typedef enum wg_status {
+    WG_OK = 0,
+    WG_ERR_INVALID_ARGUMENT = -1, /* bad sizes / missing mandatory pointer / both-or-neither optional inputs */
+    WG_ERR_ALLOC = -2,            /* an allocator callback returned NULL */
+    WG_ERR_HIP = -3,              /* a HIP runtime call or kernel launch failed (wg_last_hip_error() has the text) */
+    WG_ERR_OVERFLOW = -4          /* more than 2^31-1 (tile, Gaussian) instances */
+} wg_status;
+
+/* Replaces std::function<char*(size_t N)> (rasterizer.h:34-36, rasterize_points.cu:27-33): must return a
+ * device pointer to at least `bytes` bytes that stays valid until the matching backward call. */
+typedef char* (*wg_alloc_fn)(size_t bytes, void* user);
+
+/* Exact scratch sizes (bytes), for callers that preallocate. */
+size_t wg_geometry_buffer_size(int P);
+size_t wg_image_buffer_size(int width, int height);
+size_t wg_binning_buffer_size(int num_rendered);
+
+/*
+ * Rasterizer::forward (rasterizer.h:33-59, rasterizer_impl.cu:198-340).
+ * Returns num_rendered (>= 0) = number of (tile, Gaussian) instances, or a negative wg_status.
+ * out_color: float[3*H*W] planar CHW.  radii: int[P] or NULL.  One host<->device sync (the read-back
+ * of num_rendered that sizes the binning buffer, as rasterizer_impl.cu:284).
+ */
+int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user,
+                         wg_alloc_fn binning_alloc, void* binning_user,
+                         wg_alloc_fn image_alloc, void* image_user,
+                         int P, int D, int M,
+                         const float* background,
+                         int width, int height,
+                         const float* means3D,
+                         const float* shs,
+                         const float* colors_precomp,
+                         const float* opacities,
+                         const float* scales,
+                         float scale_modifier,
+                         const float* rotations,
+                         const float* cov3D_precomp,
+                         const float* viewmatrix,
+                         const float* projmatrix,
+                         const float* cam_pos,
+                         float tan_fovx, float tan_fovy,
+                         float kernel_size,
+                         const float* subpixel_offset,
+                         int prefiltered,
+                         float* out_color,
+                         int* radii,
+                         int debug,
+                         void* stream);
+
+/*
+ * Rasterizer::backward (rasterizer.h:61-88, rasterizer_impl.cu:344-443).
+ * Gradient outputs must be zero-filled by the caller (rasterize_points.cu:157-165).
+ * dL_dconic is float[P*4] (2x2 per Gaussian; [0],[1],[3] used), dL_dmean2D float[P*3]
+ * (x, y in NDC-scaled units, z = abs-gradient, backward.cu:590-595).  dL_dsh may be NULL when M == 0.
+ */
+int wg_rasterize_backward(int P, int D, int M, int R,
+                          const float* background,
+                          int width, int height,
+                          const float* means3D,
+                          const float* shs,
+                          const float* colors_precomp,
+                          const float* scales,
+                          float scale_modifier,
+                          const float* rotations,
+                          const float* cov3D_precomp,
+                          const float* viewmatrix,
+                          const float* projmatrix,
+                          const float* campos,
+                          float tan_fovx, float tan_fovy,
+                          float kernel_size,
+                          const float* subpixel_offset,
+                          const int* radii,
+                          char* geom_buffer,
+                          char* binning_buffer,
+                          char* image_buffer,
+                          const float* dL_dpix,
+                          float* dL_dmean2D,
+                          float* dL_dconic,
+                          float* dL_dopacity,
+                          float* dL_dcolor,
+                          float* dL_dmean3D,
+                          float* dL_dcov3D,
+                          float* dL_dsh,
+                          float* dL_dscale,
+                          float* dL_drot,
+                          int debug,
+                          void* stream);
+
+/* Rasterizer::markVisible (rasterizer.h:26-31, rasterizer_impl.cu:141-153). present: unsigned char[P]. */
+int wg_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                    unsigned char* present, void* stream);
+
+/* ---- introspection used by the parity tests (device pointers into the opaque buffers) ---- */
+typedef struct wg_geometry_view {
+    const float* depths;          /* [P]   view-space z (forward.cu:262) */
+    const int* radii;             /* [P]   internal copy */
+    const float* splats;          /* [P*12] 48-byte records: mx,my,conic.x,conic.y | conic.z,opacity*coef,r,g | b,0,0,0 */
+    const float* cov3D;           /* [P*6] */
+    const unsigned char* clamped; /* [P]   bit c set <=> SH colour channel c was clamped at 0 (forward.cu:67-69) */
+    const uint32_t* tiles_touched;/* [P] */
+    const uint32_t* point_offsets;/* [P]   inclusive prefix sum */
+} wg_geometry_view;
+
+typedef struct wg_binning_view {
+    const uint32_t* point_list;       /* [R] Gaussian ids sorted by (tile | depth), stable */
+    const uint64_t* point_list_keys;  /* [R] sorted keys */
+} wg_binning_view;
+
+typedef struct wg_image_view {
+    const float* final_T;       /* [H*W] */
+    const uint32_t* n_contrib;  /* [H*W] */
+    const uint32_t* ranges;     /* [tiles*2] (start,end) */
+    const uint32_t* tile_last;  /* [tiles] max n_contrib over the tile's pixels */
+} wg_image_view;
+
+int wg_view_geometry(char* geom_buffer, int P, wg_geometry_view* out);
+int wg_view_binning(char* binning_buffer, int R, wg_binning_view* out);
+int wg_view_image(char* image_buffer, int width, int height, wg_image_view* out);
+
+/* ---- per-stage timing with HIP events, recorded on the caller's stream (used by bench.py's roofline) ----
+ * wg_profile_enable(1): every subsequent forward/backward call brackets each stage with a pair of events.
+ * wg_profile_read(): synchronises the recorded events, adds their durations to the running totals and
+ * returns them; wg_profile_reset() clears the totals. */
+enum { WG_STAGE_PREPROCESS = 0, WG_STAGE_SCAN, WG_STAGE_DUPLICATE_KEYS, WG_STAGE_SORT, WG_STAGE_TILE_RANGES,
+       WG_STAGE_RENDER_FORWARD, WG_STAGE_RENDER_BACKWARD, WG_STAGE_PREPROCESS_BACKWARD, WG_STAGE_COUNT };
+typedef struct wg_stage_times {
+    double total_ms[WG_STAGE_COUNT];
+    long long launches[WG_STAGE_COUNT];
+} wg_stage_times;
+int wg_profile_enable(int enable);
+int wg_profile_read(wg_stage_times* out);
+int wg_profile_reset(void);
+const char* wg_stage_name(int stage);
+
+const char* wg_status_string(int status);
+const char* wg_last_hip_error(void);
+const char* wg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WG_RASTERIZER_H_INCLUDED */

@@ -86,6 +86,8 @@ class OracleContext:
         "final_T": ("real", lambda s: (s.H, s.W)),
         "n_contrib": (np.uint32, lambda s: (s.H, s.W)),
         "ranges": (np.uint32, lambda s: (s.tiles, 2)),
+        "frag_alpha": ("real", lambda s: (s.H, s.W)),
+        "frag_T": ("real", lambda s: (s.H, s.W)),
     }
 
     def __init__(self, lib, handle, precision, P, W, H):

@@ -126,8 +126,8 @@ static inline void getRect(real px, real py, int max_radius, int gx, int gy, int
                            int* rmax_y) {
     *rmin_x = imin(gx, imax(0, (int)((px - (real)max_radius) / (real)BLOCK_X)));
     *rmin_y = imin(gy, imax(0, (int)((py - (real)max_radius) / (real)BLOCK_Y)));
-    *rmax_x = imin(gx, imax(0, (int)((px + (real)max_radius + (real)(BLOCK_X - 1)) / (real)BLOCK_X)));
-    *rmax_y = imin(gy, imax(0, (int)((py + (real)max_radius + (real)(BLOCK_Y - 1)) / (real)BLOCK_Y)));
+    *rmax_x = imin(gx, imax(0, (int)((px + (real)max_radius + (real)BLOCK_X - (real)1) / (real)BLOCK_X)));
+    *rmax_y = imin(gy, imax(0, (int)((py + (real)max_radius + (real)BLOCK_Y - (real)1) / (real)BLOCK_Y)));
 }
 
 /* auxiliary.h:107-117 */
@@ -164,6 +164,9 @@ typedef struct wgo_ctx {
     real* final_T;
     uint32_t* n_contrib;
     uint32_t* ranges; /* [Tn,2] */
+    /* test aid (not in the reference): per-pixel distance to the nearest threshold decision */
+    real* frag_alpha; /* min over evaluated pairs of |alpha*255 - 1| */
+    real* frag_T;     /* min over blended-or-terminating pairs of |test_T*1e4 - 1| */
 } wgo_ctx;
 
 /* forward.cu:20-71 */
@@ -308,7 +311,7 @@ WGO_API void wgo_free(wgo_ctx* c) {
     free(c->depths); free(c->clamped); free(c->radii); free(c->means2D); free(c->cov3D);
     free(c->conic_opacity); free(c->rgb); free(c->tiles_touched); free(c->point_offsets);
     free(c->keys_unsorted); free(c->vals_unsorted); free(c->keys); free(c->point_list);
-    free(c->final_T); free(c->n_contrib); free(c->ranges);
+    free(c->final_T); free(c->n_contrib); free(c->ranges); free(c->frag_alpha); free(c->frag_T);
     free(c);
 }
 
@@ -348,6 +351,8 @@ WGO_API wgo_ctx* wgo_forward(int P, int D, int M, const real* background, int wi
     c->final_T = (real*)calloc(N ? N : 1, sizeof(real));
     c->n_contrib = (uint32_t*)calloc(N ? N : 1, sizeof(uint32_t));
     c->ranges = (uint32_t*)calloc((Tn ? Tn : 1) * 2, sizeof(uint32_t));
+    c->frag_alpha = (real*)calloc(N ? N : 1, sizeof(real));
+    c->frag_T = (real*)calloc(N ? N : 1, sizeof(real));
 
     /* K1: preprocessCUDA, forward.cu:167-268 */
 #pragma omp parallel for schedule(static)
@@ -479,22 +484,28 @@ WGO_API wgo_ctx* wgo_forward(int P, int D, int M, const real* background, int wi
                 real T = (real)1.0;
                 uint32_t contributor = 0, last_contributor = 0;
                 real C[NUM_CHANNELS] = {0, 0, 0};
+                real fr_a = (real)1e30, fr_t = (real)1e30;
                 for (uint32_t k = r0; k < r1; k++) {
                     contributor++;
                     const uint32_t g = c->point_list[k];
                     real dx = c->means2D[2 * g] - pixf_x, dy = c->means2D[2 * g + 1] - pixf_y;
                     const real* con_o = c->conic_opacity + 4 * (size_t)g;
                     real power = (real)-0.5 * (con_o[0] * dx * dx + con_o[2] * dy * dy) - con_o[1] * dx * dy;
+                    if (R_FABS(power) < fr_a) fr_a = R_FABS(power);
                     if (power > (real)0.0) continue;
                     real alpha = rmin((real)0.99, con_o[3] * R_EXP(power));
+                    if (R_FABS(alpha * (real)255.0 - (real)1.0) < fr_a) fr_a = R_FABS(alpha * (real)255.0 - (real)1.0);
                     if (alpha < (real)1.0 / (real)255.0) continue;
                     real test_T = T * ((real)1.0 - alpha);
+                    if (R_FABS(test_T * (real)10000.0 - (real)1.0) < fr_t) fr_t = R_FABS(test_T * (real)10000.0 - (real)1.0);
                     if (test_T < (real)0.0001) break; /* done = true */
                     for (int ch = 0; ch < NUM_CHANNELS; ch++) C[ch] += features[(size_t)g * NUM_CHANNELS + ch] * alpha * T;
                     T = test_T;
                     last_contributor = contributor;
                 }
                 c->final_T[pix_id] = T;
+                c->frag_alpha[pix_id] = fr_a;
+                c->frag_T[pix_id] = fr_t;
                 c->n_contrib[pix_id] = last_contributor;
                 for (int ch = 0; ch < NUM_CHANNELS; ch++) out_color[(size_t)ch * H * W + pix_id] = C[ch] + T * background[ch];
             }
@@ -902,3 +913,5 @@ GETTER(point_list, uint32_t, point_list, c->R)
 GETTER(final_T, real, final_T, (size_t)c->W * c->H)
 GETTER(n_contrib, uint32_t, n_contrib, (size_t)c->W * c->H)
 GETTER(ranges, uint32_t, ranges, 2 * (size_t)c->gx * c->gy)
+GETTER(frag_alpha, real, frag_alpha, (size_t)c->W * c->H)
+GETTER(frag_T, real, frag_T, (size_t)c->W * c->H)

@@ -1,0 +1,243 @@
+"""GPU parity tests: the HIP path (drop-in package -> C-ABI -> gfx950 kernels) against the CPU oracle on identical
+seeded inputs.  Bars (BASELINE.json north_star): integers / indices bit-exact; forward RGB <= 1e-4 abs per channel;
+gradients <= 1e-3 max-rel-err per tensor.
+
+Forward tolerance and threshold decisions: the compositing loop has three discontinuities (power > 0, alpha < 1/255,
+T*(1-alpha) < 1e-4; forward.cu:357-372).  Two correct float32 evaluations that differ in the last ulp of exp() can
+take different branches when a decision sits within ~1e-6 of its threshold, which moves that one pixel by up to
+~4e-3.  The oracle records each pixel's distance to its nearest decision (frag_alpha / frag_T); pixels with a safety
+margin ("solid", >99% of the image) must meet 1e-4, the remaining "fragile" pixels are counted and bounded.
+"""
+import numpy as np
+import pytest
+import torch
+
+import wg_scenes as S
+from wg_testlib import (compare_forward, compare_grads, make_settings, rel_err, run_hip, run_hip_native, to_dev)
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("a HIP device is required for -m gpu tests (no CPU fallback exists)")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    _need_gpu()
+
+
+CASES = {
+    # name: (P, W, H, sh_degree or None for precomputed colours, scale_mult)
+    "config1_sh0_256": (10000, 256, 256, 0, 1.0),
+    "sh3_640x360": (30000, 640, 360, 3, 1.5),
+    "precomp_ragged_250x130": (8000, 250, 130, None, 3.0),  # image not a multiple of 16: partial tiles
+    "sh1_big_splats": (1500, 320, 200, 1, 12.0),            # long per-tile lists, saturating pixels
+}
+
+
+def _scene(name):
+    P, W, H, deg, sm = CASES[name]
+    cam = S.make_camera(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=deg, seed=11, scale_mult=sm)
+    return cloud, cam, (deg if deg is not None else 0)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_preprocess_and_binning_bit_exact(oracle, name):
+    cloud, cam, deg = _scene(name)
+    o = oracle.run_scene(cloud, cam, sh_degree=deg)
+    h = run_hip_native(cloud, cam, sh_degree=deg)
+    octx = o["ctx"]
+    g, b, im = h["views"]["geometry"], h["views"]["binning"], h["views"]["image"]
+    radii = h["radii"].cpu().numpy()
+    # integers: exact
+    np.testing.assert_array_equal(radii, o["radii"])
+    np.testing.assert_array_equal(g["radii"].cpu().numpy(), o["radii"])
+    np.testing.assert_array_equal(g["tiles_touched"].cpu().numpy().view(np.uint32), octx.get("tiles_touched"))
+    np.testing.assert_array_equal(g["point_offsets"].cpu().numpy().view(np.uint32), octx.get("point_offsets"))
+    assert h["num_rendered"] == o["num_rendered"]
+    vis = o["radii"] > 0
+    # floats produced by the contraction-free preprocess kernel: bit-exact against the literal oracle
+    np.testing.assert_array_equal(g["depths"].cpu().numpy()[vis].view(np.uint32), octx.get("depths")[vis].view(np.uint32))
+    sp = g["splats"].cpu().numpy()
+    np.testing.assert_array_equal(sp[vis, 0:2], octx.get("means2D")[vis])
+    co = octx.get("conic_opacity")
+    np.testing.assert_array_equal(sp[vis, 2:4], co[vis, 0:2])
+    np.testing.assert_array_equal(sp[vis, 4], co[vis, 2])
+    np.testing.assert_allclose(sp[vis, 5], co[vis, 3], rtol=2e-7, atol=0)  # opacity * coef (coef goes through double sqrt)
+    rgb_ref = cloud["colors_precomp"] if "colors_precomp" in cloud else octx.get("rgb")
+    np.testing.assert_array_equal(sp[vis, 6:9], rgb_ref[vis])
+    if "shs" in cloud:
+        cl = g["clamped"].cpu().numpy()
+        ocl = octx.get("clamped")
+        np.testing.assert_array_equal(cl[vis], (ocl[vis, 0] | (ocl[vis, 1] << 1) | (ocl[vis, 2] << 2)))
+    np.testing.assert_array_equal(g["cov3D"].cpu().numpy()[vis], octx.get("cov3D")[vis])
+    # binning: sorted (tile|depth) keys, stable order of Gaussian ids, tile ranges
+    np.testing.assert_array_equal(b["point_list_keys"].cpu().numpy().view(np.uint64), octx.get("keys"))
+    np.testing.assert_array_equal(b["point_list"].cpu().numpy().view(np.uint32), octx.get("point_list"))
+    np.testing.assert_array_equal(im["ranges"].cpu().numpy().view(np.uint32), octx.get("ranges"))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_rgb_parity(oracle, name):
+    cloud, cam, deg = _scene(name)
+    rng = np.random.default_rng(3)
+    bg = np.array([0.2, 0.5, 0.8], np.float32)
+    so = rng.uniform(-0.5, 0.5, size=(cam["height"], cam["width"], 2)).astype(np.float32) if "ragged" in name else None
+    o = oracle.run_scene(cloud, cam, sh_degree=deg, bg=bg, subpixel_offset=so)
+    h = run_hip(cloud, cam, sh_degree=deg, bg=bg, subpixel_offset=so)
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    c = compare_forward(h["color"], o)
+    assert c["max_err_solid"] <= 1e-4, c
+    assert c["n_fragile"] <= 0.01 * c["n_pixels"], c           # the margin thresholds leave >= 99% of pixels strict
+    assert c["n_over_in_fragile"] <= max(3, 2e-4 * c["n_pixels"]), c  # and only a handful of those actually flip
+    assert c["max_err_all"] <= 2e-2, c
+    # accumulation = 1 - final_T
+    acc_ref = 1.0 - o["ctx"].get("final_T")
+    ok = np.abs(h["accumulation"] - acc_ref) <= 1e-4
+    assert ok.mean() >= 0.999
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_backward_gradient_parity(oracle, name):
+    cloud, cam, deg = _scene(name)
+    cot = S.make_cotangent(cam["width"], cam["height"])
+    bg = np.array([0.1, 0.3, 0.2], np.float32)
+    o = oracle.run_scene(cloud, cam, sh_degree=deg, bg=bg, cotangent=cot)
+    h = run_hip(cloud, cam, sh_degree=deg, bg=bg, cotangent=cot)
+    errs = compare_grads(h["grads"], o["grads"])
+    assert set(errs) >= {"means3D", "means2D", "opacities", "scales", "rotations"}
+    for k, e in errs.items():
+        assert e <= 1e-3, (k, e, errs)
+    # culled Gaussians get exactly zero gradient everywhere
+    culled = o["radii"] == 0
+    for k, g in h["grads"].items():
+        assert not np.abs(g[culled]).any(), k
+
+
+def test_config2_500k_1080p_sh3_fwd_bwd(oracle):
+    """BASELINE.json configs[1]: 500k synthetic Gaussians, 1920x1080, SH deg 3, fwd+bwd, gradcheck vs reference (oracle)."""
+    W, H, P = 1920, 1080, 500_000
+    cam = S.make_camera(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=3, seed=0)
+    cot = S.make_cotangent(W, H)
+    o = oracle.run_scene(cloud, cam, sh_degree=3, cotangent=cot)
+    h = run_hip(cloud, cam, sh_degree=3, cotangent=cot)
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    c = compare_forward(h["color"], o)
+    assert c["max_err_solid"] <= 1e-4, c
+    assert c["n_over_in_fragile"] <= 2e-4 * c["n_pixels"], c
+    errs = compare_grads(h["grads"], o["grads"])
+    for k, e in errs.items():
+        assert e <= 1e-3, (k, e, errs)
+
+
+def test_cov3d_precomp_path(oracle):
+    """cov3D_precomp instead of scales+rotations (forward.cu:217-220): gradient flows to cov3Ds_precomp."""
+    W, H, P = 200, 120, 3000
+    cam = S.make_camera(W, H)
+    base = S.make_cloud(P, W, H, sh_degree=None, seed=5, scale_mult=4.0)
+    o0 = oracle.run_scene(base, cam)
+    cloud = dict(means3D=base["means3D"], opacities=base["opacities"], colors_precomp=base["colors_precomp"],
+                 cov3D_precomp=np.where((o0["radii"] > 0)[:, None], o0["ctx"].get("cov3D"), 1e-4 * np.eye(3).reshape(-1)[[0, 1, 2, 4, 5, 8]]).astype(np.float32))
+    cot = S.make_cotangent(W, H)
+    o = oracle.run_scene(cloud, cam, cotangent=cot)
+    h = run_hip(cloud, cam, sh_degree=0, cotangent=cot)
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    assert compare_forward(h["color"], o)["max_err_solid"] <= 1e-4
+    assert rel_err(h["grads"]["cov3Ds_precomp"], o["grads"]["cov3Ds_precomp"]) <= 1e-3
+    assert rel_err(h["grads"]["means3D"], o["grads"]["means3D"]) <= 1e-3
+
+
+def test_operator_surface_semantics():
+    """Argument validation, sentinels, P == 0, means2D gradient carrier shared by two calls, markVisible, debug."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    W, H, P = 96, 64, 500
+    cam = S.make_camera(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=None, seed=2, scale_mult=6.0)
+    rs = make_settings(cam, 0)
+    rast = GaussianRasterizer(rs)
+    t = {k: to_dev(v) for k, v in cloud.items()}
+    means2D = torch.zeros_like(t["means3D"])
+    with pytest.raises(Exception):  # neither SH nor colours
+        rast(t["means3D"], means2D, t["opacities"], scales=t["scales"], rotations=t["rotations"])
+    with pytest.raises(Exception):  # both
+        rast(t["means3D"], means2D, t["opacities"], shs=torch.zeros(P, 1, 3, device="cuda"), colors_precomp=t["colors_precomp"],
+             scales=t["scales"], rotations=t["rotations"])
+    with pytest.raises(Exception):  # scales without rotations and no covariance
+        rast(t["means3D"], means2D, t["opacities"], colors_precomp=t["colors_precomp"], scales=t["scales"])
+    with pytest.raises(RuntimeError):  # bad means3D shape (rasterize_points.cu:59-61)
+        rast(t["means3D"][:, :2], means2D, t["opacities"], colors_precomp=t["colors_precomp"], scales=t["scales"], rotations=t["rotations"])
+
+    # P == 0 -> zero image (no background), empty radii
+    e3 = torch.zeros(0, 3, device="cuda")
+    col, rad, acc = rast(e3, e3, torch.zeros(0, 1, device="cuda"), colors_precomp=e3, scales=e3, rotations=torch.zeros(0, 4, device="cuda"))
+    assert col.shape == (3, H, W) and not col.any() and rad.numel() == 0 and acc.shape == (H, W)
+
+    # two calls share one means2D carrier: its .grad is the sum (method.py:1576,1602) and has the abs-grad channel
+    means2D = torch.zeros_like(t["means3D"], requires_grad=True)
+    m3 = t["means3D"].clone().requires_grad_(True)
+    cot = to_dev(S.make_cotangent(W, H))
+    c1, r1, a1 = rast(m3, means2D, t["opacities"], colors_precomp=t["colors_precomp"], scales=t["scales"], rotations=t["rotations"])
+    c2, _, _ = rast(m3, means2D, t["opacities"], colors_precomp=t["colors_precomp"] * 0.5, scales=t["scales"], rotations=t["rotations"])
+    assert r1.dtype == torch.int32 and not r1.requires_grad and a1.shape == (H, W)
+    ((c1 * cot).sum() + (c2 * cot).sum()).backward()
+    g = means2D.grad
+    assert g.shape == (P, 3) and (g[:, 2] >= 0).all() and (g[:, 2] >= (g[:, 0].abs() + g[:, 1].abs()) * 0.49).all()
+    single = torch.zeros_like(t["means3D"], requires_grad=True)
+    c1b, _, _ = rast(m3, single, t["opacities"], colors_precomp=t["colors_precomp"], scales=t["scales"], rotations=t["rotations"])
+    (c1b * cot).sum().backward()
+    assert torch.allclose(g[:, :2], 1.5 * single.grad[:, :2], rtol=1e-3, atol=1e-9)
+
+    # markVisible == near-plane test
+    pts = t["means3D"].clone()
+    pts[::3, 2] = 0.1
+    vis = rast.markVisible(pts)
+    assert vis.dtype == torch.bool and (vis == (pts[:, 2] > 0.2)).all()
+
+    # return_accumulation=False -> None; debug=True path runs (sync after every stage)
+    rs2 = make_settings(cam, 0, debug=True, return_accumulation=False)
+    col2, _, acc2 = GaussianRasterizer(rs2)(t["means3D"], torch.zeros_like(t["means3D"]), t["opacities"], colors_precomp=t["colors_precomp"],
+                                            scales=t["scales"], rotations=t["rotations"])
+    assert acc2 is None and torch.allclose(col2, c1.detach(), atol=1e-6)
+
+
+def test_runs_on_non_default_stream_and_is_deterministic_forward():
+    from diff_gaussian_rasterization import GaussianRasterizer
+    W, H, P = 320, 192, 20000
+    cam = S.make_camera(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=2, seed=9, scale_mult=2.0)
+    t = {k: to_dev(v) for k, v in cloud.items()}
+    rast = GaussianRasterizer(make_settings(cam, 2))
+    args = dict(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                rotations=t["rotations"])
+    ref, _, _ = rast(**args)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        out, _, _ = rast(**args)
+    s.synchronize()
+    assert torch.equal(out, ref)  # forward is bit-reproducible (no atomics on the forward path)
+
+
+def test_all_culled_and_single_gaussian(oracle):
+    W, H = 64, 48
+    cam = S.make_camera(W, H)
+    bg = np.array([0.3, 0.6, 0.9], np.float32)
+    cloud = S.make_cloud(40, W, H, sh_degree=None, seed=4)
+    cloud["means3D"][:, 2] = -1.0  # everything behind the camera
+    h = run_hip(cloud, cam, sh_degree=0, bg=bg, cotangent=S.make_cotangent(W, H))
+    assert not (h["radii"] > 0).any()
+    np.testing.assert_allclose(h["color"], np.broadcast_to(bg[:, None, None], (3, H, W)))
+    assert not h["accumulation"].any()
+    assert all(not np.abs(g).any() for g in h["grads"].values())
+    one = dict(means3D=np.array([[0.05, -0.02, 2.0]], np.float32), scales=np.array([[0.2, 0.1, 0.05]], np.float32),
+               rotations=np.array([[0.8, 0.2, -0.4, 0.4]], np.float32) / np.float32(np.sqrt(1.0)), opacities=np.array([[0.9]], np.float32),
+               colors_precomp=np.array([[0.9, 0.5, 0.1]], np.float32))
+    cot = S.make_cotangent(W, H)
+    o = oracle.run_scene(one, cam, bg=bg, cotangent=cot)
+    h = run_hip(one, cam, sh_degree=0, bg=bg, cotangent=cot)
+    assert compare_forward(h["color"], o)["max_err_solid"] <= 1e-4
+    for k, e in compare_grads(h["grads"], o["grads"]).items():
+        assert e <= 1e-3, (k, e)

@@ -1,0 +1,300 @@
+// C-ABI entry points (include/wg_rasterizer.h) -- the orchestration that Rasterizer::forward / ::backward /
+// ::markVisible do in the reference (rasterizer_impl.cu:141-153, 198-340, 344-443).
+#include "wg_common.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_hip_error;
+
+int hip_fail(hipError_t e, const char* where) {
+    g_last_hip_error = std::string(where) + ": " + hipGetErrorString(e);
+    return WG_ERR_HIP;
+}
+
+// ---- optional per-stage event timing (wg_profile_*) ----
+struct StageProfiler {
+    bool enabled = false;
+    std::mutex mu;
+    struct Rec { int stage; hipEvent_t a, b; };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    wg_stage_times totals{};
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
+StageProfiler g_prof;
+
+struct StageScope {
+    int stage; hipStream_t stream; hipEvent_t a = nullptr, b = nullptr; bool on;
+    StageScope(int s, hipStream_t st) : stage(s), stream(st), on(g_prof.enabled) {
+        if (!on) return;
+        std::lock_guard<std::mutex> l(g_prof.mu);
+        a = g_prof.get(); b = g_prof.get();
+        if (a) (void)hipEventRecord(a, stream);
+    }
+    ~StageScope() {
+        if (!on || !a || !b) return;
+        (void)hipEventRecord(b, stream);
+        std::lock_guard<std::mutex> l(g_prof.mu);
+        g_prof.pending.push_back({stage, a, b});
+    }
+};
+
+// debug == true reproduces CHECK_CUDA (auxiliary.h:166-173): synchronise after every stage and report.
+#define WG_STAGE(stage_id, expr, name)                                           \
+    do {                                                                         \
+        hipError_t e_;                                                           \
+        {                                                                        \
+            StageScope scope_(stage_id, stream);                                 \
+            e_ = (expr);                                                         \
+        }                                                                        \
+        if (e_ != hipSuccess) return hip_fail(e_, name);                         \
+        if (debug) {                                                             \
+            e_ = hipStreamSynchronize(stream);                                   \
+            if (e_ != hipSuccess) return hip_fail(e_, name " (debug sync)");     \
+        }                                                                        \
+    } while (0)
+
+template <typename F>
+size_t required_bytes(F carve_fn) {
+    char* p = nullptr;
+    carve_fn(p);
+    return reinterpret_cast<size_t>(p) + wg::ALIGN;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t wg_geometry_buffer_size(int P) {
+    return required_bytes([&](char*& c) { wg::GeometryState::fromChunk(c, (size_t)(P > 0 ? P : 0)); });
+}
+size_t wg_image_buffer_size(int width, int height) {
+    const size_t N = (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0);
+    const size_t tiles = (size_t)((width + wg::TILE_X - 1) / wg::TILE_X) * (size_t)((height + wg::TILE_Y - 1) / wg::TILE_Y);
+    return required_bytes([&](char*& c) { wg::ImageState::fromChunk(c, N, tiles); });
+}
+size_t wg_binning_buffer_size(int R) {
+    return required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)(R > 0 ? R : 0)); });
+}
+
+int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
+                         wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                         int height, const float* means3D, const float* shs, const float* colors_precomp,
+                         const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                         float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
+                         float* out_color, int* radii, int debug, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!geometry_alloc || !binning_alloc || !image_alloc) return WG_ERR_INVALID_ARGUMENT;
+    if (P < 0 || width <= 0 || height <= 0 || D < 0 || D > 3) return WG_ERR_INVALID_ARGUMENT;
+    if (!background || !out_color || !viewmatrix || !projmatrix || !subpixel_offset) return WG_ERR_INVALID_ARGUMENT;
+    if (P > 0) {
+        if (!means3D || !opacities) return WG_ERR_INVALID_ARGUMENT;
+        // exactly one colour source / one covariance source (GaussianRasterizer.forward, __init__.py:212-216)
+        if ((shs == nullptr) == (colors_precomp == nullptr)) return WG_ERR_INVALID_ARGUMENT;
+        if (cov3D_precomp == nullptr && (!scales || !rotations)) return WG_ERR_INVALID_ARGUMENT;
+        if (shs != nullptr && (!cam_pos || M < (D + 1) * (D + 1))) return WG_ERR_INVALID_ARGUMENT;
+    }
+
+    const int gx = (width + wg::TILE_X - 1) / wg::TILE_X, gy = (height + wg::TILE_Y - 1) / wg::TILE_Y;
+    const int tiles = gx * gy;
+
+    char* geom_chunk = geometry_alloc(wg_geometry_buffer_size(P), geometry_user);
+    char* img_chunk = image_alloc(wg_image_buffer_size(width, height), image_user);
+    if (!geom_chunk || !img_chunk) return WG_ERR_ALLOC;
+    wg::GeometryState geom = wg::GeometryState::fromChunk(geom_chunk, (size_t)P);
+    wg::ImageState img = wg::ImageState::fromChunk(img_chunk, (size_t)width * height, (size_t)tiles);
+
+    wg::FwdParams fp;
+    fp.P = P; fp.D = D; fp.M = M; fp.W = width; fp.H = height; fp.gx = gx; fp.gy = gy;
+    fp.means3D = means3D; fp.shs = shs; fp.colors_precomp = colors_precomp; fp.opacities = opacities;
+    fp.scales = scales; fp.scale_modifier = scale_modifier; fp.rotations = rotations; fp.cov3D_precomp = cov3D_precomp;
+    fp.viewmatrix = viewmatrix; fp.projmatrix = projmatrix; fp.cam_pos = cam_pos;
+    fp.tan_fovx = tan_fovx; fp.tan_fovy = tan_fovy;
+    fp.focal_y = height / (2.0f * tan_fovy);  // rasterizer_impl.cu:224-225
+    fp.focal_x = width / (2.0f * tan_fovx);
+    fp.kernel_size = kernel_size; fp.prefiltered = prefiltered;
+
+    int num_rendered = 0;
+    if (P > 0) {
+        WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, geom, radii, stream), "preprocess");
+        WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
+        // the one host sync of the forward pass (rasterizer_impl.cu:284): sizes the binning buffer
+        uint32_t total = 0;
+        hipError_t e = hipMemcpyAsync(&total, geom.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) return hip_fail(e, "num_rendered readback");
+        e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return hip_fail(e, "num_rendered readback sync");
+        if (total > 0x7fffffffu) return WG_ERR_OVERFLOW;
+        num_rendered = (int)total;
+    }
+
+    char* bin_chunk = binning_alloc(wg_binning_buffer_size(num_rendered), binning_user);
+    if (!bin_chunk) return WG_ERR_ALLOC;
+    wg::BinningState bin = wg::BinningState::fromChunk(bin_chunk, (size_t)num_rendered);
+
+    if (num_rendered > 0) {
+        WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_duplicate_keys(P, geom, bin, gx, stream), "duplicate_keys");
+        const int bit = (int)wg::higher_msb((uint32_t)tiles);  // rasterizer_impl.cu:303
+        WG_STAGE(WG_STAGE_SORT, wg::run_sort(bin, num_rendered, 32 + bit, stream), "radix_sort_pairs");
+    }
+    WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_ranges(num_rendered, bin, img, tiles, stream), "tile_ranges");
+    WG_STAGE(WG_STAGE_RENDER_FORWARD, wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, stream),
+             "render_forward");
+    return num_rendered;
+}
+
+int wg_rasterize_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                          const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                          const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                          const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
+                          const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
+                          char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                          float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                          float* dL_drot, int debug, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    (void)colors_precomp;  // colours were copied into the splat records by the forward pass
+    if (P < 0 || R < 0 || width <= 0 || height <= 0) return WG_ERR_INVALID_ARGUMENT;
+    if (P == 0) return WG_OK;
+    if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background || !subpixel_offset) return WG_ERR_INVALID_ARGUMENT;
+    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D) return WG_ERR_INVALID_ARGUMENT;
+    if (shs != nullptr && (!dL_dsh || !campos)) return WG_ERR_INVALID_ARGUMENT;
+    if (scales != nullptr && (!rotations || !dL_dscale || !dL_drot)) return WG_ERR_INVALID_ARGUMENT;
+    if (scales == nullptr && cov3D_precomp == nullptr) return WG_ERR_INVALID_ARGUMENT;
+
+    const int gx = (width + wg::TILE_X - 1) / wg::TILE_X, gy = (height + wg::TILE_Y - 1) / wg::TILE_Y;
+    wg::GeometryState geom = wg::GeometryState::fromChunk(geom_buffer, (size_t)P);
+    wg::BinningState bin = wg::BinningState::fromChunk(binning_buffer, (size_t)R);
+    wg::ImageState img = wg::ImageState::fromChunk(image_buffer, (size_t)width * height, (size_t)gx * gy);
+    if (radii == nullptr) radii = geom.radii;  // rasterizer_impl.cu:381-384
+
+    if (R > 0)
+        WG_STAGE(WG_STAGE_RENDER_BACKWARD, wg::launch_render_backward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, dL_dpix,
+                                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, stream),
+                 "render_backward");
+
+    wg::BwdParams bp;
+    bp.P = P; bp.D = D; bp.M = M; bp.W = width; bp.H = height;
+    bp.means3D = means3D; bp.shs = shs; bp.scales = scales; bp.scale_modifier = scale_modifier; bp.rotations = rotations;
+    bp.cov3D = (cov3D_precomp != nullptr) ? cov3D_precomp : geom.cov3D;  // rasterizer_impl.cu:418
+    bp.viewmatrix = viewmatrix; bp.projmatrix = projmatrix; bp.campos = campos;
+    bp.tan_fovx = tan_fovx; bp.tan_fovy = tan_fovy;
+    bp.focal_y = height / (2.0f * tan_fovy);
+    bp.focal_x = width / (2.0f * tan_fovx);
+    bp.kernel_size = kernel_size; bp.radii = radii;
+    WG_STAGE(WG_STAGE_PREPROCESS_BACKWARD, wg::launch_preprocess_backward(bp, geom, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+                                            dL_dscale, dL_drot, stream),
+             "preprocess_backward");
+    return WG_OK;
+}
+
+int wg_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, unsigned char* present,
+                    void* stream_) {
+    (void)projmatrix;  // the reference projects but only tests view-space z (auxiliary.h:149-154)
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (P < 0) return WG_ERR_INVALID_ARGUMENT;
+    if (P == 0) return WG_OK;
+    if (!means3D || !viewmatrix || !present) return WG_ERR_INVALID_ARGUMENT;
+    hipError_t e = wg::launch_mark_visible(P, means3D, viewmatrix, present, stream);
+    if (e != hipSuccess) return hip_fail(e, "mark_visible");
+    return WG_OK;
+}
+
+int wg_view_geometry(char* geom_buffer, int P, wg_geometry_view* out) {
+    if (!geom_buffer || !out || P < 0) return WG_ERR_INVALID_ARGUMENT;
+    wg::GeometryState g = wg::GeometryState::fromChunk(geom_buffer, (size_t)P);
+    out->depths = g.depths;
+    out->radii = g.radii;
+    out->splats = reinterpret_cast<const float*>(g.splats);
+    out->cov3D = g.cov3D;
+    out->clamped = g.clamped;
+    out->tiles_touched = g.tiles_touched;
+    out->point_offsets = g.point_offsets;
+    return WG_OK;
+}
+
+int wg_view_binning(char* binning_buffer, int R, wg_binning_view* out) {
+    if (!binning_buffer || !out || R < 0) return WG_ERR_INVALID_ARGUMENT;
+    wg::BinningState b = wg::BinningState::fromChunk(binning_buffer, (size_t)R);
+    out->point_list = b.point_list;
+    out->point_list_keys = b.keys;
+    return WG_OK;
+}
+
+int wg_view_image(char* image_buffer, int width, int height, wg_image_view* out) {
+    if (!image_buffer || !out || width <= 0 || height <= 0) return WG_ERR_INVALID_ARGUMENT;
+    const int gx = (width + wg::TILE_X - 1) / wg::TILE_X, gy = (height + wg::TILE_Y - 1) / wg::TILE_Y;
+    wg::ImageState img = wg::ImageState::fromChunk(image_buffer, (size_t)width * height, (size_t)gx * gy);
+    out->final_T = img.final_T;
+    out->n_contrib = img.n_contrib;
+    out->ranges = reinterpret_cast<const uint32_t*>(img.ranges);
+    out->tile_last = img.tile_last;
+    return WG_OK;
+}
+
+int wg_profile_enable(int enable) {
+    g_prof.enabled = enable != 0;
+    return WG_OK;
+}
+
+int wg_profile_reset(void) {
+    std::lock_guard<std::mutex> l(g_prof.mu);
+    for (auto& r : g_prof.pending) { g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b); }
+    g_prof.pending.clear();
+    g_prof.totals = wg_stage_times{};
+    return WG_OK;
+}
+
+int wg_profile_read(wg_stage_times* out) {
+    if (!out) return WG_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> l(g_prof.mu);
+    for (auto& r : g_prof.pending) {
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) return hip_fail(e, "profile event sync");
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, r.a, r.b);
+        if (e != hipSuccess) return hip_fail(e, "profile event elapsed");
+        g_prof.totals.total_ms[r.stage] += ms;
+        g_prof.totals.launches[r.stage] += 1;
+        g_prof.pool.push_back(r.a);
+        g_prof.pool.push_back(r.b);
+    }
+    g_prof.pending.clear();
+    *out = g_prof.totals;
+    return WG_OK;
+}
+
+const char* wg_stage_name(int stage) {
+    static const char* names[WG_STAGE_COUNT] = {"preprocess", "scan", "duplicate_keys", "sort", "tile_ranges",
+                                                "render_forward", "render_backward", "preprocess_backward"};
+    return (stage >= 0 && stage < WG_STAGE_COUNT) ? names[stage] : "?";
+}
+
+const char* wg_status_string(int status) {
+    switch (status) {
+        case WG_OK: return "ok";
+        case WG_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case WG_ERR_ALLOC: return "scratch allocator returned NULL";
+        case WG_ERR_HIP: return "HIP runtime error";
+        case WG_ERR_OVERFLOW: return "more than 2^31-1 tile instances";
+        default: return status > 0 ? "ok (num_rendered)" : "unknown error";
+    }
+}
+
+const char* wg_last_hip_error(void) { return g_last_hip_error.c_str(); }
+
+const char* wg_version(void) { return "wg_rasterizer 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,199 @@
+// K1 (per-Gaussian preprocess) and K12 (markVisible) for gfx950.
+//
+// Replaces preprocessCUDA / computeCov3D / computeCov2D / computeColorFromSH (forward.cu:20-268),
+// in_frustum / getRect / ndc2Pix (auxiliary.h:41-56,139-164) and checkFrustum (rasterizer_impl.cu:54-66).
+//
+// This translation unit is compiled with -ffp-contract=off and spells every float operation in the
+// operation order the reference source implies (including its silent double promotions), so that the
+// integer results that drive everything downstream -- radii, tile rectangles, tiles_touched, depth
+// keys -- are bit-identical to the CPU oracle's.  It is a streaming kernel: ~60-250 B read and
+// ~70 B written per Gaussian, no reuse, so the work is laid out one Gaussian per lane with the
+// per-Gaussian outputs packed into one 48-byte record that the render kernels gather in one go.
+#include "wg_common.h"
+
+#pragma clang fp contract(off)
+
+namespace wg {
+
+__constant__ const float SH_C0 = 0.28209479177387814f;
+__constant__ const float SH_C1 = 0.4886025119029199f;
+__constant__ const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                     -1.0925484305920792f, 0.5462742152960396f};
+__constant__ const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                     -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+// SH -> RGB for one channel (forward.cu:30-63); sh points at coefficient 0 of this channel, stride 3.
+__device__ __forceinline__ float sh_channel(int deg, const float* __restrict__ sh, float x, float y, float z) {
+    float result = SH_C0 * sh[0];
+    if (deg > 0) {
+        result = result - SH_C1 * y * sh[3] + SH_C1 * z * sh[6] - SH_C1 * x * sh[9];
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z;
+            float xy = x * y, yz = y * z, xz = x * z;
+            result = result + SH_C2[0] * xy * sh[12] + SH_C2[1] * yz * sh[15] + SH_C2[2] * (2.0f * zz - xx - yy) * sh[18] +
+                     SH_C2[3] * xz * sh[21] + SH_C2[4] * (xx - yy) * sh[24];
+            if (deg > 2) {
+                result = result + SH_C3[0] * y * (3.0f * xx - yy) * sh[27] + SH_C3[1] * xy * z * sh[30] +
+                         SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33] + SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36] +
+                         SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39] + SH_C3[5] * z * (xx - yy) * sh[42] +
+                         SH_C3[6] * x * (xx - 3.0f * yy) * sh[45];
+            }
+        }
+    }
+    return result + 0.5f;
+}
+
+__global__ void __launch_bounds__(256) preprocess_kernel(FwdParams p, GeometryState g, int* __restrict__ radii_out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.P) return;
+
+    // forward.cu:200-201
+    int radius_i = 0;
+    uint32_t touched = 0;
+
+    const float* vm = p.viewmatrix;
+    const float* pm = p.projmatrix;
+    const float px = p.means3D[3 * idx], py = p.means3D[3 * idx + 1], pz = p.means3D[3 * idx + 2];
+
+    // in_frustum: auxiliary.h:152-163 (near cull only)
+    const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
+    const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
+    const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+    bool alive = !(vz <= 0.2f);
+    if (!alive && p.prefiltered) {
+        // auxiliary.h:156-160: the reference printf()s and __trap()s; same contract here.
+        printf("Point is filtered although prefiltered is set. This shouldn't happen!");
+        __builtin_trap();
+    }
+
+    if (alive) {
+        // forward.cu:209-212
+        const float hx = pm[0] * px + pm[4] * py + pm[8] * pz + pm[12];
+        const float hy = pm[1] * px + pm[5] * py + pm[9] * pz + pm[13];
+        const float hw = pm[3] * px + pm[7] * py + pm[11] * pz + pm[15];
+        const float p_w = 1.0f / (hw + 0.0000001f);
+        const float projx = hx * p_w, projy = hy * p_w;
+
+        // ---- 3D covariance (forward.cu:129-163) ----
+        float c0, c1, c2, c3, c4, c5;
+        if (p.cov3D_precomp != nullptr) {
+            const float* c = p.cov3D_precomp + 6 * (size_t)idx;
+            c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; c5 = c[5];
+        } else {
+            const float s0 = p.scale_modifier * p.scales[3 * idx], s1 = p.scale_modifier * p.scales[3 * idx + 1],
+                        s2 = p.scale_modifier * p.scales[3 * idx + 2];
+            const float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            // column-major R as filled by the reference (forward.cu:145-149); M[c][r] = s_r * R[c][r]
+            const float M00 = s0 * (1.f - 2.f * (y * y + z * z)), M01 = s1 * (2.f * (x * y - r * z)), M02 = s2 * (2.f * (x * z + r * y));
+            const float M10 = s0 * (2.f * (x * y + r * z)), M11 = s1 * (1.f - 2.f * (x * x + z * z)), M12 = s2 * (2.f * (y * z - r * x));
+            const float M20 = s0 * (2.f * (x * z - r * y)), M21 = s1 * (2.f * (y * z + r * x)), M22 = s2 * (1.f - 2.f * (x * x + y * y));
+            // Sigma[c][r] = M[r][0]*M[c][0] + M[r][1]*M[c][1] + M[r][2]*M[c][2]
+            c0 = M00 * M00 + M01 * M01 + M02 * M02;
+            c1 = M10 * M00 + M11 * M01 + M12 * M02;
+            c2 = M20 * M00 + M21 * M01 + M22 * M02;
+            c3 = M10 * M10 + M11 * M11 + M12 * M12;
+            c4 = M20 * M10 + M21 * M11 + M22 * M12;
+            c5 = M20 * M20 + M21 * M21 + M22 * M22;
+            float* dst = g.cov3D + 6 * (size_t)idx;
+            dst[0] = c0; dst[1] = c1; dst[2] = c2; dst[3] = c3; dst[4] = c4; dst[5] = c5;
+        }
+
+        // ---- EWA 2D covariance + mip filter (forward.cu:74-124) ----
+        const float limx = 1.3f * p.tan_fovx, limy = 1.3f * p.tan_fovy;
+        const float txtz = vx / vz, tytz = vy / vz;
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+        const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+        const float j00 = p.focal_x / vz, j02 = -(p.focal_x * tx) / (vz * vz);
+        const float j11 = p.focal_y / vz, j12 = -(p.focal_y * ty) / (vz * vz);
+        // T = W*J with W[c][r] = vm[c + 4r]
+        const float T00 = vm[0] * j00 + vm[2] * j02, T01 = vm[4] * j00 + vm[6] * j02, T02 = vm[8] * j00 + vm[10] * j02;
+        const float T10 = vm[1] * j11 + vm[2] * j12, T11 = vm[5] * j11 + vm[6] * j12, T12 = vm[9] * j11 + vm[10] * j12;
+        // A[c][r] = T[r][0]*V[0][c] + T[r][1]*V[1][c] + T[r][2]*V[2][c]  (V symmetric from cov3D)
+        const float A00 = T00 * c0 + T01 * c1 + T02 * c2, A10 = T00 * c1 + T01 * c3 + T02 * c4, A20 = T00 * c2 + T01 * c4 + T02 * c5;
+        const float A01 = T10 * c0 + T11 * c1 + T12 * c2, A11 = T10 * c1 + T11 * c3 + T12 * c4, A21 = T10 * c2 + T11 * c4 + T12 * c5;
+        float cov00 = A00 * T00 + A10 * T01 + A20 * T02;
+        const float cov01 = A01 * T00 + A11 * T01 + A21 * T02;
+        float cov11 = A01 * T10 + A11 * T11 + A21 * T12;
+
+        // forward.cu:112-118 -- max(1e-6, float) and "+1e-6" are double arithmetic in the reference
+        const float det_0 = (float)fmax(1e-6, (double)(cov00 * cov11 - cov01 * cov01));
+        const float det_1 = (float)fmax(1e-6, (double)((cov00 + p.kernel_size) * (cov11 + p.kernel_size) - cov01 * cov01));
+        float coef = (float)sqrt((double)det_0 / ((double)det_1 + 1e-6) + 1e-6);
+        if ((double)det_0 <= 1e-6 || (double)det_1 <= 1e-6) coef = 0.0f;
+        cov00 += p.kernel_size;
+        cov11 += p.kernel_size;
+
+        // forward.cu:231-249
+        const float det = cov00 * cov11 - cov01 * cov01;
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float conx = cov11 * det_inv, cony = -cov01 * det_inv, conz = cov00 * det_inv;
+            const float mid = 0.5f * (cov00 + cov11);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            // ndc2Pix, auxiliary.h:41-44 (double)
+            const float pixx = (float)((((double)projx + 1.0) * (double)p.W - 1.0) * 0.5);
+            const float pixy = (float)((((double)projy + 1.0) * (double)p.H - 1.0) * 0.5);
+            // getRect, auxiliary.h:46-56
+            const int mr = (int)my_radius;
+            const int rminx = min(p.gx, max(0, (int)((pixx - mr) / TILE_X)));
+            const int rminy = min(p.gy, max(0, (int)((pixy - mr) / TILE_Y)));
+            const int rmaxx = min(p.gx, max(0, (int)((pixx + mr + TILE_X - 1) / TILE_X)));
+            const int rmaxy = min(p.gy, max(0, (int)((pixy + mr + TILE_Y - 1) / TILE_Y)));
+            const int ntiles = (rmaxx - rminx) * (rmaxy - rminy);
+            if (ntiles != 0) {
+                float cr, cg, cb;
+                if (p.colors_precomp == nullptr) {
+                    // computeColorFromSH, forward.cu:20-71
+                    float dx = px - p.cam_pos[0], dy = py - p.cam_pos[1], dz = pz - p.cam_pos[2];
+                    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                    dx = dx / len; dy = dy / len; dz = dz / len;
+                    const float* sh = p.shs + (size_t)idx * p.M * 3;
+                    cr = sh_channel(p.D, sh + 0, dx, dy, dz);
+                    cg = sh_channel(p.D, sh + 1, dx, dy, dz);
+                    cb = sh_channel(p.D, sh + 2, dx, dy, dz);
+                    g.clamped[idx] = (unsigned char)((cr < 0 ? 1 : 0) | (cg < 0 ? 2 : 0) | (cb < 0 ? 4 : 0));
+                    cr = fmaxf(cr, 0.0f); cg = fmaxf(cg, 0.0f); cb = fmaxf(cb, 0.0f);
+                } else {
+                    cr = p.colors_precomp[3 * idx]; cg = p.colors_precomp[3 * idx + 1]; cb = p.colors_precomp[3 * idx + 2];
+                }
+                g.depths[idx] = vz;
+                radius_i = mr;
+                touched = (uint32_t)ntiles;
+                float4* rec = g.splats + 3 * (size_t)idx;
+                rec[0] = make_float4(pixx, pixy, conx, cony);
+                rec[1] = make_float4(conz, p.opacities[idx] * coef, cr, cg);
+                rec[2] = make_float4(cb, 0.f, 0.f, 0.f);
+                g.rects[idx] = make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy);
+            }
+        }
+    }
+    g.radii[idx] = radius_i;
+    if (radii_out) radii_out[idx] = radius_i;
+    g.tiles_touched[idx] = touched;
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                           const float* __restrict__ vm, unsigned char* __restrict__ present) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const float px = means3D[3 * idx], py = means3D[3 * idx + 1], pz = means3D[3 * idx + 2];
+    const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+    present[idx] = !(vz <= 0.2f);  // auxiliary.h:154
+}
+
+hipError_t launch_preprocess(const FwdParams& p, const GeometryState& g, int* radii_out, hipStream_t stream) {
+    if (p.P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((p.P + 255) / 256), dim3(256), 0, stream, p, g, radii_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t stream) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, viewmatrix, present);
+    return hipGetLastError();
+}
+
+}  // namespace wg

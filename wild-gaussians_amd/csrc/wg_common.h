@@ -1,0 +1,112 @@
+// Internal shared declarations of the MI355X rasterizer library (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/wg_rasterizer.h"
+
+namespace wg {
+
+constexpr int TILE_X = WG_TILE_X;
+constexpr int TILE_Y = WG_TILE_Y;
+constexpr int TILE_PIX = TILE_X * TILE_Y;
+constexpr size_t ALIGN = 256;
+constexpr int SPLAT_FLOATS = 12;  // 48-byte record per Gaussian, see wg_geometry_view
+
+// ---- scratch carving (the role of obtain()/fromChunk(), rasterizer_impl.h:22-28, .cu:155-194) ----
+template <typename T>
+__host__ inline void carve(char*& chunk, T*& ptr, size_t count) {
+    uintptr_t p = (reinterpret_cast<uintptr_t>(chunk) + ALIGN - 1) & ~(uintptr_t)(ALIGN - 1);
+    ptr = reinterpret_cast<T*>(p);
+    chunk = reinterpret_cast<char*>(ptr + count);
+}
+
+struct GeometryState {
+    float* depths;
+    int* radii;
+    float4* splats;  // 3 float4 per Gaussian
+    float* cov3D;
+    unsigned char* clamped;
+    ushort4* rects;  // tile rectangle (min.x, min.y, max.x, max.y)
+    uint32_t* tiles_touched;
+    uint32_t* point_offsets;
+    char* scan_temp;
+    size_t scan_temp_bytes;
+    static GeometryState fromChunk(char*& chunk, size_t P);
+};
+
+struct ImageState {
+    float* final_T;  // MUST stay first: documented in wg_rasterizer.h
+    uint32_t* n_contrib;
+    uint2* ranges;
+    uint32_t* tile_last;
+    static ImageState fromChunk(char*& chunk, size_t N, size_t tiles);
+};
+
+struct BinningState {
+    uint32_t* point_list;
+    uint32_t* point_list_unsorted;
+    uint64_t* keys;
+    uint64_t* keys_unsorted;
+    char* sort_temp;
+    size_t sort_temp_bytes;
+    static BinningState fromChunk(char*& chunk, size_t R);
+};
+
+size_t query_scan_temp_bytes(size_t P);
+size_t query_sort_temp_bytes(size_t R);
+
+struct FwdParams {
+    int P, D, M, W, H, gx, gy;
+    const float* means3D;
+    const float* shs;
+    const float* colors_precomp;
+    const float* opacities;
+    const float* scales;
+    float scale_modifier;
+    const float* rotations;
+    const float* cov3D_precomp;
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* cam_pos;
+    float tan_fovx, tan_fovy, focal_x, focal_y, kernel_size;
+    int prefiltered;
+};
+
+// kernels / stages (each launches on `stream`, returns hipGetLastError())
+hipError_t launch_preprocess(const FwdParams& p, const GeometryState& g, int* radii_out, hipStream_t stream);
+hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t stream);
+hipError_t run_scan(const GeometryState& g, int P, hipStream_t stream);
+hipError_t launch_duplicate_keys(int P, const GeometryState& g, const BinningState& b, int gx, hipStream_t stream);
+hipError_t run_sort(const BinningState& b, int R, int end_bit, hipStream_t stream);
+hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& img, int tiles, hipStream_t stream);
+hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
+                                 const GeometryState& g, const float* subpixel_offset, const float* background,
+                                 float* out_color, hipStream_t stream);
+hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
+                                  const GeometryState& g, const float* subpixel_offset, const float* background,
+                                  const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                  float* dL_dcolor, hipStream_t stream);
+
+struct BwdParams {
+    int P, D, M, W, H;
+    const float* means3D;
+    const float* shs;
+    const float* scales;
+    float scale_modifier;
+    const float* rotations;
+    const float* cov3D;  // precomputed or geometry-state copy
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* campos;
+    float tan_fovx, tan_fovy, focal_x, focal_y, kernel_size;
+    const int* radii;
+};
+hipError_t launch_preprocess_backward(const BwdParams& p, const GeometryState& g, const float* dL_dmean2D,
+                                      const float* dL_dconic, float* dL_dopacity, const float* dL_dcolor,
+                                      float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                                      float* dL_drot, hipStream_t stream);
+
+uint32_t higher_msb(uint32_t n);
+
+}  // namespace wg

@@ -1,0 +1,285 @@
+"""``diff_gaussian_rasterization._C`` -- binding of the MI355X rasterizer's C-ABI library.
+
+Stands where the reference's pybind11 module of the same name stands
+(submodules/diff-gaussian-rasterization/ext.cpp:15-19, rasterize_points.{h,cu}) and exports the same
+three functions with the same argument order and return tuples:
+
+    rasterize_gaussians(...)          -> (num_rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer)
+    rasterize_gaussians_backward(...) -> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
+                                          dL_dscales, dL_drotations)
+    mark_visible(means3D, viewmatrix, projmatrix) -> bool[P]
+
+It is a thin ctypes layer over ``libwg_rasterizer.so`` (include/wg_rasterizer.h): torch is used only to
+allocate device memory and to supply the current HIP stream.  There is NO fallback: if the HIP library has
+not been built, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libwg_rasterizer.so")
+
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        f"{_LIB_PATH} is missing: build the HIP library first "
+        "(python wild-gaussians_amd/build.py, or __graft_entry__.build()).  There is no CPU fallback.")
+
+_lib = C.CDLL(_LIB_PATH)
+
+_ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+
+_lib.wg_rasterize_forward.restype = _i
+_lib.wg_rasterize_forward.argtypes = [_ALLOC_FN, _vp, _ALLOC_FN, _vp, _ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
+                                      _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _vp, _i, _vp, _vp, _i, _vp]
+_lib.wg_rasterize_backward.restype = _i
+_lib.wg_rasterize_backward.argtypes = [_i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f,
+                                       _vp, _vp, _vp, _vp, _vp, _vp] + [_vp] * 9 + [_i, _vp]
+_lib.wg_mark_visible.restype = _i
+_lib.wg_mark_visible.argtypes = [_i, _vp, _vp, _vp, _vp, _vp]
+for _name in ("wg_geometry_buffer_size", "wg_binning_buffer_size"):
+    getattr(_lib, _name).restype = C.c_size_t
+    getattr(_lib, _name).argtypes = [_i]
+_lib.wg_image_buffer_size.restype = C.c_size_t
+_lib.wg_image_buffer_size.argtypes = [_i, _i]
+for _name in ("wg_status_string",):
+    getattr(_lib, _name).restype = C.c_char_p
+    getattr(_lib, _name).argtypes = [_i]
+for _name in ("wg_last_hip_error", "wg_version"):
+    getattr(_lib, _name).restype = C.c_char_p
+    getattr(_lib, _name).argtypes = []
+
+
+class _GeometryView(C.Structure):
+    _fields_ = [(n, _vp) for n in ("depths", "radii", "splats", "cov3D", "clamped", "tiles_touched", "point_offsets")]
+
+
+class _BinningView(C.Structure):
+    _fields_ = [(n, _vp) for n in ("point_list", "point_list_keys")]
+
+
+class _ImageView(C.Structure):
+    _fields_ = [(n, _vp) for n in ("final_T", "n_contrib", "ranges", "tile_last")]
+
+
+_lib.wg_view_geometry.restype = _i
+_lib.wg_view_geometry.argtypes = [_vp, _i, C.POINTER(_GeometryView)]
+_lib.wg_view_binning.restype = _i
+_lib.wg_view_binning.argtypes = [_vp, _i, C.POINTER(_BinningView)]
+_lib.wg_view_image.restype = _i
+_lib.wg_view_image.argtypes = [_vp, _i, _i, C.POINTER(_ImageView)]
+
+IMAGE_STATE_ALIGNMENT = 256  # final_T sits at the first 256-byte aligned address of imgBuffer (wg_rasterizer.h)
+
+
+def _check(status: int, what: str) -> int:
+    if status < 0:
+        msg = _lib.wg_status_string(status).decode()
+        if status == -3:
+            msg += ": " + _lib.wg_last_hip_error().decode()
+        raise RuntimeError(f"{what} failed: {msg}")
+    return status
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    """float32, contiguous, on `device`; zero-sized tensors are the reference's "absent" sentinel."""
+    if t.numel() == 0:
+        return t
+    if t.device != device or t.dtype != torch.float32:
+        t = t.to(device=device, dtype=torch.float32)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: torch.Tensor):
+    return t.data_ptr() if t.numel() != 0 else None
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _Scratch:
+    """One resizable byte tensor per scratch buffer: the role of resizeFunctional (rasterize_points.cu:27-33)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.callback = _ALLOC_FN(self._alloc)
+
+    def _alloc(self, nbytes, _user):
+        self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.tensor.data_ptr()
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                        projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width, sh, degree,
+                        campos, prefiltered, debug):
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:59-61
+    if not means3D.is_cuda:
+        raise RuntimeError("means3D must live on a HIP device: this rasterizer has no CPU path")
+    device = means3D.device
+    P, H, W = means3D.size(0), int(image_height), int(image_width)
+
+    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=device)
+    radii = torch.zeros((P,), dtype=torch.int32, device=device)
+    geom, binning, img = _Scratch(device), _Scratch(device), _Scratch(device)
+    if P == 0:  # rasterize_points.cu:83: nothing is launched, the image stays zero
+        return 0, out_color, radii, geom.tensor, binning.tensor, img.tensor
+
+    means3D = _f32(means3D, device)
+    background, colors, opacity = _f32(background, device), _f32(colors, device), _f32(opacity, device)
+    scales, rotations, cov3D_precomp = _f32(scales, device), _f32(rotations, device), _f32(cov3D_precomp, device)
+    viewmatrix, projmatrix, campos = _f32(viewmatrix, device), _f32(projmatrix, device), _f32(campos, device)
+    subpixel_offset, sh = _f32(subpixel_offset, device), _f32(sh, device)
+    M = sh.size(1) if sh.numel() != 0 else 0  # rasterize_points.cu:85-89
+
+    with torch.cuda.device(device):
+        rendered = _lib.wg_rasterize_forward(
+            geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
+            _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
+            _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+            float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
+            int(bool(debug)), _stream(device))
+    _check(rendered, "wg_rasterize_forward")
+    return rendered, out_color, radii, geom.tensor, binning.tensor, img.tensor
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, dL_dout_color, sh,
+                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+    device = means3D.device
+    P = means3D.size(0)
+    H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+    sh = _f32(sh, device)
+    M = sh.size(1) if sh.numel() != 0 else 0
+
+    # rasterize_points.cu:157-165: gradient tensors start at zero (the per-tile pass accumulates into four of them)
+    dL_dmeans2D = torch.zeros((P, 3), dtype=torch.float32, device=device)
+    dL_dcolors = torch.zeros((P, 3), dtype=torch.float32, device=device)
+    dL_dconic = torch.zeros((P, 2, 2), dtype=torch.float32, device=device)
+    dL_dopacity = torch.zeros((P, 1), dtype=torch.float32, device=device)
+    dL_dmeans3D = torch.zeros((P, 3), dtype=torch.float32, device=device)
+    dL_dcov3D = torch.zeros((P, 6), dtype=torch.float32, device=device)
+    dL_dsh = torch.zeros((P, M, 3), dtype=torch.float32, device=device)
+    dL_dscales = torch.zeros((P, 3), dtype=torch.float32, device=device)
+    dL_drotations = torch.zeros((P, 4), dtype=torch.float32, device=device)
+
+    if P != 0:
+        means3D = _f32(means3D, device)
+        background, colors = _f32(background, device), _f32(colors, device)
+        scales, rotations, cov3D_precomp = _f32(scales, device), _f32(rotations, device), _f32(cov3D_precomp, device)
+        viewmatrix, projmatrix, campos = _f32(viewmatrix, device), _f32(projmatrix, device), _f32(campos, device)
+        subpixel_offset, dL_dout_color = _f32(subpixel_offset, device), _f32(dL_dout_color, device)
+        radii = radii if radii.is_contiguous() else radii.contiguous()
+        with torch.cuda.device(device):
+            status = _lib.wg_rasterize_backward(
+                P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
+                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
+                float(tan_fovx), float(tan_fovy), float(kernel_size), _ptr(subpixel_offset), _ptr(radii),
+                geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL_dout_color),
+                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(), dL_drotations.data_ptr(),
+                int(bool(debug)), _stream(device))
+        _check(status, "wg_rasterize_backward")
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    device = means3D.device
+    P = means3D.size(0)
+    present = torch.zeros((P,), dtype=torch.bool, device=device)
+    if P != 0:
+        means3D, viewmatrix, projmatrix = _f32(means3D, device), _f32(viewmatrix, device), _f32(projmatrix, device)
+        with torch.cuda.device(device):
+            _check(_lib.wg_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix), present.data_ptr(),
+                                        _stream(device)), "wg_mark_visible")
+    return present
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Introspection for the parity tests: typed views into the opaque scratch buffers (device tensors, no copy).
+def _from_ptr(ptr, shape, dtype, owner):
+    import numpy as np  # noqa: F401  (torch.frombuffer cannot wrap device memory; use the CUDA array interface)
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    n = 1
+    for s in shape:
+        n *= s
+    typestr = {torch.float32: "<f4", torch.int32: "<i4", torch.uint8: "|u1", torch.int64: "<i8"}[dtype]
+    h.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+    t = torch.as_tensor(h, device=owner.device) if n else torch.empty(shape, dtype=dtype, device=owner.device)
+    t._wg_owner = owner  # keep the scratch buffer alive
+    return t
+
+
+def view_geometry(geomBuffer, P):
+    v = _GeometryView()
+    _check(_lib.wg_view_geometry(geomBuffer.data_ptr(), int(P), C.byref(v)), "wg_view_geometry")
+    return dict(depths=_from_ptr(v.depths, (P,), torch.float32, geomBuffer), radii=_from_ptr(v.radii, (P,), torch.int32, geomBuffer),
+                splats=_from_ptr(v.splats, (P, 12), torch.float32, geomBuffer), cov3D=_from_ptr(v.cov3D, (P, 6), torch.float32, geomBuffer),
+                clamped=_from_ptr(v.clamped, (P,), torch.uint8, geomBuffer),
+                tiles_touched=_from_ptr(v.tiles_touched, (P,), torch.int32, geomBuffer),
+                point_offsets=_from_ptr(v.point_offsets, (P,), torch.int32, geomBuffer))
+
+
+def view_binning(binningBuffer, R):
+    v = _BinningView()
+    _check(_lib.wg_view_binning(binningBuffer.data_ptr(), int(R), C.byref(v)), "wg_view_binning")
+    return dict(point_list=_from_ptr(v.point_list, (R,), torch.int32, binningBuffer),
+                point_list_keys=_from_ptr(v.point_list_keys, (R,), torch.int64, binningBuffer))
+
+
+def view_image(imageBuffer, H, W):
+    v = _ImageView()
+    _check(_lib.wg_view_image(imageBuffer.data_ptr(), int(W), int(H), C.byref(v)), "wg_view_image")
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    return dict(final_T=_from_ptr(v.final_T, (H, W), torch.float32, imageBuffer),
+                n_contrib=_from_ptr(v.n_contrib, (H, W), torch.int32, imageBuffer),
+                ranges=_from_ptr(v.ranges, (tiles, 2), torch.int32, imageBuffer),
+                tile_last=_from_ptr(v.tile_last, (tiles,), torch.int32, imageBuffer))
+
+
+def version() -> str:
+    return _lib.wg_version().decode()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Per-stage HIP-event timing (wg_profile_* in wg_rasterizer.h); used by bench.py for the roofline object.
+STAGE_COUNT = 8
+
+
+class _StageTimes(C.Structure):
+    _fields_ = [("total_ms", C.c_double * STAGE_COUNT), ("launches", C.c_longlong * STAGE_COUNT)]
+
+
+_lib.wg_profile_enable.restype = _i
+_lib.wg_profile_enable.argtypes = [_i]
+_lib.wg_profile_reset.restype = _i
+_lib.wg_profile_reset.argtypes = []
+_lib.wg_profile_read.restype = _i
+_lib.wg_profile_read.argtypes = [C.POINTER(_StageTimes)]
+_lib.wg_stage_name.restype = C.c_char_p
+_lib.wg_stage_name.argtypes = [_i]
+
+
+def profile_enable(on: bool) -> None:
+    _check(_lib.wg_profile_enable(int(bool(on))), "wg_profile_enable")
+
+
+def profile_reset() -> None:
+    _check(_lib.wg_profile_reset(), "wg_profile_reset")
+
+
+def profile_read() -> dict:
+    """{stage name: (total_ms, launches)} accumulated since the last profile_reset()."""
+    st = _StageTimes()
+    _check(_lib.wg_profile_read(C.byref(st)), "wg_profile_read")
+    return {_lib.wg_stage_name(i).decode(): (float(st.total_ms[i]), int(st.launches[i])) for i in range(STAGE_COUNT)}

@@ -1,0 +1,146 @@
+"""Drop-in ``diff_gaussian_rasterization`` for WildGaussians on AMD MI355X (gfx950).
+
+Public surface = what ``wildgaussians/method.py:26,1529-1631`` imports and calls, i.e. the surface of the reference's
+``submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py``:
+
+* ``GaussianRasterizationSettings`` -- 15-field NamedTuple, same field names and order (reference :175-190)
+* ``GaussianRasterizer(raster_settings)`` -- ``nn.Module``; ``forward(means3D, means2D, opacities, shs=None,
+  colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None) -> (color, radii, accumulation)`` and
+  ``markVisible(positions)`` (reference :192-241)
+* ``rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+  raster_settings)`` (reference :21-42)
+
+Semantics kept from the reference: exactly-one-of validation raising ``Exception``; "not provided" inputs are the
+zero-sized ``torch.Tensor([])`` sentinel; gradients come back for (means3D, means2D, sh, colors_precomp, opacities,
+scales, rotations, cov3Ds_precomp); ``means2D`` is a zero [P,3] carrier whose gradient holds (d/dx_ndc, d/dy_ndc,
+sum|.|) (reference backward.cu:590-595, read at method.py:1471-1476); ``radii`` and ``accumulation`` are
+non-differentiable; ``debug=True`` dumps the CPU copy of the arguments to snapshot_{fw,bw}.dump when the native call
+raises.  The native side is ``_C`` -> ``libwg_rasterizer.so`` (hand-written HIP); there is no CPU/PyTorch fallback.
+"""
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    kernel_size: float
+    subpixel_offset: torch.Tensor
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    return_accumulation: bool
+
+
+def _absent() -> torch.Tensor:
+    return torch.Tensor([])
+
+
+def _snapshot(args, path: str) -> None:
+    torch.save(tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args), path)
+
+
+def _call_native(fn, args, debug: bool, dump_path: str, what: str):
+    """Run a native entry point; in debug mode keep a CPU copy of the inputs and dump it if the call raises."""
+    if not debug:
+        return fn(*args)
+    saved = tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(saved, dump_path)
+        print(f"\nAn error occured in {what}. Writing {dump_path} for debugging.\n")
+        raise
+
+
+def _accumulation_from_image_state(img_buffer: torch.Tensor, height: int, width: int) -> torch.Tensor:
+    """accumulation = 1 - final_T; final_T is the first array of the image-state buffer (wg_rasterizer.h)."""
+    align = _C.IMAGE_STATE_ALIGNMENT
+    start = (-img_buffer.data_ptr()) % align
+    final_T = img_buffer[start:start + 4 * height * width].view(torch.float32)
+    return (1.0 - final_T).view(height, width)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        native_args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                       rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset,
+                       rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        num_rendered, color, radii, geom_buf, binning_buf, img_buf = _call_native(
+            _C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
+
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf)
+
+        accumulation = None
+        if rs.return_accumulation:
+            if means3D.shape[0] == 0:
+                accumulation = torch.zeros((rs.image_height, rs.image_width), dtype=torch.float32, device=color.device)
+            else:
+                accumulation = _accumulation_from_image_state(img_buf, rs.image_height, rs.image_width)
+        return color, radii, accumulation
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii, _grad_accumulation):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf = ctx.saved_tensors
+        native_args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                       rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset, grad_out_color, sh,
+                       rs.sh_degree, rs.campos, geom_buf, ctx.num_rendered, binning_buf, img_buf, rs.debug)
+        (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations) = _call_native(
+            _C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
+        # order of forward()'s inputs; None for raster_settings
+        return g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3Ds, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Boolean mask of points that pass the near-plane test of the preprocess stage (view-space z > 0.2)."""
+        rs = self.raster_settings
+        with torch.no_grad():
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs: Optional[torch.Tensor] = None,
+                colors_precomp: Optional[torch.Tensor] = None, scales: Optional[torch.Tensor] = None,
+                rotations: Optional[torch.Tensor] = None, cov3D_precomp: Optional[torch.Tensor] = None):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        has_scale_rot = scales is not None or rotations is not None
+        complete_scale_rot = scales is not None and rotations is not None
+        if (cov3D_precomp is None and not complete_scale_rot) or (cov3D_precomp is not None and has_scale_rot):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        return rasterize_gaussians(
+            means3D, means2D,
+            _absent() if shs is None else shs,
+            _absent() if colors_precomp is None else colors_precomp,
+            opacities,
+            _absent() if scales is None else scales,
+            _absent() if rotations is None else rotations,
+            _absent() if cov3D_precomp is None else cov3D_precomp,
+            self.raster_settings)

@@ -1,0 +1,70 @@
+"""View-parallel harness: one process per GPU, one camera per rank, Gaussians replicated, and the ONLY collective is
+an all-reduce of the scalar loss (BASELINE.json north_star).  The rasterizer itself has no cross-view
+state, so there is no data-path collective.  Backend: ``nccl`` (= RCCL over xGMI on ROCm) on GPUs, ``gloo`` in the CPU
+tests.  The reference has no distributed code at all; this is new host logic.
+"""
+from __future__ import annotations
+
+import os
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+import wg_scenes as S
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun / torch.distributed.run environment (1-process default)."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend: str | None = None) -> tuple[int, int, int]:
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    return rank, local_rank, world
+
+
+def views_for_rank(num_views: int, rank: int, world: int) -> List[int]:
+    """rank r renders views {r, r+G, r+2G, ...}."""
+    return list(range(rank, num_views, world))
+
+
+def view_cameras(num_views: int, width: int, height: int, yaw_step_deg: float = 5.0):
+    """BASELINE.json configs[3]: the base camera yawed by k * 5 degrees."""
+    return [S.make_camera(width, height, yaw_deg=yaw_step_deg * k) for k in range(num_views)]
+
+
+def allreduce_loss(loss: torch.Tensor) -> torch.Tensor:
+    """SUM all-reduce of a 1-element fp32 tensor: 4 bytes on the wire per step, latency-bound."""
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+    return loss
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device) -> float:
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device) -> float:
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

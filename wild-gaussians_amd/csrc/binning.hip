@@ -57,18 +57,26 @@ ImageState ImageState::fromChunk(char*& chunk, size_t N, size_t tiles) {
     carve(chunk, img.n_contrib, N ? N : 1);
     carve(chunk, img.ranges, tiles ? tiles : 1);
     carve(chunk, img.tile_last, tiles ? tiles : 1);
+    carve(chunk, img.tile_count, tiles ? tiles : 1);
+    carve(chunk, img.tile_offset, tiles + 1);
+    carve(chunk, img.chunk_hist, (tiles ? tiles : 1) * (size_t)BIN_CHUNKS);
+    carve(chunk, img.stats, 1);
     return img;
 }
 
-BinningState BinningState::fromChunk(char*& chunk, size_t R) {
-    BinningState b;
+BinningState BinningState::fromChunk(char*& chunk, size_t R, bool global_sort) {
+    BinningState b{};
     const size_t Ra = R ? R : 1;
     carve(chunk, b.point_list, Ra);
-    carve(chunk, b.point_list_unsorted, Ra);
-    carve(chunk, b.keys, Ra);
-    carve(chunk, b.keys_unsorted, Ra);
-    b.sort_temp_bytes = query_sort_temp_bytes(Ra);
-    carve(chunk, b.sort_temp, b.sort_temp_bytes);
+    if (!global_sort) {
+        carve(chunk, b.bucket_keys, Ra);
+    } else {
+        carve(chunk, b.point_list_unsorted, Ra);
+        carve(chunk, b.keys, Ra);
+        carve(chunk, b.keys_unsorted, Ra);
+        b.sort_temp_bytes = query_sort_temp_bytes(Ra);
+        carve(chunk, b.sort_temp, b.sort_temp_bytes);
+    }
     return b;
 }
 
@@ -115,6 +123,7 @@ hipError_t run_sort(const BinningState& b, int R, int end_bit, hipStream_t strea
                                      (unsigned)end_bit, stream);
 }
 
+// identifyTileRanges (rasterizer_impl.cu:116-138): only needed when the frame has too many tiles for the LDS histogram.
 __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= L) return;
@@ -135,6 +144,223 @@ hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& im
     if (e != hipSuccess) return e;
     if (R <= 0) return hipSuccess;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, stream, R, b.keys, img.ranges);
+    return hipGetLastError();
+}
+
+// =====================================================================================================
+// Tile-sort path (default).  The (tile | depth) ordering is produced by a counting sort on the tile id
+// followed by an independent sort of each tile's bucket in LDS.  Global atomics on ~10^4 hot counters are
+// memory-side operations on MI355X (measured: 7.4M of them cost 0.4-0.6 ms), so the counting sort only ever
+// touches LDS atomics: the Gaussians are cut into BIN_CHUNKS chunks, one workgroup per chunk, and
+//   tile_count_kernel   : chunk_hist[c][t] = #instances of chunk c in tile t        (histogram in LDS)
+//   chunk_scan_kernel   : chunk_hist[c][t] <- sum_{c' < c} chunk_hist[c'][t];  tile_count[t] = column total
+//   tile_scan_kernel    : tile_offset = exclusive_scan(tile_count); ranges; {num_rendered, max_tile_count}
+//   tile_scatter_kernel : cursor[t] (LDS) = tile_offset[t] + chunk_hist[c][t];
+//                         bucket_keys[cursor[t]++] = depth_bits << 32 | gaussian_id
+//   tile_sort_kernel    : one workgroup per tile sorts its bucket in LDS (bitonic network on 64-bit keys)
+//                         and writes the low words (Gaussian ids) to point_list
+// Sorting (depth_bits, id) ascending inside a tile is exactly the order a stable sort of (tile|depth) keys
+// leaves (ties keep ascending Gaussian id, the emission order of duplicateWithKeys), so point_list and
+// ranges are bit-identical to the reference's -- whatever order the LDS atomics happened in.  Traffic per
+// instance: 8 B scatter + 8 B read + 4 B write, against 6 radix passes x 24 B for the 45-bit global sort.
+
+__device__ __forceinline__ void chunk_bounds(int P, int chunk, int& begin, int& end) {
+    const int per = (P + BIN_CHUNKS - 1) / BIN_CHUNKS;
+    begin = min(P, chunk * per);
+    end = min(P, begin + per);
+}
+
+__global__ void __launch_bounds__(256) tile_count_kernel(int P, const int* __restrict__ radii, const ushort4* __restrict__ rects,
+                                                         uint32_t* __restrict__ chunk_hist, int gx, int tiles) {
+    extern __shared__ uint32_t hist[];
+    const int tid = threadIdx.x, chunk = blockIdx.x;
+    for (int t = tid; t < tiles; t += 256) hist[t] = 0;
+    __syncthreads();
+    int begin, end;
+    chunk_bounds(P, chunk, begin, end);
+    for (int idx = begin + tid; idx < end; idx += 256) {
+        if (radii[idx] > 0) {
+            const ushort4 r = rects[idx];
+            for (int y = r.y; y < r.w; y++)
+                for (int x = r.x; x < r.z; x++) atomicAdd(&hist[y * gx + x], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* out = chunk_hist + (size_t)chunk * tiles;
+    for (int t = tid; t < tiles; t += 256) out[t] = hist[t];
+}
+
+// Column scan: for each tile, exclusive prefix over the chunks.  Workgroup = 4 waves x 64 tiles; wave w owns a
+// quarter of the chunks, lane = tile (loads are 256-byte coalesced rows of chunk_hist).
+__global__ void __launch_bounds__(256) chunk_scan_kernel(uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ tile_count, int tiles) {
+    __shared__ uint32_t part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    constexpr int Q = BIN_CHUNKS / 4;
+    uint32_t sum = 0;
+    if (t < tiles)
+        for (int c = wave * Q; c < (wave + 1) * Q; c++) sum += chunk_hist[(size_t)c * tiles + t];
+    part[wave][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int w = 0; w < wave; w++) run += part[w][lane];
+    if (t < tiles) {
+        for (int c = wave * Q; c < (wave + 1) * Q; c++) {
+            const size_t i = (size_t)c * tiles + t;
+            const uint32_t v = chunk_hist[i];
+            chunk_hist[i] = run;
+            run += v;
+        }
+        if (wave == 3) tile_count[t] = run;
+    }
+}
+
+__global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
+                                                         uint2* __restrict__ ranges, BinStats* __restrict__ stats, int tiles) {
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t wave_max[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (tiles + 1023) / 1024;
+    const int begin = tid * per, end = min(tiles, begin + per);
+    uint32_t local = 0, lmax = 0;
+    for (int i = begin; i < end; i++) {
+        const uint32_t c = tile_count[i];
+        local += c;
+        lmax = max(lmax, c);
+    }
+    // inclusive scan of `local` across the 1024 threads: wave scan, then scan of wave totals
+    uint32_t incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += up;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, m));
+    if (lane == 63) wave_sum[wave] = incl;
+    if (lane == 0) wave_max[wave] = lmax;
+    __syncthreads();
+    uint32_t wave_base = 0, total = 0, gmax = 0;
+    for (int w = 0; w < 16; w++) {
+        if (w < wave) wave_base += wave_sum[w];
+        total += wave_sum[w];
+        gmax = max(gmax, wave_max[w]);
+    }
+    uint32_t run = wave_base + incl - local;  // exclusive prefix of this thread's first tile
+    for (int i = begin; i < end; i++) {
+        const uint32_t c = tile_count[i];
+        tile_offset[i] = run;
+        ranges[i] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u);  // empty tiles stay (0,0) as after the reference's memset
+        run += c;
+    }
+    if (tid == 0) {
+        tile_offset[tiles] = total;
+        stats->num_rendered = total;
+        stats->max_tile_count = gmax;
+    }
+}
+
+__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const float* __restrict__ depths, const int* __restrict__ radii,
+                                                           const ushort4* __restrict__ rects, const uint32_t* __restrict__ tile_offset,
+                                                           const uint32_t* __restrict__ chunk_hist, uint64_t* __restrict__ bucket_keys,
+                                                           int gx, int tiles) {
+    extern __shared__ uint32_t cursor[];
+    const int tid = threadIdx.x, chunk = blockIdx.x;
+    const uint32_t* base = chunk_hist + (size_t)chunk * tiles;
+    for (int t = tid; t < tiles; t += 256) cursor[t] = tile_offset[t] + base[t];
+    __syncthreads();
+    int begin, end;
+    chunk_bounds(P, chunk, begin, end);
+    for (int idx = begin + tid; idx < end; idx += 256) {
+        if (radii[idx] > 0) {
+            const ushort4 r = rects[idx];
+            const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx;
+            for (int y = r.y; y < r.w; y++)
+                for (int x = r.x; x < r.z; x++) {
+                    const uint32_t pos = atomicAdd(&cursor[y * gx + x], 1u);
+                    bucket_keys[pos] = key;
+                }
+        }
+    }
+}
+
+// Bitonic sort of n <= npow2 64-bit keys held in LDS (npow2 = power of two, padded with ~0).
+__global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint64_t* __restrict__ bucket_keys,
+                                                        uint32_t* __restrict__ point_list, int tiles) {
+    extern __shared__ uint64_t skeys[];
+    const int tile = blockIdx.x;
+    const uint32_t begin = tile_offset[tile];
+    const uint32_t n = tile_offset[tile + 1] - begin;
+    if (n == 0) return;
+    const int tid = threadIdx.x;
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (uint32_t i = tid; i < np2; i += 256) skeys[i] = i < n ? bucket_keys[begin + i] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= np2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (np2 >> 1); t += 256) {
+                // t-th compare-exchange of this stage: partner indices i < l = i ^ j
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t l = i | j;
+                const uint64_t a = skeys[i], b = skeys[l];
+                const bool ascending = (i & k) == 0;
+                if ((a > b) == ascending) {
+                    skeys[i] = b;
+                    skeys[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < n; i += 256) point_list[begin + i] = (uint32_t)skeys[i];
+}
+
+static hipError_t ensure_lds(const void* fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, hipStream_t stream) {
+    const size_t lds = (size_t)tiles * sizeof(uint32_t);
+    hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_count_kernel), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tile_count_kernel, dim3(BIN_CHUNKS), dim3(256), lds, stream, P, g.radii, g.rects, img.chunk_hist, gx, tiles);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3((tiles + 63) / 64), dim3(256), 0, stream, img.chunk_hist, img.tile_count, tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_scan(const ImageState& img, int tiles, hipStream_t stream) {
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges, img.stats, tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
+                               hipStream_t stream) {
+    if (P <= 0) return hipSuccess;
+    const size_t lds = (size_t)tiles * sizeof(uint32_t);
+    hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_kernel), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(BIN_CHUNKS), dim3(256), lds, stream, P, g.depths, g.radii, g.rects, img.tile_offset,
+                       img.chunk_hist, b.bucket_keys, gx, tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, int tiles, uint32_t max_count, hipStream_t stream) {
+    if (tiles <= 0 || max_count == 0) return hipSuccess;
+    uint32_t np2 = 1;
+    while (np2 < max_count) np2 <<= 1;
+    const size_t lds = (size_t)np2 * sizeof(uint64_t);
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(TILE_SORT_MAX * sizeof(uint64_t)));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles), dim3(256), lds, stream, img.tile_offset, b.bucket_keys, b.point_list, tiles);
     return hipGetLastError();
 }
 

@@ -35,23 +35,40 @@ struct GeometryState {
     static GeometryState fromChunk(char*& chunk, size_t P);
 };
 
+struct BinStats {  // read back by the host once per forward (the reference's num_rendered sync point)
+    uint32_t num_rendered;
+    uint32_t max_tile_count;
+};
+
 struct ImageState {
     float* final_T;  // MUST stay first: documented in wg_rasterizer.h
     uint32_t* n_contrib;
     uint2* ranges;
     uint32_t* tile_last;
+    uint32_t* tile_count;   // per-tile instance count
+    uint32_t* tile_offset;  // exclusive prefix sum of tile_count
+    uint32_t* chunk_hist;   // [chunks][tiles] per-chunk tile histogram, turned into per-chunk bases by the column scan
+    BinStats* stats;
     static ImageState fromChunk(char*& chunk, size_t N, size_t tiles);
 };
 
+// Binning scratch.  Two layouts share the point_list prefix (all the backward pass needs):
+//   tile-sort path (default): point_list u32[R] | bucket_keys u64[R]
+//   global-sort fallback    : point_list u32[R] | point_list_unsorted u32[R] | keys u64[R] | keys_unsorted u64[R] | temp
 struct BinningState {
     uint32_t* point_list;
+    uint64_t* bucket_keys;  // (depth_bits << 32 | gaussian id), grouped by tile, unsorted within a tile
     uint32_t* point_list_unsorted;
     uint64_t* keys;
     uint64_t* keys_unsorted;
     char* sort_temp;
     size_t sort_temp_bytes;
-    static BinningState fromChunk(char*& chunk, size_t R);
+    static BinningState fromChunk(char*& chunk, size_t R, bool global_sort);
 };
+
+constexpr uint32_t TILE_SORT_MAX = 8192;  // longest per-tile list the LDS sort handles (64 KiB of keys)
+constexpr int BIN_CHUNKS = 512;           // Gaussian chunks (= workgroups) of the LDS counting sort
+constexpr int BIN_MAX_TILES = 36864;      // tiles*4 B must fit one workgroup's LDS (144 KiB): up to 4K frames
 
 size_t query_scan_temp_bytes(size_t P);
 size_t query_sort_temp_bytes(size_t R);
@@ -80,6 +97,10 @@ hipError_t run_scan(const GeometryState& g, int P, hipStream_t stream);
 hipError_t launch_duplicate_keys(int P, const GeometryState& g, const BinningState& b, int gx, hipStream_t stream);
 hipError_t run_sort(const BinningState& b, int R, int end_bit, hipStream_t stream);
 hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& img, int tiles, hipStream_t stream);
+hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, hipStream_t stream);
+hipError_t launch_tile_scan(const ImageState& img, int tiles, hipStream_t stream);
+hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles, hipStream_t stream);
+hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, int tiles, uint32_t max_count, hipStream_t stream);
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                  const GeometryState& g, const float* subpixel_offset, const float* background,
                                  float* out_color, hipStream_t stream);

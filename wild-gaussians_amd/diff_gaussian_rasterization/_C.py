@@ -59,7 +59,7 @@ class _GeometryView(C.Structure):
 
 
 class _BinningView(C.Structure):
-    _fields_ = [(n, _vp) for n in ("point_list", "point_list_keys")]
+    _fields_ = [(n, _vp) for n in ("point_list",)]
 
 
 class _ImageView(C.Structure):
@@ -233,8 +233,7 @@ def view_geometry(geomBuffer, P):
 def view_binning(binningBuffer, R):
     v = _BinningView()
     _check(_lib.wg_view_binning(binningBuffer.data_ptr(), int(R), C.byref(v)), "wg_view_binning")
-    return dict(point_list=_from_ptr(v.point_list, (R,), torch.int32, binningBuffer),
-                point_list_keys=_from_ptr(v.point_list_keys, (R,), torch.int64, binningBuffer))
+    return dict(point_list=_from_ptr(v.point_list, (R,), torch.int32, binningBuffer))
 
 
 def view_image(imageBuffer, H, W):
@@ -245,6 +244,15 @@ def view_image(imageBuffer, H, W):
                 n_contrib=_from_ptr(v.n_contrib, (H, W), torch.int32, imageBuffer),
                 ranges=_from_ptr(v.ranges, (tiles, 2), torch.int32, imageBuffer),
                 tile_last=_from_ptr(v.tile_last, (tiles,), torch.int32, imageBuffer))
+
+
+_lib.wg_set_option.restype = _i
+_lib.wg_set_option.argtypes = [C.c_char_p, _i]
+
+
+def set_option(name: str, value: int) -> None:
+    """wg_set_option: e.g. set_option("force_global_sort", 1) selects the rocPRIM global-sort binning path."""
+    _check(_lib.wg_set_option(name.encode(), int(value)), f"wg_set_option({name})")
 
 
 def version() -> str:

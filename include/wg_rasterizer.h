@@ -136,7 +136,7 @@ int wg_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
 typedef struct wg_geometry_view {
     const float* depths;          /* [P]   view-space z (forward.cu:262) */
     const int* radii;             /* [P]   internal copy */
-    const float* splats;          /* [P*12] 48-byte records: mx,my,conic.x,conic.y | conic.z,opacity*coef,r,g | b,0,0,0 */
+    const float* splats;          /* [P*12] 48-byte records: mx,my,conic.x,conic.y | conic.z,opacity*coef,0,r | g,b,0,0 */
     const float* cov3D;           /* [P*6] */
     const unsigned char* clamped; /* [P]   bit c set <=> SH colour channel c was clamped at 0 (forward.cu:67-69) */
     const uint32_t* tiles_touched;/* [P] */

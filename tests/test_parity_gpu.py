@@ -75,7 +75,7 @@ def test_preprocess_and_binning_bit_exact(oracle, name, binning):
     np.testing.assert_array_equal(sp[vis, 4], co[vis, 2])
     np.testing.assert_allclose(sp[vis, 5], co[vis, 3], rtol=2e-7, atol=0)  # opacity * coef (coef goes through double sqrt)
     rgb_ref = cloud["colors_precomp"] if "colors_precomp" in cloud else octx.get("rgb")
-    np.testing.assert_array_equal(sp[vis, 6:9], rgb_ref[vis])
+    np.testing.assert_array_equal(sp[vis, 7:10], rgb_ref[vis])
     if "shs" in cloud:
         cl = g["clamped"].cpu().numpy()
         ocl = octx.get("clamped")

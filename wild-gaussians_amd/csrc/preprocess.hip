@@ -164,8 +164,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(FwdParams p, GeometrySt
                 touched = (uint32_t)ntiles;
                 float4* rec = g.splats + 3 * (size_t)idx;
                 rec[0] = make_float4(pixx, pixy, conx, cony);
-                rec[1] = make_float4(conz, p.opacities[idx] * coef, cr, cg);
-                rec[2] = make_float4(cb, 0.f, 0.f, 0.f);
+                rec[1] = make_float4(conz, p.opacities[idx] * coef, 0.f, cr);  // .z is reserved: the render kernels park a strip mask there
+                rec[2] = make_float4(cg, cb, 0.f, 0.f);
                 g.rects[idx] = make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy);
             }
         }

@@ -1,17 +1,18 @@
 // K9: per-tile back-to-front gradient walk for gfx950.  Replaces renderCUDA (backward.cu:435-606).
 //
-// Same wave-per-tile mapping as the forward kernel (render_fwd.hip): 64 lanes x 4 strips = 256 pixels.
-// What changes relative to the reference's design:
-//   * the walk starts at the tile's last contributing instance (tile_last, produced by the forward
-//     kernel) instead of the end of the tile's list, so instances no pixel ever reached are never read;
+// Same wave-per-tile mapping as the forward kernel (render_fwd.hip): 64 lanes x 4 strips = 256 pixels, the same
+// batch staging through LDS and the same per-instance strip masks.  What changes relative to the reference:
+//   * the walk starts at the tile's last contributing instance (tile_last, produced by the forward kernel)
+//     instead of the end of the tile's list, so instances no pixel ever reached are never read;
 //   * the reference issues 10 float atomicAdds to global memory per contributing (pixel, Gaussian) pair
-//     (backward.cu:568-603).  Here each lane first sums its 4 pixels' contributions in registers, the
-//     wave then reduces the 10 partial sums across its 64 lanes with DPP row operations (no LDS, no
-//     barrier), and ONE lane issues the 10 hardware float atomics per (tile, Gaussian) instance:
-//     256x fewer atomics than the reference for a fully covered tile;
+//     (backward.cu:568-603).  Here each lane first sums its 4 pixels' contributions in registers, then the wave
+//     reduces the 10 partial sums with a butterfly (transpose-reduce): v_permlane32_swap / v_permlane16_swap
+//     halve the number of live values per step instead of reducing them one by one (26 VALU ops for all ten,
+//     against 60 for ten 6-step DPP reductions), leaving value k's total in lane LANE_OF[k].  Those ten lanes
+//     then issue ONE global_atomic_add_f32 instruction per (tile, Gaussian) instance: 256x fewer atomics than the
+//     reference for a fully covered tile;
 //   * the "last_alpha / last_color" lazy recurrence (backward.cu:560-561,572) is applied eagerly
-//     (accum_rec' = alpha*c + (1-alpha)*accum_rec right after use), the same values with 16 fewer
-//     live registers per lane.
+//     (accum_rec' = alpha*c + (1-alpha)*accum_rec right after use): same values, 16 fewer live registers.
 // The gradient arithmetic is the reference's hand-derived backward, not autograd of the forward:
 // straight-through min(0.99,.), NDC-scaled dL_dmean2D (0.5*W, 0.5*H), abs-gradient in .z
 // (backward.cu:593-595), conic gradient in .x/.y/.w of a float4 (backward.cu:598-600).
@@ -22,16 +23,49 @@ namespace wg {
 
 constexpr int BATCH = 64;
 
-// Sum over the 64 lanes of a wave; the total is valid in lane 63.
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    // quad_perm [1,0,3,2], [2,3,0,1]; row_ror 4, 8; row_bcast 15 (rows 1,3), row_bcast 31 (rows 2,3)
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
-    return v;
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+
+// pair_x32: (a, b) -> one register: lanes 0-31 hold a[l] + a[l+32], lanes 32-63 hold b[l-32] + b[l]
+// pair_x16: (a, b) -> one register: even 16-lane rows hold a summed over the row pair, odd rows hold b likewise
+__device__ __forceinline__ float pair_x32(float a, float b) {
+    // (hipcc 7.2 mis-selects "r[0] + r[1]" of __builtin_amdgcn_permlane32_swap as "r[0] + r[0]", so the swap is spelled
+    // in asm; the s_nops are the VALU-write -> permlane-swap and permlane-swap -> VALU-read wait states, which hipcc
+    // does not insert around inline asm.)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float pair_x16(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
+// Butterfly reduction of ten per-lane values over the 64 lanes of a wave.  On return lane l holds, in the
+// returned register, the full-wave total of value index
+//     bit1(l) == 0 :  4*bit0(l) + 2*bit4(l) + bit5(l)        (values 0..7)
+//     bit1(l) == 1 :  8 + bit5(l)                             (values 8, 9)
+// (bits 2 and 3 of the lane index do not matter: those lanes hold copies).
+__device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
+                                             float v8, float v9, int lane) {
+    // xor 32: ten -> five;  w_k = v_{2k + bit5}
+    const float w0 = pair_x32(v0, v1), w1 = pair_x32(v2, v3), w2 = pair_x32(v4, v5), w3 = pair_x32(v6, v7), w4 = pair_x32(v8, v9);
+    // xor 16: five -> three;  u_m = w_{2m + bit4}, u2 = w4
+    const float u0 = pair_x16(w0, w1), u1 = pair_x16(w2, w3), u2 = pair_x16(w4, w4);
+    // xor 1 (quad_perm [1,0,3,2]): x0 = u_{bit0}, x1 = u2
+    const bool b0 = lane & 1;
+    const float keep0 = b0 ? u1 : u0, send0 = b0 ? u0 : u1;
+    const float x0 = keep0 + dpp_f<0xB1>(send0);
+    const float x1 = u2 + dpp_f<0xB1>(u2);
+    // xor 2 (quad_perm [2,3,0,1]): y = bit1 ? x1 : x0
+    const bool b1 = lane & 2;
+    const float keep1 = b1 ? x1 : x0, send1 = b1 ? x0 : x1;
+    float y = keep1 + dpp_f<0x4E>(send1);
+    // lanes l, l+4, l+8, l+12 of each row: row_ror 4, row_ror 8
+    y += dpp_f<0x124>(y);
+    y += dpp_f<0x128>(y);
+    return y;
 }
 
 __global__ void __launch_bounds__(64) render_backward_kernel(
@@ -54,8 +88,22 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
+    // which of the ten reduced values this lane owns after butterfly10(), and where it accumulates it:
+    //   0,1,2 -> dL_dcolor[3id + k]; 3,4,5 -> dL_dmean2D[3id + k-3]; 6,7,8 -> dL_dconic[4id + {0,1,3}]; 9 -> dL_dopacity[id]
+    const int vidx = (lane & 2) ? 8 + ((lane >> 5) & 1) : 4 * (lane & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
+    const bool owner = (lane & 12) == 0;  // lanes with bits 2,3 clear: one lane per value (two spare for value 8/9 copies)
+    float* abase;
+    uint32_t astride;
+    if (vidx < 3) { abase = dL_dcolor + vidx; astride = 3; }
+    else if (vidx < 6) { abase = dL_dmean2D + (vidx - 3); astride = 3; }
+    else if (vidx < 9) { abase = dL_dconic + (vidx == 8 ? 3 : vidx - 6); astride = 4; }
+    else { abase = dL_dopacity; astride = 1; }
+    // values 8 and 9 (bit1 set) are replicated over bits 0 and 4: let only the bit0 == bit4 == 0 copy issue
+    const bool issue = owner && !((lane & 2) && (lane & 17));
+
     float pfx[4], pfy[4], T[4], tfb[4], dLr[4], dLg[4], dLb[4], recr[4], recg[4], recb[4];
     int last[4];
+    StripBounds sb;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int py = py0 + 4 * s;
@@ -75,6 +123,11 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
         pfy[s] = (float)py + off.y;
         tfb[s] = -T[s] * (bg0 * dLr[s] + bg1 * dLg[s] + bg2 * dLb[s]);  // -T_final * <bg, dL_dpixel>
         recr[s] = recg[s] = recb[s] = 0.f;
+        const float inf = __builtin_huge_valf();
+        sb.x0[s] = wave_min_uniform(inside ? pfx[s] : inf);
+        sb.x1[s] = wave_max_uniform(inside ? pfx[s] : -inf);
+        sb.y0[s] = wave_min_uniform(inside ? pfy[s] : inf);
+        sb.y1[s] = wave_max_uniform(inside ? pfy[s] : -inf);
     }
 
     const uint2 range = ranges[tile];
@@ -85,36 +138,35 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
         __syncthreads();
         if (posl >= 0) {
             const uint32_t id = point_list[range.x + posl];
+            const float4 q0 = splats[3 * (size_t)id];
+            float4 q1 = splats[3 * (size_t)id + 1];
+            q1.z = __uint_as_float(strip_mask(q0, q1, sb));
             lds_id[lane] = id;
-            lds[3 * lane] = splats[3 * (size_t)id];
-            lds[3 * lane + 1] = splats[3 * (size_t)id + 1];
+            lds[3 * lane] = q0;
+            lds[3 * lane + 1] = q1;
             lds[3 * lane + 2] = splats[3 * (size_t)id + 2];
         }
         __syncthreads();
         const int cnt = min(BATCH, hi);
         for (int j = 0; j < cnt; j++) {
+            const float4 r1 = lds[3 * j + 1];
+            const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(r1.z));
+            if (m == 0) continue;
             const int pos = hi - 1 - j;  // "contributor" after the decrement at backward.cu:531
             const float4 r0 = lds[3 * j];
-            const float4 r1 = lds[3 * j + 1];
             const SplatCoef sc = make_coef(r0, r1);
             const float o = sc.o;
-            float G[4], alpha[4], dxs[4], dys[4];
-            uint32_t hit = 0;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const bool pass = eval_alpha(sc, pfx[s], pfy[s], dxs[s], dys[s], G[s], alpha[s]);
-                if (pos < last[s] && pass) hit |= 1u << s;
-            }
-            if (__ballot(hit != 0) == 0ull) continue;
-
-            const float cbch = lds[3 * j + 2].x;
-            const float colr = r1.z, colg = r1.w;
+            const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
+            const float colr = r1.w, colg = gb.x, colb = gb.y;
             float acr = 0.f, acg = 0.f, acb = 0.f, amx = 0.f, amy = 0.f, aab = 0.f, axx = 0.f, axy = 0.f, ayy = 0.f, aop = 0.f;
+            bool any = false;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                if (__ballot((hit >> s) & 1u) == 0ull) continue;
-                if ((hit >> s) & 1u) {
-                    const float a = alpha[s];
+                if (!(m & (1u << s))) continue;  // wave-uniform
+                float dx, dy, G, a;
+                const bool pass = eval_alpha(sc, pfx[s], pfy[s], dx, dy, G, a);
+                if (pos < last[s] && pass) {
+                    any = true;
                     const float inv = __builtin_amdgcn_rcpf(1.0f - a);
                     const float Tn = T[s] * inv;  // T / (1 - alpha), backward.cu:548
                     T[s] = Tn;
@@ -122,43 +174,29 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
                     acr += w * dLr[s];
                     acg += w * dLg[s];
                     acb += w * dLb[s];
-                    const float dr = colr - recr[s], dg = colg - recg[s], db = cbch - recb[s];
+                    const float dr = colr - recr[s], dg = colg - recg[s], db = colb - recb[s];
                     float dLda = dr * dLr[s] + dg * dLg[s] + db * dLb[s];
                     recr[s] += a * dr;  // accum_rec for the next (nearer) contributor
                     recg[s] += a * dg;
                     recb[s] += a * db;
                     dLda = dLda * Tn + tfb[s] * inv;
                     const float dLdG = o * dLda;
-                    const float gdx = G[s] * dxs[s], gdy = G[s] * dys[s];
+                    const float gdx = G * dx, gdy = G * dy;
                     const float dGdx = -gdx * r0.z - gdy * r0.w;
                     const float dGdy = -gdy * r1.x - gdx * r0.w;
                     const float mx = dLdG * dGdx * ddelx_dx, my = dLdG * dGdy * ddely_dy;
                     amx += mx;
                     amy += my;
                     aab += fabsf(mx) + fabsf(my);
-                    axx += -0.5f * gdx * dxs[s] * dLdG;
-                    axy += -0.5f * gdx * dys[s] * dLdG;
-                    ayy += -0.5f * gdy * dys[s] * dLdG;
-                    aop += G[s] * dLda;
+                    axx += -0.5f * gdx * dx * dLdG;
+                    axy += -0.5f * gdx * dy * dLdG;
+                    ayy += -0.5f * gdy * dy * dLdG;
+                    aop += G * dLda;
                 }
             }
-            acr = wave_sum_to_lane63(acr); acg = wave_sum_to_lane63(acg); acb = wave_sum_to_lane63(acb);
-            amx = wave_sum_to_lane63(amx); amy = wave_sum_to_lane63(amy); aab = wave_sum_to_lane63(aab);
-            axx = wave_sum_to_lane63(axx); axy = wave_sum_to_lane63(axy); ayy = wave_sum_to_lane63(ayy);
-            aop = wave_sum_to_lane63(aop);
-            if (lane == 63) {
-                const size_t id = lds_id[j];
-                unsafeAtomicAdd(dL_dcolor + 3 * id + 0, acr);
-                unsafeAtomicAdd(dL_dcolor + 3 * id + 1, acg);
-                unsafeAtomicAdd(dL_dcolor + 3 * id + 2, acb);
-                unsafeAtomicAdd(dL_dmean2D + 3 * id + 0, amx);
-                unsafeAtomicAdd(dL_dmean2D + 3 * id + 1, amy);
-                unsafeAtomicAdd(dL_dmean2D + 3 * id + 2, aab);
-                unsafeAtomicAdd(dL_dconic + 4 * id + 0, axx);
-                unsafeAtomicAdd(dL_dconic + 4 * id + 1, axy);
-                unsafeAtomicAdd(dL_dconic + 4 * id + 3, ayy);
-                unsafeAtomicAdd(dL_dopacity + id, aop);
-            }
+            if (__ballot(any) == 0ull) continue;
+            const float total = butterfly10(acr, acg, acb, amx, amy, aab, axx, axy, ayy, aop, lane);
+            if (issue) unsafeAtomicAdd(abase + (size_t)astride * lds_id[j], total);
         }
     }
 }

@@ -9,8 +9,12 @@
 //     splat record (position, conic, opacity, colour -- one gather instead of the reference's four
 //     arrays + a colour fetch from global per contributing pair, forward.cu:376) into registers while the
 //     previous batch is being composited (software prefetch), then parks it in LDS.
-//   * strips whose 64 lanes all miss an instance skip the blend with one wave-uniform branch; the walk
-//     stops as soon as every pixel of the tile is saturated (checked per instance, not per 256-batch).
+//   * while staging, lane l also computes instance l's strip-reachability mask (wg_alpha.h: the 1/255
+//     iso-ellipse's bounding box against the four strips' sample boxes).  The per-instance loop reads that
+//     mask as a wave-uniform scalar: unreachable strips cost nothing, unreachable instances one branch.
+//     The mask is conservative, so the blended result is unchanged.
+//   * saturated strips (every pixel hit the T < 1e-4 stop) are dropped from the uniform mask; the walk ends
+//     when no strip is left.
 //   * block -> tile mapping is XCD-aware: blocks are dealt round-robin to the 8 XCDs, so XCD x is given a
 //     contiguous band of tiles and its private 4 MiB L2 only has to hold that band's splat records.
 //
@@ -41,6 +45,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
     float pfx[4], pfy[4], T[4], Cr[4], Cg[4], Cb[4];
     uint32_t last[4];
     uint32_t alive = 0;  // bit s set <=> pixel of strip s still accumulating
+    StripBounds sb;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int py = py0 + 4 * s;
@@ -55,7 +60,16 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
         T[s] = 1.0f;
         Cr[s] = Cg[s] = Cb[s] = 0.f;
         last[s] = 0;
+        const float inf = __builtin_huge_valf();
+        sb.x0[s] = wave_min_uniform(inside ? pfx[s] : inf);
+        sb.x1[s] = wave_max_uniform(inside ? pfx[s] : -inf);
+        sb.y0[s] = wave_min_uniform(inside ? pfy[s] : inf);
+        sb.y1[s] = wave_max_uniform(inside ? pfy[s] : -inf);
     }
+    uint32_t strips_alive = 0;  // wave-uniform: strips with at least one unsaturated pixel
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+        if (__ballot((alive >> s) & 1u) != 0ull) strips_alive |= 1u << s;
 
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
@@ -69,7 +83,8 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
         a2 = splats[3 * (size_t)id + 2];
     }
 
-    for (int base = 0; base < n; base += BATCH) {
+    for (int base = 0; base < n && strips_alive != 0; base += BATCH) {
+        a1.z = __uint_as_float(strip_mask(a0, a1, sb));
         __syncthreads();
         lds[3 * lane] = a0;
         lds[3 * lane + 1] = a1;
@@ -83,41 +98,43 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
         }
         const int cnt = min(BATCH, n - base);
         for (int j = 0; j < cnt; j++) {
-            if (__ballot(alive != 0) == 0ull) goto finished;
-            const float4 r0 = lds[3 * j];      // mx, my, conic.x, conic.y
-            const float4 r1 = lds[3 * j + 1];  // conic.z, opacity, r, g
+            const float4 r1 = lds[3 * j + 1];  // conic.z, opacity, strip mask, red
+            const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(r1.z)) & strips_alive;
+            if (m == 0) continue;
+            const float4 r0 = lds[3 * j];  // mx, my, conic.x, conic.y
             const SplatCoef sc = make_coef(r0, r1);
-            float alpha[4];
-            uint32_t hit = 0;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                float dx, dy, G;
-                const bool pass = eval_alpha(sc, pfx[s], pfy[s], dx, dy, G, alpha[s]);
-                if (((alive >> s) & 1u) && pass) hit |= 1u << s;
-            }
-            if (__ballot(hit != 0) == 0ull) continue;
-            const float cbch = lds[3 * j + 2].x;
             const uint32_t pos = (uint32_t)(base + j + 1);
+            const uint32_t alive_before = alive;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                if (__ballot((hit >> s) & 1u) == 0ull) continue;
-                if ((hit >> s) & 1u) {
-                    const float test_T = T[s] * (1.0f - alpha[s]);
+                if (!(m & (1u << s))) continue;  // wave-uniform
+                float dx, dy, G, alpha;
+                const bool pass = eval_alpha(sc, pfx[s], pfy[s], dx, dy, G, alpha);
+                if (((alive >> s) & 1u) && pass) {
+                    const float test_T = T[s] * (1.0f - alpha);
                     if (test_T < 0.0001f) {
                         alive &= ~(1u << s);  // done (forward.cu:368-372): this instance is not blended
                     } else {
-                        const float w = alpha[s] * T[s];
-                        Cr[s] += r1.z * w;
-                        Cg[s] += r1.w * w;
-                        Cb[s] += cbch * w;
+                        const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
+                        const float w = alpha * T[s];
+                        Cr[s] += r1.w * w;
+                        Cg[s] += gb.x * w;
+                        Cb[s] += gb.y * w;
                         T[s] = test_T;
                         last[s] = pos;
                     }
                 }
             }
+            if (__ballot(alive != alive_before) != 0ull) {  // some pixel saturated: refresh the strip liveness
+                strips_alive = 0;
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+                    if (__ballot((alive >> s) & 1u) != 0ull) strips_alive |= 1u << s;
+                if (strips_alive == 0) break;
+            }
         }
     }
-finished:
+
     uint32_t lmax = 0;
     const size_t plane = (size_t)W * H;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];

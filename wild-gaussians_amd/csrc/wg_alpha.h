@@ -1,5 +1,5 @@
-// Shared per-(pixel, splat) falloff evaluation, used by BOTH render kernels so that the forward and the
-// backward pass take identical skip decisions (forward.cu:353-366 == backward.cu:536-546).
+// Shared per-(pixel, splat) falloff evaluation and per-(tile, splat) strip culling, used by BOTH render kernels
+// so that the forward and the backward pass take identical skip decisions (forward.cu:353-366 == backward.cu:536-546).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -13,6 +13,7 @@ struct SplatCoef {
     float o;           // opacity * mip-filter coef
 };
 
+// record layout (preprocess.hip): r0 = (mx, my, conic.x, conic.y), r1 = (conic.z, opacity, strip mask, red), r2 = (green, blue, -, -)
 __device__ __forceinline__ SplatCoef make_coef(const float4 r0, const float4 r1) {
     SplatCoef c;
     c.mx = r0.x;
@@ -42,6 +43,48 @@ __device__ __forceinline__ int xcd_tile(int b, int tiles) {
     const int q = tiles >> 3, rem = tiles & 7;
     const int xcd = b & 7, i = b >> 3;
     return xcd * q + min(xcd, rem) + i;
+}
+
+// ---- wave64 min / max with DPP row operations; result valid in lane 63, returned as a wave-uniform value ----
+#define WG_DPP_STEP(op, ctrl, rmask)                                                                                   \
+    v = op(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), \
+                                                                    ctrl, rmask, 0xF, false)))
+__device__ __forceinline__ float wave_min_uniform(float v) {
+    WG_DPP_STEP(fminf, 0xB1, 0xF); WG_DPP_STEP(fminf, 0x4E, 0xF); WG_DPP_STEP(fminf, 0x124, 0xF); WG_DPP_STEP(fminf, 0x128, 0xF);
+    WG_DPP_STEP(fminf, 0x142, 0xA); WG_DPP_STEP(fminf, 0x143, 0xC);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_uniform(float v) {
+    WG_DPP_STEP(fmaxf, 0xB1, 0xF); WG_DPP_STEP(fmaxf, 0x4E, 0xF); WG_DPP_STEP(fmaxf, 0x124, 0xF); WG_DPP_STEP(fmaxf, 0x128, 0xF);
+    WG_DPP_STEP(fmaxf, 0x142, 0xA); WG_DPP_STEP(fmaxf, 0x143, 0xC);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#undef WG_DPP_STEP
+
+// Sample-position bounding boxes of the four 16x4 strips of a tile (wave-uniform).
+struct StripBounds {
+    float x0[4], x1[4], y0[4], y1[4];
+};
+
+// Conservative per-(splat, strip) reachability mask.  A pixel can only pass alpha >= 1/255 when
+// power >= -ln(255*o), i.e. inside the ellipse d^T Q d <= 2 ln(255 o); the mask tests that ellipse's axis-aligned
+// bounding box (inflated by 0.1% + 0.01 px so float rounding can never exclude a pixel the exact test would keep)
+// against each strip's sample-position box.  Splats with an indefinite conic keep all strips.
+__device__ __forceinline__ uint32_t strip_mask(const float4 r0, const float4 r1, const StripBounds& sb) {
+    const float o = r1.y, A = r0.z, B = r0.w, C = r1.x;
+    if (!(o * 1.001f >= (1.0f / 255.0f))) return 0u;
+    const float det = A * C - B * B;
+    if (!(det > 0.0f) || !(A > 0.0f) || !(C > 0.0f)) return 0xFu;
+    const float tau2 = 2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(255.0f * o) * 1.002f + 0.002f;  // 2 ln(255 o), inflated
+    const float idet = 1.0f / det;
+    const float ex = __builtin_sqrtf(fmaxf(tau2 * C * idet, 0.0f)) + 0.01f;
+    const float ey = __builtin_sqrtf(fmaxf(tau2 * A * idet, 0.0f)) + 0.01f;
+    const float mx = r0.x, my = r0.y;
+    uint32_t m = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+        if (mx + ex >= sb.x0[s] && mx - ex <= sb.x1[s] && my + ey >= sb.y0[s] && my - ey <= sb.y1[s]) m |= 1u << s;
+    return m;
 }
 
 }  // namespace wg

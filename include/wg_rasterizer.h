@@ -91,8 +91,10 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user,
 
 /*
  * Rasterizer::backward (rasterizer.h:61-88, rasterizer_impl.cu:344-443).
- * Gradient outputs must be zero-filled by the caller (rasterize_points.cu:157-165).
- * dL_dconic is float[P*4] (2x2 per Gaussian; [0],[1],[3] used), dL_dmean2D float[P*3]
+ * The reference requires all nine gradient outputs zero-filled by the caller (rasterize_points.cu:157-165).  Here only
+ * the four accumulation targets of the per-tile pass -- dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor -- must be
+ * zero on entry; dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot are fully overwritten (zeros for culled Gaussians).
+ * dL_dconic is float[P*4], 16-byte aligned (2x2 per Gaussian; [0],[1],[3] used), dL_dmean2D float[P*3]
  * (x, y in NDC-scaled units, z = abs-gradient, backward.cu:590-595).  dL_dsh may be NULL when M == 0.
  */
 int wg_rasterize_backward(int P, int D, int M, int R,

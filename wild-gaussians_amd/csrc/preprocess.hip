@@ -23,7 +23,7 @@ __constant__ const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -
                                      -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
 
 // SH -> RGB for one channel (forward.cu:30-63); sh points at coefficient 0 of this channel, stride 3.
-__device__ __forceinline__ float sh_channel(int deg, const float* __restrict__ sh, float x, float y, float z) {
+__device__ __forceinline__ float sh_channel(int deg, const float* sh, float x, float y, float z) {
     float result = SH_C0 * sh[0];
     if (deg > 0) {
         result = result - SH_C1 * y * sh[3] + SH_C1 * z * sh[6] - SH_C1 * x * sh[9];
@@ -43,8 +43,27 @@ __device__ __forceinline__ float sh_channel(int deg, const float* __restrict__ s
     return result + 0.5f;
 }
 
-__global__ void __launch_bounds__(256) preprocess_kernel(FwdParams p, GeometryState g, int* __restrict__ radii_out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// FAST_SH (M == 16, 16-byte aligned): the wave moves its 64 Gaussians' 12 KiB SH block with coalesced 16-byte loads
+// and transposes it through LDS (pitch 13 float4, conflict-free b128 accesses) instead of 48 loads at a 192-byte
+// lane stride.  The values, and the order of the arithmetic on them, are unchanged.
+constexpr int SH_PITCH4 = 13;
+
+template <bool FAST_SH>
+__global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometryState g, int* __restrict__ radii_out) {
+    __shared__ float4 stage[FAST_SH ? 64 * SH_PITCH4 : 1];
+    const int lane = threadIdx.x;
+    const int base = blockIdx.x * 64;
+    const int idx = base + lane;
+    if (FAST_SH) {
+        const float4* src = reinterpret_cast<const float4*>(p.shs) + (size_t)base * 12;
+        const int nvalid = min(64, p.P - base) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int f = i * 64 + lane;
+            if (f < nvalid) stage[(f / 12) * SH_PITCH4 + (f % 12)] = src[f];
+        }
+        __syncthreads();
+    }
     if (idx >= p.P) return;
 
     // forward.cu:200-201
@@ -150,10 +169,22 @@ __global__ void __launch_bounds__(256) preprocess_kernel(FwdParams p, GeometrySt
                     float dx = px - p.cam_pos[0], dy = py - p.cam_pos[1], dz = pz - p.cam_pos[2];
                     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
                     dx = dx / len; dy = dy / len; dz = dz / len;
-                    const float* sh = p.shs + (size_t)idx * p.M * 3;
-                    cr = sh_channel(p.D, sh + 0, dx, dy, dz);
-                    cg = sh_channel(p.D, sh + 1, dx, dy, dz);
-                    cb = sh_channel(p.D, sh + 2, dx, dy, dz);
+                    if (FAST_SH) {
+                        float sh[48];
+#pragma unroll
+                        for (int q = 0; q < 12; q++) {
+                            const float4 v = stage[lane * SH_PITCH4 + q];
+                            sh[4 * q] = v.x; sh[4 * q + 1] = v.y; sh[4 * q + 2] = v.z; sh[4 * q + 3] = v.w;
+                        }
+                        cr = sh_channel(p.D, sh + 0, dx, dy, dz);
+                        cg = sh_channel(p.D, sh + 1, dx, dy, dz);
+                        cb = sh_channel(p.D, sh + 2, dx, dy, dz);
+                    } else {
+                        const float* sh = p.shs + (size_t)idx * p.M * 3;
+                        cr = sh_channel(p.D, sh + 0, dx, dy, dz);
+                        cg = sh_channel(p.D, sh + 1, dx, dy, dz);
+                        cb = sh_channel(p.D, sh + 2, dx, dy, dz);
+                    }
                     g.clamped[idx] = (unsigned char)((cr < 0 ? 1 : 0) | (cg < 0 ? 2 : 0) | (cb < 0 ? 4 : 0));
                     cr = fmaxf(cr, 0.0f); cg = fmaxf(cg, 0.0f); cb = fmaxf(cb, 0.0f);
                 } else {
@@ -186,7 +217,11 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* _
 
 hipError_t launch_preprocess(const FwdParams& p, const GeometryState& g, int* radii_out, hipStream_t stream) {
     if (p.P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(preprocess_kernel, dim3((p.P + 255) / 256), dim3(256), 0, stream, p, g, radii_out);
+    const bool fast = p.shs != nullptr && p.colors_precomp == nullptr && p.M == 16 && (reinterpret_cast<uintptr_t>(p.shs) % 16 == 0);
+    if (fast)
+        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((p.P + 63) / 64), dim3(64), 0, stream, p, g, radii_out);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<false>, dim3((p.P + 63) / 64), dim3(64), 0, stream, p, g, radii_out);
     return hipGetLastError();
 }
 

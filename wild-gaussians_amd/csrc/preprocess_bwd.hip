@@ -1,8 +1,15 @@
 // K10 + K11 fused: per-Gaussian backward of the preprocess stage for gfx950.
 // Replaces computeCov2DCUDA (backward.cu:144-310), preprocessCUDA backward (backward.cu:382-432), the SH
 // backward (backward.cu:20-139) and the covariance backward (backward.cu:314-377), which the reference runs
-// as two kernels with dL_dcov3D / dL_dmean3D round-tripping through HBM in between.  One lane per
-// Gaussian, streaming: every input is read once, every output written once.
+// as two kernels with dL_dcov3D / dL_dmean3D round-tripping through HBM in between.
+//
+// Streaming kernel, one Gaussian per lane, one 64-lane wave per workgroup.  The only wide per-Gaussian arrays
+// are the SH coefficients in (192 B at M = 16) and their gradients out (192 B): read or written one float per
+// lane they are a 192-byte-stride access (64 different cache lines per instruction, 96 such instructions).  With
+// M == 16 the wave instead moves its 64 Gaussians' 12 KiB block with 16-byte coalesced accesses and transposes
+// it through LDS (row pitch 52 floats = 13 float4: conflict-free ds_read/ds_write_b128 for every 16-lane group).
+// Every output except the four accumulation targets of the per-tile pass is fully written here (zeros for culled
+// Gaussians), so the caller does not have to clear them.
 //
 // The formulas are the reference's hand-derived ones, including its quirks:
 //  - dL_dopacity arrives w.r.t. the mip-filtered opacity and leaves multiplied by coef (or zeroed when the
@@ -14,225 +21,292 @@
 
 namespace wg {
 
-__constant__ const float BSH_C0 = 0.28209479177387814f;
-__constant__ const float BSH_C1 = 0.4886025119029199f;
-__constant__ const float BSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
-                                      -1.0925484305920792f, 0.5462742152960396f};
-__constant__ const float BSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
-                                      -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+constexpr float C0 = 0.28209479177387814f;
+constexpr float C1 = 0.4886025119029199f;
+constexpr float C2a = 1.0925484305920792f, C2b = -1.0925484305920792f, C2c = 0.31539156525252005f, C2d = -1.0925484305920792f,
+                C2e = 0.5462742152960396f;
+constexpr float C3a = -0.5900435899266435f, C3b = 2.890611442640554f, C3c = -0.4570457994644658f, C3d = 0.3731763325901154f,
+                C3e = -0.4570457994644658f, C3f = 1.445305721320277f, C3g = -0.5900435899266435f;
 
-__global__ void __launch_bounds__(256) preprocess_backward_kernel(
+constexpr int SH_PITCH4 = 13;  // float4 per Gaussian in LDS (12 used + 1 pad)
+
+// SH basis values B[k] and their derivatives w.r.t. the (unnormalised-looking) direction components, for the
+// polynomial of forward.cu:30-62; coefficients of degrees above `deg` are zeroed.
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* B, float* Dx, float* Dy, float* Dz) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    const float m1 = deg > 0 ? 1.f : 0.f, m2 = deg > 1 ? 1.f : 0.f, m3 = deg > 2 ? 1.f : 0.f;
+    B[0] = C0; Dx[0] = 0.f; Dy[0] = 0.f; Dz[0] = 0.f;
+    B[1] = m1 * -C1 * y; Dx[1] = 0.f; Dy[1] = m1 * -C1; Dz[1] = 0.f;
+    B[2] = m1 * C1 * z; Dx[2] = 0.f; Dy[2] = 0.f; Dz[2] = m1 * C1;
+    B[3] = m1 * -C1 * x; Dx[3] = m1 * -C1; Dy[3] = 0.f; Dz[3] = 0.f;
+    B[4] = m2 * C2a * xy; Dx[4] = m2 * C2a * y; Dy[4] = m2 * C2a * x; Dz[4] = 0.f;
+    B[5] = m2 * C2b * yz; Dx[5] = 0.f; Dy[5] = m2 * C2b * z; Dz[5] = m2 * C2b * y;
+    B[6] = m2 * C2c * (2.f * zz - xx - yy); Dx[6] = m2 * C2c * -2.f * x; Dy[6] = m2 * C2c * -2.f * y; Dz[6] = m2 * C2c * 4.f * z;
+    B[7] = m2 * C2d * xz; Dx[7] = m2 * C2d * z; Dy[7] = 0.f; Dz[7] = m2 * C2d * x;
+    B[8] = m2 * C2e * (xx - yy); Dx[8] = m2 * C2e * 2.f * x; Dy[8] = m2 * C2e * -2.f * y; Dz[8] = 0.f;
+    B[9] = m3 * C3a * y * (3.f * xx - yy); Dx[9] = m3 * C3a * 6.f * xy; Dy[9] = m3 * C3a * 3.f * (xx - yy); Dz[9] = 0.f;
+    B[10] = m3 * C3b * xy * z; Dx[10] = m3 * C3b * yz; Dy[10] = m3 * C3b * xz; Dz[10] = m3 * C3b * xy;
+    B[11] = m3 * C3c * y * (4.f * zz - xx - yy); Dx[11] = m3 * C3c * -2.f * xy; Dy[11] = m3 * C3c * (-3.f * yy + 4.f * zz - xx);
+    Dz[11] = m3 * C3c * 8.f * yz;
+    B[12] = m3 * C3d * z * (2.f * zz - 3.f * xx - 3.f * yy); Dx[12] = m3 * C3d * -6.f * xz; Dy[12] = m3 * C3d * -6.f * yz;
+    Dz[12] = m3 * C3d * 3.f * (2.f * zz - xx - yy);
+    B[13] = m3 * C3e * x * (4.f * zz - xx - yy); Dx[13] = m3 * C3e * (-3.f * xx + 4.f * zz - yy); Dy[13] = m3 * C3e * -2.f * xy;
+    Dz[13] = m3 * C3e * 8.f * xz;
+    B[14] = m3 * C3f * z * (xx - yy); Dx[14] = m3 * C3f * 2.f * xz; Dy[14] = m3 * C3f * -2.f * yz; Dz[14] = m3 * C3f * (xx - yy);
+    B[15] = m3 * C3g * x * (xx - 3.f * yy); Dx[15] = m3 * C3g * 3.f * (xx - yy); Dy[15] = m3 * C3g * -6.f * xy; Dz[15] = 0.f;
+}
+
+template <bool FAST_SH>
+__global__ void __launch_bounds__(64) preprocess_backward_kernel(
     BwdParams p, const float4* __restrict__ splats, const unsigned char* __restrict__ clamped,
     const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
     const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
     float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.P || !(p.radii[idx] > 0)) return;
+    __shared__ float4 stage[FAST_SH ? 64 * SH_PITCH4 : 1];
+    const int lane = threadIdx.x;
+    const int base = blockIdx.x * 64;
+    const int idx = base + lane;
+    const bool in = idx < p.P;
+    const bool vis = in && p.radii[idx] > 0;
 
-    const float* vm = p.viewmatrix;
-    const float* proj = p.projmatrix;
-    const float mx = p.means3D[3 * idx], my = p.means3D[3 * idx + 1], mz = p.means3D[3 * idx + 2];
-    const float* cv = p.cov3D + 6 * (size_t)idx;
-    const float v0 = cv[0], v1 = cv[1], v2 = cv[2], v3 = cv[3], v4 = cv[4], v5 = cv[5];
-
-    // ------------------------------------------------------------------ K10: backward.cu:167-310
-    const float dcx = dL_dconic[4 * idx], dcy = dL_dconic[4 * idx + 1], dcz = dL_dconic[4 * idx + 3];
-    const float combined_opacity = splats[3 * (size_t)idx + 1].y;
-
-    float tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
-    float ty = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
-    const float tz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
-    const float limx = 1.3f * p.tan_fovx, limy = 1.3f * p.tan_fovy;
-    const float txtz = tx / tz, tytz = ty / tz;
-    tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
-    ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
-    const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
-    const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-
-    const float hx = p.focal_x, hy = p.focal_y;
-    const float j00 = hx / tz, j02 = -(hx * tx) / (tz * tz), j11 = hy / tz, j12 = -(hy * ty) / (tz * tz);
-    // T[c][r] (c = column 0/1, r = row): see preprocess.hip
-    const float T00 = vm[0] * j00 + vm[2] * j02, T01 = vm[4] * j00 + vm[6] * j02, T02 = vm[8] * j00 + vm[10] * j02;
-    const float T10 = vm[1] * j11 + vm[2] * j12, T11 = vm[5] * j11 + vm[6] * j12, T12 = vm[9] * j11 + vm[10] * j12;
-    // P0k = sum_r T[0][r] V[k][r], P1k likewise (V symmetric)
-    const float P00 = T00 * v0 + T01 * v1 + T02 * v2, P01 = T00 * v1 + T01 * v3 + T02 * v4, P02 = T00 * v2 + T01 * v4 + T02 * v5;
-    const float P10 = T10 * v0 + T11 * v1 + T12 * v2, P11 = T10 * v1 + T11 * v3 + T12 * v4, P12 = T10 * v2 + T11 * v4 + T12 * v5;
-    const float a0 = P00 * T00 + P01 * T01 + P02 * T02;  // cov2D[0][0] before the filter
-    const float b = P10 * T00 + P11 * T01 + P12 * T02;   // cov2D[0][1]
-    const float c0 = P10 * T10 + P11 * T11 + P12 * T12;  // cov2D[1][1]
-    const float ks = p.kernel_size;
-
-    const float det_0 = fmaxf(1e-6f, a0 * c0 - b * b);
-    const float det_1 = fmaxf(1e-6f, (a0 + ks) * (c0 + ks) - b * b);
-    const float coef = sqrtf(det_0 / (det_1 + 1e-6f) + 1e-6f);
-    const bool degenerate = (det_0 <= 1e-6f) || (det_1 <= 1e-6f);
-
-    const float dLdo_in = dL_dopacity[idx];
-    const float opacity = combined_opacity / (coef + 1e-6f);
-    const float dL_dcoef = dLdo_in * opacity;
-    const float dL_dsqrtcoef = dL_dcoef * 0.5f / (coef + 1e-6f);
-    const float dL_ddet0 = dL_dsqrtcoef / (det_1 + 1e-6f);
-    const float dL_ddet1 = dL_dsqrtcoef * det_0 * (-1.f / (det_1 * det_1 + 1e-6f));
-    const float dcoef_da = dL_ddet0 * c0 + dL_ddet1 * (c0 + ks);
-    const float dcoef_db = (dL_ddet0 + dL_ddet1) * (-2.f * b);
-    const float dcoef_dc = dL_ddet0 * a0 + dL_ddet1 * (a0 + ks);
-
-    const float a = a0 + ks, c = c0 + ks;
-    const float denom = a * c - b * b;
-    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
-    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (denom2inv != 0.f) {
-        dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcz);
-        dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c) * dcx);
-        dL_db = denom2inv * 2 * (b * c * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
-        if (degenerate) {
-            dL_dopacity[idx] = 0.f;
-        } else {
-            dL_da += dcoef_da;
-            dL_dc += dcoef_dc;
-            dL_db += dcoef_db;
-            dL_dopacity[idx] = dLdo_in * coef;
+    if (FAST_SH) {  // 64 Gaussians x 12 float4, coalesced; row pitch 13 float4 in LDS
+        const float4* src = reinterpret_cast<const float4*>(p.shs) + (size_t)base * 12;
+        const int nvalid = min(64, p.P - base) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int f = i * 64 + lane;
+            if (f < nvalid) stage[(f / 12) * SH_PITCH4 + (f % 12)] = src[f];
         }
-        dcov[0] = T00 * T00 * dL_da + T00 * T10 * dL_db + T10 * T10 * dL_dc;
-        dcov[3] = T01 * T01 * dL_da + T01 * T11 * dL_db + T11 * T11 * dL_dc;
-        dcov[5] = T02 * T02 * dL_da + T02 * T12 * dL_db + T12 * T12 * dL_dc;
-        dcov[1] = 2 * T00 * T01 * dL_da + (T00 * T11 + T01 * T10) * dL_db + 2 * T10 * T11 * dL_dc;
-        dcov[2] = 2 * T00 * T02 * dL_da + (T00 * T12 + T02 * T10) * dL_db + 2 * T10 * T12 * dL_dc;
-        dcov[4] = 2 * T02 * T01 * dL_da + (T01 * T12 + T02 * T11) * dL_db + 2 * T11 * T12 * dL_dc;
+        __syncthreads();
     }
-    {
+
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gmx = 0.f, gmy = 0.f, gmz = 0.f;
+    float dsh[FAST_SH ? 48 : 1];
+    if (FAST_SH) {
+#pragma unroll
+        for (int k = 0; k < 48; k++) dsh[k] = 0.f;
+    }
+    float dsc[3] = {0.f, 0.f, 0.f};
+    float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    if (vis) {
+        const float* vm = p.viewmatrix;
+        const float* proj = p.projmatrix;
+        const float mx = p.means3D[3 * idx], my = p.means3D[3 * idx + 1], mz = p.means3D[3 * idx + 2];
+        const float* cv = p.cov3D + 6 * (size_t)idx;
+        const float v0 = cv[0], v1 = cv[1], v2 = cv[2], v3 = cv[3], v4 = cv[4], v5 = cv[5];
+
+        // ------------------------------------------------------------------ K10: backward.cu:167-310
+        const float4 dconic = reinterpret_cast<const float4*>(dL_dconic)[idx];
+        const float dcx = dconic.x, dcy = dconic.y, dcz = dconic.w;
+        const float combined_opacity = splats[3 * (size_t)idx + 1].y;
+
+        float tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
+        float ty = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
+        const float tz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+        const float limx = 1.3f * p.tan_fovx, limy = 1.3f * p.tan_fovy;
+        const float txtz = tx / tz, tytz = ty / tz;
+        tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+        ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+
+        const float hx = p.focal_x, hy = p.focal_y;
+        const float j00 = hx / tz, j02 = -(hx * tx) / (tz * tz), j11 = hy / tz, j12 = -(hy * ty) / (tz * tz);
+        // T[c][r] (c = column 0/1, r = row): see preprocess.hip
+        const float T00 = vm[0] * j00 + vm[2] * j02, T01 = vm[4] * j00 + vm[6] * j02, T02 = vm[8] * j00 + vm[10] * j02;
+        const float T10 = vm[1] * j11 + vm[2] * j12, T11 = vm[5] * j11 + vm[6] * j12, T12 = vm[9] * j11 + vm[10] * j12;
+        // P0k = sum_r T[0][r] V[k][r], P1k likewise (V symmetric)
+        const float P00 = T00 * v0 + T01 * v1 + T02 * v2, P01 = T00 * v1 + T01 * v3 + T02 * v4, P02 = T00 * v2 + T01 * v4 + T02 * v5;
+        const float P10 = T10 * v0 + T11 * v1 + T12 * v2, P11 = T10 * v1 + T11 * v3 + T12 * v4, P12 = T10 * v2 + T11 * v4 + T12 * v5;
+        const float a0 = P00 * T00 + P01 * T01 + P02 * T02;  // cov2D[0][0] before the filter
+        const float b = P10 * T00 + P11 * T01 + P12 * T02;   // cov2D[0][1]
+        const float c0 = P10 * T10 + P11 * T11 + P12 * T12;  // cov2D[1][1]
+        const float ks = p.kernel_size;
+
+        const float det_0 = fmaxf(1e-6f, a0 * c0 - b * b);
+        const float det_1 = fmaxf(1e-6f, (a0 + ks) * (c0 + ks) - b * b);
+        const float coef = sqrtf(det_0 / (det_1 + 1e-6f) + 1e-6f);
+        const bool degenerate = (det_0 <= 1e-6f) || (det_1 <= 1e-6f);
+
+        const float dLdo_in = dL_dopacity[idx];
+        const float opacity = combined_opacity / (coef + 1e-6f);
+        const float dL_dcoef = dLdo_in * opacity;
+        const float dL_dsqrtcoef = dL_dcoef * 0.5f / (coef + 1e-6f);
+        const float dL_ddet0 = dL_dsqrtcoef / (det_1 + 1e-6f);
+        const float dL_ddet1 = dL_dsqrtcoef * det_0 * (-1.f / (det_1 * det_1 + 1e-6f));
+        const float dcoef_da = dL_ddet0 * c0 + dL_ddet1 * (c0 + ks);
+        const float dcoef_db = (dL_ddet0 + dL_ddet1) * (-2.f * b);
+        const float dcoef_dc = dL_ddet0 * a0 + dL_ddet1 * (a0 + ks);
+
+        const float a = a0 + ks, c = c0 + ks;
+        const float denom = a * c - b * b;
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        if (denom2inv != 0.f) {
+            dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcz);
+            dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c) * dcx);
+            dL_db = denom2inv * 2 * (b * c * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
+            if (degenerate) {
+                dL_dopacity[idx] = 0.f;
+            } else {
+                dL_da += dcoef_da;
+                dL_dc += dcoef_dc;
+                dL_db += dcoef_db;
+                dL_dopacity[idx] = dLdo_in * coef;
+            }
+            dcov[0] = T00 * T00 * dL_da + T00 * T10 * dL_db + T10 * T10 * dL_dc;
+            dcov[3] = T01 * T01 * dL_da + T01 * T11 * dL_db + T11 * T11 * dL_dc;
+            dcov[5] = T02 * T02 * dL_da + T02 * T12 * dL_db + T12 * T12 * dL_dc;
+            dcov[1] = 2 * T00 * T01 * dL_da + (T00 * T11 + T01 * T10) * dL_db + 2 * T10 * T11 * dL_dc;
+            dcov[2] = 2 * T00 * T02 * dL_da + (T00 * T12 + T02 * T10) * dL_db + 2 * T10 * T12 * dL_dc;
+            dcov[4] = 2 * T02 * T01 * dL_da + (T01 * T12 + T02 * T11) * dL_db + 2 * T11 * T12 * dL_dc;
+        }
+
+        // dL/dT (backward.cu:273-284), dL/dJ (:288-291), dL/dt (:293-300)
+        const float dT00 = 2 * P00 * dL_da + P10 * dL_db, dT01 = 2 * P01 * dL_da + P11 * dL_db, dT02 = 2 * P02 * dL_da + P12 * dL_db;
+        const float dT10 = 2 * P10 * dL_dc + P00 * dL_db, dT11 = 2 * P11 * dL_dc + P01 * dL_db, dT12 = 2 * P12 * dL_dc + P02 * dL_db;
+        const float dJ00 = vm[0] * dT00 + vm[4] * dT01 + vm[8] * dT02;
+        const float dJ02 = vm[2] * dT00 + vm[6] * dT01 + vm[10] * dT02;
+        const float dJ11 = vm[1] * dT10 + vm[5] * dT11 + vm[9] * dT12;
+        const float dJ12 = vm[2] * dT10 + vm[6] * dT11 + vm[10] * dT12;
+        const float itz = 1.f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+        const float dtx = x_grad_mul * -hx * itz2 * dJ02;
+        const float dty = y_grad_mul * -hy * itz2 * dJ12;
+        const float dtz = -hx * itz2 * dJ00 - hy * itz2 * dJ11 + (2 * hx * tx) * itz3 * dJ02 + (2 * hy * ty) * itz3 * dJ12;
+        // transformVec4x3Transpose, auxiliary.h:89-97
+        gmx = vm[0] * dtx + vm[1] * dty + vm[2] * dtz;
+        gmy = vm[4] * dtx + vm[5] * dty + vm[6] * dtz;
+        gmz = vm[8] * dtx + vm[9] * dty + vm[10] * dtz;
+
+        // ------------------------------------------------------------------ K11: backward.cu:406-423
+        {
+            const float hw = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
+            const float m_w = 1.0f / (hw + 0.0000001f);
+            const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
+            const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
+            const float g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1];
+            gmx += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+            gmy += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+            gmz += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+        }
+
+        // ------------------------------------------------------------------ SH backward, backward.cu:20-139
+        if (p.shs != nullptr) {
+            const float ox = mx - p.campos[0], oy = my - p.campos[1], oz = mz - p.campos[2];
+            const float sum2 = ox * ox + oy * oy + oz * oz;
+            const float ilen = 1.0f / sqrtf(sum2);
+            float B[16], Dx[16], Dy[16], Dz[16];
+            sh_basis(p.D, ox * ilen, oy * ilen, oz * ilen, B, Dx, Dy, Dz);
+            const unsigned char cl = clamped[idx];
+            float dRGB[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) dRGB[ch] = ((cl >> ch) & 1) ? 0.f : dL_dcolor[3 * idx + ch];
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;  // dL_ddir
+            if (FAST_SH) {
+                float sh[48];
+#pragma unroll
+                for (int q = 0; q < 12; q++) {
+                    const float4 v = stage[lane * SH_PITCH4 + q];
+                    sh[4 * q] = v.x; sh[4 * q + 1] = v.y; sh[4 * q + 2] = v.z; sh[4 * q + 3] = v.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        dsh[3 * k + ch] = B[k] * dRGB[ch];
+                        const float w = sh[3 * k + ch] * dRGB[ch];
+                        ddx += Dx[k] * w;
+                        ddy += Dy[k] * w;
+                        ddz += Dz[k] * w;
+                    }
+            } else {
+                const float* sh = p.shs + (size_t)idx * p.M * 3;
+                float* d = dL_dsh + (size_t)idx * p.M * 3;
+                const int ncoef = (p.D + 1) * (p.D + 1);
+                for (int k = 0; k < p.M; k++)
+                    for (int ch = 0; ch < 3; ch++) {
+                        float bk = 0.f, dxk = 0.f, dyk = 0.f, dzk = 0.f;
+                        if (k < ncoef && k < 16) { bk = B[k]; dxk = Dx[k]; dyk = Dy[k]; dzk = Dz[k]; }
+                        d[3 * k + ch] = bk * dRGB[ch];
+                        const float w = sh[3 * k + ch] * dRGB[ch];
+                        ddx += dxk * w;
+                        ddy += dyk * w;
+                        ddz += dzk * w;
+                    }
+            }
+            // dnormvdv, auxiliary.h:107-117
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            gmx += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+            gmy += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+            gmz += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+        }
+
+        // ------------------------------------------------------------------ covariance backward, backward.cu:314-377
+        if (p.scales != nullptr) {
+            const float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            const float s[3] = {p.scale_modifier * p.scales[3 * idx], p.scale_modifier * p.scales[3 * idx + 1],
+                                p.scale_modifier * p.scales[3 * idx + 2]};
+            // R[c][r] column-major as filled by the reference
+            const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                                   {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                                   {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+            // dL_dSigma (symmetric, off-diagonals halved), dS[c][k]
+            const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                    {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                    {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+            // dL_dM[c][w] = sum_k 2*M[k][w]*dS[c][k],  M[k][w] = s_w * R[k][w]
+            float dM[3][3];
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+                for (int w = 0; w < 3; w++)
+                    dM[cc][w] = 2.f * s[w] * (R[0][w] * dS[cc][0] + R[1][w] * dS[cc][1] + R[2][w] * dS[cc][2]);
+            // dL_dscale_w = sum_c R[c][w] * dM[c][w]
+#pragma unroll
+            for (int w = 0; w < 3; w++) dsc[w] = R[0][w] * dM[0][w] + R[1][w] * dM[1][w] + R[2][w] * dM[2][w];
+            // D(c,r) = dL_dMt[c][r] * s_c = dM[r][c] * s_c
+#define D(c_, r_) (dM[r_][c_] * s[c_])
+            dq.x = 2 * z * (D(0, 1) - D(1, 0)) + 2 * y * (D(2, 0) - D(0, 2)) + 2 * x * (D(1, 2) - D(2, 1));
+            dq.y = 2 * y * (D(1, 0) + D(0, 1)) + 2 * z * (D(2, 0) + D(0, 2)) + 2 * r * (D(1, 2) - D(2, 1)) - 4 * x * (D(2, 2) + D(1, 1));
+            dq.z = 2 * x * (D(1, 0) + D(0, 1)) + 2 * r * (D(2, 0) - D(0, 2)) + 2 * z * (D(1, 2) + D(2, 1)) - 4 * y * (D(2, 2) + D(0, 0));
+            dq.w = 2 * r * (D(0, 1) - D(1, 0)) + 2 * x * (D(2, 0) + D(0, 2)) + 2 * y * (D(1, 2) + D(2, 1)) - 4 * z * (D(1, 1) + D(0, 0));
+#undef D
+        }
+    }
+
+    // ---- outputs: written for every Gaussian of the range (zeros when culled) ----
+    if (in) {
         float* o = dL_dcov3D + 6 * (size_t)idx;
         o[0] = dcov[0]; o[1] = dcov[1]; o[2] = dcov[2]; o[3] = dcov[3]; o[4] = dcov[4]; o[5] = dcov[5];
-    }
-
-    // dL/dT (backward.cu:273-284), dL/dJ (:288-291), dL/dt (:293-300)
-    const float dT00 = 2 * P00 * dL_da + P10 * dL_db, dT01 = 2 * P01 * dL_da + P11 * dL_db, dT02 = 2 * P02 * dL_da + P12 * dL_db;
-    const float dT10 = 2 * P10 * dL_dc + P00 * dL_db, dT11 = 2 * P11 * dL_dc + P01 * dL_db, dT12 = 2 * P12 * dL_dc + P02 * dL_db;
-    const float dJ00 = vm[0] * dT00 + vm[4] * dT01 + vm[8] * dT02;
-    const float dJ02 = vm[2] * dT00 + vm[6] * dT01 + vm[10] * dT02;
-    const float dJ11 = vm[1] * dT10 + vm[5] * dT11 + vm[9] * dT12;
-    const float dJ12 = vm[2] * dT10 + vm[6] * dT11 + vm[10] * dT12;
-    const float itz = 1.f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
-    const float dtx = x_grad_mul * -hx * itz2 * dJ02;
-    const float dty = y_grad_mul * -hy * itz2 * dJ12;
-    const float dtz = -hx * itz2 * dJ00 - hy * itz2 * dJ11 + (2 * hx * tx) * itz3 * dJ02 + (2 * hy * ty) * itz3 * dJ12;
-    // transformVec4x3Transpose, auxiliary.h:89-97
-    float gmx = vm[0] * dtx + vm[1] * dty + vm[2] * dtz;
-    float gmy = vm[4] * dtx + vm[5] * dty + vm[6] * dtz;
-    float gmz = vm[8] * dtx + vm[9] * dty + vm[10] * dtz;
-
-    // ------------------------------------------------------------------ K11: backward.cu:406-423
-    {
-        const float hw = proj[3] * mx + proj[7] * my + proj[11] * mz + proj[15];
-        const float m_w = 1.0f / (hw + 0.0000001f);
-        const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
-        const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
-        const float g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1];
-        gmx += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
-        gmy += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
-        gmz += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
-    }
-
-    // ------------------------------------------------------------------ SH backward, backward.cu:20-139
-    if (p.shs != nullptr) {
-        const float ox = mx - p.campos[0], oy = my - p.campos[1], oz = mz - p.campos[2];
-        const float sum2 = ox * ox + oy * oy + oz * oz;
-        const float ilen = 1.0f / sqrtf(sum2);
-        const float x = ox * ilen, y = oy * ilen, z = oz * ilen;
-        const unsigned char cl = clamped[idx];
-        const float* sh = p.shs + (size_t)idx * p.M * 3;
-        float* dsh = dL_dsh + (size_t)idx * p.M * 3;
-        const int deg = p.D;
-        float ddx = 0.f, ddy = 0.f, ddz = 0.f;  // dL_ddir
-        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-            const float dRGB = ((cl >> ch) & 1) ? 0.f : dL_dcolor[3 * idx + ch];
-            const float* s = sh + ch;
-            float* d = dsh + ch;
-            d[0] = BSH_C0 * dRGB;
-            if (deg > 0) {
-                d[3] = -BSH_C1 * y * dRGB;
-                d[6] = BSH_C1 * z * dRGB;
-                d[9] = -BSH_C1 * x * dRGB;
-                float rx = -BSH_C1 * s[9], ry = -BSH_C1 * s[3], rz = BSH_C1 * s[6];
-                if (deg > 1) {
-                    d[12] = BSH_C2[0] * xy * dRGB;
-                    d[15] = BSH_C2[1] * yz * dRGB;
-                    d[18] = BSH_C2[2] * (2.f * zz - xx - yy) * dRGB;
-                    d[21] = BSH_C2[3] * xz * dRGB;
-                    d[24] = BSH_C2[4] * (xx - yy) * dRGB;
-                    rx += BSH_C2[0] * y * s[12] + BSH_C2[2] * 2.f * -x * s[18] + BSH_C2[3] * z * s[21] + BSH_C2[4] * 2.f * x * s[24];
-                    ry += BSH_C2[0] * x * s[12] + BSH_C2[1] * z * s[15] + BSH_C2[2] * 2.f * -y * s[18] + BSH_C2[4] * 2.f * -y * s[24];
-                    rz += BSH_C2[1] * y * s[15] + BSH_C2[2] * 2.f * 2.f * z * s[18] + BSH_C2[3] * x * s[21];
-                    if (deg > 2) {
-                        d[27] = BSH_C3[0] * y * (3.f * xx - yy) * dRGB;
-                        d[30] = BSH_C3[1] * xy * z * dRGB;
-                        d[33] = BSH_C3[2] * y * (4.f * zz - xx - yy) * dRGB;
-                        d[36] = BSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * dRGB;
-                        d[39] = BSH_C3[4] * x * (4.f * zz - xx - yy) * dRGB;
-                        d[42] = BSH_C3[5] * z * (xx - yy) * dRGB;
-                        d[45] = BSH_C3[6] * x * (xx - 3.f * yy) * dRGB;
-                        rx += BSH_C3[0] * s[27] * 3.f * 2.f * xy + BSH_C3[1] * s[30] * yz + BSH_C3[2] * s[33] * -2.f * xy +
-                              BSH_C3[3] * s[36] * -3.f * 2.f * xz + BSH_C3[4] * s[39] * (-3.f * xx + 4.f * zz - yy) +
-                              BSH_C3[5] * s[42] * 2.f * xz + BSH_C3[6] * s[45] * 3.f * (xx - yy);
-                        ry += BSH_C3[0] * s[27] * 3.f * (xx - yy) + BSH_C3[1] * s[30] * xz +
-                              BSH_C3[2] * s[33] * (-3.f * yy + 4.f * zz - xx) + BSH_C3[3] * s[36] * -3.f * 2.f * yz +
-                              BSH_C3[4] * s[39] * -2.f * xy + BSH_C3[5] * s[42] * -2.f * yz + BSH_C3[6] * s[45] * -3.f * 2.f * xy;
-                        rz += BSH_C3[1] * s[30] * xy + BSH_C3[2] * s[33] * 4.f * 2.f * yz + BSH_C3[3] * s[36] * 3.f * (2.f * zz - xx - yy) +
-                              BSH_C3[4] * s[39] * 4.f * 2.f * xz + BSH_C3[5] * s[42] * (xx - yy);
-                    }
-                }
-                ddx += rx * dRGB;
-                ddy += ry * dRGB;
-                ddz += rz * dRGB;
-            }
+        dL_dmean3D[3 * idx] = gmx;
+        dL_dmean3D[3 * idx + 1] = gmy;
+        dL_dmean3D[3 * idx + 2] = gmz;
+        if (p.scales != nullptr) {
+            dL_dscale[3 * idx] = dsc[0];
+            dL_dscale[3 * idx + 1] = dsc[1];
+            dL_dscale[3 * idx + 2] = dsc[2];
+            reinterpret_cast<float4*>(dL_drot)[idx] = dq;
         }
-        // dnormvdv, auxiliary.h:107-117
-        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-        gmx += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
-        gmy += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
-        gmz += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+        if (!FAST_SH && p.shs != nullptr && !vis) {
+            float* d = dL_dsh + (size_t)idx * p.M * 3;
+            for (int k = 0; k < p.M * 3; k++) d[k] = 0.f;
+        }
     }
-    dL_dmean3D[3 * idx] = gmx;
-    dL_dmean3D[3 * idx + 1] = gmy;
-    dL_dmean3D[3 * idx + 2] = gmz;
-
-    // ------------------------------------------------------------------ covariance backward, backward.cu:314-377
-    if (p.scales != nullptr) {
-        const float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
-        const float r = q.x, x = q.y, y = q.z, z = q.w;
-        const float s[3] = {p.scale_modifier * p.scales[3 * idx], p.scale_modifier * p.scales[3 * idx + 1],
-                            p.scale_modifier * p.scales[3 * idx + 2]};
-        // R[c][r] column-major as filled by the reference
-        const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
-                               {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
-                               {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
-        // dL_dSigma (symmetric, off-diagonals halved), dS[c][k]
-        const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
-                                {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
-                                {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
-        // dL_dM[c][w] = sum_k 2*M[k][w]*dS[c][k],  M[k][w] = s_w * R[k][w]
-        float dM[3][3];
+    if (FAST_SH) {
+        __syncthreads();  // every lane has consumed its SH inputs
 #pragma unroll
-        for (int cc = 0; cc < 3; cc++)
+        for (int q = 0; q < 12; q++) stage[lane * SH_PITCH4 + q] = make_float4(dsh[4 * q], dsh[4 * q + 1], dsh[4 * q + 2], dsh[4 * q + 3]);
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(dL_dsh) + (size_t)base * 12;
+        const int nvalid = min(64, p.P - base) * 12;
 #pragma unroll
-            for (int w = 0; w < 3; w++)
-                dM[cc][w] = 2.f * s[w] * (R[0][w] * dS[cc][0] + R[1][w] * dS[cc][1] + R[2][w] * dS[cc][2]);
-        // dL_dscale_w = sum_c R[c][w] * dM[c][w]
-        float* dsc = dL_dscale + 3 * (size_t)idx;
-#pragma unroll
-        for (int w = 0; w < 3; w++) dsc[w] = R[0][w] * dM[0][w] + R[1][w] * dM[1][w] + R[2][w] * dM[2][w];
-        // D(c,r) = dL_dMt[c][r] * s_c = dM[r][c] * s_c
-#define D(c_, r_) (dM[r_][c_] * s[c_])
-        float4 dq;
-        dq.x = 2 * z * (D(0, 1) - D(1, 0)) + 2 * y * (D(2, 0) - D(0, 2)) + 2 * x * (D(1, 2) - D(2, 1));
-        dq.y = 2 * y * (D(1, 0) + D(0, 1)) + 2 * z * (D(2, 0) + D(0, 2)) + 2 * r * (D(1, 2) - D(2, 1)) - 4 * x * (D(2, 2) + D(1, 1));
-        dq.z = 2 * x * (D(1, 0) + D(0, 1)) + 2 * r * (D(2, 0) - D(0, 2)) + 2 * z * (D(1, 2) + D(2, 1)) - 4 * y * (D(2, 2) + D(0, 0));
-        dq.w = 2 * r * (D(0, 1) - D(1, 0)) + 2 * x * (D(2, 0) + D(0, 2)) + 2 * y * (D(1, 2) + D(2, 1)) - 4 * z * (D(1, 1) + D(0, 0));
-#undef D
-        reinterpret_cast<float4*>(dL_drot)[idx] = dq;
+        for (int i = 0; i < 12; i++) {
+            const int f = i * 64 + lane;
+            if (f < nvalid) dst[f] = stage[(f / 12) * SH_PITCH4 + (f % 12)];
+        }
     }
 }
 
@@ -241,8 +315,15 @@ hipError_t launch_preprocess_backward(const BwdParams& p, const GeometryState& g
                                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                                       float* dL_drot, hipStream_t stream) {
     if (p.P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((p.P + 255) / 256), dim3(256), 0, stream, p, g.splats, g.clamped,
-                       dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    const dim3 grid((p.P + 63) / 64), block(64);
+    const bool fast = p.shs != nullptr && p.M == 16 && (reinterpret_cast<uintptr_t>(p.shs) % 16 == 0) &&
+                      (reinterpret_cast<uintptr_t>(dL_dsh) % 16 == 0);
+    if (fast)
+        hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, 0, stream, p, g.splats, g.clamped, dL_dmean2D, dL_dconic,
+                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    else
+        hipLaunchKernelGGL(preprocess_backward_kernel<false>, grid, block, 0, stream, p, g.splats, g.clamped, dL_dmean2D, dL_dconic,
+                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     return hipGetLastError();
 }
 

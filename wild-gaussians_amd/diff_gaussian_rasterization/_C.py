@@ -158,16 +158,21 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     sh = _f32(sh, device)
     M = sh.size(1) if sh.numel() != 0 else 0
 
-    # rasterize_points.cu:157-165: gradient tensors start at zero (the per-tile pass accumulates into four of them)
-    dL_dmeans2D = torch.zeros((P, 3), dtype=torch.float32, device=device)
-    dL_dcolors = torch.zeros((P, 3), dtype=torch.float32, device=device)
-    dL_dconic = torch.zeros((P, 2, 2), dtype=torch.float32, device=device)
-    dL_dopacity = torch.zeros((P, 1), dtype=torch.float32, device=device)
-    dL_dmeans3D = torch.zeros((P, 3), dtype=torch.float32, device=device)
-    dL_dcov3D = torch.zeros((P, 6), dtype=torch.float32, device=device)
-    dL_dsh = torch.zeros((P, M, 3), dtype=torch.float32, device=device)
-    dL_dscales = torch.zeros((P, 3), dtype=torch.float32, device=device)
-    dL_drotations = torch.zeros((P, 4), dtype=torch.float32, device=device)
+    # The reference zero-fills nine gradient tensors per call (rasterize_points.cu:157-165).  Here only the four
+    # accumulation targets of the per-tile pass need clearing -- they share one allocation, hence one memset -- and
+    # everything else is fully written by the per-Gaussian kernel (zeros for culled Gaussians).
+    acc = torch.zeros((P * 11,), dtype=torch.float32, device=device)
+    dL_dconic = acc[0:4 * P].view(P, 2, 2)
+    dL_dmeans2D = acc[4 * P:7 * P].view(P, 3)
+    dL_dcolors = acc[7 * P:10 * P].view(P, 3)
+    dL_dopacity = acc[10 * P:11 * P].view(P, 1)
+    have_scales = scales.numel() != 0
+    alloc = torch.empty if P != 0 else torch.zeros
+    dL_dmeans3D = alloc((P, 3), dtype=torch.float32, device=device)
+    dL_dcov3D = alloc((P, 6), dtype=torch.float32, device=device)
+    dL_dsh = alloc((P, M, 3), dtype=torch.float32, device=device)
+    dL_dscales = (alloc if have_scales else torch.zeros)((P, 3), dtype=torch.float32, device=device)
+    dL_drotations = (alloc if have_scales else torch.zeros)((P, 4), dtype=torch.float32, device=device)
 
     if P != 0:
         means3D = _f32(means3D, device)

@@ -20,12 +20,13 @@ def main(path):
         ccols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
         if ccols:
             kn = "kernel_name" if "kernel_name" in ccols else "name"
-            q = f"select {kn}, counter_name, count(*), sum(value), avg(value) from counters_collection group by {kn}, counter_name order by {kn}"
+            q = (f"select {kn}, counter_name, count(distinct dispatch_id), sum(value) / count(distinct dispatch_id), avg(duration) "
+                 f"from counters_collection group by {kn}, counter_name order by {kn}")
             rows = list(db.execute(q))
             if rows:
-                print("\nPMC counters (sum over dispatches / avg per dispatch):")
-                for n, cn, c, s, a in rows:
-                    print(f"{n[:70]:70s} {cn:28s} n={c:4d} sum={s:16.0f} avg={a:16.1f}")
+                print("\nPMC counters (value summed over all XCDs/SEs, averaged per dispatch):")
+                for n, cn, c, a, d in rows:
+                    print(f"{n[:60]:60s} {cn:24s} dispatches={c:4d} per_dispatch={a:18.0f} avg_dur_us={d/1e3:9.1f}")
     except sqlite3.Error as e:
         print("no counters:", e)
 

@@ -100,6 +100,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     else { abase = dL_dopacity; astride = 1; }
     // values 8 and 9 (bit1 set) are replicated over bits 0 and 4: let only the bit0 == bit4 == 0 copy issue
     const bool issue = owner && !((lane & 2) && (lane & 17));
+    // constant factor of this lane's value (see the per-pair sums below); values 3..8 also carry the splat's opacity
+    const bool oscale = vidx >= 3 && vidx <= 8;
+    const float vscale = vidx == 3 ? -ddelx_dx : vidx == 4 ? -ddely_dy : (vidx >= 6 && vidx <= 8) ? -0.5f : 1.0f;
 
     float pfx[4], pfy[4], T[4], tfb[4], dLr[4], dLg[4], dLb[4], recr[4], recg[4], recb[4];
     int last[4];
@@ -158,15 +161,23 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             const float o = sc.o;
             const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
             const float colr = r1.w, colg = gb.x, colb = gb.y;
-            float acr = 0.f, acg = 0.f, acb = 0.f, amx = 0.f, amy = 0.f, aab = 0.f, axx = 0.f, axy = 0.f, ayy = 0.f, aop = 0.f;
+            // Per-lane partial sums over this lane's (up to four) pixels.  Constant factors of the reference's
+            // expressions are applied once, after the wave reduction:
+            //   q = G * dL_dalpha;   u = A dx + B dy;   v = C dy + B dx        (dG/ddelx = -G u, dG/ddely = -G v)
+            //   dL_dmean2D.x = -o * 0.5W * sum(q u)           dL_dconic.xx = -0.5 o * sum(q dx dx)
+            //   dL_dmean2D.y = -o * 0.5H * sum(q v)           dL_dconic.xy = -0.5 o * sum(q dx dy)
+            //   dL_dmean2D.z =  o * sum(|q| (0.5W |u| + 0.5H |v|))   dL_dconic.yy = -0.5 o * sum(q dy dy)
+            //   dL_dopacity  = sum(q)
+            float acr = 0.f, acg = 0.f, acb = 0.f, sx = 0.f, sy = 0.f, sab = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f, sq = 0.f;
             bool any = false;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 if (!(m & (1u << s))) continue;  // wave-uniform
-                float dx, dy, G, a;
-                const bool pass = eval_alpha(sc, pfx[s], pfy[s], dx, dy, G, a);
+                PairEval e;
+                const bool pass = eval_alpha(sc, pfx[s], pfy[s], e);
                 if (pos < last[s] && pass) {
                     any = true;
+                    const float a = e.alpha;
                     const float inv = __builtin_amdgcn_rcpf(1.0f - a);
                     const float Tn = T[s] * inv;  // T / (1 - alpha), backward.cu:548
                     T[s] = Tn;
@@ -180,23 +191,21 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
                     recg[s] += a * dg;
                     recb[s] += a * db;
                     dLda = dLda * Tn + tfb[s] * inv;
-                    const float dLdG = o * dLda;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dGdx = -gdx * r0.z - gdy * r0.w;
-                    const float dGdy = -gdy * r1.x - gdx * r0.w;
-                    const float mx = dLdG * dGdx * ddelx_dx, my = dLdG * dGdy * ddely_dy;
-                    amx += mx;
-                    amy += my;
-                    aab += fabsf(mx) + fabsf(my);
-                    axx += -0.5f * gdx * dx * dLdG;
-                    axy += -0.5f * gdx * dy * dLdG;
-                    ayy += -0.5f * gdy * dy * dLdG;
-                    aop += G * dLda;
+                    const float q = e.G * dLda;
+                    const float u = r0.z * e.dx + r0.w * e.dy;
+                    const float v = r1.x * e.dy + r0.w * e.dx;
+                    sq += q;
+                    sx += q * u;
+                    sy += q * v;
+                    sab += fabsf(q) * (ddelx_dx * fabsf(u) + ddely_dy * fabsf(v));
+                    sxx += q * e.xx;
+                    sxy += q * e.xy;
+                    syy += q * e.yy;
                 }
             }
             if (__ballot(any) == 0ull) continue;
-            const float total = butterfly10(acr, acg, acb, amx, amy, aab, axx, axy, ayy, aop, lane);
-            if (issue) unsafeAtomicAdd(abase + (size_t)astride * lds_id[j], total);
+            const float total = butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
+            if (issue) unsafeAtomicAdd(abase + (size_t)astride * lds_id[j], total * (oscale ? (vidx == 5 ? fabsf(o) : o) * vscale : vscale));
         }
     }
 }

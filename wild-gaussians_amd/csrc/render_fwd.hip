@@ -108,8 +108,9 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 if (!(m & (1u << s))) continue;  // wave-uniform
-                float dx, dy, G, alpha;
-                const bool pass = eval_alpha(sc, pfx[s], pfy[s], dx, dy, G, alpha);
+                PairEval e;
+                const bool pass = eval_alpha(sc, pfx[s], pfy[s], e);
+                const float alpha = e.alpha;
                 if (((alive >> s) & 1u) && pass) {
                     const float test_T = T[s] * (1.0f - alpha);
                     if (test_T < 0.0001f) {

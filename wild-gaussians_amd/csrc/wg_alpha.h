@@ -26,14 +26,21 @@ __device__ __forceinline__ SplatCoef make_coef(const float4 r0, const float4 r1)
 }
 
 // Returns true when the pair passes the reference's two skips: power <= 0 and alpha >= 1/255.
-// G = exp(power) (unclamped), alpha = min(0.99, o*G).
-__device__ __forceinline__ bool eval_alpha(const SplatCoef& c, float pfx, float pfy, float& dx, float& dy, float& G, float& alpha) {
-    dx = c.mx - pfx;
-    dy = c.my - pfy;
-    const float p2 = dx * (c.ca * dx + c.cb * dy) + c.cc * dy * dy;  // log2(e) * power
-    G = __builtin_amdgcn_exp2f(p2);
-    alpha = fminf(0.99f, c.o * G);
-    return p2 <= 0.0f && alpha >= (1.0f / 255.0f);
+// G = exp(power) (unclamped), alpha = min(0.99, o*G).  The three second-order products of the offset are returned
+// because the backward pass needs them again for the conic gradient.
+struct PairEval {
+    float dx, dy, xx, xy, yy, G, alpha;
+};
+__device__ __forceinline__ bool eval_alpha(const SplatCoef& c, float pfx, float pfy, PairEval& e) {
+    e.dx = c.mx - pfx;
+    e.dy = c.my - pfy;
+    e.xx = e.dx * e.dx;
+    e.xy = e.dx * e.dy;
+    e.yy = e.dy * e.dy;
+    const float p2 = c.ca * e.xx + c.cb * e.xy + c.cc * e.yy;  // log2(e) * power
+    e.G = __builtin_amdgcn_exp2f(p2);
+    e.alpha = fminf(0.99f, c.o * e.G);
+    return p2 <= 0.0f && e.alpha >= (1.0f / 255.0f);
 }
 
 // XCD-aware block -> tile map: blocks are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), so

@@ -125,11 +125,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     device = means3D.device
     P, H, W = means3D.size(0), int(image_height), int(image_width)
 
-    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=device)
-    radii = torch.zeros((P,), dtype=torch.int32, device=device)
     geom, binning, img = _Scratch(device), _Scratch(device), _Scratch(device)
     if P == 0:  # rasterize_points.cu:83: nothing is launched, the image stays zero
-        return 0, out_color, radii, geom.tensor, binning.tensor, img.tensor
+        return (0, torch.zeros((3, H, W), dtype=torch.float32, device=device), torch.zeros((0,), dtype=torch.int32, device=device),
+                geom.tensor, binning.tensor, img.tensor)
+    # both outputs are fully written by the kernels (every pixel, every Gaussian): no need for the reference's zero fill
+    out_color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+    radii = torch.empty((P,), dtype=torch.int32, device=device)
 
     means3D = _f32(means3D, device)
     background, colors, opacity = _f32(background, device), _f32(colors, device), _f32(opacity, device)

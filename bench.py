@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--colors", choices=["sh", "precomp"], default="sh")
+    ap.add_argument("--forward-only", action="store_true", help="stress mode: time only the forward pass (e.g. 10M Gaussians @ 4K)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (parity + CPU timing)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events in the timed region")
     args = ap.parse_args()
@@ -83,8 +84,8 @@ def main():
 
     rs = make_settings(cam, deg, device=device)
     rast = GaussianRasterizer(rs)
-    t = {k: to_dev(v, device).requires_grad_(True) for k, v in cloud.items()}
-    means2D = torch.zeros((P, 3), device=device, requires_grad=True)
+    t = {k: to_dev(v, device).requires_grad_(not args.forward_only) for k, v in cloud.items()}
+    means2D = torch.zeros((P, 3), device=device, requires_grad=not args.forward_only)
     cot = to_dev(cot_np, device)
     cot_flat = cot.reshape(-1)
 
@@ -116,6 +117,8 @@ def main():
         VP.barrier()
         return VP.max_over_ranks(time.perf_counter() - t0, device)
 
+    if args.forward_only:
+        train_step = fwd_step
     for _ in range(args.warmup):
         train_step()
     torch.cuda.synchronize(device)
@@ -151,7 +154,8 @@ def main():
     iters_per_s = world * args.steps / t_train
     fwd_fps = world * args.steps / t_fwd
     out = {
-        "metric": "train_iters_per_s (fwd+bwd of the rasterizer, 1M Gaussians @1080p)",
+        "metric": ("forward_fps (forward only)" if args.forward_only else
+                   "train_iters_per_s (fwd+bwd of the rasterizer, 1M Gaussians @1080p)"),
         "value": round(iters_per_s, 3),
         "unit": "iter/s",
         "n_gpus": world,
@@ -194,7 +198,7 @@ def main():
                                     "backward_GBps": round(Bb / (tb * 1e-3) / 1e9, 1) if tb else None,
                                     "forward_kernel_ms": round(tf, 4), "backward_kernel_ms": round(tb, 4)}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.forward_only:
         # CPU leg: the oracle (a CPU port of the reference's algorithm) on the same workload, timed on the host
         # cores, and used as the checker for the parity part of the metric.  Never on the measured path.
         from oracle import oracle

@@ -247,3 +247,59 @@ def test_all_culled_and_single_gaussian(oracle):
     assert compare_forward(h["color"], o)["max_err_solid"] <= 1e-4
     for k, e in compare_grads(h["grads"], o["grads"]).items():
         assert e <= 1e-3, (k, e)
+
+
+def test_long_tile_lists_fall_back_to_global_sort(oracle):
+    """More than 8192 instances in one tile: the LDS tile sort cannot hold the bucket, the library must switch to the
+    rocPRIM global sort by itself and still produce the reference's order."""
+    W, H, P = 64, 48, 9000
+    cam = S.make_camera(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=None, seed=21, scale_mult=1.0)
+    cloud["means3D"][:, :2] *= 0.05          # everything near the optical axis ...
+    cloud["scales"][:] = 0.3                 # ... and big enough to cover the whole 4x3-tile frame
+    cloud["opacities"][:] = 0.004            # below 1/255 after the mip filter for most: lists stay long, nothing saturates
+    o = oracle.run_scene(cloud, cam)
+    rg = o["ctx"].get("ranges")
+    assert (rg[:, 1] - rg[:, 0]).max() > 8192
+    h = run_hip_native(cloud, cam, sh_degree=0)
+    assert h["num_rendered"] == o["num_rendered"]
+    np.testing.assert_array_equal(h["views"]["binning"]["point_list"].cpu().numpy().view(np.uint32), o["ctx"].get("point_list"))
+    np.testing.assert_array_equal(h["views"]["image"]["ranges"].cpu().numpy().view(np.uint32), rg)
+    cot = S.make_cotangent(W, H)
+    o = oracle.run_scene(cloud, cam, cotangent=cot)
+    hh = run_hip(cloud, cam, sh_degree=0, cotangent=cot)
+    assert compare_forward(hh["color"], o)["max_err_solid"] <= 1e-4
+    for k, e in compare_grads(hh["grads"], o["grads"]).items():
+        assert e <= 1e-3, (k, e)
+
+
+def test_frame_with_more_tiles_than_the_lds_histogram_holds(oracle):
+    """> 36864 tiles (beyond 4K): the tile histogram no longer fits one workgroup's LDS; binning goes through the
+    per-Gaussian prefix sum + global sort + key-boundary ranges, like the reference."""
+    W, H, P = 4096, 2400, 20000  # 256 x 150 = 38400 tiles
+    cam = S.make_camera(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=None, seed=8, scale_mult=2.0)
+    o = oracle.run_scene(cloud, cam)
+    h = run_hip_native(cloud, cam, sh_degree=0)
+    assert h["num_rendered"] == o["num_rendered"]
+    np.testing.assert_array_equal(h["views"]["binning"]["point_list"].cpu().numpy().view(np.uint32), o["ctx"].get("point_list"))
+    np.testing.assert_array_equal(h["views"]["image"]["ranges"].cpu().numpy().view(np.uint32), o["ctx"].get("ranges"))
+    c = compare_forward(h["color"].cpu().numpy(), o)
+    assert c["max_err_solid"] <= 1e-4, c
+
+
+def test_huge_splats_cover_every_tile(oracle):
+    """A few screen-filling Gaussians (rect = whole grid) mixed with small ones; saturating centre pixels."""
+    W, H = 200, 136
+    cam = S.make_camera(W, H)
+    cloud = S.make_cloud(600, W, H, sh_degree=2, seed=13, scale_mult=3.0)
+    cloud["scales"][:12] = 2.5
+    cloud["opacities"][:12] = 0.97
+    cot = S.make_cotangent(W, H)
+    o = oracle.run_scene(cloud, cam, sh_degree=2, cotangent=cot)
+    h = run_hip(cloud, cam, sh_degree=2, cotangent=cot)
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    c = compare_forward(h["color"], o)
+    assert c["max_err_solid"] <= 1e-4, c
+    for k, e in compare_grads(h["grads"], o["grads"]).items():
+        assert e <= 1e-3, (k, e)

@@ -174,7 +174,7 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     if (num_rendered > 0) {
         if (!global_sort) {
             WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, stream), "tile_scatter");
-            WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, tiles, max_tile_count, stream), "tile_sort");
+            WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, geom, tiles, max_tile_count, stream), "tile_sort");
         } else {
             if (!huge_frame) WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
             WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_duplicate_keys(P, geom, bin, gx, stream), "duplicate_keys");

@@ -69,7 +69,7 @@ BinningState BinningState::fromChunk(char*& chunk, size_t R, bool global_sort) {
     const size_t Ra = R ? R : 1;
     carve(chunk, b.point_list, Ra);
     if (!global_sort) {
-        carve(chunk, b.bucket_keys, Ra);
+        carve(chunk, b.bucket_ids, Ra);
     } else {
         carve(chunk, b.point_list_unsorted, Ra);
         carve(chunk, b.keys, Ra);
@@ -155,14 +155,14 @@ hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& im
 //   tile_count_kernel   : chunk_hist[c][t] = #instances of chunk c in tile t        (histogram in LDS)
 //   chunk_scan_kernel   : chunk_hist[c][t] <- sum_{c' < c} chunk_hist[c'][t];  tile_count[t] = column total
 //   tile_scan_kernel    : tile_offset = exclusive_scan(tile_count); ranges; {num_rendered, max_tile_count}
-//   tile_scatter_kernel : cursor[t] (LDS) = tile_offset[t] + chunk_hist[c][t];
-//                         bucket_keys[cursor[t]++] = depth_bits << 32 | gaussian_id
+//   tile_scatter_kernel : cursor[t] (LDS) = tile_offset[t] + chunk_hist[c][t];  bucket_ids[cursor[t]++] = gaussian_id
 //   tile_sort_kernel    : one workgroup per tile sorts its bucket in LDS (bitonic network on 64-bit keys)
 //                         and writes the low words (Gaussian ids) to point_list
 // Sorting (depth_bits, id) ascending inside a tile is exactly the order a stable sort of (tile|depth) keys
 // leaves (ties keep ascending Gaussian id, the emission order of duplicateWithKeys), so point_list and
 // ranges are bit-identical to the reference's -- whatever order the LDS atomics happened in.  Traffic per
-// instance: 8 B scatter + 8 B read + 4 B write, against 6 radix passes x 24 B for the 45-bit global sort.
+// instance: 4 B scatter + 4 B read + 4 B depth gather (L2) + 4 B write, against 6 radix passes x 24 B for the 45-bit
+// global sort.
 
 __device__ __forceinline__ void chunk_bounds(int P, int chunk, int& begin, int& end) {
     const int per = (P + BIN_CHUNKS - 1) / BIN_CHUNKS;
@@ -260,10 +260,9 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
     }
 }
 
-__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const float* __restrict__ depths, const int* __restrict__ radii,
-                                                           const ushort4* __restrict__ rects, const uint32_t* __restrict__ tile_offset,
-                                                           const uint32_t* __restrict__ chunk_hist, uint64_t* __restrict__ bucket_keys,
-                                                           int gx, int tiles) {
+__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const int* __restrict__ radii, const ushort4* __restrict__ rects,
+                                                           const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ chunk_hist,
+                                                           uint32_t* __restrict__ bucket_ids, int gx, int tiles) {
     extern __shared__ uint32_t cursor[];
     const int tid = threadIdx.x, chunk = blockIdx.x;
     const uint32_t* base = chunk_hist + (size_t)chunk * tiles;
@@ -274,45 +273,75 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const float* _
     for (int idx = begin + tid; idx < end; idx += 256) {
         if (radii[idx] > 0) {
             const ushort4 r = rects[idx];
-            const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx;
             for (int y = r.y; y < r.w; y++)
                 for (int x = r.x; x < r.z; x++) {
                     const uint32_t pos = atomicAdd(&cursor[y * gx + x], 1u);
-                    bucket_keys[pos] = key;
+                    bucket_ids[pos] = (uint32_t)idx;  // 4 bytes per instance; the depth half of the key is gathered at sort time
                 }
         }
     }
 }
 
-// Bitonic sort of n <= npow2 64-bit keys held in LDS (npow2 = power of two, padded with ~0).
-__global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint64_t* __restrict__ bucket_keys,
-                                                        uint32_t* __restrict__ point_list, int tiles) {
+// Bitonic sort of a tile's bucket in LDS.  Keys are (depth_bits << 32 | gaussian id), built while loading (the id
+// comes from the bucket, the depth from the 4 B/Gaussian depth array, which stays in L2); padded to a power of two
+// with ~0.  Workgroup = 4 waves; the key array is cut into 256-key blocks and for every compare-exchange distance
+// j < 256 a block is private to one wave, so those stages run without any workgroup barrier (LDS operations of one
+// wave complete in order).  Only the j >= 256 stages (3 of 55 at 1024 keys) synchronise the workgroup.
+__device__ __forceinline__ void bitonic_ce(uint64_t* skeys, uint32_t t, uint32_t j, uint32_t k) {
+    const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+    const uint32_t l = i | j;
+    const uint64_t a = skeys[i], b = skeys[l];
+    const bool ascending = (i & k) == 0;
+    if ((a > b) == ascending) {
+        skeys[i] = b;
+        skeys[l] = a;
+    }
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // order this wave's LDS writes before its later LDS reads (no other wave touches the block)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bucket_ids,
+                                                        const float* __restrict__ depths, uint32_t* __restrict__ point_list, int tiles) {
     extern __shared__ uint64_t skeys[];
     const int tile = blockIdx.x;
     const uint32_t begin = tile_offset[tile];
     const uint32_t n = tile_offset[tile + 1] - begin;
     if (n == 0) return;
-    const int tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t np2 = 1;
     while (np2 < n) np2 <<= 1;
-    for (uint32_t i = tid; i < np2; i += 256) skeys[i] = i < n ? bucket_keys[begin + i] : ~0ull;
+    for (uint32_t i = tid; i < np2; i += 256) {
+        uint64_t key = ~0ull;
+        if (i < n) {
+            const uint32_t id = bucket_ids[begin + i];
+            key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
+        }
+        skeys[i] = key;
+    }
     __syncthreads();
+    const uint32_t nblocks = (np2 + 255) >> 8;  // 256-key blocks (one partial block when np2 < 256)
+    const uint32_t half_block = np2 < 256 ? (np2 >> 1) : 128;
     for (uint32_t k = 2; k <= np2; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < (np2 >> 1); t += 256) {
-                // t-th compare-exchange of this stage: partner indices i < l = i ^ j
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t l = i | j;
-                const uint64_t a = skeys[i], b = skeys[l];
-                const bool ascending = (i & k) == 0;
-                if ((a > b) == ascending) {
-                    skeys[i] = b;
-                    skeys[l] = a;
-                }
-            }
+        uint32_t j = k >> 1;
+        // distances that span blocks: all threads, workgroup barrier after each stage
+        for (; j >= 256; j >>= 1) {
+            for (uint32_t t = tid; t < (np2 >> 1); t += 256) bitonic_ce(skeys, t, j, k);
             __syncthreads();
         }
+        // distances inside a 256-key block: wave w owns blocks w, w+4, ...; no workgroup barrier
+        for (; j > 0; j >>= 1) {
+            for (uint32_t blk = wave; blk < nblocks; blk += 4)
+                for (uint32_t c = lane; c < half_block; c += 64) bitonic_ce(skeys, blk * 128 + c, j, k);
+            wave_lds_fence();
+        }
+        if (k >= 256 && (k << 1) <= np2) __syncthreads();  // the next k starts with a cross-block distance
     }
+    __syncthreads();
     for (uint32_t i = tid; i < n; i += 256) point_list[begin + i] = (uint32_t)skeys[i];
 }
 
@@ -343,12 +372,13 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
     const size_t lds = (size_t)tiles * sizeof(uint32_t);
     hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_kernel), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(BIN_CHUNKS), dim3(256), lds, stream, P, g.depths, g.radii, g.rects, img.tile_offset,
-                       img.chunk_hist, b.bucket_keys, gx, tiles);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(BIN_CHUNKS), dim3(256), lds, stream, P, g.radii, g.rects, img.tile_offset,
+                       img.chunk_hist, b.bucket_ids, gx, tiles);
     return hipGetLastError();
 }
 
-hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, int tiles, uint32_t max_count, hipStream_t stream) {
+hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
+                            hipStream_t stream) {
     if (tiles <= 0 || max_count == 0) return hipSuccess;
     uint32_t np2 = 1;
     while (np2 < max_count) np2 <<= 1;
@@ -360,7 +390,7 @@ hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, int ti
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles), dim3(256), lds, stream, img.tile_offset, b.bucket_keys, b.point_list, tiles);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles), dim3(256), lds, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list, tiles);
     return hipGetLastError();
 }
 

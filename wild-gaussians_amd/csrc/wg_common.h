@@ -53,11 +53,11 @@ struct ImageState {
 };
 
 // Binning scratch.  Two layouts share the point_list prefix (all the backward pass needs):
-//   tile-sort path (default): point_list u32[R] | bucket_keys u64[R]
+//   tile-sort path (default): point_list u32[R] | bucket_ids u32[R]
 //   global-sort fallback    : point_list u32[R] | point_list_unsorted u32[R] | keys u64[R] | keys_unsorted u64[R] | temp
 struct BinningState {
     uint32_t* point_list;
-    uint64_t* bucket_keys;  // (depth_bits << 32 | gaussian id), grouped by tile, unsorted within a tile
+    uint32_t* bucket_ids;   // Gaussian ids grouped by tile, unsorted within a tile
     uint32_t* point_list_unsorted;
     uint64_t* keys;
     uint64_t* keys_unsorted;
@@ -100,7 +100,8 @@ hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& im
 hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, hipStream_t stream);
 hipError_t launch_tile_scan(const ImageState& img, int tiles, hipStream_t stream);
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles, hipStream_t stream);
-hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, int tiles, uint32_t max_count, hipStream_t stream);
+hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
+                            hipStream_t stream);
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                  const GeometryState& g, const float* subpixel_offset, const float* background,
                                  float* out_color, hipStream_t stream);

@@ -184,8 +184,18 @@ def main():
         dom = max(stages, key=lambda k: stages[k][0])
         B = algorithmic_bytes(dom, P, V, int(R), N, tiles, M, args.colors == "sh")
         ach = B / (per_stage[dom] * 1e-3) / 1e9 if per_stage[dom] > 0 else 0.0
+        # HBM traffic per launch from PMC counters: taken in separate rocprofv3 --pmc passes (scripts/profile_gpu.sh) and
+        # committed as profiles/pmc_traffic.json; used only when it was collected on this very workload
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            if pt.get("workload") == f"{P} Gaussians, {W}x{H}, {args.colors}" and dom in pt["stages"]:
+                traffic = pt["stages"][dom]["hbm_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": B, "avg_launch_ms": round(per_stage[dom], 4)}
         # whole forward / backward pipelines against the same roofline, for context
         fwd_names = ["preprocess", "scan", "duplicate_keys", "sort", "tile_ranges", "render_forward"]

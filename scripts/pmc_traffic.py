@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 PMC summary (scripts/profile_gpu.sh -> pmc_summary.txt) into per-stage HBM traffic per launch.
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so it is doubled before comparing with a
+byte count; WRITE_SIZE (and narrow / gather access patterns) are uncalibrated and taken as reported.
+usage: pmc_traffic.py pmc_summary.txt "<workload string>" > profiles/pmc_traffic.json"""
+import json
+import re
+import sys
+
+STAGE_OF = {"preprocess_kernel": "preprocess", "tile_count_kernel": "scan", "chunk_scan_kernel": "scan", "tile_scan_kernel": "scan",
+            "tile_scatter_kernel": "duplicate_keys", "tile_sort_kernel": "sort", "render_forward_kernel": "render_forward",
+            "render_backward_kernel": "render_backward", "preprocess_backward_kernel": "preprocess_backward"}
+vals = {}
+for line in open(sys.argv[1]):
+    m = re.match(r"(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*\d+\s+per_dispatch=\s*(\d+)", line)
+    if not m:
+        continue
+    name = re.sub(r"^void ", "", m.group(1)).split("(")[0].replace("wg::", "").split("<")[0]
+    st = STAGE_OF.get(name)
+    if st:
+        vals.setdefault(st, {"FETCH_SIZE_KiB": 0, "WRITE_SIZE_KiB": 0})[m.group(2) + "_KiB"] += int(m.group(3))
+out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving; WRITE_SIZE as reported)",
+       "stages": {k: dict(v, hbm_bytes=(2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024) for k, v in vals.items()}}
+print(json.dumps(out, indent=1))

@@ -23,4 +23,4 @@ for CS in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_B
 done
 rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4
 cat $OUT/kernel_trace_summary.txt | cut -c1-150 | head -16
-cat $OUT/pmc_summary.txt | cut -c1-160
+python scripts/pmc_traffic.py $OUT/pmc_summary.txt "1000000 Gaussians, 1920x1080, sh" > $OUT/pmc_traffic.json; cat $OUT/pmc_traffic.json

@@ -282,11 +282,19 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const int* __r
     }
 }
 
-// Bitonic sort of a tile's bucket in LDS.  Keys are (depth_bits << 32 | gaussian id), built while loading (the id
-// comes from the bucket, the depth from the 4 B/Gaussian depth array, which stays in L2); padded to a power of two
-// with ~0.  Workgroup = 4 waves; the key array is cut into 256-key blocks and for every compare-exchange distance
-// j < 256 a block is private to one wave, so those stages run without any workgroup barrier (LDS operations of one
-// wave complete in order).  Only the j >= 256 stages (3 of 55 at 1024 keys) synchronise the workgroup.
+// ---- per-tile sort ----------------------------------------------------------------------------------------------------
+// Bitonic sort of a tile's bucket.  Keys are (depth_bits << 32 | gaussian id), built while loading (the id comes from the
+// bucket, the depth from the 4 B/Gaussian depth array, which stays in L2); padded to a power of two with ~0.
+//
+// Levels k <= 1024 run on 1024-key chunks held IN REGISTERS, 4 consecutive keys per thread (256 threads):
+//   distance 1, 2      : compare-exchange between a thread's own registers;
+//   distance 4 .. 128  : the partner key sits in lane  l ^ (j/4)  of the same wave -> DPP quad_perm / row_ror,
+//                        ds_swizzle or ds_bpermute (crossbar only: no LDS memory traffic, no bank conflicts, no barrier);
+//   distance 256, 512  : the partner is in another wave -> one round trip through LDS with workgroup barriers
+//                        (3 of the 55 stages of a 1024-key sort).
+// A first version kept the keys in LDS for every stage; rocprofv3 showed its LDS pipe ~80 % busy (37 % of that bank
+// conflicts on the 64-bit accesses).  Levels k > 1024 (tiles listing more than 1024 instances) merge the sorted chunks
+// with compare-exchanges in LDS.
 __device__ __forceinline__ void bitonic_ce(uint64_t* skeys, uint32_t t, uint32_t j, uint32_t k) {
     const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
     const uint32_t l = i | j;
@@ -305,6 +313,79 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int D>  // value of lane (l ^ D), D in {1, 2, 4, 8, 16, 32}
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if constexpr (D == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);  // row_ror 8
+    else if constexpr (D == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);                     // xor 4 (bit mode)
+    else if constexpr (D == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                    // xor 16
+    else return (uint32_t)__shfl_xor((int)v, 32);
+}
+
+struct SortCtx {
+    uint64_t key[4];
+    uint32_t t;      // thread index in the workgroup
+    uint32_t gidx;   // global (within the tile's padded array) index of key[0]
+    uint64_t* chunk; // this chunk's 1024 keys in LDS (exchange buffer for the cross-wave stages)
+};
+
+__device__ __forceinline__ void keep(uint64_t& mine, uint64_t other, bool keep_min) {
+    const bool other_less = other < mine;
+    mine = (other_less == keep_min) ? other : mine;
+}
+
+template <int K, int J>
+__device__ __forceinline__ void sort_stage(SortCtx& c) {
+    if constexpr (J < 4) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if ((r & J) == 0) {
+                const bool asc = ((c.gidx + r) & K) == 0;
+                uint64_t& a = c.key[r];
+                uint64_t& b = c.key[r | J];
+                if ((a > b) == asc) {
+                    const uint64_t tmp = a;
+                    a = b;
+                    b = tmp;
+                }
+            }
+        }
+    } else {
+        const bool asc = (c.gidx & K) == 0;
+        const bool lower = (c.t & (J / 4)) == 0;
+        const bool keep_min = lower == asc;
+        if constexpr (J < 256) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t lo = lane_xor<J / 4>((uint32_t)c.key[r]);
+                const uint32_t hi = lane_xor<J / 4>((uint32_t)(c.key[r] >> 32));
+                keep(c.key[r], ((uint64_t)hi << 32) | lo, keep_min);
+            }
+        } else {
+            uint64_t* mine = c.chunk + 4 * c.t;
+            mine[0] = c.key[0]; mine[1] = c.key[1]; mine[2] = c.key[2]; mine[3] = c.key[3];
+            __syncthreads();
+            const uint64_t* theirs = c.chunk + 4 * (c.t ^ (J / 4));
+            const uint64_t o0 = theirs[0], o1 = theirs[1], o2 = theirs[2], o3 = theirs[3];
+            __syncthreads();
+            keep(c.key[0], o0, keep_min); keep(c.key[1], o1, keep_min); keep(c.key[2], o2, keep_min); keep(c.key[3], o3, keep_min);
+        }
+    }
+}
+
+template <int K, int J>
+__device__ __forceinline__ void sort_stages(SortCtx& c) {
+    sort_stage<K, J>(c);
+    if constexpr (J > 1) sort_stages<K, J / 2>(c);
+}
+
+template <int K>
+__device__ __forceinline__ void sort_levels(SortCtx& c, uint32_t kmax) {
+    if constexpr (K > 2) sort_levels<K / 2>(c, kmax);
+    if (K <= kmax) sort_stages<K, K / 2>(c);  // kmax is workgroup-uniform
+}
+
 __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bucket_ids,
                                                         const float* __restrict__ depths, uint32_t* __restrict__ point_list, int tiles) {
     extern __shared__ uint64_t skeys[];
@@ -313,35 +394,54 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restri
     const uint32_t n = tile_offset[tile + 1] - begin;
     if (n == 0) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t np2 = 1;
+    uint32_t np2 = 4;  // at least one key quartet
     while (np2 < n) np2 <<= 1;
-    for (uint32_t i = tid; i < np2; i += 256) {
-        uint64_t key = ~0ull;
-        if (i < n) {
-            const uint32_t id = bucket_ids[begin + i];
-            key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
+
+    // ---- levels k <= 1024: register-resident chunks of 1024 keys ----
+    const uint32_t kmax = min(np2, 1024u);
+    const uint32_t nchunks = (np2 + 1023) >> 10;
+    for (uint32_t ch = 0; ch < nchunks; ch++) {
+        SortCtx c;
+        c.t = tid;
+        c.gidx = ch * 1024 + 4 * tid;
+        c.chunk = skeys + ch * 1024;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t i = c.gidx + r;
+            uint64_t key = ~0ull;
+            if (i < n) {
+                const uint32_t id = bucket_ids[begin + i];
+                key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
+            }
+            c.key[r] = key;
         }
-        skeys[i] = key;
+        sort_levels<1024>(c, kmax);
+        if (nchunks == 1) {  // common case: the tile is done, write the ids straight from registers
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (c.gidx + r < n) point_list[begin + c.gidx + r] = (uint32_t)c.key[r];
+            return;
+        }
+        uint64_t* mine = c.chunk + 4 * tid;
+        mine[0] = c.key[0]; mine[1] = c.key[1]; mine[2] = c.key[2]; mine[3] = c.key[3];
     }
     __syncthreads();
-    const uint32_t nblocks = (np2 + 255) >> 8;  // 256-key blocks (one partial block when np2 < 256)
-    const uint32_t half_block = np2 < 256 ? (np2 >> 1) : 128;
-    for (uint32_t k = 2; k <= np2; k <<= 1) {
+
+    // ---- levels k > 1024: merge the sorted chunks with compare-exchanges in LDS ----
+    const uint32_t nblocks = np2 >> 8;
+    for (uint32_t k = 2048; k <= np2; k <<= 1) {
         uint32_t j = k >> 1;
-        // distances that span blocks: all threads, workgroup barrier after each stage
-        for (; j >= 256; j >>= 1) {
+        for (; j >= 256; j >>= 1) {  // distances that span 256-key blocks: all threads, workgroup barrier per stage
             for (uint32_t t = tid; t < (np2 >> 1); t += 256) bitonic_ce(skeys, t, j, k);
             __syncthreads();
         }
-        // distances inside a 256-key block: wave w owns blocks w, w+4, ...; no workgroup barrier
-        for (; j > 0; j >>= 1) {
+        for (; j > 0; j >>= 1) {  // inside a block: wave w owns blocks w, w+4, ...; no workgroup barrier
             for (uint32_t blk = wave; blk < nblocks; blk += 4)
-                for (uint32_t c = lane; c < half_block; c += 64) bitonic_ce(skeys, blk * 128 + c, j, k);
+                for (uint32_t cidx = lane; cidx < 128; cidx += 64) bitonic_ce(skeys, blk * 128 + cidx, j, k);
             wave_lds_fence();
         }
-        if (k >= 256 && (k << 1) <= np2) __syncthreads();  // the next k starts with a cross-block distance
+        __syncthreads();
     }
-    __syncthreads();
     for (uint32_t i = tid; i < n; i += 256) point_list[begin + i] = (uint32_t)skeys[i];
 }
 
@@ -380,7 +480,7 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
                             hipStream_t stream) {
     if (tiles <= 0 || max_count == 0) return hipSuccess;
-    uint32_t np2 = 1;
+    uint32_t np2 = 1024;  // the cross-wave stages of a register chunk exchange through a 1024-key LDS buffer
     while (np2 < max_count) np2 <<= 1;
     const size_t lds = (size_t)np2 * sizeof(uint64_t);
     static bool attr_set = false;

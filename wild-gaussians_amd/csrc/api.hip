@@ -215,10 +215,12 @@ int wg_rasterize_backward(int P, int D, int M, int R, const float* background, i
     wg::ImageState img = wg::ImageState::fromChunk(image_buffer, (size_t)width * height, (size_t)gx * gy);
     if (radii == nullptr) radii = geom.radii;  // rasterizer_impl.cu:381-384
 
-    if (R > 0)
+    if (R > 0) {
+        WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_order(img.tile_last, nullptr, img.order_bwd, gx * gy, stream), "tile_order");
         WG_STAGE(WG_STAGE_RENDER_BACKWARD, wg::launch_render_backward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, dL_dpix,
                                             dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, stream),
                  "render_backward");
+    }
 
     wg::BwdParams bp;
     bp.P = P; bp.D = D; bp.M = M; bp.W = width; bp.H = height;

@@ -69,7 +69,7 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
 }
 
 __global__ void __launch_bounds__(64) render_backward_kernel(
-    int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_last,
     const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     __shared__ float4 lds[BATCH * 3];
     __shared__ uint32_t lds_id[BATCH];
 
-    const int tile = xcd_tile(blockIdx.x, tiles);
+    const int tile = (int)order[xcd_tile(blockIdx.x, tiles)];
     const int hi0 = (int)tile_last[tile];
     if (hi0 == 0) return;
     const int lane = threadIdx.x;
@@ -216,7 +216,7 @@ hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState
                                   float* dL_dcolor, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(render_backward_kernel, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats,
+    hipLaunchKernelGGL(render_backward_kernel, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.order_bwd, img.ranges, b.point_list, g.splats,
                        reinterpret_cast<const float2*>(subpixel_offset), background, img.final_T, img.n_contrib, img.tile_last,
                        dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
     return hipGetLastError();

@@ -30,13 +30,13 @@ namespace wg {
 constexpr int BATCH = 64;
 
 __global__ void __launch_bounds__(64) render_forward_kernel(
-    int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last,
     float* __restrict__ out_color) {
     __shared__ float4 lds[BATCH * 3];
 
-    const int tile = xcd_tile(blockIdx.x, tiles);
+    const int tile = order ? (int)order[xcd_tile(blockIdx.x, tiles)] : xcd_tile(blockIdx.x, tiles);
     const int lane = threadIdx.x;
     const int tx = tile % gx, ty = tile / gx;
     const int px = tx * TILE_X + (lane & 15);
@@ -162,7 +162,7 @@ hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState&
                                  float* out_color, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(render_forward_kernel, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats,
+    hipLaunchKernelGGL(render_forward_kernel, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, (const uint32_t*)nullptr, img.ranges, b.point_list, g.splats,
                        reinterpret_cast<const float2*>(subpixel_offset), background, img.final_T, img.n_contrib, img.tile_last,
                        out_color);
     return hipGetLastError();

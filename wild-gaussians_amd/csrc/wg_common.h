@@ -48,6 +48,8 @@ struct ImageState {
     uint32_t* tile_count;   // per-tile instance count
     uint32_t* tile_offset;  // exclusive prefix sum of tile_count
     uint32_t* chunk_hist;   // [chunks][tiles] per-chunk tile histogram, turned into per-chunk bases by the column scan
+    uint32_t* order_fwd;    // launch order of the forward render: per XCD band, tiles by descending list length
+    uint32_t* order_bwd;    // launch order of the backward render: per XCD band, tiles by descending walked length
     BinStats* stats;
     static ImageState fromChunk(char*& chunk, size_t N, size_t tiles);
 };
@@ -97,6 +99,7 @@ hipError_t run_scan(const GeometryState& g, int P, hipStream_t stream);
 hipError_t launch_duplicate_keys(int P, const GeometryState& g, const BinningState& b, int gx, hipStream_t stream);
 hipError_t run_sort(const BinningState& b, int R, int end_bit, hipStream_t stream);
 hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& img, int tiles, hipStream_t stream);
+hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_or_null, uint32_t* order, int tiles, hipStream_t stream);
 hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, hipStream_t stream);
 hipError_t launch_tile_scan(const ImageState& img, int tiles, hipStream_t stream);
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles, hipStream_t stream);

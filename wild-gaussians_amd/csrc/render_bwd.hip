@@ -139,22 +139,27 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
         // lane l stages the instance at list position hi-1-l (back to front, backward.cu:517)
         const int posl = hi - 1 - lane;
         __syncthreads();
+        uint32_t mymask = 0;
         if (posl >= 0) {
             const uint32_t id = point_list[range.x + posl];
             const float4 q0 = splats[3 * (size_t)id];
-            float4 q1 = splats[3 * (size_t)id + 1];
-            q1.z = __uint_as_float(strip_mask(q0, q1, sb));
+            const float4 q1 = splats[3 * (size_t)id + 1];
+            mymask = strip_mask(q0, q1, sb);
             lds_id[lane] = id;
             lds[3 * lane] = q0;
             lds[3 * lane + 1] = q1;
             lds[3 * lane + 2] = splats[3 * (size_t)id + 2];
         }
         __syncthreads();
-        const int cnt = min(BATCH, hi);
-        for (int j = 0; j < cnt; j++) {
+        // the batch's strip masks as wave-uniform 64-bit words (see render_fwd.hip)
+        uint64_t reach[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) reach[s] = __ballot((mymask >> s) & 1u);
+        uint64_t todo = reach[0] | reach[1] | reach[2] | reach[3];
+        while (todo != 0ull) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
             const float4 r1 = lds[3 * j + 1];
-            const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(r1.z));
-            if (m == 0) continue;
             const int pos = hi - 1 - j;  // "contributor" after the decrement at backward.cu:531
             const float4 r0 = lds[3 * j];
             const SplatCoef sc = make_coef(r0, r1);
@@ -172,7 +177,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             bool any = false;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                if (!(m & (1u << s))) continue;  // wave-uniform
+                if (((reach[s] >> j) & 1ull) == 0ull) continue;  // wave-uniform
                 PairEval e;
                 const bool pass = eval_alpha(sc, pfx[s], pfy[s], e);
                 if (pos < last[s] && pass) {

@@ -11,7 +11,7 @@
 //     previous batch is being composited (software prefetch), then parks it in LDS.
 //   * while staging, lane l also computes instance l's strip-reachability mask (wg_alpha.h: the 1/255
 //     iso-ellipse's bounding box against the four strips' sample boxes).  The per-instance loop reads that
-//     mask as a wave-uniform scalar: unreachable strips cost nothing, unreachable instances one branch.
+//     masks as four wave-uniform 64-bit ballots: unreachable strips and unreachable instances cost nothing.
 //     The mask is conservative, so the blended result is unchanged.
 //   * saturated strips (every pixel hit the T < 1e-4 stop) are dropped from the uniform mask; the walk ends
 //     when no strip is left.
@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
     }
 
     for (int base = 0; base < n && strips_alive != 0; base += BATCH) {
-        a1.z = __uint_as_float(strip_mask(a0, a1, sb));
+        const int cnt = min(BATCH, n - base);
+        const uint32_t mymask = lane < cnt ? strip_mask(a0, a1, sb) : 0u;
         __syncthreads();
         lds[3 * lane] = a0;
         lds[3 * lane + 1] = a1;
@@ -96,18 +97,25 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
             a1 = splats[3 * (size_t)id + 1];
             a2 = splats[3 * (size_t)id + 2];
         }
-        const int cnt = min(BATCH, n - base);
-        for (int j = 0; j < cnt; j++) {
-            const float4 r1 = lds[3 * j + 1];  // conic.z, opacity, strip mask, red
-            const uint32_t m = __builtin_amdgcn_readfirstlane(__float_as_uint(r1.z)) & strips_alive;
-            if (m == 0) continue;
-            const float4 r0 = lds[3 * j];  // mx, my, conic.x, conic.y
+        // The batch's strip masks as four wave-uniform 64-bit words (bit j of word s: instance j can reach strip s):
+        // the walk below never touches an instance no live strip can see, and knows which strips to evaluate before
+        // the instance's record has even been read.
+        uint64_t reach[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) reach[s] = ((strips_alive >> s) & 1u) ? __ballot((mymask >> s) & 1u) : 0ull;
+        uint64_t todo = reach[0] | reach[1] | reach[2] | reach[3];
+        while (todo != 0ull) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            if (((reach[0] | reach[1] | reach[2] | reach[3]) >> j & 1ull) == 0ull) continue;  // its strips died meanwhile
+            const float4 r0 = lds[3 * j];      // mx, my, conic.x, conic.y
+            const float4 r1 = lds[3 * j + 1];  // conic.z, opacity, -, red
             const SplatCoef sc = make_coef(r0, r1);
             const uint32_t pos = (uint32_t)(base + j + 1);
             const uint32_t alive_before = alive;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                if (!(m & (1u << s))) continue;  // wave-uniform
+                if (((reach[s] >> j) & 1ull) == 0ull) continue;  // wave-uniform
                 PairEval e;
                 const bool pass = eval_alpha(sc, pfx[s], pfy[s], e);
                 const float alpha = e.alpha;
@@ -129,8 +137,10 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
             if (__ballot(alive != alive_before) != 0ull) {  // some pixel saturated: refresh the strip liveness
                 strips_alive = 0;
 #pragma unroll
-                for (int s = 0; s < 4; s++)
+                for (int s = 0; s < 4; s++) {
                     if (__ballot((alive >> s) & 1u) != 0ull) strips_alive |= 1u << s;
+                    else reach[s] = 0ull;
+                }
                 if (strips_alive == 0) break;
             }
         }

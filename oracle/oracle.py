@@ -25,11 +25,11 @@ _LIBS = {}
 
 def build(force: bool = False) -> None:
     """Compile the oracle's C restatement (gcc, a few seconds)."""
-    need = force or not all(os.path.exists(os.path.join(_HERE, f"libwg_oracle_{p}.so")) for p in ("f32", "f64"))
-    src_m = os.path.getmtime(os.path.join(_HERE, "wg_oracle.c"))
-    for p in ("f32", "f64"):
-        so = os.path.join(_HERE, f"libwg_oracle_{p}.so")
-        if os.path.exists(so) and os.path.getmtime(so) < src_m:
+    pairs = [(f"libwg_oracle_{p}.so", "wg_oracle.c") for p in ("f32", "f64")] + [("libwg_knn_oracle.so", "wg_knn_oracle.c")]
+    need = force
+    for so, src in pairs:
+        so, src = os.path.join(_HERE, so), os.path.join(_HERE, src)
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
             need = True
     if need:
         subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
@@ -228,4 +228,29 @@ def run_scene(cloud, cam, sh_degree=3, kernel_size=0.1, bg=None, scale_modifier=
                                          kernel_size, so, cotangent, shs, sh_degree, cam["campos"], ctx)
         names = ["means2D", "colors_precomp", "opacities", "means3D", "cov3Ds_precomp", "sh", "scales", "rotations", "conic"]
         out["grads"] = dict(zip(names, g))
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# simple_knn._C.distCUDA2 (submodules/simple-knn/spatial.cu:15-26)
+def _knn_lib():
+    if "knn" not in _LIBS:
+        path = os.path.join(_HERE, "libwg_knn_oracle.so")
+        if not os.path.exists(path):
+            build()
+        lib = C.CDLL(path)
+        for f in (lib.wgo_knn, lib.wgo_knn_bruteforce):
+            f.restype, f.argtypes = None, [C.c_int, C.c_void_p, C.c_void_p]
+        _LIBS["knn"] = lib
+    return _LIBS["knn"]
+
+
+def dist_cuda2(points, bruteforce: bool = False) -> np.ndarray:
+    """distCUDA2(points[P,3]) -> mean squared distance to the 3 nearest neighbours, float32[P]."""
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    P = pts.shape[0]
+    out = np.zeros((P,), dtype=np.float32)
+    if P:
+        fn = _knn_lib().wgo_knn_bruteforce if bruteforce else _knn_lib().wgo_knn
+        fn(P, pts.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     return out

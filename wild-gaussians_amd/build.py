@@ -28,8 +28,9 @@ SOURCES = {
     "render_bwd.hip": ["-munsafe-fp-atomics"],
     "preprocess_bwd.hip": [],
     "api.hip": [],
+    "knn.hip": ["-ffp-contract=off"],  # simple_knn.distCUDA2 replacement (include/wg_knn.h)
 }
-HEADERS = ["wg_common.h", "wg_alpha.h", os.path.join(INCLUDE, "wg_rasterizer.h")]
+HEADERS = ["wg_common.h", "wg_alpha.h", os.path.join(INCLUDE, "wg_rasterizer.h"), os.path.join(INCLUDE, "wg_knn.h")]
 
 
 def _newer(target: str, deps) -> bool:

@@ -60,8 +60,9 @@ size_t wg_binning_buffer_size(int num_rendered);
 /*
  * Rasterizer::forward (rasterizer.h:33-59, rasterizer_impl.cu:198-340).
  * Returns num_rendered (>= 0) = number of (tile, Gaussian) instances, or a negative wg_status.
- * out_color: float[3*H*W] planar CHW.  radii: int[P] or NULL.  One host<->device sync (the read-back
- * of num_rendered that sizes the binning buffer, as rasterizer_impl.cu:284).
+ * out_color: float[3*H*W] planar CHW.  radii: int[P] or NULL.  One host<->device rendezvous (the read-back
+ * of num_rendered that sizes the binning buffer, as rasterizer_impl.cu:284): the host waits until the first
+ * three kernels have run, but work queued on the stream before the call is only waited for, never flushed twice.
  */
 int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user,
                          wg_alloc_fn binning_alloc, void* binning_user,
@@ -177,7 +178,9 @@ const char* wg_stage_name(int stage);
 
 /* Tuning / test switches.  "force_global_sort" (0/1): bin with the rocPRIM global radix sort of 64-bit
  * (tile|depth) keys (the reference's scheme, and the automatic fallback when a tile lists more than 8192
- * instances) instead of the default counting-sort + per-tile LDS sort.  Both give identical results. */
+ * instances) instead of the default counting-sort + per-tile LDS sort.  Both give identical results.
+ * "host_mailbox" (1/0, default 1): read num_rendered back through a pinned host mailbox that the device writes and the
+ * host polls, instead of a device-to-host copy followed by a stream synchronise. */
 int wg_set_option(const char* name, int value);
 
 const char* wg_status_string(int status);

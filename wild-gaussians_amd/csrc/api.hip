@@ -3,6 +3,7 @@
 #include "wg_common.h"
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -34,6 +35,40 @@ struct StageProfiler {
     }
 };
 StageProfiler g_prof;
+
+// One pinned mailbox per host thread (see wg::HostMailbox).  nullptr if pinned memory is unavailable: the forward pass
+// then falls back to hipMemcpyAsync + hipStreamSynchronize.
+struct Mailbox {
+    wg::HostMailbox* host = nullptr;
+    wg::HostMailbox* dev = nullptr;
+    uint32_t seq = 0;
+    bool tried = false;
+    ~Mailbox() {
+        if (host) (void)hipHostFree(host);
+    }
+};
+thread_local Mailbox t_mailbox;
+bool g_use_mailbox = true;  // wg_set_option("host_mailbox", 0) restores the copy + synchronise read-back
+
+Mailbox* get_mailbox() {
+    Mailbox& m = t_mailbox;
+    if (!m.tried) {
+        m.tried = true;
+        void* h = nullptr;
+        if (hipHostMalloc(&h, sizeof(wg::HostMailbox), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                m.host = static_cast<wg::HostMailbox*>(h);
+                m.dev = static_cast<wg::HostMailbox*>(d);
+                std::memset(h, 0, sizeof(wg::HostMailbox));
+            } else {
+                (void)hipHostFree(h);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    return (g_use_mailbox && m.host) ? &m : nullptr;
+}
 bool g_force_global_sort = false;  // wg_set_option("force_global_sort", 1): exercise the fallback binning path
 
 struct StageScope {
@@ -131,11 +166,14 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     int num_rendered = 0;
     uint32_t max_tile_count = 0;
     bool huge_frame = false;
+    Mailbox* mbox = nullptr;
     if (P > 0) {
         WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, geom, radii, stream), "preprocess");
         if (tiles <= wg::BIN_MAX_TILES) {
             WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_count(P, geom, img, gx, tiles, stream), "tile_count");
-            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, stream), "tile_scan");
+            mbox = debug ? nullptr : get_mailbox();
+            if (mbox) mbox->seq += 1;
+            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, mbox ? mbox->dev : nullptr, mbox ? mbox->seq : 0, stream), "tile_scan");
         } else {
             huge_frame = true;  // tile histogram does not fit LDS: count through the per-Gaussian prefix sum instead
             WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
@@ -143,15 +181,36 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
         // the one host sync of the forward pass (rasterizer_impl.cu:284): sizes the binning buffer
         wg::BinStats st{};
         hipError_t e;
-        if (!huge_frame) {
+        bool have_stats = false;
+        if (mbox) {
+            // poll the mailbox (bounded: ~2 s, then fall back to a real synchronise so that a failed launch is reported)
+            volatile uint32_t* seqp = &mbox->host->seq;
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (*seqp != mbox->seq) {
+                if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+                __builtin_ia32_pause();
+            }
+            if (*seqp == mbox->seq) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                st.num_rendered = mbox->host->num_rendered;
+                st.max_tile_count = mbox->host->max_tile_count;
+                have_stats = true;
+            }
+        }
+        if (have_stats) {
+            e = hipSuccess;
+        } else if (!huge_frame) {
             e = hipMemcpyAsync(&st, img.stats, sizeof(st), hipMemcpyDeviceToHost, stream);
         } else {
             e = hipMemcpyAsync(&st.num_rendered, geom.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
             st.max_tile_count = 0xffffffffu;
         }
         if (e != hipSuccess) return hip_fail(e, "num_rendered readback");
-        e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) return hip_fail(e, "num_rendered readback sync");
+        if (!have_stats) {
+            e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return hip_fail(e, "num_rendered readback sync");
+        }
         if (st.num_rendered > 0x7fffffffu) return WG_ERR_OVERFLOW;
         num_rendered = (int)st.num_rendered;
         max_tile_count = st.max_tile_count;
@@ -283,6 +342,7 @@ int wg_view_image(char* image_buffer, int width, int height, wg_image_view* out)
 int wg_set_option(const char* name, int value) {
     if (!name) return WG_ERR_INVALID_ARGUMENT;
     if (std::strcmp(name, "force_global_sort") == 0) { g_force_global_sort = value != 0; return WG_OK; }
+    if (std::strcmp(name, "host_mailbox") == 0) { g_use_mailbox = value != 0; return WG_OK; }
     return WG_ERR_INVALID_ARGUMENT;
 }
 

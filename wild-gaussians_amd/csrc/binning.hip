@@ -220,7 +220,8 @@ __global__ void __launch_bounds__(256) chunk_scan_kernel(uint32_t* __restrict__ 
 }
 
 __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
-                                                         uint2* __restrict__ ranges, BinStats* __restrict__ stats, int tiles) {
+                                                         uint2* __restrict__ ranges, BinStats* __restrict__ stats, int tiles,
+                                                         HostMailbox* mailbox, uint32_t seq) {
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t wave_max[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -261,6 +262,11 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
         tile_offset[tiles] = total;
         stats->num_rendered = total;
         stats->max_tile_count = gmax;
+        if (mailbox) {
+            mailbox->num_rendered = total;
+            mailbox->max_tile_count = gmax;
+            __hip_atomic_store(&mailbox->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -525,8 +531,9 @@ hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& im
     return hipGetLastError();
 }
 
-hipError_t launch_tile_scan(const ImageState& img, int tiles, hipStream_t stream) {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges, img.stats, tiles);
+hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, hipStream_t stream) {
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges, img.stats, tiles,
+                       mailbox_dev, seq);
     return hipGetLastError();
 }
 

@@ -40,6 +40,15 @@ struct BinStats {  // read back by the host once per forward (the reference's nu
     uint32_t max_tile_count;
 };
 
+// Host-visible (pinned, mapped, coherent) mailbox the tile scan writes the same two numbers to, followed by a sequence
+// number with system-scope release: the host polls it instead of paying a D2H copy + stream synchronise.
+struct HostMailbox {
+    uint32_t num_rendered;
+    uint32_t max_tile_count;
+    uint32_t seq;
+    uint32_t pad;
+};
+
 struct ImageState {
     float* final_T;  // MUST stay first: documented in wg_rasterizer.h
     uint32_t* n_contrib;
@@ -101,7 +110,7 @@ hipError_t run_sort(const BinningState& b, int R, int end_bit, hipStream_t strea
 hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& img, int tiles, hipStream_t stream);
 hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_or_null, uint32_t* order, int tiles, hipStream_t stream);
 hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, hipStream_t stream);
-hipError_t launch_tile_scan(const ImageState& img, int tiles, hipStream_t stream);
+hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, hipStream_t stream);
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles, hipStream_t stream);
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
                             hipStream_t stream);

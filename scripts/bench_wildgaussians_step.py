@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2]: "Photo Tourism Trevi-scale: 3M Gaussians + per-Gaussian appearance embedding, 1600x1200, full
+train step on 1x MI355X".
+
+The reference's own training step (wildgaussians/method.py:1880-2024) cannot run on the GPU box (no reference checkout, no
+omegaconf/plyfile, DINOv2 weights need network), so this script restates the CALLER side of one step around the drop-in
+operator, following the call pattern of `_render_internal` (method.py:1479-1631) with `uncertainty_mode=disabled`:
+
+  activations + 3D filter (method.py:1060-1086) -> SH -> RGB in torch (method.py:493-548, 1555-1565)
+  -> rasterize raw colours                                   (hot path, forward #1)
+  -> appearance MLP on (colour, 24-d Fourier embedding, 32-d image embedding) (method.py:874-900) -> SH -> RGB
+  -> rasterize toned colours                                 (hot path, forward #2)
+  -> loss = 0.8 * L1(toned, gt) + 0.2 * DSSIM(raw, gt)       (method.py:1948-1965)  -> backward (hot path x2) -> Adam
+
+It is measurement scaffolding, not part of the product: only `diff_gaussian_rasterization` is the thing under test.
+usage: python scripts/bench_wildgaussians_step.py [--gaussians 3000000 --width 1600 --height 1200 --steps 20 --warmup 5]
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "wild-gaussians_amd"))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+C0, C1 = 0.28209479177387814, 0.4886025119029199
+C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658, 1.445305721320277,
+      -0.5900435899266435]
+
+
+def sh_to_rgb(sh, d):  # sh [P,3,16], d [P,3] unit directions; real SH basis up to degree 3
+    x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+    r = C0 * sh[..., 0] - C1 * y * sh[..., 1] + C1 * z * sh[..., 2] - C1 * x * sh[..., 3]
+    r = r + C2[0] * xy * sh[..., 4] + C2[1] * yz * sh[..., 5] + C2[2] * (2 * zz - xx - yy) * sh[..., 6] + C2[3] * xz * sh[..., 7] + \
+        C2[4] * (xx - yy) * sh[..., 8]
+    r = r + C3[0] * y * (3 * xx - yy) * sh[..., 9] + C3[1] * xy * z * sh[..., 10] + C3[2] * y * (4 * zz - xx - yy) * sh[..., 11] + \
+        C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12] + C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + \
+        C3[5] * z * (xx - yy) * sh[..., 14] + C3[6] * x * (xx - 3 * yy) * sh[..., 15]
+    return torch.clamp_min(r + 0.5, 0.0)
+
+
+def ssim_map(a, b):  # 11x11 Gaussian window, sigma 1.5, per channel
+    k = torch.arange(11, device=a.device, dtype=a.dtype) - 5
+    g = torch.exp(-(k * k) / (2 * 1.5 ** 2))
+    g = (g / g.sum())
+    w = (g[:, None] * g[None, :])[None, None].repeat(3, 1, 1, 1)
+    f = lambda t: F.conv2d(t[None], w, padding=5, groups=3)[0]
+    mu1, mu2 = f(a), f(b)
+    s1, s2, s12 = f(a * a) - mu1 * mu1, f(b * b) - mu2 * mu2, f(a * b) - mu1 * mu2
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    return ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s1 + s2 + c2))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gaussians", type=int, default=3_000_000)
+    ap.add_argument("--width", type=int, default=1600)
+    ap.add_argument("--height", type=int, default=1200)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    args = ap.parse_args()
+    import wg_scenes as S
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from tests.wg_testlib import make_settings, to_dev
+    dev = torch.device("cuda", 0)
+    P, W, H = args.gaussians, args.width, args.height
+    cloud = S.make_cloud(P, W, H, sh_degree=3, seed=0)
+    cam = S.make_camera(W, H)
+    rs = make_settings(cam, 0, device=dev)
+    rast = GaussianRasterizer(rs)
+    campos = to_dev(cam["campos"], dev)
+    prm = {
+        "xyz": to_dev(cloud["means3D"], dev), "scales": torch.log(to_dev(cloud["scales"], dev)),
+        "rotations": to_dev(cloud["rotations"], dev),
+        "opacities": torch.logit(to_dev(cloud["opacities"], dev)),
+        "features": to_dev(cloud["shs"].reshape(P, 48), dev),
+        "embeddings": torch.randn(P, 24, device=dev) * 0.1,   # per-Gaussian appearance embedding (6 * 4 Fourier features)
+        "image_embedding": torch.zeros(32, device=dev),       # per-image appearance vector
+    }
+    prm = {k: nn.Parameter(v) for k, v in prm.items()}
+    filter_3d = torch.full((P, 1), 1e-3, device=dev)
+    mlp = nn.Sequential(nn.Linear(3 + 24 + 32, 128), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 6)).to(dev)
+    opt = torch.optim.Adam([{"params": [p], "lr": 1e-4} for p in prm.values()] + [{"params": mlp.parameters(), "lr": 5e-4}], eps=1e-15)
+    gt = torch.rand(3, H, W, device=dev)
+
+    def step():
+        means2D = torch.zeros_like(prm["xyz"], requires_grad=True)
+        rot = F.normalize(prm["rotations"])
+        raw_s = torch.exp(prm["scales"])
+        s2 = raw_s * raw_s
+        s2f = s2 + filter_3d * filter_3d
+        scales = s2f.sqrt()
+        opac = torch.sigmoid(prm["opacities"]) * torch.sqrt(s2.prod(1) / s2f.prod(1))[:, None]
+        feats = prm["features"].clamp_max(1.0)
+        d = F.normalize(prm["xyz"] - campos[None], dim=1)
+        colors = sh_to_rgb(feats.view(P, 16, 3).transpose(1, 2), d)
+        kw = dict(means3D=prm["xyz"], means2D=means2D, opacities=opac, scales=scales, rotations=rot)
+        raw, radii, acc = rast(colors_precomp=colors, **kw)
+        inp = torch.cat((feats[:, :3], prm["embeddings"], prm["image_embedding"][None].expand(P, -1)), dim=-1)
+        offset, mul = torch.split(mlp(inp) * 0.01, [3, 3], dim=-1)
+        toned_f = feats * mul.repeat(1, 16) + torch.cat((offset / C0, torch.zeros(P, 45, device=dev)), dim=-1)
+        toned = sh_to_rgb(toned_f.clamp_max(1.0).view(P, 16, 3).transpose(1, 2), d)
+        img, _, _ = rast(colors_precomp=toned, **kw)
+        loss = 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - ssim_map(raw, gt)).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    # the operator's share: the same two forward + two backward calls alone
+    t = {k: v.detach() for k, v in prm.items()}
+    col = torch.rand(P, 3, device=dev, requires_grad=True)
+    m3 = t["xyz"].clone().requires_grad_(True)
+    sc, ro, op = torch.exp(t["scales"]), F.normalize(t["rotations"]), torch.sigmoid(t["opacities"])
+    cot = torch.randn(3, H, W, device=dev) / (3 * H * W)
+
+    vis = [None]
+
+    def op_only():
+        m2 = torch.zeros_like(m3, requires_grad=True)
+        a, rad, _ = rast(means3D=m3, means2D=m2, opacities=op, colors_precomp=col, scales=sc, rotations=ro)
+        vis[0] = rad
+        b, _, _ = rast(means3D=m3, means2D=m2, opacities=op, colors_precomp=col, scales=sc, rotations=ro)
+        m3.grad = None
+        col.grad = None
+        (a + b).backward(cot)
+    for _ in range(3):
+        op_only()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        op_only()
+    torch.cuda.synchronize()
+    dop = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"workload": f"WildGaussians-style train step: {P} Gaussians + appearance MLP, {W}x{H}, 2 fwd + 2 bwd raster calls, "
+                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)",
+                      "train_step_ms": round(dt * 1e3, 3), "train_steps_per_s": round(1.0 / dt, 2),
+                      "rasterizer_only_ms (2 fwd + 2 bwd)": round(dop * 1e3, 3), "rasterizer_share": round(dop / dt, 3),
+                      "visible": int((vis[0] > 0).sum().item()), "loss": float(step().item())}))
+
+
+if __name__ == "__main__":
+    main()

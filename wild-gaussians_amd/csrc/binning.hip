@@ -310,15 +310,15 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const int* __r
 // Bitonic sort of a tile's bucket.  Keys are (depth_bits << 32 | gaussian id), built while loading (the id comes from the
 // bucket, the depth from the 4 B/Gaussian depth array, which stays in L2); padded to a power of two with ~0.
 //
-// Levels k <= 1024 run on 1024-key chunks held IN REGISTERS, 4 consecutive keys per thread (256 threads):
-//   distance 1, 2      : compare-exchange between a thread's own registers;
-//   distance 4 .. 128  : the partner key sits in lane  l ^ (j/4)  of the same wave -> DPP quad_perm / row_ror,
-//                        ds_swizzle or ds_bpermute (crossbar only: no LDS memory traffic, no bank conflicts, no barrier);
-//   distance 256, 512  : the partner is in another wave -> one round trip through LDS with workgroup barriers
-//                        (3 of the 55 stages of a 1024-key sort).
+// The whole network runs on keys held IN REGISTERS, E consecutive keys per thread (256 threads, E = 4 for tiles of up to
+// 1024 instances, 8 / 16 / 32 for longer lists up to 8192):
+//   distance < E          : compare-exchange between a thread's own registers;
+//   distance E .. 32E     : the partner keys sit in lane  l ^ (j/E)  of the same wave -> DPP quad_perm / row_ror,
+//                           ds_swizzle or ds_bpermute (crossbar only: no LDS memory traffic, no bank conflicts, no barrier);
+//   distance 64E, 128E    : the partner is in another wave -> one round trip through LDS with workgroup barriers
+//                           (3 of the 55 stages of a 1024-key sort).
 // A first version kept the keys in LDS for every stage; rocprofv3 showed its LDS pipe ~80 % busy (37 % of that bank
-// conflicts on the 64-bit accesses).  Levels k > 1024 (tiles listing more than 1024 instances) merge the sorted chunks
-// with compare-exchanges in LDS.
+// conflicts on the 64-bit accesses).
 __device__ __forceinline__ void bitonic_ce(uint64_t* skeys, uint32_t t, uint32_t j, uint32_t k) {
     const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
     const uint32_t l = i | j;
@@ -328,13 +328,6 @@ __device__ __forceinline__ void bitonic_ce(uint64_t* skeys, uint32_t t, uint32_t
         skeys[i] = b;
         skeys[l] = a;
     }
-}
-
-__device__ __forceinline__ void wave_lds_fence() {
-    // order this wave's LDS writes before its later LDS reads (no other wave touches the block)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <int D>  // value of lane (l ^ D), D in {1, 2, 4, 8, 16, 32}
@@ -347,11 +340,12 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
     else return (uint32_t)__shfl_xor((int)v, 32);
 }
 
+template <int E>
 struct SortCtx {
-    uint64_t key[4];
-    uint32_t t;      // thread index in the workgroup
-    uint32_t gidx;   // global (within the tile's padded array) index of key[0]
-    uint64_t* chunk; // this chunk's 1024 keys in LDS (exchange buffer for the cross-wave stages)
+    uint64_t key[E];  // E consecutive keys of the tile's padded array
+    uint32_t t;       // thread index in the workgroup
+    uint32_t gidx;    // index of key[0] in the padded array (= E * t: one chunk of 256*E keys covers the tile)
+    uint64_t* xchg;   // LDS exchange buffer (256*E keys) for the cross-wave stages
 };
 
 __device__ __forceinline__ void keep(uint64_t& mine, uint64_t other, bool keep_min) {
@@ -359,11 +353,11 @@ __device__ __forceinline__ void keep(uint64_t& mine, uint64_t other, bool keep_m
     mine = (other_less == keep_min) ? other : mine;
 }
 
-template <int K, int J>
-__device__ __forceinline__ void sort_stage(SortCtx& c) {
-    if constexpr (J < 4) {
+template <int E, int K, int J>
+__device__ __forceinline__ void sort_stage(SortCtx<E>& c) {
+    if constexpr (J < E) {  // both keys of every pair live in this thread's registers
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < E; r++) {
             if ((r & J) == 0) {
                 const bool asc = ((c.gidx + r) & K) == 0;
                 uint64_t& a = c.key[r];
@@ -377,108 +371,84 @@ __device__ __forceinline__ void sort_stage(SortCtx& c) {
         }
     } else {
         const bool asc = (c.gidx & K) == 0;
-        const bool lower = (c.t & (J / 4)) == 0;
+        const bool lower = (c.t & (J / E)) == 0;
         const bool keep_min = lower == asc;
-        if constexpr (J < 256) {
+        if constexpr (J < 64 * E) {  // the partner keys sit in lane l ^ (J/E) of this wave
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint32_t lo = lane_xor<J / 4>((uint32_t)c.key[r]);
-                const uint32_t hi = lane_xor<J / 4>((uint32_t)(c.key[r] >> 32));
+            for (int r = 0; r < E; r++) {
+                const uint32_t lo = lane_xor<J / E>((uint32_t)c.key[r]);
+                const uint32_t hi = lane_xor<J / E>((uint32_t)(c.key[r] >> 32));
                 keep(c.key[r], ((uint64_t)hi << 32) | lo, keep_min);
             }
-        } else {
-            uint64_t* mine = c.chunk + 4 * c.t;
-            mine[0] = c.key[0]; mine[1] = c.key[1]; mine[2] = c.key[2]; mine[3] = c.key[3];
+        } else {  // the partner keys sit in another wave: one round trip through LDS
+            uint64_t* mine = c.xchg + E * c.t;
+#pragma unroll
+            for (int r = 0; r < E; r++) mine[r] = c.key[r];
             __syncthreads();
-            const uint64_t* theirs = c.chunk + 4 * (c.t ^ (J / 4));
-            const uint64_t o0 = theirs[0], o1 = theirs[1], o2 = theirs[2], o3 = theirs[3];
+            const uint64_t* theirs = c.xchg + E * (c.t ^ (J / E));
+            uint64_t other[E];
+#pragma unroll
+            for (int r = 0; r < E; r++) other[r] = theirs[r];
             __syncthreads();
-            keep(c.key[0], o0, keep_min); keep(c.key[1], o1, keep_min); keep(c.key[2], o2, keep_min); keep(c.key[3], o3, keep_min);
+#pragma unroll
+            for (int r = 0; r < E; r++) keep(c.key[r], other[r], keep_min);
         }
     }
 }
 
-template <int K, int J>
-__device__ __forceinline__ void sort_stages(SortCtx& c) {
-    sort_stage<K, J>(c);
-    if constexpr (J > 1) sort_stages<K, J / 2>(c);
+template <int E, int K, int J>
+__device__ __forceinline__ void sort_stages(SortCtx<E>& c) {
+    sort_stage<E, K, J>(c);
+    if constexpr (J > 1) sort_stages<E, K, J / 2>(c);
 }
 
-template <int K>
-__device__ __forceinline__ void sort_levels(SortCtx& c, uint32_t kmax) {
-    if constexpr (K > 2) sort_levels<K / 2>(c, kmax);
-    if (K <= kmax) sort_stages<K, K / 2>(c);  // kmax is workgroup-uniform
+template <int E, int K>
+__device__ __forceinline__ void sort_levels(SortCtx<E>& c, uint32_t kmax) {
+    if constexpr (K > 2) sort_levels<E, K / 2>(c, kmax);
+    if (K <= kmax) sort_stages<E, K, K / 2>(c);  // kmax is workgroup-uniform
 }
 
+// One workgroup per tile; E keys per thread, so the kernel sorts tiles of up to 256*E instances.  Launched once with E = 4
+// for the tiles listing at most 1024 instances and, if longer lists exist, once more with E = 8/16/32 for those.
+template <int E>
 __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bucket_ids,
-                                                        const float* __restrict__ depths, uint32_t* __restrict__ point_list, int tiles) {
+                                                        const float* __restrict__ depths, uint32_t* __restrict__ point_list, uint32_t n_min,
+                                                        uint32_t n_max) {
     extern __shared__ uint64_t skeys[];
     const int tile = blockIdx.x;
     const uint32_t begin = tile_offset[tile];
     const uint32_t n = tile_offset[tile + 1] - begin;
-    if (n == 0) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t np2 = 4;  // at least one key quartet
+    if (n < n_min || n > n_max) return;  // n == 0, or a tile the other launch takes care of
+    uint32_t np2 = E;  // at least one key group
     while (np2 < n) np2 <<= 1;
-
-    // ---- levels k <= 1024: register-resident chunks of 1024 keys ----
-    const uint32_t kmax = min(np2, 1024u);
-    const uint32_t nchunks = (np2 + 1023) >> 10;
-    for (uint32_t ch = 0; ch < nchunks; ch++) {
-        SortCtx c;
-        c.t = tid;
-        c.gidx = ch * 1024 + 4 * tid;
-        c.chunk = skeys + ch * 1024;
+    SortCtx<E> c;
+    c.t = threadIdx.x;
+    c.gidx = E * threadIdx.x;
+    c.xchg = skeys;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint32_t i = c.gidx + r;
-            uint64_t key = ~0ull;
-            if (i < n) {
-                const uint32_t id = bucket_ids[begin + i];
-                key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
-            }
-            c.key[r] = key;
+    for (int r = 0; r < E; r++) {
+        const uint32_t i = c.gidx + r;
+        uint64_t key = ~0ull;
+        if (i < n) {
+            const uint32_t id = bucket_ids[begin + i];
+            key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
         }
-        sort_levels<1024>(c, kmax);
-        if (nchunks == 1) {  // common case: the tile is done, write the ids straight from registers
+        c.key[r] = key;
+    }
+    sort_levels<E, 256 * E>(c, np2);
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                if (c.gidx + r < n) point_list[begin + c.gidx + r] = (uint32_t)c.key[r];
-            return;
-        }
-        uint64_t* mine = c.chunk + 4 * tid;
-        mine[0] = c.key[0]; mine[1] = c.key[1]; mine[2] = c.key[2]; mine[3] = c.key[3];
-    }
-    __syncthreads();
-
-    // ---- levels k > 1024: merge the sorted chunks with compare-exchanges in LDS ----
-    const uint32_t nblocks = np2 >> 8;
-    for (uint32_t k = 2048; k <= np2; k <<= 1) {
-        uint32_t j = k >> 1;
-        for (; j >= 256; j >>= 1) {  // distances that span 256-key blocks: all threads, workgroup barrier per stage
-            for (uint32_t t = tid; t < (np2 >> 1); t += 256) bitonic_ce(skeys, t, j, k);
-            __syncthreads();
-        }
-        for (; j > 0; j >>= 1) {  // inside a block: wave w owns blocks w, w+4, ...; no workgroup barrier
-            for (uint32_t blk = wave; blk < nblocks; blk += 4)
-                for (uint32_t cidx = lane; cidx < 128; cidx += 64) bitonic_ce(skeys, blk * 128 + cidx, j, k);
-            wave_lds_fence();
-        }
-        __syncthreads();
-    }
-    for (uint32_t i = tid; i < n; i += 256) point_list[begin + i] = (uint32_t)skeys[i];
+    for (int r = 0; r < E; r++)
+        if (c.gidx + r < n) point_list[begin + c.gidx + r] = (uint32_t)c.key[r];
 }
 
 // ---- launch order of the render kernels ---------------------------------------------------------------------------
 // The render kernels run one wave per tile and all ~8k waves are resident at once (<= 8 per SIMD), so the kernel ends
-// when the SIMD with the largest SUM of tile costs ends: with tiles dealt in image order that sum varies by ~+-30 %
-// (measured: VALU busy 79 % in the forward kernel).  Dealing the tiles of each XCD band in descending cost order
+// when the SIMD with the largest SUM of tile costs ends.  Dealing the tiles of each XCD band in descending cost order
 // gives every SIMD one tile of each size class.  One workgroup per band sorts (cost, tile) in LDS; bands with more than
 // 8192 tiles keep the image order.  Pure scheduling: results do not depend on it.  Used for the backward kernel, whose
 // per-tile cost (tile_last, the walked length) is known exactly from the forward pass: 0.752 -> 0.660 ms.  The forward
 // kernel's only predictor, the list length, did not help (its walked fraction is what varies), so it keeps image order.
 constexpr uint32_t ORDER_MAX = 8192;
-__device__ __forceinline__ void bitonic_ce(uint64_t* skeys, uint32_t t, uint32_t j, uint32_t k);
 
 __global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __restrict__ cost, const uint2* __restrict__ ranges,
                                                           uint32_t* __restrict__ order, int tiles) {
@@ -548,21 +518,25 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
     return hipGetLastError();
 }
 
+template <int E>
+static hipError_t launch_tile_sort_e(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t n_min,
+                                     uint32_t n_max, hipStream_t stream) {
+    const size_t lds = (size_t)256 * E * sizeof(uint64_t);  // exchange buffer of the cross-wave stages
+    hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_sort_kernel<E>), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tile_sort_kernel<E>, dim3(tiles), dim3(256), lds, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list, n_min,
+                       n_max);
+    return hipGetLastError();
+}
+
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
                             hipStream_t stream) {
     if (tiles <= 0 || max_count == 0) return hipSuccess;
-    uint32_t np2 = 1024;  // the cross-wave stages of a register chunk exchange through a 1024-key LDS buffer
-    while (np2 < max_count) np2 <<= 1;
-    const size_t lds = (size_t)np2 * sizeof(uint64_t);
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(TILE_SORT_MAX * sizeof(uint64_t)));
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles), dim3(256), lds, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list, tiles);
-    return hipGetLastError();
+    hipError_t e = launch_tile_sort_e<4>(img, b, g, tiles, 1u, 1024u, stream);
+    if (e != hipSuccess || max_count <= 1024) return e;
+    if (max_count <= 2048) return launch_tile_sort_e<8>(img, b, g, tiles, 1025u, 2048u, stream);
+    if (max_count <= 4096) return launch_tile_sort_e<16>(img, b, g, tiles, 1025u, 4096u, stream);
+    return launch_tile_sort_e<32>(img, b, g, tiles, 1025u, TILE_SORT_MAX, stream);
 }
 
 }  // namespace wg

@@ -12,7 +12,8 @@
 //     then issue ONE global_atomic_add_f32 instruction per (tile, Gaussian) instance: 256x fewer atomics than the
 //     reference for a fully covered tile;
 //   * the "last_alpha / last_color" lazy recurrence (backward.cu:560-561,572) is applied eagerly
-//     (accum_rec' = alpha*c + (1-alpha)*accum_rec right after use): same values, 16 fewer live registers.
+//     (accum_rec' = alpha*c + (1-alpha)*accum_rec right after use) and accum_rec is carried as its dot product with the
+//     pixel's dL_dpixel (the only way it is ever used): one register per pixel instead of seven.
 // The gradient arithmetic is the reference's hand-derived backward, not autograd of the forward:
 // straight-through min(0.99,.), NDC-scaled dL_dmean2D (0.5*W, 0.5*H), abs-gradient in .z
 // (backward.cu:593-595), conic gradient in .x/.y/.w of a float4 (backward.cu:598-600).
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     const bool oscale = vidx >= 3 && vidx <= 8;
     const float vscale = vidx == 3 ? -ddelx_dx : vidx == 4 ? -ddely_dy : (vidx >= 6 && vidx <= 8) ? -0.5f : 1.0f;
 
-    float pfx[4], pfy[4], T[4], tfb[4], dLr[4], dLg[4], dLb[4], recr[4], recg[4], recb[4];
+    float pfx[4], pfy[4], T[4], tfb[4], dLr[4], dLg[4], dLb[4], recd[4];
     int last[4];
     StripBounds sb;
 #pragma unroll
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
         pfx[s] = (float)px + off.x;
         pfy[s] = (float)py + off.y;
         tfb[s] = -T[s] * (bg0 * dLr[s] + bg1 * dLg[s] + bg2 * dLb[s]);  // -T_final * <bg, dL_dpixel>
-        recr[s] = recg[s] = recb[s] = 0.f;
+        recd[s] = 0.f;
         const float inf = __builtin_huge_valf();
         sb.x0[s] = wave_min_uniform(inside ? pfx[s] : inf);
         sb.x1[s] = wave_max_uniform(inside ? pfx[s] : -inf);
@@ -190,12 +191,12 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
                     acr += w * dLr[s];
                     acg += w * dLg[s];
                     acb += w * dLb[s];
-                    const float dr = colr - recr[s], dg = colg - recg[s], db = colb - recb[s];
-                    float dLda = dr * dLr[s] + dg * dLg[s] + db * dLb[s];
-                    recr[s] += a * dr;  // accum_rec for the next (nearer) contributor
-                    recg[s] += a * dg;
-                    recb[s] += a * db;
-                    dLda = dLda * Tn + tfb[s] * inv;
+                    // sum_ch (c_ch - accum_rec_ch) * dL_ch, with accum_rec carried as its dot product with dL_dpixel:
+                    // accum_rec' = alpha*c + (1-alpha)*accum_rec  (backward.cu:560)  =>  recd' = recd + alpha*(cd - recd)
+                    const float cd = colr * dLr[s] + colg * dLg[s] + colb * dLb[s];
+                    const float diff = cd - recd[s];
+                    recd[s] += a * diff;
+                    const float dLda = diff * Tn + tfb[s] * inv;
                     const float q = e.G * dLda;
                     const float u = r0.z * e.dx + r0.w * e.dy;
                     const float v = r1.x * e.dy + r0.w * e.dx;

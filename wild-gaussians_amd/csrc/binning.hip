@@ -60,7 +60,6 @@ ImageState ImageState::fromChunk(char*& chunk, size_t N, size_t tiles) {
     carve(chunk, img.tile_count, tiles ? tiles : 1);
     carve(chunk, img.tile_offset, tiles + 1);
     carve(chunk, img.chunk_hist, (tiles ? tiles : 1) * (size_t)BIN_CHUNKS);
-    carve(chunk, img.order_fwd, tiles ? tiles : 1);
     carve(chunk, img.order_bwd, tiles ? tiles : 1);
     carve(chunk, img.stats, 1);
     return img;

@@ -9,9 +9,7 @@ namespace wg {
 
 constexpr int TILE_X = WG_TILE_X;
 constexpr int TILE_Y = WG_TILE_Y;
-constexpr int TILE_PIX = TILE_X * TILE_Y;
 constexpr size_t ALIGN = 256;
-constexpr int SPLAT_FLOATS = 12;  // 48-byte record per Gaussian, see wg_geometry_view
 
 // ---- scratch carving (the role of obtain()/fromChunk(), rasterizer_impl.h:22-28, .cu:155-194) ----
 template <typename T>
@@ -57,7 +55,6 @@ struct ImageState {
     uint32_t* tile_count;   // per-tile instance count
     uint32_t* tile_offset;  // exclusive prefix sum of tile_count
     uint32_t* chunk_hist;   // [chunks][tiles] per-chunk tile histogram, turned into per-chunk bases by the column scan
-    uint32_t* order_fwd;    // launch order of the forward render: per XCD band, tiles by descending list length
     uint32_t* order_bwd;    // launch order of the backward render: per XCD band, tiles by descending walked length
     BinStats* stats;
     static ImageState fromChunk(char*& chunk, size_t N, size_t tiles);
@@ -77,7 +74,7 @@ struct BinningState {
     static BinningState fromChunk(char*& chunk, size_t R, bool global_sort);
 };
 
-constexpr uint32_t TILE_SORT_MAX = 8192;  // longest per-tile list the LDS sort handles (64 KiB of keys)
+constexpr uint32_t TILE_SORT_MAX = 8192;  // longest per-tile list the register sort handles (32 keys per thread)
 constexpr int BIN_CHUNKS = 512;           // Gaussian chunks (= workgroups) of the LDS counting sort
 constexpr int BIN_MAX_TILES = 36864;      // tiles*4 B must fit one workgroup's LDS (144 KiB): up to 4K frames
 

@@ -211,8 +211,7 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 # ----------------------------------------------------------------------------------------------------------
 # Introspection for the parity tests: typed views into the opaque scratch buffers (device tensors, no copy).
 def _from_ptr(ptr, shape, dtype, owner):
-    import numpy as np  # noqa: F401  (torch.frombuffer cannot wrap device memory; use the CUDA array interface)
-
+    # torch.frombuffer cannot wrap device memory; the CUDA array interface can
     class _Holder:
         pass
 

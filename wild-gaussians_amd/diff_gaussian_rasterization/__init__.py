@@ -49,10 +49,6 @@ def _absent() -> torch.Tensor:
     return torch.Tensor([])
 
 
-def _snapshot(args, path: str) -> None:
-    torch.save(tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args), path)
-
-
 def _call_native(fn, args, debug: bool, dump_path: str, what: str):
     """Run a native entry point; in debug mode keep a CPU copy of the inputs and dump it if the call raises."""
     if not debug:

@@ -24,8 +24,8 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": [],
-    "render_fwd.hip": [],
-    "render_bwd.hip": ["-munsafe-fp-atomics"],
+    "render_fwd.hip": ["-fno-slp-vectorize"],
+    "render_bwd.hip": ["-munsafe-fp-atomics", "-fno-slp-vectorize"],
     "preprocess_bwd.hip": [],
     "api.hip": [],
     "knn.hip": ["-ffp-contract=off"],  # simple_knn.distCUDA2 replacement (include/wg_knn.h)

@@ -22,11 +22,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + INCLUDE, "-I" + CSRC]
 # per-file extra flags: the preprocess kernel must not fuse multiply-adds (integer outputs bit-exact vs oracle)
 SOURCES = {
-    "preprocess.hip": ["-ffp-contract=off"],
-    "binning.hip": [],
+    "preprocess.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
+    "binning.hip": ["-fno-slp-vectorize"],
     "render_fwd.hip": ["-fno-slp-vectorize"],
     "render_bwd.hip": ["-munsafe-fp-atomics", "-fno-slp-vectorize"],
-    "preprocess_bwd.hip": [],
+    "preprocess_bwd.hip": ["-fno-slp-vectorize"],
     "api.hip": [],
     "knn.hip": ["-ffp-contract=off"],  # simple_knn.distCUDA2 replacement (include/wg_knn.h)
 }

@@ -407,17 +407,10 @@ __device__ __forceinline__ void sort_levels(SortCtx<E>& c, uint32_t kmax) {
     if (K <= kmax) sort_stages<E, K, K / 2>(c);  // kmax is workgroup-uniform
 }
 
-// One workgroup per tile; E keys per thread, so the kernel sorts tiles of up to 256*E instances.  Launched once with E = 4
-// for the tiles listing at most 1024 instances and, if longer lists exist, once more with E = 8/16/32 for those.
+// One workgroup per tile; E keys per thread sort a tile of up to 256*E instances.
 template <int E>
-__global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bucket_ids,
-                                                        const float* __restrict__ depths, uint32_t* __restrict__ point_list, uint32_t n_min,
-                                                        uint32_t n_max) {
-    extern __shared__ uint64_t skeys[];
-    const int tile = blockIdx.x;
-    const uint32_t begin = tile_offset[tile];
-    const uint32_t n = tile_offset[tile + 1] - begin;
-    if (n < n_min || n > n_max) return;  // n == 0, or a tile the other launch takes care of
+__device__ __forceinline__ void tile_sort_body(uint64_t* skeys, uint32_t begin, uint32_t n, const uint32_t* __restrict__ bucket_ids,
+                                               const float* __restrict__ depths, uint32_t* __restrict__ point_list) {
     uint32_t np2 = E;  // at least one key group
     while (np2 < n) np2 <<= 1;
     SortCtx<E> c;
@@ -438,6 +431,28 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restri
 #pragma unroll
     for (int r = 0; r < E; r++)
         if (c.gidx + r < n) point_list[begin + c.gidx + r] = (uint32_t)c.key[r];
+}
+
+// The host knows the longest list (mailbox) and launches the instantiation whose EMAX covers it; inside, every workgroup
+// takes the smallest E that holds its own tile, so the few long tiles sort while the short ones do (a second launch for
+// them cost 23 us on the headline scene: one 2048-key network is a 20 us dependency chain).  EMAX = 32 would cost the
+// short tiles their occupancy (118 VGPRs, 64 KB LDS), so lists of 4097..8192 get their own launch after the <16> one.
+template <int EMAX>
+__global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bucket_ids,
+                                                        const float* __restrict__ depths, uint32_t* __restrict__ point_list, uint32_t n_min,
+                                                        uint32_t n_max) {
+    extern __shared__ uint64_t skeys[];
+    const int tile = blockIdx.x;
+    const uint32_t begin = tile_offset[tile];
+    const uint32_t n = tile_offset[tile + 1] - begin;
+    if (n < n_min || n > n_max) return;  // n == 0, or a tile the other launch takes care of
+    if constexpr (EMAX == 32) {
+        tile_sort_body<32>(skeys, begin, n, bucket_ids, depths, point_list);
+    } else {
+        if (EMAX == 4 || n <= 1024) tile_sort_body<4>(skeys, begin, n, bucket_ids, depths, point_list);
+        else if (EMAX == 8 || n <= 2048) tile_sort_body<(EMAX >= 8 ? 8 : 4)>(skeys, begin, n, bucket_ids, depths, point_list);
+        else tile_sort_body<(EMAX >= 16 ? 16 : 4)>(skeys, begin, n, bucket_ids, depths, point_list);
+    }
 }
 
 // ---- launch order of the render kernels ---------------------------------------------------------------------------
@@ -531,11 +546,11 @@ static hipError_t launch_tile_sort_e(const ImageState& img, const BinningState& 
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
                             hipStream_t stream) {
     if (tiles <= 0 || max_count == 0) return hipSuccess;
-    hipError_t e = launch_tile_sort_e<4>(img, b, g, tiles, 1u, 1024u, stream);
-    if (e != hipSuccess || max_count <= 1024) return e;
-    if (max_count <= 2048) return launch_tile_sort_e<8>(img, b, g, tiles, 1025u, 2048u, stream);
-    if (max_count <= 4096) return launch_tile_sort_e<16>(img, b, g, tiles, 1025u, 4096u, stream);
-    return launch_tile_sort_e<32>(img, b, g, tiles, 1025u, TILE_SORT_MAX, stream);
+    if (max_count <= 1024) return launch_tile_sort_e<4>(img, b, g, tiles, 1u, 1024u, stream);
+    if (max_count <= 2048) return launch_tile_sort_e<8>(img, b, g, tiles, 1u, 2048u, stream);
+    hipError_t e = launch_tile_sort_e<16>(img, b, g, tiles, 1u, 4096u, stream);
+    if (e != hipSuccess || max_count <= 4096) return e;
+    return launch_tile_sort_e<32>(img, b, g, tiles, 4097u, TILE_SORT_MAX, stream);
 }
 
 }  // namespace wg

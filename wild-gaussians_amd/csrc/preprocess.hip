@@ -48,38 +48,66 @@ __device__ __forceinline__ float sh_channel(int deg, const float* sh, float x, f
 // lane stride.  The values, and the order of the arithmetic on them, are unchanged.
 constexpr int SH_PITCH4 = 13;
 
-template <bool FAST_SH>
+template <bool FAST_SH, bool PRECOMP>
 __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometryState g, int* __restrict__ radii_out) {
     __shared__ float4 stage[FAST_SH ? 64 * SH_PITCH4 : 1];
     const int lane = threadIdx.x;
     const int base = blockIdx.x * 64;
     const int idx = base + lane;
+    const bool inside = idx < p.P;
+    const int ld = inside ? idx : p.P - 1;  // out-of-range lanes of the last wave shadow the last Gaussian and store nothing
+
+    // All of this wave's loads are issued up front: the 12 KiB SH block stays in flight in registers while the geometry
+    // below is computed, and only then goes through LDS.
+    // camera constants into scalar registers before the ordering fences below (which would turn them into vector loads)
+    float vm[16], pm[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        vm[i] = p.viewmatrix[i];
+        pm[i] = p.projmatrix[i];
+    }
+    const float camx = p.cam_pos[0], camy = p.cam_pos[1], camz = p.cam_pos[2];
+    // Geometry inputs first, SH block second: the memory counter retires loads in issue order, so whatever the geometry
+    // waits for has to be issued ahead of the twelve SH loads for those to stay in flight behind it.
+    float px = p.means3D[3 * ld], py = p.means3D[3 * ld + 1], pz = p.means3D[3 * ld + 2];
+    const float opacity = p.opacities[ld];
+    float sc0 = 0.f, sc1 = 0.f, sc2 = 0.f;
+    float4 quat = make_float4(0.f, 0.f, 0.f, 0.f);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f;
+    if (!PRECOMP) {  // a template parameter, not a branch: a join here makes the compiler wait for every load in flight
+        sc0 = p.scales[3 * ld]; sc1 = p.scales[3 * ld + 1]; sc2 = p.scales[3 * ld + 2];
+        quat = reinterpret_cast<const float4*>(p.rotations)[ld];
+    } else {
+        const float* c = p.cov3D_precomp + 6 * (size_t)ld;
+        c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; c5 = c[5];
+    }
+    // (named registers, not an array: hipcc leaves a 12 x float4 array in scratch)
+    float4 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7, sr8, sr9, sr10, sr11;
+    sr0 = sr1 = sr2 = sr3 = sr4 = sr5 = sr6 = sr7 = sr8 = sr9 = sr10 = sr11 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (FAST_SH) {
         const float4* src = reinterpret_cast<const float4*>(p.shs) + (size_t)base * 12;
-        const int nvalid = min(64, p.P - base) * 12;
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const int f = i * 64 + lane;
-            if (f < nvalid) stage[(f / 12) * SH_PITCH4 + (f % 12)] = src[f];
-        }
-        __syncthreads();
+        const int last = min(64, p.P - base) * 12 - 1;
+#define WG_SH_LOAD(i) sr##i = src[min(i * 64 + lane, last)];
+        WG_SH_LOAD(0) WG_SH_LOAD(1) WG_SH_LOAD(2) WG_SH_LOAD(3) WG_SH_LOAD(4) WG_SH_LOAD(5)
+        WG_SH_LOAD(6) WG_SH_LOAD(7) WG_SH_LOAD(8) WG_SH_LOAD(9) WG_SH_LOAD(10) WG_SH_LOAD(11)
+#undef WG_SH_LOAD
     }
-    if (idx >= p.P) return;
+    // pin the order: nothing of the geometry below may be scheduled ahead of the SH loads, nor the LDS staging ahead of it
+    asm volatile("" : "+v"(px), "+v"(py), "+v"(pz) : : "memory");
 
     // forward.cu:200-201
     int radius_i = 0;
     uint32_t touched = 0;
-
-    const float* vm = p.viewmatrix;
-    const float* pm = p.projmatrix;
-    const float px = p.means3D[3 * idx], py = p.means3D[3 * idx + 1], pz = p.means3D[3 * idx + 2];
+    bool vis = false;
+    float pixx = 0.f, pixy = 0.f, conx = 0.f, cony = 0.f, conz = 0.f, coef = 0.f;
+    int rminx = 0, rminy = 0, rmaxx = 0, rmaxy = 0;
 
     // in_frustum: auxiliary.h:152-163 (near cull only)
     const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
     const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
     const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
-    bool alive = !(vz <= 0.2f);
-    if (!alive && p.prefiltered) {
+    const bool alive = inside && !(vz <= 0.2f);
+    if (inside && !alive && p.prefiltered) {
         // auxiliary.h:156-160: the reference printf()s and __trap()s; same contract here.
         printf("Point is filtered although prefiltered is set. This shouldn't happen!");
         __builtin_trap();
@@ -94,14 +122,9 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
         const float projx = hx * p_w, projy = hy * p_w;
 
         // ---- 3D covariance (forward.cu:129-163) ----
-        float c0, c1, c2, c3, c4, c5;
-        if (p.cov3D_precomp != nullptr) {
-            const float* c = p.cov3D_precomp + 6 * (size_t)idx;
-            c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3]; c4 = c[4]; c5 = c[5];
-        } else {
-            const float s0 = p.scale_modifier * p.scales[3 * idx], s1 = p.scale_modifier * p.scales[3 * idx + 1],
-                        s2 = p.scale_modifier * p.scales[3 * idx + 2];
-            const float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
+        if (!PRECOMP) {
+            const float s0 = p.scale_modifier * sc0, s1 = p.scale_modifier * sc1, s2 = p.scale_modifier * sc2;
+            const float4 q = quat;
             const float r = q.x, x = q.y, y = q.z, z = q.w;
             // column-major R as filled by the reference (forward.cu:145-149); M[c][r] = s_r * R[c][r]
             const float M00 = s0 * (1.f - 2.f * (y * y + z * z)), M01 = s1 * (2.f * (x * y - r * z)), M02 = s2 * (2.f * (x * z + r * y));
@@ -138,7 +161,7 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
         // forward.cu:112-118 -- max(1e-6, float) and "+1e-6" are double arithmetic in the reference
         const float det_0 = (float)fmax(1e-6, (double)(cov00 * cov11 - cov01 * cov01));
         const float det_1 = (float)fmax(1e-6, (double)((cov00 + p.kernel_size) * (cov11 + p.kernel_size) - cov01 * cov01));
-        float coef = (float)sqrt((double)det_0 / ((double)det_1 + 1e-6) + 1e-6);
+        coef = (float)sqrt((double)det_0 / ((double)det_1 + 1e-6) + 1e-6);
         if ((double)det_0 <= 1e-6 || (double)det_1 <= 1e-6) coef = 0.0f;
         cov00 += p.kernel_size;
         cov11 += p.kernel_size;
@@ -147,59 +170,78 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
         const float det = cov00 * cov11 - cov01 * cov01;
         if (det != 0.0f) {
             const float det_inv = 1.f / det;
-            const float conx = cov11 * det_inv, cony = -cov01 * det_inv, conz = cov00 * det_inv;
+            conx = cov11 * det_inv; cony = -cov01 * det_inv; conz = cov00 * det_inv;
             const float mid = 0.5f * (cov00 + cov11);
             const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
             const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
             const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
             // ndc2Pix, auxiliary.h:41-44 (double)
-            const float pixx = (float)((((double)projx + 1.0) * (double)p.W - 1.0) * 0.5);
-            const float pixy = (float)((((double)projy + 1.0) * (double)p.H - 1.0) * 0.5);
+            pixx = (float)((((double)projx + 1.0) * (double)p.W - 1.0) * 0.5);
+            pixy = (float)((((double)projy + 1.0) * (double)p.H - 1.0) * 0.5);
             // getRect, auxiliary.h:46-56
             const int mr = (int)my_radius;
-            const int rminx = min(p.gx, max(0, (int)((pixx - mr) / TILE_X)));
-            const int rminy = min(p.gy, max(0, (int)((pixy - mr) / TILE_Y)));
-            const int rmaxx = min(p.gx, max(0, (int)((pixx + mr + TILE_X - 1) / TILE_X)));
-            const int rmaxy = min(p.gy, max(0, (int)((pixy + mr + TILE_Y - 1) / TILE_Y)));
+            rminx = min(p.gx, max(0, (int)((pixx - mr) / TILE_X)));
+            rminy = min(p.gy, max(0, (int)((pixy - mr) / TILE_Y)));
+            rmaxx = min(p.gx, max(0, (int)((pixx + mr + TILE_X - 1) / TILE_X)));
+            rmaxy = min(p.gy, max(0, (int)((pixy + mr + TILE_Y - 1) / TILE_Y)));
             const int ntiles = (rmaxx - rminx) * (rmaxy - rminy);
             if (ntiles != 0) {
-                float cr, cg, cb;
-                if (p.colors_precomp == nullptr) {
-                    // computeColorFromSH, forward.cu:20-71
-                    float dx = px - p.cam_pos[0], dy = py - p.cam_pos[1], dz = pz - p.cam_pos[2];
-                    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-                    dx = dx / len; dy = dy / len; dz = dz / len;
-                    if (FAST_SH) {
-                        float sh[48];
-#pragma unroll
-                        for (int q = 0; q < 12; q++) {
-                            const float4 v = stage[lane * SH_PITCH4 + q];
-                            sh[4 * q] = v.x; sh[4 * q + 1] = v.y; sh[4 * q + 2] = v.z; sh[4 * q + 3] = v.w;
-                        }
-                        cr = sh_channel(p.D, sh + 0, dx, dy, dz);
-                        cg = sh_channel(p.D, sh + 1, dx, dy, dz);
-                        cb = sh_channel(p.D, sh + 2, dx, dy, dz);
-                    } else {
-                        const float* sh = p.shs + (size_t)idx * p.M * 3;
-                        cr = sh_channel(p.D, sh + 0, dx, dy, dz);
-                        cg = sh_channel(p.D, sh + 1, dx, dy, dz);
-                        cb = sh_channel(p.D, sh + 2, dx, dy, dz);
-                    }
-                    g.clamped[idx] = (unsigned char)((cr < 0 ? 1 : 0) | (cg < 0 ? 2 : 0) | (cb < 0 ? 4 : 0));
-                    cr = fmaxf(cr, 0.0f); cg = fmaxf(cg, 0.0f); cb = fmaxf(cb, 0.0f);
-                } else {
-                    cr = p.colors_precomp[3 * idx]; cg = p.colors_precomp[3 * idx + 1]; cb = p.colors_precomp[3 * idx + 2];
-                }
-                g.depths[idx] = vz;
+                vis = true;
                 radius_i = mr;
                 touched = (uint32_t)ntiles;
-                float4* rec = g.splats + 3 * (size_t)idx;
-                rec[0] = make_float4(pixx, pixy, conx, cony);
-                rec[1] = make_float4(conz, p.opacities[idx] * coef, 0.f, cr);  // .z is reserved: the render kernels park a strip mask there
-                rec[2] = make_float4(cg, cb, 0.f, 0.f);
-                g.rects[idx] = make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy);
             }
         }
+    }
+
+    asm volatile("" : "+v"(pixx), "+v"(radius_i) : : "memory");
+    if (FAST_SH) {
+        const int nvalid = min(64, p.P - base) * 12;
+#define WG_SH_STAGE(i)                                                          \
+    {                                                                           \
+        const int f = i * 64 + lane;                                            \
+        if (f < nvalid) stage[(f / 12) * SH_PITCH4 + (f % 12)] = sr##i;         \
+    }
+        WG_SH_STAGE(0) WG_SH_STAGE(1) WG_SH_STAGE(2) WG_SH_STAGE(3) WG_SH_STAGE(4) WG_SH_STAGE(5)
+        WG_SH_STAGE(6) WG_SH_STAGE(7) WG_SH_STAGE(8) WG_SH_STAGE(9) WG_SH_STAGE(10) WG_SH_STAGE(11)
+#undef WG_SH_STAGE
+        __syncthreads();
+    }
+    if (!inside) return;
+
+    if (vis) {
+        float cr, cg, cb;
+        if (p.colors_precomp == nullptr) {
+            // computeColorFromSH, forward.cu:20-71
+            float dx = px - camx, dy = py - camy, dz = pz - camz;
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            dx = dx / len; dy = dy / len; dz = dz / len;
+            if (FAST_SH) {
+                float sh[48];
+#pragma unroll
+                for (int q = 0; q < 12; q++) {
+                    const float4 v = stage[lane * SH_PITCH4 + q];
+                    sh[4 * q] = v.x; sh[4 * q + 1] = v.y; sh[4 * q + 2] = v.z; sh[4 * q + 3] = v.w;
+                }
+                cr = sh_channel(p.D, sh + 0, dx, dy, dz);
+                cg = sh_channel(p.D, sh + 1, dx, dy, dz);
+                cb = sh_channel(p.D, sh + 2, dx, dy, dz);
+            } else {
+                const float* sh = p.shs + (size_t)idx * p.M * 3;
+                cr = sh_channel(p.D, sh + 0, dx, dy, dz);
+                cg = sh_channel(p.D, sh + 1, dx, dy, dz);
+                cb = sh_channel(p.D, sh + 2, dx, dy, dz);
+            }
+            g.clamped[idx] = (unsigned char)((cr < 0 ? 1 : 0) | (cg < 0 ? 2 : 0) | (cb < 0 ? 4 : 0));
+            cr = fmaxf(cr, 0.0f); cg = fmaxf(cg, 0.0f); cb = fmaxf(cb, 0.0f);
+        } else {
+            cr = p.colors_precomp[3 * idx]; cg = p.colors_precomp[3 * idx + 1]; cb = p.colors_precomp[3 * idx + 2];
+        }
+        g.depths[idx] = vz;
+        float4* rec = g.splats + 3 * (size_t)idx;
+        rec[0] = make_float4(pixx, pixy, conx, cony);
+        rec[1] = make_float4(conz, opacity * coef, 0.f, cr);  // .z is reserved: the render kernels park a strip mask there
+        rec[2] = make_float4(cg, cb, 0.f, 0.f);
+        g.rects[idx] = make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy);
     }
     g.radii[idx] = radius_i;
     if (radii_out) radii_out[idx] = radius_i;
@@ -218,10 +260,12 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* _
 hipError_t launch_preprocess(const FwdParams& p, const GeometryState& g, int* radii_out, hipStream_t stream) {
     if (p.P <= 0) return hipSuccess;
     const bool fast = p.shs != nullptr && p.colors_precomp == nullptr && p.M == 16 && (reinterpret_cast<uintptr_t>(p.shs) % 16 == 0);
-    if (fast)
-        hipLaunchKernelGGL(preprocess_kernel<true>, dim3((p.P + 63) / 64), dim3(64), 0, stream, p, g, radii_out);
-    else
-        hipLaunchKernelGGL(preprocess_kernel<false>, dim3((p.P + 63) / 64), dim3(64), 0, stream, p, g, radii_out);
+    const bool pre = p.cov3D_precomp != nullptr;
+    const dim3 grid((p.P + 63) / 64), block(64);
+    if (fast && !pre) hipLaunchKernelGGL((preprocess_kernel<true, false>), grid, block, 0, stream, p, g, radii_out);
+    else if (fast) hipLaunchKernelGGL((preprocess_kernel<true, true>), grid, block, 0, stream, p, g, radii_out);
+    else if (!pre) hipLaunchKernelGGL((preprocess_kernel<false, false>), grid, block, 0, stream, p, g, radii_out);
+    else hipLaunchKernelGGL((preprocess_kernel<false, true>), grid, block, 0, stream, p, g, radii_out);
     return hipGetLastError();
 }
 

@@ -56,7 +56,9 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     B[15] = m3 * C3g * x * (xx - 3.f * yy); Dx[15] = m3 * C3g * 3.f * (xx - yy); Dy[15] = m3 * C3g * -6.f * xy; Dz[15] = 0.f;
 }
 
-template <bool FAST_SH>
+// Load schedule: the memory counter retires in issue order, so every per-Gaussian input is requested first, the
+// 12 KiB SH block second (into registers), and only the SH part of the arithmetic -- placed last -- waits for it.
+template <bool FAST_SH, bool HAS_SCALES>
 __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     BwdParams p, const float4* __restrict__ splats, const unsigned char* __restrict__ clamped,
     const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
@@ -67,40 +69,63 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     const int base = blockIdx.x * 64;
     const int idx = base + lane;
     const bool in = idx < p.P;
-    const bool vis = in && p.radii[idx] > 0;
+    const int ld = in ? idx : p.P - 1;
 
-    if (FAST_SH) {  // 64 Gaussians x 12 float4, coalesced; row pitch 13 float4 in LDS
-        const float4* src = reinterpret_cast<const float4*>(p.shs) + (size_t)base * 12;
-        const int nvalid = min(64, p.P - base) * 12;
+    float vm[16], proj[16];
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const int f = i * 64 + lane;
-            if (f < nvalid) stage[(f / 12) * SH_PITCH4 + (f % 12)] = src[f];
-        }
-        __syncthreads();
+    for (int i = 0; i < 16; i++) {
+        vm[i] = p.viewmatrix[i];
+        proj[i] = p.projmatrix[i];
     }
+    const float camx = p.campos[0], camy = p.campos[1], camz = p.campos[2];
+
+    // (non-const: they are operands of the ordering fence below, which keeps the compiler from sinking the loads)
+    int radius = p.radii[ld];
+    float mx = p.means3D[3 * ld], my = p.means3D[3 * ld + 1], mz = p.means3D[3 * ld + 2];
+    const float* cv = p.cov3D + 6 * (size_t)ld;
+    float v0 = cv[0], v1 = cv[1], v2 = cv[2], v3 = cv[3], v4 = cv[4], v5 = cv[5];
+    float4 dconic = reinterpret_cast<const float4*>(dL_dconic)[ld];
+    float combined_opacity = splats[3 * (size_t)ld + 1].y;
+    float dLdo_in = dL_dopacity[ld];
+    float g2x = dL_dmean2D[3 * ld], g2y = dL_dmean2D[3 * ld + 1];
+    int cl = clamped[ld];
+    float dcol0 = dL_dcolor[3 * ld], dcol1 = dL_dcolor[3 * ld + 1], dcol2 = dL_dcolor[3 * ld + 2];
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sc0 = 0.f, sc1 = 0.f, sc2 = 0.f;
+    if (HAS_SCALES) {
+        q = reinterpret_cast<const float4*>(p.rotations)[ld];
+        sc0 = p.scales[3 * ld]; sc1 = p.scales[3 * ld + 1]; sc2 = p.scales[3 * ld + 2];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the machine scheduler would otherwise slip some of the loads above behind the SH ones
+    float4 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7, sr8, sr9, sr10, sr11;
+    sr0 = sr1 = sr2 = sr3 = sr4 = sr5 = sr6 = sr7 = sr8 = sr9 = sr10 = sr11 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FAST_SH) {  // 64 Gaussians x 12 float4, coalesced
+        const float4* src = reinterpret_cast<const float4*>(p.shs) + (size_t)base * 12;
+        const int last = min(64, p.P - base) * 12 - 1;
+#define WG_SH_LOAD(i) sr##i = src[min(i * 64 + lane, last)];
+        WG_SH_LOAD(0) WG_SH_LOAD(1) WG_SH_LOAD(2) WG_SH_LOAD(3) WG_SH_LOAD(4) WG_SH_LOAD(5)
+        WG_SH_LOAD(6) WG_SH_LOAD(7) WG_SH_LOAD(8) WG_SH_LOAD(9) WG_SH_LOAD(10) WG_SH_LOAD(11)
+#undef WG_SH_LOAD
+    }
+    // nothing below moves above the SH loads, none of the loads above sinks below them
+    asm volatile(""
+                 : "+v"(mx), "+v"(my), "+v"(mz), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(dconic.x), "+v"(dconic.y),
+                   "+v"(dconic.w), "+v"(combined_opacity), "+v"(dLdo_in), "+v"(g2x), "+v"(g2y), "+v"(cl), "+v"(dcol0), "+v"(dcol1),
+                   "+v"(dcol2), "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w), "+v"(sc0), "+v"(sc1), "+v"(sc2), "+v"(radius)
+                 :
+                 : "memory");
+    const bool vis = in && radius > 0;
 
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float gmx = 0.f, gmy = 0.f, gmz = 0.f;
-    float dsh[FAST_SH ? 48 : 1];
-    if (FAST_SH) {
-#pragma unroll
-        for (int k = 0; k < 48; k++) dsh[k] = 0.f;
-    }
     float dsc[3] = {0.f, 0.f, 0.f};
     float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dLdo_out = dLdo_in;
+    bool write_dLdo = false;
 
     if (vis) {
-        const float* vm = p.viewmatrix;
-        const float* proj = p.projmatrix;
-        const float mx = p.means3D[3 * idx], my = p.means3D[3 * idx + 1], mz = p.means3D[3 * idx + 2];
-        const float* cv = p.cov3D + 6 * (size_t)idx;
-        const float v0 = cv[0], v1 = cv[1], v2 = cv[2], v3 = cv[3], v4 = cv[4], v5 = cv[5];
-
         // ------------------------------------------------------------------ K10: backward.cu:167-310
-        const float4 dconic = reinterpret_cast<const float4*>(dL_dconic)[idx];
         const float dcx = dconic.x, dcy = dconic.y, dcz = dconic.w;
-        const float combined_opacity = splats[3 * (size_t)idx + 1].y;
 
         float tx = vm[0] * mx + vm[4] * my + vm[8] * mz + vm[12];
         float ty = vm[1] * mx + vm[5] * my + vm[9] * mz + vm[13];
@@ -130,7 +155,6 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
         const float coef = sqrtf(det_0 / (det_1 + 1e-6f) + 1e-6f);
         const bool degenerate = (det_0 <= 1e-6f) || (det_1 <= 1e-6f);
 
-        const float dLdo_in = dL_dopacity[idx];
         const float opacity = combined_opacity / (coef + 1e-6f);
         const float dL_dcoef = dLdo_in * opacity;
         const float dL_dsqrtcoef = dL_dcoef * 0.5f / (coef + 1e-6f);
@@ -148,13 +172,14 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
             dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcz);
             dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c) * dcx);
             dL_db = denom2inv * 2 * (b * c * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
+            write_dLdo = true;
             if (degenerate) {
-                dL_dopacity[idx] = 0.f;
+                dLdo_out = 0.f;
             } else {
                 dL_da += dcoef_da;
                 dL_dc += dcoef_dc;
                 dL_db += dcoef_db;
-                dL_dopacity[idx] = dLdo_in * coef;
+                dLdo_out = dLdo_in * coef;
             }
             dcov[0] = T00 * T00 * dL_da + T00 * T10 * dL_db + T10 * T10 * dL_dc;
             dcov[3] = T01 * T01 * dL_da + T01 * T11 * dL_db + T11 * T11 * dL_dc;
@@ -186,69 +211,15 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
             const float m_w = 1.0f / (hw + 0.0000001f);
             const float mul1 = (proj[0] * mx + proj[4] * my + proj[8] * mz + proj[12]) * m_w * m_w;
             const float mul2 = (proj[1] * mx + proj[5] * my + proj[9] * mz + proj[13]) * m_w * m_w;
-            const float g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1];
             gmx += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
             gmy += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
             gmz += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
         }
 
-        // ------------------------------------------------------------------ SH backward, backward.cu:20-139
-        if (p.shs != nullptr) {
-            const float ox = mx - p.campos[0], oy = my - p.campos[1], oz = mz - p.campos[2];
-            const float sum2 = ox * ox + oy * oy + oz * oz;
-            const float ilen = 1.0f / sqrtf(sum2);
-            float B[16], Dx[16], Dy[16], Dz[16];
-            sh_basis(p.D, ox * ilen, oy * ilen, oz * ilen, B, Dx, Dy, Dz);
-            const unsigned char cl = clamped[idx];
-            float dRGB[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) dRGB[ch] = ((cl >> ch) & 1) ? 0.f : dL_dcolor[3 * idx + ch];
-            float ddx = 0.f, ddy = 0.f, ddz = 0.f;  // dL_ddir
-            if (FAST_SH) {
-                float sh[48];
-#pragma unroll
-                for (int q = 0; q < 12; q++) {
-                    const float4 v = stage[lane * SH_PITCH4 + q];
-                    sh[4 * q] = v.x; sh[4 * q + 1] = v.y; sh[4 * q + 2] = v.z; sh[4 * q + 3] = v.w;
-                }
-#pragma unroll
-                for (int k = 0; k < 16; k++)
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
-                        dsh[3 * k + ch] = B[k] * dRGB[ch];
-                        const float w = sh[3 * k + ch] * dRGB[ch];
-                        ddx += Dx[k] * w;
-                        ddy += Dy[k] * w;
-                        ddz += Dz[k] * w;
-                    }
-            } else {
-                const float* sh = p.shs + (size_t)idx * p.M * 3;
-                float* d = dL_dsh + (size_t)idx * p.M * 3;
-                const int ncoef = (p.D + 1) * (p.D + 1);
-                for (int k = 0; k < p.M; k++)
-                    for (int ch = 0; ch < 3; ch++) {
-                        float bk = 0.f, dxk = 0.f, dyk = 0.f, dzk = 0.f;
-                        if (k < ncoef && k < 16) { bk = B[k]; dxk = Dx[k]; dyk = Dy[k]; dzk = Dz[k]; }
-                        d[3 * k + ch] = bk * dRGB[ch];
-                        const float w = sh[3 * k + ch] * dRGB[ch];
-                        ddx += dxk * w;
-                        ddy += dyk * w;
-                        ddz += dzk * w;
-                    }
-            }
-            // dnormvdv, auxiliary.h:107-117
-            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-            gmx += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
-            gmy += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
-            gmz += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
-        }
-
         // ------------------------------------------------------------------ covariance backward, backward.cu:314-377
-        if (p.scales != nullptr) {
-            const float4 q = reinterpret_cast<const float4*>(p.rotations)[idx];
+        if (HAS_SCALES) {
             const float r = q.x, x = q.y, y = q.z, z = q.w;
-            const float s[3] = {p.scale_modifier * p.scales[3 * idx], p.scale_modifier * p.scales[3 * idx + 1],
-                                p.scale_modifier * p.scales[3 * idx + 2]};
+            const float s[3] = {p.scale_modifier * sc0, p.scale_modifier * sc1, p.scale_modifier * sc2};
             // R[c][r] column-major as filled by the reference
             const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
                                    {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
@@ -277,19 +248,91 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
         }
     }
 
-    // ---- outputs: written for every Gaussian of the range (zeros when culled) ----
+    // ---- the outputs that do not depend on the SH block ----
     if (in) {
         float* o = dL_dcov3D + 6 * (size_t)idx;
         o[0] = dcov[0]; o[1] = dcov[1]; o[2] = dcov[2]; o[3] = dcov[3]; o[4] = dcov[4]; o[5] = dcov[5];
-        dL_dmean3D[3 * idx] = gmx;
-        dL_dmean3D[3 * idx + 1] = gmy;
-        dL_dmean3D[3 * idx + 2] = gmz;
-        if (p.scales != nullptr) {
+        if (write_dLdo) dL_dopacity[idx] = dLdo_out;
+        if (HAS_SCALES) {
             dL_dscale[3 * idx] = dsc[0];
             dL_dscale[3 * idx + 1] = dsc[1];
             dL_dscale[3 * idx + 2] = dsc[2];
             reinterpret_cast<float4*>(dL_drot)[idx] = dq;
         }
+    }
+
+    asm volatile("" : "+v"(gmx), "+v"(gmy), "+v"(gmz) : : "memory");  // the SH part stays below the geometry part
+    if (FAST_SH) {
+        const int nvalid = min(64, p.P - base) * 12;
+#define WG_SH_STAGE(i)                                                          \
+    {                                                                           \
+        const int f = i * 64 + lane;                                            \
+        if (f < nvalid) stage[(f / 12) * SH_PITCH4 + (f % 12)] = sr##i;         \
+    }
+        WG_SH_STAGE(0) WG_SH_STAGE(1) WG_SH_STAGE(2) WG_SH_STAGE(3) WG_SH_STAGE(4) WG_SH_STAGE(5)
+        WG_SH_STAGE(6) WG_SH_STAGE(7) WG_SH_STAGE(8) WG_SH_STAGE(9) WG_SH_STAGE(10) WG_SH_STAGE(11)
+#undef WG_SH_STAGE
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ SH backward, backward.cu:20-139
+    float dsh[FAST_SH ? 48 : 1];
+    if (FAST_SH) {
+#pragma unroll
+        for (int k = 0; k < 48; k++) dsh[k] = 0.f;
+    }
+    if (vis && p.shs != nullptr) {
+        const float ox = mx - camx, oy = my - camy, oz = mz - camz;
+        const float sum2 = ox * ox + oy * oy + oz * oz;
+        const float ilen = 1.0f / sqrtf(sum2);
+        float B[16], Dx[16], Dy[16], Dz[16];
+        sh_basis(p.D, ox * ilen, oy * ilen, oz * ilen, B, Dx, Dy, Dz);
+        const float dRGB[3] = {(cl & 1) ? 0.f : dcol0, (cl & 2) ? 0.f : dcol1, (cl & 4) ? 0.f : dcol2};
+        float ddx = 0.f, ddy = 0.f, ddz = 0.f;  // dL_ddir
+        if (FAST_SH) {
+            float sh[48];
+#pragma unroll
+            for (int qd = 0; qd < 12; qd++) {
+                const float4 v = stage[lane * SH_PITCH4 + qd];
+                sh[4 * qd] = v.x; sh[4 * qd + 1] = v.y; sh[4 * qd + 2] = v.z; sh[4 * qd + 3] = v.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    dsh[3 * k + ch] = B[k] * dRGB[ch];
+                    const float w = sh[3 * k + ch] * dRGB[ch];
+                    ddx += Dx[k] * w;
+                    ddy += Dy[k] * w;
+                    ddz += Dz[k] * w;
+                }
+        } else {
+            const float* sh = p.shs + (size_t)idx * p.M * 3;
+            float* d = dL_dsh + (size_t)idx * p.M * 3;
+            const int ncoef = (p.D + 1) * (p.D + 1);
+            for (int k = 0; k < p.M; k++)
+                for (int ch = 0; ch < 3; ch++) {
+                    float bk = 0.f, dxk = 0.f, dyk = 0.f, dzk = 0.f;
+                    if (k < ncoef && k < 16) { bk = B[k]; dxk = Dx[k]; dyk = Dy[k]; dzk = Dz[k]; }
+                    d[3 * k + ch] = bk * dRGB[ch];
+                    const float w = sh[3 * k + ch] * dRGB[ch];
+                    ddx += dxk * w;
+                    ddy += dyk * w;
+                    ddz += dzk * w;
+                }
+        }
+        // dnormvdv, auxiliary.h:107-117
+        const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        gmx += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+        gmy += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+        gmz += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+    }
+
+    // ---- outputs: written for every Gaussian of the range (zeros when culled) ----
+    if (in) {
+        dL_dmean3D[3 * idx] = gmx;
+        dL_dmean3D[3 * idx + 1] = gmy;
+        dL_dmean3D[3 * idx + 2] = gmz;
         if (!FAST_SH && p.shs != nullptr && !vis) {
             float* d = dL_dsh + (size_t)idx * p.M * 3;
             for (int k = 0; k < p.M * 3; k++) d[k] = 0.f;
@@ -298,7 +341,8 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     if (FAST_SH) {
         __syncthreads();  // every lane has consumed its SH inputs
 #pragma unroll
-        for (int q = 0; q < 12; q++) stage[lane * SH_PITCH4 + q] = make_float4(dsh[4 * q], dsh[4 * q + 1], dsh[4 * q + 2], dsh[4 * q + 3]);
+        for (int qd = 0; qd < 12; qd++)
+            stage[lane * SH_PITCH4 + qd] = make_float4(dsh[4 * qd], dsh[4 * qd + 1], dsh[4 * qd + 2], dsh[4 * qd + 3]);
         __syncthreads();
         float4* dst = reinterpret_cast<float4*>(dL_dsh) + (size_t)base * 12;
         const int nvalid = min(64, p.P - base) * 12;
@@ -318,12 +362,15 @@ hipError_t launch_preprocess_backward(const BwdParams& p, const GeometryState& g
     const dim3 grid((p.P + 63) / 64), block(64);
     const bool fast = p.shs != nullptr && p.M == 16 && (reinterpret_cast<uintptr_t>(p.shs) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(dL_dsh) % 16 == 0);
-    if (fast)
-        hipLaunchKernelGGL(preprocess_backward_kernel<true>, grid, block, 0, stream, p, g.splats, g.clamped, dL_dmean2D, dL_dconic,
-                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
-    else
-        hipLaunchKernelGGL(preprocess_backward_kernel<false>, grid, block, 0, stream, p, g.splats, g.clamped, dL_dmean2D, dL_dconic,
-                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    const bool sc = p.scales != nullptr;
+#define WG_LAUNCH(F, S)                                                                                                              \
+    hipLaunchKernelGGL((preprocess_backward_kernel<F, S>), grid, block, 0, stream, p, g.splats, g.clamped, dL_dmean2D, dL_dconic, \
+                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot)
+    if (fast && sc) WG_LAUNCH(true, true);
+    else if (fast) WG_LAUNCH(true, false);
+    else if (sc) WG_LAUNCH(false, true);
+    else WG_LAUNCH(false, false);
+#undef WG_LAUNCH
     return hipGetLastError();
 }
 

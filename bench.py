@@ -135,9 +135,25 @@ def main():
         stages = _C.profile_read()
         _C.profile_enable(False)
 
+    # per-step distribution (median and p10/p90): one event pair per step, a third pass of the same K steps
+    def step_quantiles(fn, steps):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        torch.cuda.synchronize(device)
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize(device)
+        ms = sorted(a.elapsed_time(b) for a, b in evs)
+        q = lambda f: round(ms[min(len(ms) - 1, int(f * len(ms)))], 4)
+        return {"p10": q(0.10), "p50": q(0.50), "p90": q(0.90)}
+
+    step_q = step_quantiles(train_step, args.steps)
+
     for _ in range(max(1, args.warmup // 2)):
         fwd_step()
     t_fwd = timed(fwd_step, args.steps)
+    fwd_q = step_quantiles(fwd_step, args.steps)
 
     # workload statistics of this rank's view (needed for the algorithmic byte counts)
     with torch.no_grad():
@@ -173,6 +189,8 @@ def main():
         "forward_fps": round(fwd_fps, 2),
         "forward_mpix_per_s": round(fwd_fps * N / 1e6, 1),
         "forward_ms": round(1000.0 * t_fwd / args.steps, 4),
+        "step_ms_quantiles": step_q,
+        "forward_ms_quantiles": fwd_q,
         "workload_stats": {"P": P, "V": V, "R": int(R), "N": N, "tiles": tiles, "instances_walked": walked},
     }
 

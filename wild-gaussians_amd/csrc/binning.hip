@@ -173,19 +173,65 @@ __device__ __forceinline__ void chunk_bounds(int P, int chunk, int& begin, int& 
 
 constexpr int BIN_THREADS = 1024;  // count / scatter are chains of dependent LDS atomics: latency-bound, so run 16 waves per chunk
 
-__global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const int* __restrict__ radii, const ushort4* __restrict__ rects,
-                                                         uint32_t* __restrict__ chunk_hist, int gx, int tiles) {
+// Visit every tile (x, y) of every lane's rectangle [x0,x1) x [y0,y1): f(x, y, gaussian index).  Convergent: all 64 lanes
+// of the wave must call it.  A lane walks a small rectangle itself; a rectangle of more than SERIAL_MAX tiles is handed to
+// the whole wave (its corners broadcast with readlane, 8x8 tiles per step).  Without this the kernels' duration was set by
+// the largest splat of the frame: one lane issuing ~300 dependent LDS atomics while 63 lanes and the other waves of the
+// chip had long finished (rocprofv3: 1.1 resident waves per SIMD on average over the count kernel's 20 us).
+template <int SERIAL_MAX, typename F>
+__device__ __forceinline__ void for_each_tile(bool valid, int x0, int y0, int x1, int y1, int idx, F f) {
+    const int lane = threadIdx.x & 63;
+    const int w = valid ? x1 - x0 : 0, h = valid ? y1 - y0 : 0;
+    const int n = w * h;
+    const bool big = n > SERIAL_MAX;
+    if (__ballot(!big && n > 0) != 0ull) {
+        // fixed, predicated steps instead of a per-lane loop: the LDS atomics of the steps do not wait for one another
+        int x = x0, y = y0;
+#pragma unroll
+        for (int s = 0; s < SERIAL_MAX; s++) {
+            if (!big && s < n) f(x, y, idx);
+            x++;
+            if (x == x0 + w) { x = x0; y++; }
+        }
+    }
+    uint64_t mask = __ballot(big);
+    while (mask != 0ull) {
+        const int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int bx0 = __builtin_amdgcn_readlane(x0, j), by0 = __builtin_amdgcn_readlane(y0, j);
+        const int bw = __builtin_amdgcn_readlane(w, j), bh = __builtin_amdgcn_readlane(h, j);
+        const int bidx = __builtin_amdgcn_readlane(idx, j);
+        const int lx = lane & 7, ly = lane >> 3;
+        for (int by = 0; by < bh; by += 8)
+            for (int bx = 0; bx < bw; bx += 8)
+                if (bx + lx < bw && by + ly < bh) f(bx0 + bx + lx, by0 + by + ly, bidx);
+    }
+}
+
+constexpr int PF = 8;  // rectangles a thread keeps in flight
+
+__global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const ushort4* __restrict__ rects, uint32_t* __restrict__ chunk_hist,
+                                                         int gx, int tiles) {
     extern __shared__ uint32_t hist[];
     const int tid = threadIdx.x, chunk = blockIdx.x;
     for (int t = tid; t < tiles; t += BIN_THREADS) hist[t] = 0;
     __syncthreads();
     int begin, end;
     chunk_bounds(P, chunk, begin, end);
-    for (int idx = begin + tid; idx < end; idx += BIN_THREADS) {
-        if (radii[idx] > 0) {
-            const ushort4 r = rects[idx];
-            for (int y = r.y; y < r.w; y++)
-                for (int x = r.x; x < r.z; x++) atomicAdd(&hist[y * gx + x], 1u);
+    // uniform trip counts (for_each_tile is convergent); PF rectangles are requested before the first is used, so a thread
+    // pays one memory latency per PF Gaussians instead of one each (culled Gaussians carry an all-zero rectangle)
+    for (int base = begin; base < end; base += PF * BIN_THREADS) {
+        ushort4 r[PF];
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const int idx = base + k * BIN_THREADS + tid;
+            r[k] = idx < end ? rects[idx] : make_ushort4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            if (base + k * BIN_THREADS >= end) break;
+            const bool valid = r[k].z > r[k].x && r[k].w > r[k].y;
+            for_each_tile<16>(valid, r[k].x, r[k].y, r[k].z, r[k].w, 0, [&](int x, int y, int) { atomicAdd(&hist[y * gx + x], 1u); });
         }
     }
     __syncthreads();
@@ -275,32 +321,42 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
 // with the band = the XCD the dispatcher is observed to run the block on (block b -> XCD b % 8), an XCD's L2 only ever
 // holds its own eighth of the bucket array (< 4 MiB at 1080p) and lines leave it complete.  The band assignment is a
 // speed matter only: any placement gives the same buckets.
-__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const int* __restrict__ radii, const ushort4* __restrict__ rects,
-                                                           const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ chunk_hist,
-                                                           uint32_t* __restrict__ bucket_ids, int gx, int tiles) {
+// (Measured and dropped: (i) staging a workgroup's instances tile-major in LDS and writing them out in runs brought the
+// fabric writes down to the 30 MB of payload and was not faster; (ii) per-band candidate lists built by the count kernel, so
+// that a band's workgroup does not scan the whole chunk, saved 2 us for 16 B/Gaussian of lists.  With every store and
+// atomic removed the kernel still takes 41 of its 52 us: what is left is the rectangle walk's instruction stream.)
+__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4* __restrict__ rects, const uint32_t* __restrict__ tile_offset,
+                                                           const uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ bucket_ids, int gx,
+                                                           int tiles) {
     extern __shared__ uint32_t cursor[];
     const int tid = threadIdx.x, band = blockIdx.x & 7, chunk = blockIdx.x >> 3;
     const int q = tiles >> 3, rem = tiles & 7;
     const int t0 = band * q + min(band, rem), t1 = t0 + q + (band < rem ? 1 : 0);  // this band's tiles [t0, t1)
     if (t0 >= t1) return;
-    const uint32_t* base = chunk_hist + (size_t)chunk * tiles;
-    for (int t = t0 + tid; t < t1; t += 256) cursor[t - t0] = tile_offset[t] + base[t];
+    const uint32_t* hbase = chunk_hist + (size_t)chunk * tiles;
+    for (int t = t0 + tid; t < t1; t += 256) cursor[t - t0] = tile_offset[t] + hbase[t];
     __syncthreads();
     const int y0 = t0 / gx, y1 = (t1 - 1) / gx;  // tile rows the band touches (first / last possibly partial)
     int begin, end;
     chunk_bounds(P, chunk, begin, end);
-    for (int idx = begin + tid; idx < end; idx += 256) {
-        if (radii[idx] > 0) {
-            const ushort4 r = rects[idx];
-            const int ya = max((int)r.y, y0), yb = min((int)r.w, y1 + 1);
-            for (int y = ya; y < yb; y++)
-                for (int x = r.x; x < r.z; x++) {
-                    const int t = y * gx + x;
-                    if (t >= t0 && t < t1) {
-                        const uint32_t pos = atomicAdd(&cursor[t - t0], 1u);
-                        bucket_ids[pos] = (uint32_t)idx;  // 4 bytes per instance; the depth half of the key is gathered at sort time
-                    }
+    for (int base = begin; base < end; base += PF * 256) {
+        ushort4 r[PF];
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const int idx = base + k * 256 + tid;
+            r[k] = idx < end ? rects[idx] : make_ushort4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            if (base + k * 256 >= end) break;
+            const int ya = max((int)r[k].y, y0), yb = min((int)r[k].w, y1 + 1);
+            for_each_tile<16>(r[k].z > r[k].x && yb > ya, r[k].x, ya, r[k].z, yb, base + k * 256 + tid, [&](int x, int y, int id) {
+                const int t = y * gx + x;
+                if (t >= t0 && t < t1) {
+                    const uint32_t pos = atomicAdd(&cursor[t - t0], 1u);
+                    bucket_ids[pos] = (uint32_t)id;  // 4 bytes per instance; the depth half of the key is gathered at sort time
                 }
+            });
         }
     }
 }
@@ -508,7 +564,7 @@ hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& im
     const size_t lds = (size_t)tiles * sizeof(uint32_t);
     hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_count_kernel), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tile_count_kernel, dim3(BIN_CHUNKS), dim3(BIN_THREADS), lds, stream, P, g.radii, g.rects, img.chunk_hist, gx, tiles);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(BIN_CHUNKS), dim3(BIN_THREADS), lds, stream, P, g.rects, img.chunk_hist, gx, tiles);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(chunk_scan_kernel, dim3((tiles + 63) / 64), dim3(256), 0, stream, img.chunk_hist, img.tile_count, tiles);
@@ -527,8 +583,8 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
     const size_t lds = (size_t)(tiles / 8 + 1) * sizeof(uint32_t);
     hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_kernel), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(BIN_CHUNKS * 8), dim3(256), lds, stream, P, g.radii, g.rects, img.tile_offset,
-                       img.chunk_hist, b.bucket_ids, gx, tiles);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(BIN_CHUNKS * 8), dim3(256), lds, stream, P, g.rects, img.tile_offset, img.chunk_hist,
+                       b.bucket_ids, gx, tiles);
     return hipGetLastError();
 }
 

@@ -241,8 +241,10 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
         rec[0] = make_float4(pixx, pixy, conx, cony);
         rec[1] = make_float4(conz, opacity * coef, 0.f, cr);  // .z is reserved: the render kernels park a strip mask there
         rec[2] = make_float4(cg, cb, 0.f, 0.f);
-        g.rects[idx] = make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy);
     }
+    // always written (all-zero for a culled Gaussian): the binning kernels read the rectangle only
+    g.rects[idx] = vis ? make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy)
+                       : make_ushort4(0, 0, 0, 0);
     g.radii[idx] = radius_i;
     if (radii_out) radii_out[idx] = radius_i;
     g.tiles_touched[idx] = touched;

@@ -21,7 +21,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libwg_rasterizer.so")
+_LIB_PATH = os.environ.get("WG_RASTERIZER_LIB") or os.path.join(_HERE, "libwg_rasterizer.so")  # override: another build of the same C-ABI
 
 if not os.path.exists(_LIB_PATH):
     raise ImportError(
@@ -297,3 +297,8 @@ def profile_read() -> dict:
     st = _StageTimes()
     _check(_lib.wg_profile_read(C.byref(st)), "wg_profile_read")
     return {_lib.wg_stage_name(i).decode(): (float(st.total_ms[i]), int(st.launches[i])) for i in range(STAGE_COUNT)}
+
+# WG_OPTIONS="name=value,name=value": library options applied at import (e.g. WG_OPTIONS=force_global_sort=1)
+for _kv in filter(None, os.environ.get("WG_OPTIONS", "").split(",")):
+    _k, _, _v = _kv.partition("=")
+    set_option(_k.strip(), int(_v or "1"))

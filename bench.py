@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--colors", choices=["sh", "precomp"], default="sh")
+    ap.add_argument("--scale-mult", type=float, default=1.0, help="multiply the Gaussian scales (denser per-tile lists; 1.0 = SURVEY 8d recipe)")
     ap.add_argument("--forward-only", action="store_true", help="stress mode: time only the forward pass (e.g. 10M Gaussians @ 4K)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (parity + CPU timing)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events in the timed region")
@@ -76,7 +77,7 @@ def main():
     W, H, P = args.width, args.height, args.gaussians
     N = W * H
     sh_degree = 3 if args.colors == "sh" else None
-    cloud = S.make_cloud(P, W, H, sh_degree=sh_degree, seed=0)
+    cloud = S.make_cloud(P, W, H, sh_degree=sh_degree, seed=0, scale_mult=args.scale_mult)
     cam = VP.view_cameras(world, W, H)[rank]  # one camera per rank (config 4); rank 0 = the base camera
     cot_np = S.make_cotangent(W, H)
     deg = 3 if args.colors == "sh" else 0
@@ -183,7 +184,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{P} Gaussians, {W}x{H}, {'SH deg 3' if args.colors == 'sh' else 'precomputed colours'}, "
+        "config": {"workload": f"{P} Gaussians{'' if args.scale_mult == 1.0 else f' (scales x{args.scale_mult:g})'}, {W}x{H}, "
+                               f"{'SH deg 3' if args.colors == 'sh' else 'precomputed colours'}, "
                                f"fwd+bwd, one view per GPU (view-parallel, loss all-reduce only)",
                    "gaussians": P, "width": W, "height": H, "colors": args.colors, "views_per_step": world},
         "forward_fps": round(fwd_fps, 2),
@@ -208,7 +210,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pt = json.load(f)
-            if pt.get("workload") == f"{P} Gaussians, {W}x{H}, {args.colors}" and dom in pt["stages"]:
+            if args.scale_mult == 1.0 and pt.get("workload") == f"{P} Gaussians, {W}x{H}, {args.colors}" and dom in pt["stages"]:
                 traffic = pt["stages"][dom]["hbm_bytes"]
         except (OSError, ValueError, KeyError):
             pass

@@ -166,7 +166,7 @@ int wg_view_image(char* image_buffer, int width, int height, wg_image_view* out)
  * wg_profile_read(): synchronises the recorded events, adds their durations to the running totals and
  * returns them; wg_profile_reset() clears the totals. */
 enum { WG_STAGE_PREPROCESS = 0, WG_STAGE_SCAN, WG_STAGE_DUPLICATE_KEYS, WG_STAGE_SORT, WG_STAGE_TILE_RANGES,
-       WG_STAGE_RENDER_FORWARD, WG_STAGE_RENDER_BACKWARD, WG_STAGE_PREPROCESS_BACKWARD, WG_STAGE_COUNT };
+       WG_STAGE_RENDER_FORWARD, WG_STAGE_RENDER_BACKWARD, WG_STAGE_PREPROCESS_BACKWARD, WG_STAGE_RENDER_FIXUP, WG_STAGE_COUNT };
 typedef struct wg_stage_times {
     double total_ms[WG_STAGE_COUNT];
     long long launches[WG_STAGE_COUNT];
@@ -180,7 +180,11 @@ const char* wg_stage_name(int stage);
  * (tile|depth) keys (the reference's scheme, and the automatic fallback when a tile lists more than 8192
  * instances) instead of the default counting-sort + per-tile LDS sort.  Both give identical results.
  * "host_mailbox" (1/0, default 1): read num_rendered back through a pinned host mailbox that the device writes and the
- * host polls, instead of a device-to-host copy followed by a stream synchronise. */
+ * host polls, instead of a device-to-host copy followed by a stream synchronise.
+ * "lazy_sort" (1/0, default 1): when some tile lists more than "lazy_min_len" (256..2048, default 2048) instances, sort only
+ * a depth-nearest front of about "lazy_target" (default 820) instances of each long list -- at most "lazy_cap" (default 2048)
+ * -- and extend it per tile, in order, only where the forward pass runs past it.  Images, radii, n_contrib and gradients are
+ * those of the fully sorted lists; the unsorted tails of the internal lists are simply never read. */
 int wg_set_option(const char* name, int value);
 
 const char* wg_status_string(int status);

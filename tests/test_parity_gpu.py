@@ -406,3 +406,82 @@ def test_depth_collisions_keep_gaussian_index_order(oracle):
     assert compare_forward(hh["color"], o)["max_err_solid"] <= 1e-4
     for k, e in compare_grads(hh["grads"], o["grads"]).items():
         assert e <= 1e-3, (k, e)
+
+
+# ---- lazy front sort (long per-tile lists) ---------------------------------------------------------------------------------
+@pytest.fixture()
+def lazy_options():
+    from diff_gaussian_rasterization import _C
+
+    def set_(**kw):
+        for k, v in kw.items():
+            _C.set_option(k, v)
+    yield set_
+    set_(lazy_sort=1, lazy_min_len=2048, lazy_target=820, lazy_cap=2048)
+
+
+def _dense_scene():
+    W, H, P = 320, 200, 30000   # ~1000 instances per tile, pixels stop after ~220
+    cam = S.make_camera(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=1, seed=5, scale_mult=7.0)
+    return cloud, cam, W, H
+
+
+@pytest.mark.parametrize("opts", [dict(lazy_min_len=256, lazy_target=100, lazy_cap=256),   # fronts of ~100, several fix-up rounds
+                                  dict(lazy_min_len=256, lazy_target=60, lazy_cap=64),     # cap close to target: re-selections
+                                  dict(lazy_min_len=300, lazy_target=2000, lazy_cap=2048)])  # target beyond the list: q saturates
+def test_lazy_sort_gives_the_fully_sorted_results(oracle, lazy_options, opts):
+    """With the lazy sort only a depth-nearest front of each long list is sorted, extended where the forward pass runs past it.
+    Everything the operator returns must be what the fully sorted lists give: the colour bit for bit (same instance sequence,
+    same arithmetic), n_contrib / final_T / tile_last likewise, the walked list prefix identical to the oracle's order (what lies
+    behind it in point_list is never read: the unsorted rest of a tile stays in the bucket array)."""
+    cloud, cam, W, H = _dense_scene()
+    o = oracle.run_scene(cloud, cam, sh_degree=1)
+    rg = o["ctx"].get("ranges")
+    assert (rg[:, 1] - rg[:, 0]).max() > 600   # long lists: the lazy path is taken with these options
+    lazy_options(lazy_sort=0)
+    full = run_hip_native(cloud, cam, sh_degree=1)
+    np.testing.assert_array_equal(full["views"]["binning"]["point_list"].cpu().numpy().view(np.uint32), o["ctx"].get("point_list"))
+    lazy_options(lazy_sort=1, **opts)
+    lz = run_hip_native(cloud, cam, sh_degree=1)
+    assert lz["num_rendered"] == full["num_rendered"]
+    assert torch.equal(lz["color"], full["color"])
+    for k in ("final_T", "n_contrib", "tile_last", "ranges"):
+        assert torch.equal(lz["views"]["image"][k], full["views"]["image"][k]), k
+    pl = lz["views"]["binning"]["point_list"].cpu().numpy().view(np.uint32)
+    ref = o["ctx"].get("point_list")
+    tl = lz["views"]["image"]["tile_last"].cpu().numpy()
+    walked_short = 0
+    for t in range(rg.shape[0]):
+        b, n, w = int(rg[t, 0]), int(rg[t, 1] - rg[t, 0]), int(tl[t])
+        np.testing.assert_array_equal(pl[b:b + w], ref[b:b + w])
+        walked_short += w < n
+    assert walked_short > 0  # some tiles really stopped early
+    cot = S.make_cotangent(W, H)
+    oo = oracle.run_scene(cloud, cam, sh_degree=1, cotangent=cot)
+    hh = run_hip(cloud, cam, sh_degree=1, cotangent=cot)
+    assert compare_forward(hh["color"], oo)["max_err_solid"] <= 1e-4
+    for k, e in compare_grads(hh["grads"], oo["grads"]).items():
+        assert e <= 1e-3, (k, e)
+
+
+def test_lazy_sort_at_default_thresholds_on_a_dense_frame(oracle, lazy_options):
+    """Lists of several thousand instances with the default thresholds (front ~820, fix-up fronts ~1536)."""
+    W, H, P = 96, 64, 30000
+    cam = S.make_camera(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=0, seed=9, scale_mult=6.0)
+    cot = S.make_cotangent(W, H)
+    o = oracle.run_scene(cloud, cam, sh_degree=0, cotangent=cot)
+    rg = o["ctx"].get("ranges")
+    assert (rg[:, 1] - rg[:, 0]).max() > 2048
+    h = run_hip(cloud, cam, sh_degree=0, cotangent=cot)
+    c = compare_forward(h["color"], o)
+    assert c["max_err_solid"] <= 1e-4, c
+    for k, e in compare_grads(h["grads"], o["grads"]).items():
+        assert e <= 1e-3, (k, e)
+    lazy_options(lazy_sort=0)
+    full = run_hip_native(cloud, cam, sh_degree=0)
+    lazy_options(lazy_sort=1)
+    lz = run_hip_native(cloud, cam, sh_degree=0)
+    assert torch.equal(lz["color"], full["color"])
+    assert torch.equal(lz["views"]["image"]["n_contrib"], full["views"]["image"]["n_contrib"])

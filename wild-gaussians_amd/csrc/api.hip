@@ -220,7 +220,11 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     }
 
     // Longest per-tile list decides the binning path: LDS tile sort (default) or global radix sort (fallback).
-    const bool global_sort = g_force_global_sort || huge_frame || max_tile_count > wg::TILE_SORT_MAX;
+    // Longest per-tile list decides the binning path: full register sort of every tile, lazy front sort when lists are long,
+    // global radix sort (the reference's scheme) when forced, when the frame is too large for the LDS histogram, or when a
+    // list exceeds the register sort and the lazy sort is switched off.
+    const bool lazy = wg::g_lazy.enabled && !g_force_global_sort && !huge_frame && max_tile_count > wg::g_lazy.min_len;
+    const bool global_sort = g_force_global_sort || huge_frame || (!lazy && max_tile_count > wg::TILE_SORT_MAX);
     size_t bin_bytes = required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)num_rendered, global_sort); });
     char* bin_chunk = binning_alloc(bin_bytes, binning_user);
     if (!bin_chunk) return WG_ERR_ALLOC;
@@ -233,7 +237,8 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     if (num_rendered > 0) {
         if (!global_sort) {
             WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, stream), "tile_scatter");
-            WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, geom, tiles, max_tile_count, stream), "tile_sort");
+            if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, stream), "tile_sort_lazy");
+            else WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, geom, tiles, max_tile_count, stream), "tile_sort");
         } else {
             if (!huge_frame) WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
             WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_duplicate_keys(P, geom, bin, gx, stream), "duplicate_keys");
@@ -244,9 +249,14 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
             if (huge_frame) WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_ranges(num_rendered, bin, img, tiles, stream), "tile_ranges");
         }
     }
+    const bool lazy_render = lazy && num_rendered > 0 && !global_sort;
     WG_STAGE(WG_STAGE_RENDER_FORWARD,
-             wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, stream),
+             wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, lazy_render, stream),
              "render_forward");
+    if (lazy_render)
+        WG_STAGE(WG_STAGE_RENDER_FIXUP,
+                 wg::launch_render_fixup(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, stream),
+                 "render_fixup");
     return num_rendered;
 }
 
@@ -343,6 +353,15 @@ int wg_set_option(const char* name, int value) {
     if (!name) return WG_ERR_INVALID_ARGUMENT;
     if (std::strcmp(name, "force_global_sort") == 0) { g_force_global_sort = value != 0; return WG_OK; }
     if (std::strcmp(name, "host_mailbox") == 0) { g_use_mailbox = value != 0; return WG_OK; }
+    if (std::strcmp(name, "lazy_sort") == 0) { wg::g_lazy.enabled = value != 0; return WG_OK; }
+    if (std::strcmp(name, "lazy_min_len") == 0 || std::strcmp(name, "lazy_target") == 0 || std::strcmp(name, "lazy_cap") == 0) {
+        // min_len >= 256 (the selection samples 256 entries) and min_len, cap <= 2048 (the 8-keys-per-thread network)
+        if (value < 1 || value > 2048) return WG_ERR_INVALID_ARGUMENT;
+        if (name[5] == 'm') { if (value < 256) return WG_ERR_INVALID_ARGUMENT; wg::g_lazy.min_len = (uint32_t)value; }
+        else if (name[5] == 't') wg::g_lazy.target = (uint32_t)value;
+        else wg::g_lazy.cap = (uint32_t)value;
+        return WG_OK;
+    }
     return WG_ERR_INVALID_ARGUMENT;
 }
 
@@ -380,7 +399,7 @@ int wg_profile_read(wg_stage_times* out) {
 
 const char* wg_stage_name(int stage) {
     static const char* names[WG_STAGE_COUNT] = {"preprocess", "scan", "duplicate_keys", "sort", "tile_ranges",
-                                                "render_forward", "render_backward", "preprocess_backward"};
+                                                "render_forward", "render_backward", "preprocess_backward", "render_fixup"};
     return (stage >= 0 && stage < WG_STAGE_COUNT) ? names[stage] : "?";
 }
 

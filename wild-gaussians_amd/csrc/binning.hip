@@ -5,6 +5,7 @@
 #include <cstring>
 #include <cstdlib>
 #include "wg_common.h"
+#include "wg_sort.h"
 
 #include <rocprim/rocprim.hpp>
 
@@ -61,6 +62,8 @@ ImageState ImageState::fromChunk(char*& chunk, size_t N, size_t tiles) {
     carve(chunk, img.tile_offset, tiles + 1);
     carve(chunk, img.chunk_hist, (tiles ? tiles : 1) * (size_t)BIN_CHUNKS);
     carve(chunk, img.order_bwd, tiles ? tiles : 1);
+    carve(chunk, img.seg_end, tiles ? tiles : 1);
+    carve(chunk, img.tile_state, tiles ? tiles : 1);
     carve(chunk, img.stats, 1);
     return img;
 }
@@ -374,121 +377,6 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4*
 //                           (3 of the 55 stages of a 1024-key sort).
 // A first version kept the keys in LDS for every stage; rocprofv3 showed its LDS pipe ~80 % busy (37 % of that bank
 // conflicts on the 64-bit accesses).
-__device__ __forceinline__ void bitonic_ce(uint64_t* skeys, uint32_t t, uint32_t j, uint32_t k) {
-    const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-    const uint32_t l = i | j;
-    const uint64_t a = skeys[i], b = skeys[l];
-    const bool ascending = (i & k) == 0;
-    if ((a > b) == ascending) {
-        skeys[i] = b;
-        skeys[l] = a;
-    }
-}
-
-template <int D>  // value of lane (l ^ D), D in {1, 2, 4, 8, 16, 32}
-__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
-    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
-    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    else if constexpr (D == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);  // row_ror 8
-    else if constexpr (D == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);                     // xor 4 (bit mode)
-    else if constexpr (D == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                    // xor 16
-    else return (uint32_t)__shfl_xor((int)v, 32);
-}
-
-template <int E>
-struct SortCtx {
-    uint64_t key[E];  // E consecutive keys of the tile's padded array
-    uint32_t t;       // thread index in the workgroup
-    uint32_t gidx;    // index of key[0] in the padded array (= E * t: one chunk of 256*E keys covers the tile)
-    uint64_t* xchg;   // LDS exchange buffer (256*E keys) for the cross-wave stages
-};
-
-__device__ __forceinline__ void keep(uint64_t& mine, uint64_t other, bool keep_min) {
-    const bool other_less = other < mine;
-    mine = (other_less == keep_min) ? other : mine;
-}
-
-template <int E, int K, int J>
-__device__ __forceinline__ void sort_stage(SortCtx<E>& c) {
-    if constexpr (J < E) {  // both keys of every pair live in this thread's registers
-#pragma unroll
-        for (int r = 0; r < E; r++) {
-            if ((r & J) == 0) {
-                const bool asc = ((c.gidx + r) & K) == 0;
-                uint64_t& a = c.key[r];
-                uint64_t& b = c.key[r | J];
-                if ((a > b) == asc) {
-                    const uint64_t tmp = a;
-                    a = b;
-                    b = tmp;
-                }
-            }
-        }
-    } else {
-        const bool asc = (c.gidx & K) == 0;
-        const bool lower = (c.t & (J / E)) == 0;
-        const bool keep_min = lower == asc;
-        if constexpr (J < 64 * E) {  // the partner keys sit in lane l ^ (J/E) of this wave
-#pragma unroll
-            for (int r = 0; r < E; r++) {
-                const uint32_t lo = lane_xor<J / E>((uint32_t)c.key[r]);
-                const uint32_t hi = lane_xor<J / E>((uint32_t)(c.key[r] >> 32));
-                keep(c.key[r], ((uint64_t)hi << 32) | lo, keep_min);
-            }
-        } else {  // the partner keys sit in another wave: one round trip through LDS
-            uint64_t* mine = c.xchg + E * c.t;
-#pragma unroll
-            for (int r = 0; r < E; r++) mine[r] = c.key[r];
-            __syncthreads();
-            const uint64_t* theirs = c.xchg + E * (c.t ^ (J / E));
-            uint64_t other[E];
-#pragma unroll
-            for (int r = 0; r < E; r++) other[r] = theirs[r];
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < E; r++) keep(c.key[r], other[r], keep_min);
-        }
-    }
-}
-
-template <int E, int K, int J>
-__device__ __forceinline__ void sort_stages(SortCtx<E>& c) {
-    sort_stage<E, K, J>(c);
-    if constexpr (J > 1) sort_stages<E, K, J / 2>(c);
-}
-
-template <int E, int K>
-__device__ __forceinline__ void sort_levels(SortCtx<E>& c, uint32_t kmax) {
-    if constexpr (K > 2) sort_levels<E, K / 2>(c, kmax);
-    if (K <= kmax) sort_stages<E, K, K / 2>(c);  // kmax is workgroup-uniform
-}
-
-// One workgroup per tile; E keys per thread sort a tile of up to 256*E instances.
-template <int E>
-__device__ __forceinline__ void tile_sort_body(uint64_t* skeys, uint32_t begin, uint32_t n, const uint32_t* __restrict__ bucket_ids,
-                                               const float* __restrict__ depths, uint32_t* __restrict__ point_list) {
-    uint32_t np2 = E;  // at least one key group
-    while (np2 < n) np2 <<= 1;
-    SortCtx<E> c;
-    c.t = threadIdx.x;
-    c.gidx = E * threadIdx.x;
-    c.xchg = skeys;
-#pragma unroll
-    for (int r = 0; r < E; r++) {
-        const uint32_t i = c.gidx + r;
-        uint64_t key = ~0ull;
-        if (i < n) {
-            const uint32_t id = bucket_ids[begin + i];
-            key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
-        }
-        c.key[r] = key;
-    }
-    sort_levels<E, 256 * E>(c, np2);
-#pragma unroll
-    for (int r = 0; r < E; r++)
-        if (c.gidx + r < n) point_list[begin + c.gidx + r] = (uint32_t)c.key[r];
-}
-
 // The host knows the longest list (mailbox) and launches the instantiation whose EMAX covers it; inside, every workgroup
 // takes the smallest E that holds its own tile, so the few long tiles sort while the short ones do (a second launch for
 // them cost 23 us on the headline scene: one 2048-key network is a 20 us dependency chain).  EMAX = 32 would cost the
@@ -509,6 +397,43 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restri
         else if (EMAX == 8 || n <= 2048) tile_sort_body<(EMAX >= 8 ? 8 : 4)>(skeys, begin, n, bucket_ids, depths, point_list);
         else tile_sort_body<(EMAX >= 16 ? 16 : 4)>(skeys, begin, n, bucket_ids, depths, point_list);
     }
+}
+
+// ---- lazy sort, first round ----------------------------------------------------------------------------------------------
+// Tiles listing at most min_len instances are sorted in full.  A longer list gets a front of about `target` depth-nearest
+// instances split off (wg_sort.h: select_front) into point_list and only that front is sorted; seg_end[tile] tells the
+// forward pass how far the list is in order.  The rest of the tile stays an unsorted bag in bucket_ids[begin + F ..).
+LazyConfig g_lazy;
+
+__global__ void __launch_bounds__(256) tile_select_kernel(const uint32_t* __restrict__ tile_offset, uint32_t* bucket_ids,
+                                                          const float* __restrict__ depths, uint32_t* point_list,
+                                                          uint32_t* __restrict__ seg_end, uint32_t min_len, uint32_t target, uint32_t cap) {
+    __shared__ SelectScratch sc;
+    const int tile = blockIdx.x;
+    const uint32_t begin = tile_offset[tile];
+    const uint32_t n = tile_offset[tile + 1] - begin;
+    if (n <= min_len) {  // workgroup-uniform
+        if (threadIdx.x == 0) seg_end[tile] = n;
+        return;
+    }
+    const uint32_t F = select_front(bucket_ids + begin, n, depths, point_list + begin, target, cap, sc);
+    if (threadIdx.x == 0) seg_end[tile] = F;
+}
+
+// Sorts [0, seg_end) of every tile: straight from its bucket when that is the whole list, in place in point_list when it is
+// a front.  Fronts and full lists are at most max(min_len, cap) <= 2048 long: the 8-keys-per-thread network covers them.
+__global__ void __launch_bounds__(256) tile_sort_seg_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ seg_end,
+                                                            const uint32_t* bucket_ids, const float* __restrict__ depths,
+                                                            uint32_t* point_list) {
+    extern __shared__ uint64_t skeys[];
+    const int tile = blockIdx.x;
+    const uint32_t begin = tile_offset[tile];
+    const uint32_t n = tile_offset[tile + 1] - begin;
+    const uint32_t len = seg_end[tile];
+    if (len == 0) return;
+    const uint32_t* src = len == n ? bucket_ids : point_list;
+    if (len <= 1024) tile_sort_body<4>(skeys, begin, len, src, depths, point_list);
+    else tile_sort_body<8>(skeys, begin, len, src, depths, point_list);
 }
 
 // ---- launch order of the render kernels ---------------------------------------------------------------------------
@@ -596,6 +521,18 @@ static hipError_t launch_tile_sort_e(const ImageState& img, const BinningState& 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tile_sort_kernel<E>, dim3(tiles), dim3(256), lds, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list, n_min,
                        n_max);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, hipStream_t stream) {
+    if (tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_select_kernel, dim3(tiles), dim3(256), 0, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list,
+                       img.seg_end, g_lazy.min_len, g_lazy.target, g_lazy.cap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t lds = (size_t)256 * 8 * sizeof(uint64_t);
+    hipLaunchKernelGGL(tile_sort_seg_kernel, dim3(tiles), dim3(256), lds, stream, img.tile_offset, img.seg_end, b.bucket_ids, g.depths,
+                       b.point_list);
     return hipGetLastError();
 }
 

@@ -24,60 +24,78 @@
 // threshold decision sits within rounding distance (see tests/test_parity_gpu.py: fragile pixels).
 #include "wg_common.h"
 #include "wg_alpha.h"
+#include "wg_sort.h"
 
 namespace wg {
 
 constexpr int BATCH = 64;
 
-__global__ void __launch_bounds__(64) render_forward_kernel(
-    int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
-    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last,
-    float* __restrict__ out_color) {
-    __shared__ float4 lds[BATCH * 3];
+// ---- the per-tile walk, as device functions shared by render_forward_kernel and the lazy-sort fix-up kernel (binning.hip) ----
+// One wave owns a tile.  The walk is resumable: it composites list positions [pos_begin, pos_end) and can be continued
+// later from the state parked in the output buffers (fwd_store with complete == false / fwd_init with resume == true).
 
-    const int tile = order ? (int)order[xcd_tile(blockIdx.x, tiles)] : xcd_tile(blockIdx.x, tiles);
-    const int lane = threadIdx.x;
+__device__ void fwd_init(FwdTile& st, int W, int H, int gx, int tile, int lane, const float2* __restrict__ subpixel_offset, bool resume,
+                         const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ out_color) {
     const int tx = tile % gx, ty = tile / gx;
-    const int px = tx * TILE_X + (lane & 15);
-    const int py0 = ty * TILE_Y + (lane >> 4);
-
-    float pfx[4], pfy[4], T[4], Cr[4], Cg[4], Cb[4];
-    uint32_t last[4];
-    uint32_t alive = 0;  // bit s set <=> pixel of strip s still accumulating
-    StripBounds sb;
+    st.px = tx * TILE_X + (lane & 15);
+    st.py0 = ty * TILE_Y + (lane >> 4);
+    st.alive = 0;
+    const size_t plane = (size_t)W * H;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        const int py = py0 + 4 * s;
-        const bool inside = px < W && py < H;
+        const int py = st.py0 + 4 * s;
+        const bool inside = st.px < W && py < H;
         float2 off = make_float2(0.f, 0.f);
+        st.T[s] = 1.0f;
+        st.Cr[s] = st.Cg[s] = st.Cb[s] = 0.f;
+        st.last[s] = 0;
         if (inside) {
-            off = subpixel_offset[(size_t)W * py + px];
-            alive |= 1u << s;
+            const size_t pix = (size_t)W * py + st.px;
+            off = subpixel_offset[pix];
+            st.alive |= 1u << s;
+            if (resume) {  // parked state: T < 0 marks a pixel that already hit the T < 1e-4 stop
+                const float t = final_T[pix];
+                st.T[s] = fabsf(t);
+                if (t < 0.f) st.alive &= ~(1u << s);
+                st.last[s] = n_contrib[pix];
+                st.Cr[s] = out_color[pix];
+                st.Cg[s] = out_color[plane + pix];
+                st.Cb[s] = out_color[2 * plane + pix];
+            }
         }
-        pfx[s] = (float)px + off.x;
-        pfy[s] = (float)py + off.y;
-        T[s] = 1.0f;
-        Cr[s] = Cg[s] = Cb[s] = 0.f;
-        last[s] = 0;
+        st.pfx[s] = (float)st.px + off.x;
+        st.pfy[s] = (float)py + off.y;
         const float inf = __builtin_huge_valf();
-        sb.x0[s] = wave_min_uniform(inside ? pfx[s] : inf);
-        sb.x1[s] = wave_max_uniform(inside ? pfx[s] : -inf);
-        sb.y0[s] = wave_min_uniform(inside ? pfy[s] : inf);
-        sb.y1[s] = wave_max_uniform(inside ? pfy[s] : -inf);
+        st.sb.x0[s] = wave_min_uniform(inside ? st.pfx[s] : inf);
+        st.sb.x1[s] = wave_max_uniform(inside ? st.pfx[s] : -inf);
+        st.sb.y0[s] = wave_min_uniform(inside ? st.pfy[s] : inf);
+        st.sb.y1[s] = wave_max_uniform(inside ? st.pfy[s] : -inf);
     }
-    uint32_t strips_alive = 0;  // wave-uniform: strips with at least one unsaturated pixel
+    st.strips_alive = 0;  // wave-uniform: strips with at least one unsaturated pixel
 #pragma unroll
     for (int s = 0; s < 4; s++)
-        if (__ballot((alive >> s) & 1u) != 0ull) strips_alive |= 1u << s;
+        if (__ballot((st.alive >> s) & 1u) != 0ull) st.strips_alive |= 1u << s;
+}
 
-    const uint2 range = ranges[tile];
-    const int n = (int)(range.y - range.x);
+// lds: BATCH * 3 float4 of the wave's own LDS.  list = the tile's sorted instance list (point_list + range.x).
+__device__ void fwd_walk(FwdTile& st, float4* lds, int lane, const uint32_t* __restrict__ list, const float4* __restrict__ splats,
+                         int pos_begin, int pos_end) {
+    const int n = pos_end - pos_begin;
+    list += pos_begin;
+    float pfx[4], pfy[4], T[4], Cr[4], Cg[4], Cb[4];
+    uint32_t last[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        pfx[s] = st.pfx[s]; pfy[s] = st.pfy[s]; T[s] = st.T[s]; Cr[s] = st.Cr[s]; Cg[s] = st.Cg[s]; Cb[s] = st.Cb[s];
+        last[s] = st.last[s];
+    }
+    uint32_t alive = st.alive, strips_alive = st.strips_alive;
+    const StripBounds sb = st.sb;
 
     float4 a0, a1, a2;
     a0 = a1 = a2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < n) {
-        const uint32_t id = point_list[range.x + lane];
+    if (lane < n && strips_alive != 0) {
+        const uint32_t id = list[lane];
         a0 = splats[3 * (size_t)id];
         a1 = splats[3 * (size_t)id + 1];
         a2 = splats[3 * (size_t)id + 2];
@@ -86,13 +104,14 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
     for (int base = 0; base < n && strips_alive != 0; base += BATCH) {
         const int cnt = min(BATCH, n - base);
         const uint32_t mymask = lane < cnt ? strip_mask(a0, a1, sb) : 0u;
-        __syncthreads();
+        // (no workgroup barrier: the wave is the staging area's only user and its LDS operations execute in issue order)
+        __builtin_amdgcn_wave_barrier();
         lds[3 * lane] = a0;
         lds[3 * lane + 1] = a1;
         lds[3 * lane + 2] = a2;
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         if (base + BATCH + lane < n) {  // prefetch the next batch under this batch's math
-            const uint32_t id = point_list[range.x + base + BATCH + lane];
+            const uint32_t id = list[base + BATCH + lane];
             a0 = splats[3 * (size_t)id];
             a1 = splats[3 * (size_t)id + 1];
             a2 = splats[3 * (size_t)id + 2];
@@ -111,7 +130,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
             const float4 r0 = lds[3 * j];      // mx, my, conic.x, conic.y
             const float4 r1 = lds[3 * j + 1];  // conic.z, opacity, -, red
             const SplatCoef sc = make_coef(r0, r1);
-            const uint32_t pos = (uint32_t)(base + j + 1);
+            const uint32_t pos = (uint32_t)(pos_begin + base + j + 1);
             const uint32_t alive_before = alive;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
@@ -145,21 +164,33 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
             }
         }
     }
-
-    uint32_t lmax = 0;
-    const size_t plane = (size_t)W * H;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        const int py = py0 + 4 * s;
-        if (px < W && py < H) {
-            const size_t pix = (size_t)W * py + px;
-            final_T[pix] = T[s];
-            n_contrib[pix] = last[s];
-            out_color[pix] = Cr[s] + T[s] * bg0;
-            out_color[plane + pix] = Cg[s] + T[s] * bg1;
-            out_color[2 * plane + pix] = Cb[s] + T[s] * bg2;
-            lmax = max(lmax, last[s]);
+        st.T[s] = T[s]; st.Cr[s] = Cr[s]; st.Cg[s] = Cg[s]; st.Cb[s] = Cb[s]; st.last[s] = last[s];
+    }
+    st.alive = alive;
+    st.strips_alive = strips_alive;
+}
+
+// complete: the tile is finished (every pixel stopped, or its list is exhausted) -> final outputs.  Otherwise the state is
+// parked in the same buffers for a later fwd_init(resume): colour without background, -T for stopped pixels.
+__device__ void fwd_store(const FwdTile& st, bool complete, int W, int H, int tile, int lane, const float* __restrict__ bg,
+                          float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last,
+                          float* __restrict__ out_color) {
+    uint32_t lmax = 0;
+    const size_t plane = (size_t)W * H;
+    const float bg0 = complete ? bg[0] : 0.f, bg1 = complete ? bg[1] : 0.f, bg2 = complete ? bg[2] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int py = st.py0 + 4 * s;
+        if (st.px < W && py < H) {
+            const size_t pix = (size_t)W * py + st.px;
+            final_T[pix] = (complete || ((st.alive >> s) & 1u)) ? st.T[s] : -st.T[s];
+            n_contrib[pix] = st.last[s];
+            out_color[pix] = st.Cr[s] + st.T[s] * bg0;
+            out_color[plane + pix] = st.Cg[s] + st.T[s] * bg1;
+            out_color[2 * plane + pix] = st.Cb[s] + st.T[s] * bg2;
+            lmax = max(lmax, st.last[s]);
         }
     }
 #pragma unroll
@@ -167,14 +198,99 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
     if (lane == 0) tile_last[tile] = lmax;
 }
 
+// seg_end == nullptr: the whole list is sorted (default).  Otherwise (lazy sort, binning.hip) only the first seg_end[tile]
+// entries are; a tile that is still accumulating when they run out parks its state and reports the length it consumed in
+// tile_state[tile] (0xffffffff = finished) for the fix-up kernel.
+__global__ void __launch_bounds__(64) render_forward_kernel(
+    int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
+    const uint32_t* __restrict__ seg_end, uint32_t* __restrict__ tile_state,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last,
+    float* __restrict__ out_color) {
+    __shared__ float4 lds[BATCH * 3];
+    const int tile = xcd_tile(blockIdx.x, tiles);
+    const int lane = threadIdx.x;
+    FwdTile st;
+    fwd_init(st, W, H, gx, tile, lane, subpixel_offset, false, final_T, n_contrib, out_color);
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const int end = seg_end ? min(n, (int)seg_end[tile]) : n;
+    fwd_walk(st, lds, lane, point_list + range.x, splats, 0, end);
+    const bool complete = st.strips_alive == 0 || end == n;
+    fwd_store(st, complete, W, H, tile, lane, bg, final_T, n_contrib, tile_last, out_color);
+    if (tile_state && lane == 0) tile_state[tile] = complete ? 0xffffffffu : (uint32_t)end;
+}
+
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                  const GeometryState& g, const float* subpixel_offset, const float* background,
-                                 float* out_color, hipStream_t stream) {
+                                 float* out_color, bool lazy, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(render_forward_kernel, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, (const uint32_t*)nullptr, img.ranges, b.point_list, g.splats,
-                       reinterpret_cast<const float2*>(subpixel_offset), background, img.final_T, img.n_contrib, img.tile_last,
-                       out_color);
+    hipLaunchKernelGGL(render_forward_kernel, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats,
+                       reinterpret_cast<const float2*>(subpixel_offset), background, lazy ? img.seg_end : (const uint32_t*)nullptr,
+                       lazy ? img.tile_state : (uint32_t*)nullptr, img.final_T, img.n_contrib, img.tile_last, out_color);
+    return hipGetLastError();
+}
+
+// ---- lazy sort, later rounds (fix-up) ---------------------------------------------------------------------------------------
+// One 256-thread workgroup per tile, a no-op for finished tiles.  For a tile whose sorted front ran out while pixels were still
+// accumulating it loops: split the next front off the unsorted bag (or take all of it when short), sort it in place behind the
+// part already consumed, let wave 0 resume the walk over it -- until every pixel has stopped or the list is exhausted.  The
+// final list prefix is in exactly the order a full sort gives, so n_contrib / tile_last / the backward pass are unaffected.
+__global__ void __launch_bounds__(256) render_fixup_kernel(
+    int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, uint32_t* point_list, uint32_t* bucket_ids,
+    const float* __restrict__ depths, const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset,
+    const float* __restrict__ bg, uint32_t* __restrict__ tile_state, float* final_T, uint32_t* n_contrib,
+    uint32_t* __restrict__ tile_last, float* out_color, uint32_t target, uint32_t cap) {
+    __shared__ float4 lds[BATCH * 3];
+    __shared__ uint64_t skeys[256 * 8];
+    __shared__ SelectScratch sc;
+    __shared__ int s_complete;
+    const int tile = xcd_tile(blockIdx.x, tiles);
+    uint32_t done = tile_state[tile];
+    if (done == 0xffffffffu) return;  // workgroup-uniform
+    const int tid = threadIdx.x;
+    const bool walker = tid < 64;
+    const uint2 range = ranges[tile];
+    const uint32_t n = range.y - range.x;
+    FwdTile st;
+    if (walker) fwd_init(st, W, H, gx, tile, tid, subpixel_offset, true, final_T, n_contrib, out_color);
+    for (;;) {
+        const uint32_t m = n - done;
+        uint32_t* bag = bucket_ids + range.x + done;
+        uint32_t F;
+        const uint32_t* src;
+        if (m <= cap) {
+            F = m;
+            src = bucket_ids;
+        } else {
+            F = select_front(bag, m, depths, point_list + range.x + done, target, cap, sc);
+            src = point_list;
+        }
+        if (F <= 1024) tile_sort_body<4>(skeys, range.x + done, F, src, depths, point_list);
+        else tile_sort_body<8>(skeys, range.x + done, F, src, depths, point_list);
+        __threadfence_block();
+        __syncthreads();  // the sorted segment is visible to wave 0
+        if (walker) {
+            fwd_walk(st, lds, tid, point_list + range.x, splats, (int)done, (int)(done + F));
+            if (tid == 0) s_complete = (st.strips_alive == 0 || done + F == n) ? 1 : 0;
+        }
+        done += F;
+        __syncthreads();
+        if (s_complete) break;
+        __syncthreads();  // s_complete is rewritten next round
+    }
+    if (walker) fwd_store(st, true, W, H, tile, tid, bg, final_T, n_contrib, tile_last, out_color);
+    if (tid == 0) tile_state[tile] = 0xffffffffu;
+}
+
+hipError_t launch_render_fixup(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
+                               const float* subpixel_offset, const float* background, float* out_color, hipStream_t stream) {
+    const int tiles = gx * gy;
+    if (tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(render_fixup_kernel, dim3(tiles), dim3(256), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, b.bucket_ids,
+                       g.depths, g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.tile_state, img.final_T,
+                       img.n_contrib, img.tile_last, out_color, 1536u < g_lazy.cap ? 1536u : (g_lazy.cap * 3u) / 4u, g_lazy.cap);
     return hipGetLastError();
 }
 

@@ -73,6 +73,16 @@ struct StripBounds {
     float x0[4], x1[4], y0[4], y1[4];
 };
 
+// One wave's compositing state for a tile (render_fwd.hip): 4 pixels per lane.
+struct FwdTile {
+    float pfx[4], pfy[4], T[4], Cr[4], Cg[4], Cb[4];
+    uint32_t last[4];
+    uint32_t alive;         // bit s: this lane's pixel of strip s is still accumulating
+    uint32_t strips_alive;  // wave-uniform: strips with at least one such pixel
+    StripBounds sb;
+    int px, py0;
+};
+
 // Conservative per-(splat, strip) reachability mask.  A pixel can only pass alpha >= 1/255 when
 // power >= -ln(255*o), i.e. inside the ellipse d^T Q d <= 2 ln(255 o); the mask tests that ellipse's axis-aligned
 // bounding box (inflated by 0.1% + 0.01 px so float rounding can never exclude a pixel the exact test would keep)

@@ -56,6 +56,8 @@ struct ImageState {
     uint32_t* tile_offset;  // exclusive prefix sum of tile_count
     uint32_t* chunk_hist;   // [chunks][tiles] per-chunk tile histogram, turned into per-chunk bases by the column scan
     uint32_t* order_bwd;    // launch order of the backward render: per XCD band, tiles by descending walked length
+    uint32_t* seg_end;      // lazy sort: length of the tile's sorted front after the first round (== count when sorted in full)
+    uint32_t* tile_state;   // lazy sort: 0xffffffff = tile finished, else the list length the forward pass has consumed
     BinStats* stats;
     static ImageState fromChunk(char*& chunk, size_t N, size_t tiles);
 };
@@ -109,11 +111,21 @@ hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_o
 hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, hipStream_t stream);
 hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, hipStream_t stream);
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles, hipStream_t stream);
+struct LazyConfig {
+    bool enabled = true;
+    uint32_t min_len = 2048;  // tiles listing more than this are front-split instead of sorted in full
+    uint32_t target = 820;    // aimed front length of the first round (the 1024-key network)
+    uint32_t cap = 2048;      // hard bound of a front (the 2048-key network)
+};
+extern LazyConfig g_lazy;
+hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, hipStream_t stream);
+hipError_t launch_render_fixup(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
+                               const float* subpixel_offset, const float* background, float* out_color, hipStream_t stream);
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
                             hipStream_t stream);
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                  const GeometryState& g, const float* subpixel_offset, const float* background,
-                                 float* out_color, hipStream_t stream);
+                                 float* out_color, bool lazy, hipStream_t stream);
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                   const GeometryState& g, const float* subpixel_offset, const float* background,
                                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,

@@ -267,7 +267,7 @@ def version() -> str:
 
 # ----------------------------------------------------------------------------------------------------------
 # Per-stage HIP-event timing (wg_profile_* in wg_rasterizer.h); used by bench.py for the roofline object.
-STAGE_COUNT = 8
+STAGE_COUNT = 9  # WG_STAGE_COUNT (include/wg_rasterizer.h)
 
 
 class _StageTimes(C.Structure):

@@ -78,7 +78,8 @@ __device__ void fwd_init(FwdTile& st, int W, int H, int gx, int tile, int lane, 
 }
 
 // lds: BATCH * 3 float4 of the wave's own LDS.  list = the tile's sorted instance list (point_list + range.x).
-__device__ void fwd_walk(FwdTile& st, float4* lds, int lane, const uint32_t* __restrict__ list, const float4* __restrict__ splats,
+template <bool WGB>
+__device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, const uint32_t* __restrict__ list, const float4* __restrict__ splats,
                          int pos_begin, int pos_end) {
     const int n = pos_end - pos_begin;
     list += pos_begin;
@@ -104,12 +105,14 @@ __device__ void fwd_walk(FwdTile& st, float4* lds, int lane, const uint32_t* __r
     for (int base = 0; base < n && strips_alive != 0; base += BATCH) {
         const int cnt = min(BATCH, n - base);
         const uint32_t mymask = lane < cnt ? strip_mask(a0, a1, sb) : 0u;
-        // (no workgroup barrier: the wave is the staging area's only user and its LDS operations execute in issue order)
-        __builtin_amdgcn_wave_barrier();
+        // The wave is the staging area's only user and its LDS operations execute in issue order, so no barrier is needed for
+        // correctness.  WGB (legal only when the workgroup IS the wave) keeps the s_barrier-free __syncthreads() of the one-wave
+        // kernel anyway: hipcc schedules and allocates the compositing loop measurably better around it (0.325 vs 0.340 ms).
+        if (WGB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         lds[3 * lane] = a0;
         lds[3 * lane + 1] = a1;
         lds[3 * lane + 2] = a2;
-        __builtin_amdgcn_wave_barrier();
+        if (WGB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         if (base + BATCH + lane < n) {  // prefetch the next batch under this batch's math
             const uint32_t id = list[base + BATCH + lane];
             a0 = splats[3 * (size_t)id];
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(64) render_forward_kernel(
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const int end = seg_end ? min(n, (int)seg_end[tile]) : n;
-    fwd_walk(st, lds, lane, point_list + range.x, splats, 0, end);
+    fwd_walk<true>(st, lds, lane, point_list + range.x, splats, 0, end);
     const bool complete = st.strips_alive == 0 || end == n;
     fwd_store(st, complete, W, H, tile, lane, bg, final_T, n_contrib, tile_last, out_color);
     if (tile_state && lane == 0) tile_state[tile] = complete ? 0xffffffffu : (uint32_t)end;
@@ -272,7 +275,7 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
         __threadfence_block();
         __syncthreads();  // the sorted segment is visible to wave 0
         if (walker) {
-            fwd_walk(st, lds, tid, point_list + range.x, splats, (int)done, (int)(done + F));
+            fwd_walk<false>(st, lds, tid, point_list + range.x, splats, (int)done, (int)(done + F));
             if (tid == 0) s_complete = (st.strips_alive == 0 || done + F == n) ? 1 : 0;
         }
         done += F;

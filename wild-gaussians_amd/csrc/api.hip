@@ -236,7 +236,7 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     }
     if (num_rendered > 0) {
         if (!global_sort) {
-            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, stream), "tile_scatter");
+            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, (uint32_t)num_rendered, stream), "tile_scatter");
             if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, stream), "tile_sort_lazy");
             else WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, geom, tiles, max_tile_count, stream), "tile_sort");
         } else {
@@ -353,6 +353,7 @@ int wg_set_option(const char* name, int value) {
     if (!name) return WG_ERR_INVALID_ARGUMENT;
     if (std::strcmp(name, "force_global_sort") == 0) { g_force_global_sort = value != 0; return WG_OK; }
     if (std::strcmp(name, "host_mailbox") == 0) { g_use_mailbox = value != 0; return WG_OK; }
+    if (std::strcmp(name, "staged_scatter") == 0) { wg::g_staged_scatter = value < 0 ? -1 : (value != 0); return WG_OK; }
     if (std::strcmp(name, "lazy_sort") == 0) { wg::g_lazy.enabled = value != 0; return WG_OK; }
     if (std::strcmp(name, "lazy_min_len") == 0 || std::strcmp(name, "lazy_target") == 0 || std::strcmp(name, "lazy_cap") == 0) {
         // min_len >= 256 (the selection samples 256 entries) and min_len, cap <= 2048 (the 8-keys-per-thread network)

@@ -364,6 +364,122 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4*
     }
 }
 
+// Staged scatter, for dense frames.  The direct kernel issues one 4-byte store per instance to a random bucket position; with
+// thousands of instances per tile that is what bounds it (41.8 M instances: 0.44 ms, 4.5x write amplification at the fabric).
+// Here a workgroup owns (G consecutive chunks, XCD band), knows from the chunk histograms how many instances it will emit per
+// tile, lays them out tile-major in LDS (LDS cursors), and copies every tile's run to its bucket with consecutive lanes on
+// consecutive addresses: one write transaction per (workgroup, tile) run.  At ~900 instances per tile the runs are 2 ids long
+// and the direct kernel is as fast (measured), so the host picks this one only for long lists.  Placement inside a bucket is
+// free: the same multiset either way.
+__global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const ushort4* __restrict__ rects, const uint32_t* __restrict__ tile_offset,
+                                                                  const uint32_t* __restrict__ tile_count,
+                                                                  const uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ bucket_ids,
+                                                                  int gx, int tiles, int G, int nbmax, uint32_t cap) {
+    extern __shared__ uint32_t smem[];
+    uint32_t* gbase = smem;           // [nbmax] bucket position of this workgroup's first instance of the tile
+    uint32_t* lcur = gbase + nbmax;   // [nbmax] cursor: staging-area positions (staged) or bucket positions (direct)
+    uint32_t* wsum = lcur + nbmax;    // [16]
+    uint32_t* stage = wsum + 16;      // [cap]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int band = blockIdx.x & 7, c0 = (blockIdx.x >> 3) * G, c1 = c0 + G;
+    const int q = tiles >> 3, rem = tiles & 7;
+    const int t0 = band * q + min(band, rem), t1 = t0 + q + (band < rem ? 1 : 0);
+    const int nb = t1 - t0;
+    if (nb <= 0) return;
+    for (int i = tid; i < nb; i += 1024) {
+        const int t = t0 + i;
+        const uint32_t pre0 = chunk_hist[(size_t)c0 * tiles + t];
+        const uint32_t pre1 = c1 < BIN_CHUNKS ? chunk_hist[(size_t)c1 * tiles + t] : tile_count[t];
+        gbase[i] = tile_offset[t] + pre0;
+        lcur[i] = pre1 - pre0;
+    }
+    __syncthreads();
+    // exclusive scan of the per-tile counts -> run positions in the staging area
+    const int per = (nb + 1023) / 1024;
+    const int sb = min(nb, tid * per), se = min(nb, sb + per);
+    uint32_t local = 0;
+    for (int i = sb; i < se; i++) local += lcur[i];
+    uint32_t incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, total = 0;
+    for (int w = 0; w < 16; w++) {
+        if (w < wave) wave_base += wsum[w];
+        total += wsum[w];
+    }
+    uint32_t run = wave_base + incl - local;
+    for (int i = sb; i < se; i++) {
+        const uint32_t c = lcur[i];
+        lcur[i] = run;  // start of tile i's run in the workgroup's (virtual) tile-major sequence
+        run += c;
+    }
+    __syncthreads();
+
+    int begin, end, dummy;
+    chunk_bounds(P, c0, begin, dummy);
+    chunk_bounds(P, c1 - 1, dummy, end);
+    // The sequence is emitted in passes of as many whole tiles as fit the staging area (one pass when the share is small; a
+    // dense frame takes several, re-reading the chunk's rectangles each time).  A single tile whose run alone exceeds the area
+    // is stored directly.
+    for (int a = 0; a < nb;) {
+        const uint32_t base = lcur[a];  // untouched so far: cursors of tiles >= a have not been advanced
+        int e;
+        {  // largest e with start[e] - base <= cap (start[nb] = total); at least one tile
+            int lo = a + 1, hi = nb;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if ((mid < nb ? lcur[mid] : total) - base <= cap) lo = mid;
+                else hi = mid - 1;
+            }
+            e = lo;
+        }
+        const uint32_t pass_total = (e < nb ? lcur[e] : total) - base;
+        const bool staged = pass_total <= cap;  // false only for a single oversized tile
+        __syncthreads();                        // everybody has read the cursors this pass' scatter is about to advance
+        const int ta = t0 + a, tb = t0 + e;
+        const int ya0 = ta / gx, yb0 = (tb - 1) / gx;
+        if (pass_total > 0) {
+            for (int gb0 = begin; gb0 < end; gb0 += PF * 1024) {
+                ushort4 r[PF];
+#pragma unroll
+                for (int k = 0; k < PF; k++) {
+                    const int idx = gb0 + k * 1024 + tid;
+                    r[k] = idx < end ? rects[idx] : make_ushort4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < PF; k++) {
+                    if (gb0 + k * 1024 >= end) break;
+                    const int ya = max((int)r[k].y, ya0), yb = min((int)r[k].w, yb0 + 1);
+                    for_each_tile<16>(r[k].z > r[k].x && yb > ya, r[k].x, ya, r[k].z, yb, gb0 + k * 1024 + tid, [&](int x, int y, int id) {
+                        const int t = y * gx + x;
+                        if (t >= ta && t < tb) {
+                            const uint32_t slot = atomicAdd(&lcur[t - t0], 1u) - base;
+                            if (staged) stage[slot] = (uint32_t)id;
+                            else bucket_ids[gbase[t - t0] + slot] = (uint32_t)id;
+                        }
+                    });
+                }
+            }
+        }
+        __syncthreads();
+        if (staged && pass_total > 0) {
+            // copy-out, 16 lanes per run: after the scatter lcur[i] is the END of tile i's run, i.e. the start of tile i+1's
+            const int grp = tid >> 4, sub = tid & 15;
+            for (int i = a + grp; i < e; i += 64) {
+                const uint32_t lb = (i == a ? base : lcur[i - 1]) - base, n = lcur[i] - base - lb, gb = gbase[i];
+                for (uint32_t k = sub; k < n; k += 16) bucket_ids[gb + k] = stage[lb + k];
+            }
+            __syncthreads();  // the staging area is reused by the next pass
+        }
+        a = e;
+    }
+}
+
 // ---- per-tile sort ----------------------------------------------------------------------------------------------------
 // Bitonic sort of a tile's bucket.  Keys are (depth_bits << 32 | gaussian id), built while loading (the id comes from the
 // bucket, the depth from the 4 B/Gaussian depth array, which stays in L2); padded to a power of two with ~0.
@@ -391,49 +507,42 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restri
     const uint32_t n = tile_offset[tile + 1] - begin;
     if (n < n_min || n > n_max) return;  // n == 0, or a tile the other launch takes care of
     if constexpr (EMAX == 32) {
-        tile_sort_body<32>(skeys, begin, n, bucket_ids, depths, point_list);
+        tile_sort_body<32>(skeys, n, bucket_ids + begin, depths, point_list + begin);
     } else {
-        if (EMAX == 4 || n <= 1024) tile_sort_body<4>(skeys, begin, n, bucket_ids, depths, point_list);
-        else if (EMAX == 8 || n <= 2048) tile_sort_body<(EMAX >= 8 ? 8 : 4)>(skeys, begin, n, bucket_ids, depths, point_list);
-        else tile_sort_body<(EMAX >= 16 ? 16 : 4)>(skeys, begin, n, bucket_ids, depths, point_list);
+        if (EMAX == 4 || n <= 1024) tile_sort_body<4>(skeys, n, bucket_ids + begin, depths, point_list + begin);
+        else if (EMAX == 8 || n <= 2048) tile_sort_body<(EMAX >= 8 ? 8 : 4)>(skeys, n, bucket_ids + begin, depths, point_list + begin);
+        else tile_sort_body<(EMAX >= 16 ? 16 : 4)>(skeys, n, bucket_ids + begin, depths, point_list + begin);
     }
 }
 
 // ---- lazy sort, first round ----------------------------------------------------------------------------------------------
-// Tiles listing at most min_len instances are sorted in full.  A longer list gets a front of about `target` depth-nearest
-// instances split off (wg_sort.h: select_front) into point_list and only that front is sorted; seg_end[tile] tells the
-// forward pass how far the list is in order.  The rest of the tile stays an unsorted bag in bucket_ids[begin + F ..).
+// Tiles listing at most min_len instances are sorted in full.  Of a longer list only a front of about `target` depth-nearest
+// instances is extracted (wg_sort.h: extract_front) and sorted into point_list; seg_end[tile] tells the forward pass how far
+// the list is in order.  The tile's bucket is left as it is.
 LazyConfig g_lazy;
 
-__global__ void __launch_bounds__(256) tile_select_kernel(const uint32_t* __restrict__ tile_offset, uint32_t* bucket_ids,
-                                                          const float* __restrict__ depths, uint32_t* point_list,
-                                                          uint32_t* __restrict__ seg_end, uint32_t min_len, uint32_t target, uint32_t cap) {
+// One workgroup per tile: extract (long list) or take (short list) the ids, sort them in registers, write point_list.
+__global__ void __launch_bounds__(256) tile_front_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bucket_ids,
+                                                              const float* __restrict__ depths, uint32_t* __restrict__ point_list,
+                                                              uint32_t* __restrict__ seg_end, uint32_t min_len, uint32_t target, uint32_t cap) {
     __shared__ SelectScratch sc;
+    __shared__ uint64_t skeys[256 * 8];
     const int tile = blockIdx.x;
     const uint32_t begin = tile_offset[tile];
     const uint32_t n = tile_offset[tile + 1] - begin;
-    if (n <= min_len) {  // workgroup-uniform
-        if (threadIdx.x == 0) seg_end[tile] = n;
+    if (n == 0) {
+        if (threadIdx.x == 0) seg_end[tile] = 0;
         return;
     }
-    const uint32_t F = select_front(bucket_ids + begin, n, depths, point_list + begin, target, cap, sc);
-    if (threadIdx.x == 0) seg_end[tile] = F;
-}
-
-// Sorts [0, seg_end) of every tile: straight from its bucket when that is the whole list, in place in point_list when it is
-// a front.  Fronts and full lists are at most max(min_len, cap) <= 2048 long: the 8-keys-per-thread network covers them.
-__global__ void __launch_bounds__(256) tile_sort_seg_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ seg_end,
-                                                            const uint32_t* bucket_ids, const float* __restrict__ depths,
-                                                            uint32_t* point_list) {
-    extern __shared__ uint64_t skeys[];
-    const int tile = blockIdx.x;
-    const uint32_t begin = tile_offset[tile];
-    const uint32_t n = tile_offset[tile + 1] - begin;
-    const uint32_t len = seg_end[tile];
-    if (len == 0) return;
-    const uint32_t* src = len == n ? bucket_ids : point_list;
-    if (len <= 1024) tile_sort_body<4>(skeys, begin, len, src, depths, point_list);
-    else tile_sort_body<8>(skeys, begin, len, src, depths, point_list);
+    const uint32_t* src = bucket_ids + begin;
+    uint32_t len = n;
+    if (n > min_len) {  // workgroup-uniform
+        len = extract_front(bucket_ids + begin, n, depths, 0ull, n, target, cap, sc);
+        src = sc.ids;
+    }
+    if (len <= 1024) tile_sort_body<4>(skeys, len, src, depths, point_list + begin);
+    else tile_sort_body<8>(skeys, len, src, depths, point_list + begin);
+    if (threadIdx.x == 0) seg_end[tile] = len;
 }
 
 // ---- launch order of the render kernels ---------------------------------------------------------------------------
@@ -502,9 +611,32 @@ hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailb
     return hipGetLastError();
 }
 
+int g_staged_scatter = -1;  // wg_set_option("staged_scatter", -1 auto / 0 / 1)
+
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
-                               hipStream_t stream) {
+                               uint32_t num_rendered, hipStream_t stream) {
     if (P <= 0) return hipSuccess;
+    // staged scatter for long lists: G chunks per workgroup such that an average share fits the staging area with headroom
+    const bool want = g_staged_scatter == 1 || (g_staged_scatter < 0 && tiles > 0 && num_rendered / (uint32_t)tiles >= 1500u);
+    if (want) {
+        const int nbmax = tiles / 8 + 1;
+        const size_t fixed = ((size_t)2 * nbmax + 16) * sizeof(uint32_t);
+        // two 1024-thread workgroups per CU; a share (chunks x band) larger than the staging area is emitted in several passes
+        // (one workgroup per CU with twice the room was measured slower: 0.32 vs 0.21 ms at 8450 per tile)
+        const double share1 = (double)num_rendered / (double)(BIN_CHUNKS * 8);
+        const size_t budget = 78 * 1024;
+        if (fixed + 4096 * sizeof(uint32_t) <= budget) {
+            const uint32_t cap = (uint32_t)((budget - fixed) / sizeof(uint32_t));
+            int G = 4;
+            while (G > 1 && share1 * G * 1.5 > (double)cap) G >>= 1;
+            const size_t lds = fixed + (size_t)cap * sizeof(uint32_t);
+            hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_staged_kernel), lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(tile_scatter_staged_kernel, dim3(BIN_CHUNKS / G * 8), dim3(1024), lds, stream, P, g.rects, img.tile_offset,
+                               img.tile_count, img.chunk_hist, b.bucket_ids, gx, tiles, G, nbmax, cap);
+            return hipGetLastError();
+        }
+    }
     const size_t lds = (size_t)(tiles / 8 + 1) * sizeof(uint32_t);
     hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_kernel), lds);
     if (e != hipSuccess) return e;
@@ -526,13 +658,8 @@ static hipError_t launch_tile_sort_e(const ImageState& img, const BinningState& 
 
 hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, hipStream_t stream) {
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_select_kernel, dim3(tiles), dim3(256), 0, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list,
+    hipLaunchKernelGGL(tile_front_sort_kernel, dim3(tiles), dim3(256), 0, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list,
                        img.seg_end, g_lazy.min_len, g_lazy.target, g_lazy.cap);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    const size_t lds = (size_t)256 * 8 * sizeof(uint64_t);
-    hipLaunchKernelGGL(tile_sort_seg_kernel, dim3(tiles), dim3(256), lds, stream, img.tile_offset, img.seg_end, b.bucket_ids, g.depths,
-                       b.point_list);
     return hipGetLastError();
 }
 

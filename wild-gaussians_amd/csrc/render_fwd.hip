@@ -241,7 +241,7 @@ hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState&
 // part already consumed, let wave 0 resume the walk over it -- until every pixel has stopped or the list is exhausted.  The
 // final list prefix is in exactly the order a full sort gives, so n_contrib / tile_last / the backward pass are unaffected.
 __global__ void __launch_bounds__(256) render_fixup_kernel(
-    int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, uint32_t* point_list, uint32_t* bucket_ids,
+    int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, uint32_t* point_list, const uint32_t* __restrict__ bucket_ids,
     const float* __restrict__ depths, const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset,
     const float* __restrict__ bg, uint32_t* __restrict__ tile_state, float* final_T, uint32_t* n_contrib,
     uint32_t* __restrict__ tile_last, float* out_color, uint32_t target, uint32_t cap) {
@@ -256,26 +256,20 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     const bool walker = tid < 64;
     const uint2 range = ranges[tile];
     const uint32_t n = range.y - range.x;
+    const uint32_t* bag = bucket_ids + range.x;
+    uint32_t* list = point_list + range.x;
     FwdTile st;
     if (walker) fwd_init(st, W, H, gx, tile, tid, subpixel_offset, true, final_T, n_contrib, out_color);
     for (;;) {
-        const uint32_t m = n - done;
-        uint32_t* bag = bucket_ids + range.x + done;
-        uint32_t F;
-        const uint32_t* src;
-        if (m <= cap) {
-            F = m;
-            src = bucket_ids;
-        } else {
-            F = select_front(bag, m, depths, point_list + range.x + done, target, cap, sc);
-            src = point_list;
-        }
-        if (F <= 1024) tile_sort_body<4>(skeys, range.x + done, F, src, depths, point_list);
-        else tile_sort_body<8>(skeys, range.x + done, F, src, depths, point_list);
+        // everything at or below the last sorted key has been taken (done >= 1: only front-split tiles arrive here)
+        const uint64_t lo = depth_key(depths, list[done - 1]);
+        const uint32_t F = extract_front(bag, n, depths, lo, n - done, target, cap, sc);
+        if (F <= 1024) tile_sort_body<4>(skeys, F, sc.ids, depths, list + done);
+        else tile_sort_body<8>(skeys, F, sc.ids, depths, list + done);
         __threadfence_block();
         __syncthreads();  // the sorted segment is visible to wave 0
         if (walker) {
-            fwd_walk<false>(st, lds, tid, point_list + range.x, splats, (int)done, (int)(done + F));
+            fwd_walk<false>(st, lds, tid, list, splats, (int)done, (int)(done + F));
             if (tid == 0) s_complete = (st.strips_alive == 0 || done + F == n) ? 1 : 0;
         }
         done += F;
@@ -293,7 +287,7 @@ hipError_t launch_render_fixup(int W, int H, int gx, int gy, const ImageState& i
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(render_fixup_kernel, dim3(tiles), dim3(256), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, b.bucket_ids,
                        g.depths, g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.tile_state, img.final_T,
-                       img.n_contrib, img.tile_last, out_color, 1536u < g_lazy.cap ? 1536u : (g_lazy.cap * 3u) / 4u, g_lazy.cap);
+                       img.n_contrib, img.tile_last, out_color, 1536u < g_lazy.cap ? 1536u : (g_lazy.cap * 3u) / 4u, g_lazy.cap < FRONT_CAP ? g_lazy.cap : FRONT_CAP);
     return hipGetLastError();
 }
 

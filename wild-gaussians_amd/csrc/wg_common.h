@@ -110,7 +110,9 @@ hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& im
 hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_or_null, uint32_t* order, int tiles, hipStream_t stream);
 hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, hipStream_t stream);
 hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, hipStream_t stream);
-hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles, hipStream_t stream);
+extern int g_staged_scatter;
+hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
+                               uint32_t num_rendered, hipStream_t stream);
 struct LazyConfig {
     bool enabled = true;
     uint32_t min_len = 2048;  // tiles listing more than this are front-split instead of sorted in full

@@ -95,11 +95,11 @@ __device__ __forceinline__ void sort_levels(SortCtx<E>& c, uint32_t kmax) {
     if (K <= kmax) sort_stages<E, K, K / 2>(c);  // kmax is workgroup-uniform
 }
 
-// One workgroup per tile; E keys per thread sort a tile of up to 256*E instances.
-// src and dst may be the same array (every key is in a register before the first store).
+// One workgroup sorts n <= 256*E instance ids (E keys per thread) read from src (global or LDS) and writes them, ordered by
+// (depth, id), to dst.  src and dst may overlap (every key is in a register before the first store).
 template <int E>
-__device__ __forceinline__ void tile_sort_body(uint64_t* skeys, uint32_t begin, uint32_t n, const uint32_t* bucket_ids,
-                                               const float* __restrict__ depths, uint32_t* point_list) {
+__device__ __forceinline__ void tile_sort_body(uint64_t* skeys, uint32_t n, const uint32_t* src, const float* __restrict__ depths,
+                                               uint32_t* dst) {
     uint32_t np2 = E;  // at least one key group
     while (np2 < n) np2 <<= 1;
     SortCtx<E> c;
@@ -111,121 +111,111 @@ __device__ __forceinline__ void tile_sort_body(uint64_t* skeys, uint32_t begin, 
         const uint32_t i = c.gidx + r;
         uint64_t key = ~0ull;
         if (i < n) {
-            const uint32_t id = bucket_ids[begin + i];
+            const uint32_t id = src[i];
             key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
         }
         c.key[r] = key;
     }
     sort_levels<E, 256 * E>(c, np2);
-    __syncthreads();  // in-place use: nobody stores before everybody has loaded
+    __syncthreads();  // overlapping src / dst: nobody stores before everybody has loaded
 #pragma unroll
     for (int r = 0; r < E; r++)
-        if (c.gidx + r < n) point_list[begin + c.gidx + r] = (uint32_t)c.key[r];
+        if (c.gidx + r < n) dst[c.gidx + r] = (uint32_t)c.key[r];
 }
-
 
 // ---- lazy sort: front selection ------------------------------------------------------------------------------------
 // A long list is not sorted in full: the forward pass stops at the first few hundred entries of a dense tile (3.6 % of
-// the instances at 5000 per tile), so only a depth-nearest FRONT of the list is split off and sorted; the rest stays an
-// unsorted bag until a tile turns out to need more (render_fwd.hip: fix-up kernel).
+// the instances at 5000 per tile), so only a depth-nearest FRONT of the list is extracted and sorted; the tile's bucket
+// stays an unsorted bag, and a further front (the keys just above the last one taken) is extracted from it only if a tile
+// turns out to need more (render_fwd.hip: fix-up kernel).  Nothing is moved inside the bag: "already taken" is simply
+// "key <= the last key of the sorted part".
 __device__ __forceinline__ uint64_t depth_key(const float* __restrict__ depths, uint32_t id) {
     return ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
 }
 
-struct SelectScratch {   // LDS
+constexpr uint32_t FRONT_CAP = 2048;  // the 8-keys-per-thread network
+
+struct SelectScratch {  // LDS
     uint64_t sample[256];
     uint64_t sorted[256];
-    uint32_t wsum[8];
-    uint32_t totals[2];
+    uint32_t ids[FRONT_CAP];
+    uint32_t count;
+    uint32_t nvalid;
 };
 
-// One partition pass over bag[0..m): ids whose key <= thr are appended to front[0..) (any order), the others are compacted
-// in place to the END of the bag (bag[F..m) afterwards).  Returns F.  The bag is read in chunks from its end, so every
-// in-place store lands on entries that are already in registers.
-__device__ __forceinline__ uint32_t partition_pass(uint32_t* bag, uint32_t m, const float* __restrict__ depths, uint64_t thr,
-                                                   uint32_t* front, SelectScratch& sc) {
-    constexpr uint32_t PER = 8, CH = 256 * PER;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t f_head = 0, b_head = m;
-    for (uint32_t chunk_end = m; chunk_end > 0; chunk_end -= min(chunk_end, CH)) {
-        const uint32_t chunk_begin = chunk_end > CH ? chunk_end - CH : 0;
-        uint32_t id[PER];
-        uint32_t isf = 0, nf = 0, nb = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < PER; k++) {
-            const uint32_t i = chunk_begin + k * 256 + tid;
-            if (i < chunk_end) {
-                id[k] = bag[i];
-                if (depth_key(depths, id[k]) <= thr) { isf |= 1u << k; nf++; }
-                else nb++;
-            }
+// One pass over the bag: the ids with lo < key <= thr are appended to sc.ids (any order, at most cap kept).  Returns how
+// many there are (possibly more than cap: the caller then lowers thr and repeats).
+__device__ __forceinline__ uint32_t extract_pass(const uint32_t* __restrict__ bag, uint32_t n, const float* __restrict__ depths, uint64_t lo,
+                                                 uint64_t thr, uint32_t cap, SelectScratch& sc) {
+    const uint32_t tid = threadIdx.x;
+    __syncthreads();
+    if (tid == 0) sc.count = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + tid;
+        uint32_t id = 0;
+        bool in = false;
+        if (i < n) {
+            id = bag[i];
+            const uint64_t key = depth_key(depths, id);
+            in = key > lo && key <= thr;
         }
-        // exclusive scan of (nf, nb) over the workgroup, packed 16:16
-        const uint32_t packed = nf | (nb << 16);
-        uint32_t incl = packed;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= (uint32_t)d) incl += up;
+        const uint64_t m = __ballot(in);
+        if (m != 0ull) {  // wave-aggregated append
+            const int leader = __builtin_ctzll(m);
+            uint32_t wbase = 0;
+            if ((int)(tid & 63) == leader) wbase = atomicAdd(&sc.count, (uint32_t)__builtin_popcountll(m));
+            wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, leader);
+            const uint32_t pos = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (in && pos < cap) sc.ids[pos] = id;
         }
-        __syncthreads();  // every thread holds its entries; the previous chunk's use of wsum is over
-        if (lane == 63) sc.wsum[wave] = incl;
-        __syncthreads();
-        uint32_t base = 0, total = 0;
-        for (uint32_t w = 0; w < 4; w++) {
-            if (w < wave) base += sc.wsum[w];
-            total += sc.wsum[w];
-        }
-        const uint32_t excl = base + incl - packed;
-        uint32_t fpos = f_head + (excl & 0xffffu), bpos = b_head - (excl >> 16);
-#pragma unroll
-        for (uint32_t k = 0; k < PER; k++) {
-            const uint32_t i = chunk_begin + k * 256 + tid;
-            if (i < chunk_end) {
-                if ((isf >> k) & 1u) front[fpos++] = id[k];
-                else bag[--bpos] = id[k];
-            }
-        }
-        f_head += total & 0xffffu;
-        b_head -= total >> 16;
     }
     __syncthreads();
-    return f_head;
+    return sc.count;
 }
 
-// Splits about `target` depth-nearest ids off bag[0..m) into front[0..F), 1 <= F <= cap, leaving the others in
-// bag[F..m).  The threshold is a quantile of 256 evenly spaced samples; if the split comes out larger than cap (it is tightly
-// concentrated around target, so this is the pathological case) the front is poured back and the target halved, down to the
-// single nearest id, which always terminates.
-__device__ __forceinline__ uint32_t select_front(uint32_t* bag, uint32_t m, const float* __restrict__ depths, uint32_t* front,
-                                                 uint32_t target, uint32_t cap, SelectScratch& sc) {
+// Extracts the next front of a tile's bag: about `target` (at most cap <= FRONT_CAP, at least 1) of the ids whose key is above
+// lo, depth-nearest first, into sc.ids (unsorted); `remaining` = how many ids above lo the bag holds.  The threshold is a
+// quantile of up to 256 evenly spaced samples; should the front come out larger than cap (the count is tightly concentrated
+// around the target, so this is the pathological case) the quantile is halved, down to the single nearest id, which always
+// terminates.  Returns the front's length.
+__device__ __forceinline__ uint32_t extract_front(const uint32_t* __restrict__ bag, uint32_t n, const float* __restrict__ depths, uint64_t lo,
+                                                  uint32_t remaining, uint32_t target, uint32_t cap, SelectScratch& sc) {
     const uint32_t tid = threadIdx.x;
+    if (remaining <= cap) return extract_pass(bag, n, depths, lo, ~0ull, cap, sc);  // all that is left
+    // sample: 256 evenly spaced entries, those above lo ranked among themselves
+    const uint64_t mine = depth_key(depths, bag[(uint32_t)(((uint64_t)tid * n) >> 8)]);
+    const bool valid = mine > lo;
+    __syncthreads();
+    sc.sample[tid] = valid ? mine : ~0ull;
+    if (tid == 0) sc.nvalid = 0;
+    __syncthreads();
+    if (valid) {
+        uint32_t rank = 0;  // ties (the same entry sampled twice when n < 256) are broken by the thread index
+        for (uint32_t j = 0; j < 256; j++) rank += (sc.sample[j] < mine || (sc.sample[j] == mine && j < tid)) ? 1u : 0u;
+        sc.sorted[rank] = mine;
+        atomicAdd(&sc.nvalid, 1u);
+    }
+    __syncthreads();
+    const uint32_t k = sc.nvalid;
     for (;;) {
         uint64_t thr;
-        if (target > 0) {
-            const uint64_t mine = depth_key(depths, bag[(uint32_t)(((uint64_t)tid * m) >> 8)]);
-            __syncthreads();
-            sc.sample[tid] = mine;
-            __syncthreads();
-            uint32_t rank = 0;  // ties (m < 256 samples the same entry twice) are broken by the thread index
-            for (uint32_t j = 0; j < 256; j++) rank += (sc.sample[j] < mine || (sc.sample[j] == mine && j < tid)) ? 1u : 0u;
-            sc.sorted[rank] = mine;
-            __syncthreads();
-            const uint32_t q = min(254u, (uint32_t)(((uint64_t)target << 8) / m));
-            thr = sc.sorted[q];
-        } else {  // last resort: the single nearest entry
+        if (k > 0 && target > 0) {
+            thr = sc.sorted[min(k - 1, (uint32_t)(((uint64_t)k * target) / remaining))];
+        } else {  // no usable sample, or even the nearest sample overshoots: the single nearest id above lo
             uint64_t best = ~0ull;
-            for (uint32_t i = tid; i < m; i += 256) best = min(best, depth_key(depths, bag[i]));
+            for (uint32_t i = tid; i < n; i += 256) {
+                const uint64_t key = depth_key(depths, bag[i]);
+                if (key > lo) best = min(best, key);
+            }
             __syncthreads();
             sc.sample[tid] = best;
             __syncthreads();
             for (uint32_t j = 0; j < 256; j++) best = min(best, sc.sample[j]);
             thr = best;
         }
-        const uint32_t F = partition_pass(bag, m, depths, thr, front, sc);
+        const uint32_t F = extract_pass(bag, n, depths, lo, thr, cap, sc);
         if (F <= cap) return F;
-        for (uint32_t i = tid; i < F; i += 256) bag[i] = front[i];  // pour the front back into the gap bag[0..F)
-        __syncthreads();
         target >>= 1;
     }
 }

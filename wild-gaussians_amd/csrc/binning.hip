@@ -4,6 +4,9 @@
 // and the scratch carving of rasterizer_impl.cu:155-194.  Integer work: results are bit-exact.
 #include <cstring>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "wg_common.h"
 #include "wg_sort.h"
 
@@ -589,9 +592,21 @@ hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_o
     return hipGetLastError();
 }
 
+// Dynamic LDS above 64 KiB needs the function attribute raised.  Done once per (device, kernel, size high-water mark): the
+// call takes a driver lock and was seen to stall the launching thread for milliseconds when issued on every frame.
 static hipError_t ensure_lds(const void* fn, size_t bytes) {
     if (bytes <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> granted;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = granted[{dev, fn}];
+    if (bytes <= have) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
 }
 
 hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, hipStream_t stream) {

@@ -528,8 +528,12 @@ LazyConfig g_lazy;
 __global__ void __launch_bounds__(256) tile_front_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bucket_ids,
                                                               const float* __restrict__ depths, uint32_t* __restrict__ point_list,
                                                               uint32_t* __restrict__ seg_end, uint32_t min_len, uint32_t target, uint32_t cap) {
-    __shared__ SelectScratch sc;
-    __shared__ uint64_t skeys[256 * 8];
+    // the selection scratch (12 KB) and the sort's cross-wave exchange buffer (16 KB) are never live together: one 16 KB block,
+    // which lets 8 workgroups share a CU instead of 5 (the kernel is a chain of dependent phases, latency-bound)
+    __shared__ uint64_t smem[256 * 8];
+    static_assert(sizeof(SelectScratch) <= sizeof(uint64_t) * 256 * 8, "selection scratch must fit the exchange buffer");
+    SelectScratch& sc = *reinterpret_cast<SelectScratch*>(smem);
+    uint64_t* skeys = smem;
     const int tile = blockIdx.x;
     const uint32_t begin = tile_offset[tile];
     const uint32_t n = tile_offset[tile + 1] - begin;

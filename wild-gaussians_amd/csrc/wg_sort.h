@@ -116,6 +116,7 @@ __device__ __forceinline__ void tile_sort_body(uint64_t* skeys, uint32_t n, cons
         }
         c.key[r] = key;
     }
+    __syncthreads();  // src may share LDS with the exchange buffer (skeys): every key is in a register before it is reused
     sort_levels<E, 256 * E>(c, np2);
     __syncthreads();  // overlapping src / dst: nobody stores before everybody has loaded
 #pragma unroll
@@ -151,23 +152,30 @@ __device__ __forceinline__ uint32_t extract_pass(const uint32_t* __restrict__ ba
     __syncthreads();
     if (tid == 0) sc.count = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 256) {
-        const uint32_t i = base + tid;
-        uint32_t id = 0;
-        bool in = false;
-        if (i < n) {
-            id = bag[i];
-            const uint64_t key = depth_key(depths, id);
-            in = key > lo && key <= thr;
+    constexpr uint32_t U = 8;  // entries per thread and trip: their id loads, then their depth gathers, are all in flight together
+    for (uint32_t base = 0; base < n; base += 256 * U) {
+        uint32_t id[U];
+        uint64_t key[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t i = base + u * 256 + tid;
+            id[u] = i < n ? bag[i] : 0xffffffffu;
         }
-        const uint64_t m = __ballot(in);
-        if (m != 0ull) {  // wave-aggregated append
-            const int leader = __builtin_ctzll(m);
-            uint32_t wbase = 0;
-            if ((int)(tid & 63) == leader) wbase = atomicAdd(&sc.count, (uint32_t)__builtin_popcountll(m));
-            wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, leader);
-            const uint32_t pos = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (in && pos < cap) sc.ids[pos] = id;
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) key[u] = id[u] != 0xffffffffu ? depth_key(depths, id[u]) : 0ull;
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            if (base + u * 256 >= n) break;  // workgroup-uniform
+            const bool in = key[u] > lo && key[u] <= thr;  // padding entries carry key 0 <= lo
+            const uint64_t m = __ballot(in);
+            if (m != 0ull) {  // wave-aggregated append
+                const int leader = __builtin_ctzll(m);
+                uint32_t wbase = 0;
+                if ((int)(tid & 63) == leader) wbase = atomicAdd(&sc.count, (uint32_t)__builtin_popcountll(m));
+                wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, leader);
+                const uint32_t pos = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (in && pos < cap) sc.ids[pos] = id[u];
+            }
         }
     }
     __syncthreads();
@@ -190,11 +198,17 @@ __device__ __forceinline__ uint32_t extract_front(const uint32_t* __restrict__ b
     sc.sample[tid] = valid ? mine : ~0ull;
     if (tid == 0) sc.nvalid = 0;
     __syncthreads();
-    if (valid) {
-        uint32_t rank = 0;  // ties (the same entry sampled twice when n < 256) are broken by the thread index
-        for (uint32_t j = 0; j < 256; j++) rank += (sc.sample[j] < mine || (sc.sample[j] == mine && j < tid)) ? 1u : 0u;
-        sc.sorted[rank] = mine;
-        atomicAdd(&sc.nvalid, 1u);
+    if (valid) atomicAdd(&sc.nvalid, 1u);
+    if (tid < 64) {  // wave 0 sorts the 256 sample keys in registers (4 per lane; every stage stays inside the wave: no barrier)
+        SortCtx<4> c;
+        c.t = tid;
+        c.gidx = 4 * tid;
+        c.xchg = nullptr;
+#pragma unroll
+        for (int r = 0; r < 4; r++) c.key[r] = sc.sample[4 * tid + r];
+        sort_levels<4, 256>(c, 256u);
+#pragma unroll
+        for (int r = 0; r < 4; r++) sc.sorted[4 * tid + r] = c.key[r];  // samples at or below lo were set to ~0: they sort last
     }
     __syncthreads();
     const uint32_t k = sc.nvalid;

@@ -353,6 +353,7 @@ int wg_set_option(const char* name, int value) {
     if (!name) return WG_ERR_INVALID_ARGUMENT;
     if (std::strcmp(name, "force_global_sort") == 0) { g_force_global_sort = value != 0; return WG_OK; }
     if (std::strcmp(name, "host_mailbox") == 0) { g_use_mailbox = value != 0; return WG_OK; }
+    if (std::strcmp(name, "staged_scatter_cap") == 0) { wg::g_staged_cap = value > 0 ? value : 0; return WG_OK; }
     if (std::strcmp(name, "staged_scatter") == 0) { wg::g_staged_scatter = value < 0 ? -1 : (value != 0); return WG_OK; }
     if (std::strcmp(name, "lazy_sort") == 0) { wg::g_lazy.enabled = value != 0; return WG_OK; }
     if (std::strcmp(name, "lazy_min_len") == 0 || std::strcmp(name, "lazy_target") == 0 || std::strcmp(name, "lazy_cap") == 0) {

@@ -631,6 +631,7 @@ hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailb
 }
 
 int g_staged_scatter = -1;  // wg_set_option("staged_scatter", -1 auto / 0 / 1)
+int g_staged_cap = 0;       // wg_set_option("staged_scatter_cap", n): staging-area entries, 0 = what the LDS budget allows (tests: multi-pass)
 
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
                                uint32_t num_rendered, hipStream_t stream) {
@@ -645,7 +646,8 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
         const double share1 = (double)num_rendered / (double)(BIN_CHUNKS * 8);
         const size_t budget = 78 * 1024;
         if (fixed + 4096 * sizeof(uint32_t) <= budget) {
-            const uint32_t cap = (uint32_t)((budget - fixed) / sizeof(uint32_t));
+            uint32_t cap = (uint32_t)((budget - fixed) / sizeof(uint32_t));
+            if (g_staged_cap > 0 && (uint32_t)g_staged_cap < cap) cap = (uint32_t)g_staged_cap;
             int G = 4;
             while (G > 1 && share1 * G * 1.5 > (double)cap) G >>= 1;
             const size_t lds = fixed + (size_t)cap * sizeof(uint32_t);

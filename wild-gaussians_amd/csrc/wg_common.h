@@ -111,6 +111,7 @@ hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_o
 hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, hipStream_t stream);
 hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, hipStream_t stream);
 extern int g_staged_scatter;
+extern int g_staged_cap;
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
                                uint32_t num_rendered, hipStream_t stream);
 struct LazyConfig {

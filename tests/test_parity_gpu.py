@@ -417,7 +417,7 @@ def lazy_options():
         for k, v in kw.items():
             _C.set_option(k, v)
     yield set_
-    set_(lazy_sort=1, lazy_min_len=2048, lazy_target=820, lazy_cap=2048)
+    set_(lazy_sort=1, lazy_min_len=2048, lazy_target=820, lazy_cap=2048, depth_codes=1)
 
 
 def _dense_scene():
@@ -429,7 +429,8 @@ def _dense_scene():
 
 @pytest.mark.parametrize("opts", [dict(lazy_min_len=256, lazy_target=100, lazy_cap=256),   # fronts of ~100, several fix-up rounds
                                   dict(lazy_min_len=256, lazy_target=60, lazy_cap=64),     # cap close to target: re-selections
-                                  dict(lazy_min_len=300, lazy_target=2000, lazy_cap=2048)])  # target beyond the list: q saturates
+                                  dict(lazy_min_len=300, lazy_target=2000, lazy_cap=2048),   # target beyond the list: q saturates
+                                  dict(lazy_min_len=256, lazy_target=100, lazy_cap=256, depth_codes=0)])  # entries without depth codes
 def test_lazy_sort_gives_the_fully_sorted_results(oracle, lazy_options, opts):
     """With the lazy sort only a depth-nearest front of each long list is sorted, extended where the forward pass runs past it.
     Everything the operator returns must be what the fully sorted lists give: the colour bit for bit (same instance sequence,

@@ -69,6 +69,7 @@ Mailbox* get_mailbox() {
     }
     return (g_use_mailbox && m.host) ? &m : nullptr;
 }
+bool g_depth_codes = true;  // wg_set_option("depth_codes", 0): tests of the lazy sort without coded bucket entries (P > 2^24)
 bool g_force_global_sort = false;  // wg_set_option("force_global_sort", 1): exercise the fallback binning path
 
 struct StageScope {
@@ -225,6 +226,7 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     // list exceeds the register sort and the lazy sort is switched off.
     const bool lazy = wg::g_lazy.enabled && !g_force_global_sort && !huge_frame && max_tile_count > wg::g_lazy.min_len;
     const bool global_sort = g_force_global_sort || huge_frame || (!lazy && max_tile_count > wg::TILE_SORT_MAX);
+    const bool coded = lazy && g_depth_codes && P <= (1 << 24);  // ids fit 24 bits: bucket entries carry a coarse depth code for the front extraction
     size_t bin_bytes = required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)num_rendered, global_sort); });
     char* bin_chunk = binning_alloc(bin_bytes, binning_user);
     if (!bin_chunk) return WG_ERR_ALLOC;
@@ -236,8 +238,8 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     }
     if (num_rendered > 0) {
         if (!global_sort) {
-            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, (uint32_t)num_rendered, stream), "tile_scatter");
-            if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, stream), "tile_sort_lazy");
+            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, (uint32_t)num_rendered, coded, stream), "tile_scatter");
+            if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, coded, stream), "tile_sort_lazy");
             else WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, geom, tiles, max_tile_count, stream), "tile_sort");
         } else {
             if (!huge_frame) WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
@@ -255,7 +257,7 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
              "render_forward");
     if (lazy_render)
         WG_STAGE(WG_STAGE_RENDER_FIXUP,
-                 wg::launch_render_fixup(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, stream),
+                 wg::launch_render_fixup(coded, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, stream),
                  "render_fixup");
     return num_rendered;
 }
@@ -353,6 +355,7 @@ int wg_set_option(const char* name, int value) {
     if (!name) return WG_ERR_INVALID_ARGUMENT;
     if (std::strcmp(name, "force_global_sort") == 0) { g_force_global_sort = value != 0; return WG_OK; }
     if (std::strcmp(name, "host_mailbox") == 0) { g_use_mailbox = value != 0; return WG_OK; }
+    if (std::strcmp(name, "depth_codes") == 0) { g_depth_codes = value != 0; return WG_OK; }
     if (std::strcmp(name, "staged_scatter_cap") == 0) { wg::g_staged_cap = value > 0 ? value : 0; return WG_OK; }
     if (std::strcmp(name, "staged_scatter") == 0) { wg::g_staged_scatter = value < 0 ? -1 : (value != 0); return WG_OK; }
     if (std::strcmp(name, "lazy_sort") == 0) { wg::g_lazy.enabled = value != 0; return WG_OK; }

@@ -331,9 +331,9 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
 // fabric writes down to the 30 MB of payload and was not faster; (ii) per-band candidate lists built by the count kernel, so
 // that a band's workgroup does not scan the whole chunk, saved 2 us for 16 B/Gaussian of lists.  With every store and
 // atomic removed the kernel still takes 41 of its 52 us: what is left is the rectangle walk's instruction stream.)
-__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4* __restrict__ rects, const uint32_t* __restrict__ tile_offset,
-                                                           const uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ bucket_ids, int gx,
-                                                           int tiles) {
+__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4* __restrict__ rects, const float* __restrict__ depths,
+                                                           const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ chunk_hist,
+                                                           uint32_t* __restrict__ bucket_ids, int gx, int tiles, int coded) {
     extern __shared__ uint32_t cursor[];
     const int tid = threadIdx.x, band = blockIdx.x & 7, chunk = blockIdx.x >> 3;
     const int q = tiles >> 3, rem = tiles & 7;
@@ -347,20 +347,23 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4*
     chunk_bounds(P, chunk, begin, end);
     for (int base = begin; base < end; base += PF * 256) {
         ushort4 r[PF];
+        uint32_t entry[PF];  // Gaussian id, with the coarse depth code on top when ids fit 24 bits (wg_sort.h: depth_code)
 #pragma unroll
         for (int k = 0; k < PF; k++) {
             const int idx = base + k * 256 + tid;
             r[k] = idx < end ? rects[idx] : make_ushort4(0, 0, 0, 0);
+            entry[k] = (uint32_t)idx;
+            if (coded && idx < end) entry[k] |= depth_code(__float_as_uint(depths[idx])) << ID_BITS;
         }
 #pragma unroll
         for (int k = 0; k < PF; k++) {
             if (base + k * 256 >= end) break;
             const int ya = max((int)r[k].y, y0), yb = min((int)r[k].w, y1 + 1);
-            for_each_tile<16>(r[k].z > r[k].x && yb > ya, r[k].x, ya, r[k].z, yb, base + k * 256 + tid, [&](int x, int y, int id) {
+            for_each_tile<16>(r[k].z > r[k].x && yb > ya, r[k].x, ya, r[k].z, yb, (int)entry[k], [&](int x, int y, int id) {
                 const int t = y * gx + x;
                 if (t >= t0 && t < t1) {
                     const uint32_t pos = atomicAdd(&cursor[t - t0], 1u);
-                    bucket_ids[pos] = (uint32_t)id;  // 4 bytes per instance; the depth half of the key is gathered at sort time
+                    bucket_ids[pos] = (uint32_t)id;  // 4 bytes per instance; the exact depth is gathered at sort time
                 }
             });
         }
@@ -374,10 +377,10 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4*
 // consecutive addresses: one write transaction per (workgroup, tile) run.  At ~900 instances per tile the runs are 2 ids long
 // and the direct kernel is as fast (measured), so the host picks this one only for long lists.  Placement inside a bucket is
 // free: the same multiset either way.
-__global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const ushort4* __restrict__ rects, const uint32_t* __restrict__ tile_offset,
-                                                                  const uint32_t* __restrict__ tile_count,
+__global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const ushort4* __restrict__ rects, const float* __restrict__ depths,
+                                                                  const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ tile_count,
                                                                   const uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ bucket_ids,
-                                                                  int gx, int tiles, int G, int nbmax, uint32_t cap) {
+                                                                  int gx, int tiles, int G, int nbmax, uint32_t cap, int coded) {
     extern __shared__ uint32_t smem[];
     uint32_t* gbase = smem;           // [nbmax] bucket position of this workgroup's first instance of the tile
     uint32_t* lcur = gbase + nbmax;   // [nbmax] cursor: staging-area positions (staged) or bucket positions (direct)
@@ -449,16 +452,19 @@ __global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const 
         if (pass_total > 0) {
             for (int gb0 = begin; gb0 < end; gb0 += PF * 1024) {
                 ushort4 r[PF];
+                uint32_t entry[PF];
 #pragma unroll
                 for (int k = 0; k < PF; k++) {
                     const int idx = gb0 + k * 1024 + tid;
                     r[k] = idx < end ? rects[idx] : make_ushort4(0, 0, 0, 0);
+                    entry[k] = (uint32_t)idx;
+                    if (coded && idx < end) entry[k] |= depth_code(__float_as_uint(depths[idx])) << ID_BITS;
                 }
 #pragma unroll
                 for (int k = 0; k < PF; k++) {
                     if (gb0 + k * 1024 >= end) break;
                     const int ya = max((int)r[k].y, ya0), yb = min((int)r[k].w, yb0 + 1);
-                    for_each_tile<16>(r[k].z > r[k].x && yb > ya, r[k].x, ya, r[k].z, yb, gb0 + k * 1024 + tid, [&](int x, int y, int id) {
+                    for_each_tile<16>(r[k].z > r[k].x && yb > ya, r[k].x, ya, r[k].z, yb, (int)entry[k], [&](int x, int y, int id) {
                         const int t = y * gx + x;
                         if (t >= ta && t < tb) {
                             const uint32_t slot = atomicAdd(&lcur[t - t0], 1u) - base;
@@ -503,18 +509,18 @@ __global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const 
 template <int EMAX>
 __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bucket_ids,
                                                         const float* __restrict__ depths, uint32_t* __restrict__ point_list, uint32_t n_min,
-                                                        uint32_t n_max) {
+                                                        uint32_t n_max, uint32_t id_mask) {
     extern __shared__ uint64_t skeys[];
     const int tile = blockIdx.x;
     const uint32_t begin = tile_offset[tile];
     const uint32_t n = tile_offset[tile + 1] - begin;
     if (n < n_min || n > n_max) return;  // n == 0, or a tile the other launch takes care of
     if constexpr (EMAX == 32) {
-        tile_sort_body<32>(skeys, n, bucket_ids + begin, depths, point_list + begin);
+        tile_sort_body<32>(skeys, n, bucket_ids + begin, depths, point_list + begin, id_mask);
     } else {
-        if (EMAX == 4 || n <= 1024) tile_sort_body<4>(skeys, n, bucket_ids + begin, depths, point_list + begin);
-        else if (EMAX == 8 || n <= 2048) tile_sort_body<(EMAX >= 8 ? 8 : 4)>(skeys, n, bucket_ids + begin, depths, point_list + begin);
-        else tile_sort_body<(EMAX >= 16 ? 16 : 4)>(skeys, n, bucket_ids + begin, depths, point_list + begin);
+        if (EMAX == 4 || n <= 1024) tile_sort_body<4>(skeys, n, bucket_ids + begin, depths, point_list + begin, id_mask);
+        else if (EMAX == 8 || n <= 2048) tile_sort_body<(EMAX >= 8 ? 8 : 4)>(skeys, n, bucket_ids + begin, depths, point_list + begin, id_mask);
+        else tile_sort_body<(EMAX >= 16 ? 16 : 4)>(skeys, n, bucket_ids + begin, depths, point_list + begin, id_mask);
     }
 }
 
@@ -527,7 +533,8 @@ LazyConfig g_lazy;
 // One workgroup per tile: extract (long list) or take (short list) the ids, sort them in registers, write point_list.
 __global__ void __launch_bounds__(256) tile_front_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bucket_ids,
                                                               const float* __restrict__ depths, uint32_t* __restrict__ point_list,
-                                                              uint32_t* __restrict__ seg_end, uint32_t min_len, uint32_t target, uint32_t cap) {
+                                                              uint32_t* __restrict__ seg_end, uint32_t min_len, uint32_t target, uint32_t cap,
+                                                              uint32_t id_mask) {
     // the selection scratch (12 KB) and the sort's cross-wave exchange buffer (16 KB) are never live together: one 16 KB block,
     // which lets 8 workgroups share a CU instead of 5 (the kernel is a chain of dependent phases, latency-bound)
     __shared__ uint64_t smem[256 * 8];
@@ -544,11 +551,11 @@ __global__ void __launch_bounds__(256) tile_front_sort_kernel(const uint32_t* __
     const uint32_t* src = bucket_ids + begin;
     uint32_t len = n;
     if (n > min_len) {  // workgroup-uniform
-        len = extract_front(bucket_ids + begin, n, depths, 0ull, n, target, cap, sc);
-        src = sc.ids;
+        len = extract_front(bucket_ids + begin, n, depths, 0ull, n, target, cap, id_mask, sc);
+        src = sc.ids;  // plain ids
     }
-    if (len <= 1024) tile_sort_body<4>(skeys, len, src, depths, point_list + begin);
-    else tile_sort_body<8>(skeys, len, src, depths, point_list + begin);
+    if (len <= 1024) tile_sort_body<4>(skeys, len, src, depths, point_list + begin, id_mask);
+    else tile_sort_body<8>(skeys, len, src, depths, point_list + begin, id_mask);
     if (threadIdx.x == 0) seg_end[tile] = len;
 }
 
@@ -630,11 +637,12 @@ hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailb
     return hipGetLastError();
 }
 
+
 int g_staged_scatter = -1;  // wg_set_option("staged_scatter", -1 auto / 0 / 1)
 int g_staged_cap = 0;       // wg_set_option("staged_scatter_cap", n): staging-area entries, 0 = what the LDS budget allows (tests: multi-pass)
 
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
-                               uint32_t num_rendered, hipStream_t stream) {
+                               uint32_t num_rendered, bool coded, hipStream_t stream) {
     if (P <= 0) return hipSuccess;
     // staged scatter for long lists: G chunks per workgroup such that an average share fits the staging area with headroom
     const bool want = g_staged_scatter == 1 || (g_staged_scatter < 0 && tiles > 0 && num_rendered / (uint32_t)tiles >= 1500u);
@@ -653,16 +661,16 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
             const size_t lds = fixed + (size_t)cap * sizeof(uint32_t);
             hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_staged_kernel), lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(tile_scatter_staged_kernel, dim3(BIN_CHUNKS / G * 8), dim3(1024), lds, stream, P, g.rects, img.tile_offset,
-                               img.tile_count, img.chunk_hist, b.bucket_ids, gx, tiles, G, nbmax, cap);
+            hipLaunchKernelGGL(tile_scatter_staged_kernel, dim3(BIN_CHUNKS / G * 8), dim3(1024), lds, stream, P, g.rects, g.depths,
+                               img.tile_offset, img.tile_count, img.chunk_hist, b.bucket_ids, gx, tiles, G, nbmax, cap, coded ? 1 : 0);
             return hipGetLastError();
         }
     }
     const size_t lds = (size_t)(tiles / 8 + 1) * sizeof(uint32_t);
     hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_kernel), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(BIN_CHUNKS * 8), dim3(256), lds, stream, P, g.rects, img.tile_offset, img.chunk_hist,
-                       b.bucket_ids, gx, tiles);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(BIN_CHUNKS * 8), dim3(256), lds, stream, P, g.rects, g.depths, img.tile_offset,
+                       img.chunk_hist, b.bucket_ids, gx, tiles, coded ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -673,14 +681,15 @@ static hipError_t launch_tile_sort_e(const ImageState& img, const BinningState& 
     hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_sort_kernel<E>), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tile_sort_kernel<E>, dim3(tiles), dim3(256), lds, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list, n_min,
-                       n_max);
+                       n_max, 0xffffffffu);
     return hipGetLastError();
 }
 
-hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, hipStream_t stream) {
+hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, bool coded,
+                                 hipStream_t stream) {
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(tile_front_sort_kernel, dim3(tiles), dim3(256), 0, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list,
-                       img.seg_end, g_lazy.min_len, g_lazy.target, g_lazy.cap);
+                       img.seg_end, g_lazy.min_len, g_lazy.target, g_lazy.cap, coded ? CODED_ID_MASK : 0xffffffffu);
     return hipGetLastError();
 }
 

@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, uint32_t* point_list, const uint32_t* __restrict__ bucket_ids,
     const float* __restrict__ depths, const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset,
     const float* __restrict__ bg, uint32_t* __restrict__ tile_state, float* final_T, uint32_t* n_contrib,
-    uint32_t* __restrict__ tile_last, float* out_color, uint32_t target, uint32_t cap) {
+    uint32_t* __restrict__ tile_last, float* out_color, uint32_t target, uint32_t cap, uint32_t id_mask) {
     __shared__ float4 lds[BATCH * 3];
     __shared__ uint64_t skeys[256 * 8];
     __shared__ SelectScratch sc;
@@ -263,9 +263,9 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     for (;;) {
         // everything at or below the last sorted key has been taken (done >= 1: only front-split tiles arrive here)
         const uint64_t lo = depth_key(depths, list[done - 1]);
-        const uint32_t F = extract_front(bag, n, depths, lo, n - done, target, cap, sc);
-        if (F <= 1024) tile_sort_body<4>(skeys, F, sc.ids, depths, list + done);
-        else tile_sort_body<8>(skeys, F, sc.ids, depths, list + done);
+        const uint32_t F = extract_front(bag, n, depths, lo, n - done, target, cap, id_mask, sc);
+        if (F <= 1024) tile_sort_body<4>(skeys, F, sc.ids, depths, list + done, 0xffffffffu);
+        else tile_sort_body<8>(skeys, F, sc.ids, depths, list + done, 0xffffffffu);
         __threadfence_block();
         __syncthreads();  // the sorted segment is visible to wave 0
         if (walker) {
@@ -281,13 +281,14 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     if (tid == 0) tile_state[tile] = 0xffffffffu;
 }
 
-hipError_t launch_render_fixup(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
+hipError_t launch_render_fixup(bool coded, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
                                const float* subpixel_offset, const float* background, float* out_color, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(render_fixup_kernel, dim3(tiles), dim3(256), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, b.bucket_ids,
                        g.depths, g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.tile_state, img.final_T,
-                       img.n_contrib, img.tile_last, out_color, 1536u < g_lazy.cap ? 1536u : (g_lazy.cap * 3u) / 4u, g_lazy.cap < FRONT_CAP ? g_lazy.cap : FRONT_CAP);
+                       img.n_contrib, img.tile_last, out_color, 1536u < g_lazy.cap ? 1536u : (g_lazy.cap * 3u) / 4u, g_lazy.cap < FRONT_CAP ? g_lazy.cap : FRONT_CAP,
+                       coded ? CODED_ID_MASK : 0xffffffffu);
     return hipGetLastError();
 }
 

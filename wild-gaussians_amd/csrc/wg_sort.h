@@ -97,9 +97,10 @@ __device__ __forceinline__ void sort_levels(SortCtx<E>& c, uint32_t kmax) {
 
 // One workgroup sorts n <= 256*E instance ids (E keys per thread) read from src (global or LDS) and writes them, ordered by
 // (depth, id), to dst.  src and dst may overlap (every key is in a register before the first store).
+// id_mask strips the coarse depth code bucket entries may carry in their top byte (see depth_code below).
 template <int E>
 __device__ __forceinline__ void tile_sort_body(uint64_t* skeys, uint32_t n, const uint32_t* src, const float* __restrict__ depths,
-                                               uint32_t* dst) {
+                                               uint32_t* dst, uint32_t id_mask) {
     uint32_t np2 = E;  // at least one key group
     while (np2 < n) np2 <<= 1;
     SortCtx<E> c;
@@ -111,7 +112,7 @@ __device__ __forceinline__ void tile_sort_body(uint64_t* skeys, uint32_t n, cons
         const uint32_t i = c.gidx + r;
         uint64_t key = ~0ull;
         if (i < n) {
-            const uint32_t id = src[i];
+            const uint32_t id = src[i] & id_mask;
             key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
         }
         c.key[r] = key;
@@ -134,6 +135,17 @@ __device__ __forceinline__ uint64_t depth_key(const float* __restrict__ depths, 
     return ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
 }
 
+// Coarse, monotone 8-bit code of a depth (> 0.2, the near cull): 1/16 of an octave per step, saturating beyond 0.2 * 2^16.
+// With at most 2^24 Gaussians the scatter kernels put it in the top byte of every bucket entry, and the extraction pass below
+// decides most entries from the code alone: the exact depth (a 4-byte gather that costs a 64-byte sector, and misses the L2
+// once the depth array outgrows it) is fetched only for entries whose code equals that of a bound.
+constexpr uint32_t ID_BITS = 24;
+constexpr uint32_t CODED_ID_MASK = (1u << ID_BITS) - 1u;
+__device__ __forceinline__ uint32_t depth_code(uint32_t depth_bits) {
+    const uint32_t near_bits = 0x3E4CCCCDu;  // 0.2f
+    return depth_bits <= near_bits ? 0u : min(255u, (depth_bits - near_bits) >> 19);
+}
+
 constexpr uint32_t FRONT_CAP = 2048;  // the 8-keys-per-thread network
 
 struct SelectScratch {  // LDS
@@ -147,26 +159,37 @@ struct SelectScratch {  // LDS
 // One pass over the bag: the ids with lo < key <= thr are appended to sc.ids (any order, at most cap kept).  Returns how
 // many there are (possibly more than cap: the caller then lowers thr and repeats).
 __device__ __forceinline__ uint32_t extract_pass(const uint32_t* __restrict__ bag, uint32_t n, const float* __restrict__ depths, uint64_t lo,
-                                                 uint64_t thr, uint32_t cap, SelectScratch& sc) {
+                                                 uint64_t thr, uint32_t cap, uint32_t id_mask, SelectScratch& sc) {
     const uint32_t tid = threadIdx.x;
+    const bool coded = id_mask == CODED_ID_MASK;
+    // codes strictly between those of the bounds are inside for sure, codes beyond them outside for sure
+    const int c_lo = lo == 0ull ? -1 : (int)depth_code((uint32_t)(lo >> 32));
+    const int c_hi = thr == ~0ull ? 256 : (int)depth_code((uint32_t)(thr >> 32));
     __syncthreads();
     if (tid == 0) sc.count = 0;
     __syncthreads();
-    constexpr uint32_t U = 8;  // entries per thread and trip: their id loads, then their depth gathers, are all in flight together
+    constexpr uint32_t U = 8;  // entries per thread and trip: their loads, then their depth gathers, are all in flight together
     for (uint32_t base = 0; base < n; base += 256 * U) {
         uint32_t id[U];
+        uint32_t inside = 0;  // bit u: entry u belongs to the front
         uint64_t key[U];
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             const uint32_t i = base + u * 256 + tid;
-            id[u] = i < n ? bag[i] : 0xffffffffu;
+            uint32_t e = 0u;
+            bool valid = false;
+            if (i < n) { e = bag[i]; valid = true; }
+            id[u] = e & id_mask;
+            const int c = (int)(e >> ID_BITS);
+            const bool sure = valid && coded && c > c_lo && c < c_hi;
+            const bool maybe = valid && (!coded || c == c_lo || c == c_hi);
+            if (sure) inside |= 1u << u;
+            key[u] = maybe ? depth_key(depths, id[u]) : 0ull;  // 0 <= lo: never inside
         }
-#pragma unroll
-        for (uint32_t u = 0; u < U; u++) key[u] = id[u] != 0xffffffffu ? depth_key(depths, id[u]) : 0ull;
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             if (base + u * 256 >= n) break;  // workgroup-uniform
-            const bool in = key[u] > lo && key[u] <= thr;  // padding entries carry key 0 <= lo
+            const bool in = ((inside >> u) & 1u) || (key[u] > lo && key[u] <= thr);
             const uint64_t m = __ballot(in);
             if (m != 0ull) {  // wave-aggregated append
                 const int leader = __builtin_ctzll(m);
@@ -188,11 +211,11 @@ __device__ __forceinline__ uint32_t extract_pass(const uint32_t* __restrict__ ba
 // around the target, so this is the pathological case) the quantile is halved, down to the single nearest id, which always
 // terminates.  Returns the front's length.
 __device__ __forceinline__ uint32_t extract_front(const uint32_t* __restrict__ bag, uint32_t n, const float* __restrict__ depths, uint64_t lo,
-                                                  uint32_t remaining, uint32_t target, uint32_t cap, SelectScratch& sc) {
+                                                  uint32_t remaining, uint32_t target, uint32_t cap, uint32_t id_mask, SelectScratch& sc) {
     const uint32_t tid = threadIdx.x;
-    if (remaining <= cap) return extract_pass(bag, n, depths, lo, ~0ull, cap, sc);  // all that is left
+    if (remaining <= cap) return extract_pass(bag, n, depths, lo, ~0ull, cap, id_mask, sc);  // all that is left
     // sample: 256 evenly spaced entries, those above lo ranked among themselves
-    const uint64_t mine = depth_key(depths, bag[(uint32_t)(((uint64_t)tid * n) >> 8)]);
+    const uint64_t mine = depth_key(depths, bag[(uint32_t)(((uint64_t)tid * n) >> 8)] & id_mask);
     const bool valid = mine > lo;
     __syncthreads();
     sc.sample[tid] = valid ? mine : ~0ull;
@@ -219,7 +242,7 @@ __device__ __forceinline__ uint32_t extract_front(const uint32_t* __restrict__ b
         } else {  // no usable sample, or even the nearest sample overshoots: the single nearest id above lo
             uint64_t best = ~0ull;
             for (uint32_t i = tid; i < n; i += 256) {
-                const uint64_t key = depth_key(depths, bag[i]);
+                const uint64_t key = depth_key(depths, bag[i] & id_mask);
                 if (key > lo) best = min(best, key);
             }
             __syncthreads();
@@ -228,7 +251,7 @@ __device__ __forceinline__ uint32_t extract_front(const uint32_t* __restrict__ b
             for (uint32_t j = 0; j < 256; j++) best = min(best, sc.sample[j]);
             thr = best;
         }
-        const uint32_t F = extract_pass(bag, n, depths, lo, thr, cap, sc);
+        const uint32_t F = extract_pass(bag, n, depths, lo, thr, cap, id_mask, sc);
         if (F <= cap) return F;
         target >>= 1;
     }

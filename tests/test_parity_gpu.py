@@ -506,3 +506,51 @@ def test_staged_scatter_fills_the_same_buckets(oracle, lazy_options, cap):
     assert h["num_rendered"] == o["num_rendered"]
     np.testing.assert_array_equal(h["views"]["binning"]["point_list"].cpu().numpy().view(np.uint32), o["ctx"].get("point_list"))
     assert compare_forward(h["color"].cpu().numpy(), o)["max_err_solid"] <= 1e-4
+
+
+# ---- seeded sweep over the operator's arguments ------------------------------------------------------------------------------
+def _sweep_case(i):
+    """Case i of a deterministic sweep: odd frame sizes, fields of view, rotated / translated cameras, every SH degree and
+    precomputed colours, mip-filter sizes, non-zero background, sub-pixel offsets, scale_modifier, precomputed covariances."""
+    rng = np.random.default_rng(1000 + i)
+    W = int(rng.integers(17, 230))
+    H = int(rng.integers(17, 170))
+    fov = float(rng.uniform(35.0, 95.0))
+    yaw = float(rng.uniform(-12.0, 12.0))
+    cam = S.make_camera(W, H, fov_x_deg=fov, yaw_deg=yaw)
+    deg = [None, 0, 1, 2, 3][i % 5]
+    P = int(rng.integers(50, 2500))
+    cloud = S.make_cloud(P, W, H, sh_degree=deg, seed=2000 + i, fov_x_deg=fov, scale_mult=float(rng.uniform(0.5, 9.0)))
+    if i % 7 == 3:   # some Gaussians behind / too close to the camera, some far outside the frame
+        cloud["means3D"][: P // 5, 2] = rng.uniform(-1.0, 0.25, size=P // 5).astype(np.float32)
+        cloud["means3D"][P // 5: P // 4, 0] *= 6.0
+    kw = dict(kernel_size=float(rng.choice([0.0, 0.1, 0.3, 1.0])),
+              bg=rng.uniform(0, 1, size=3).astype(np.float32) if i % 2 else None,
+              subpixel_offset=rng.uniform(-0.5, 0.5, size=(H, W, 2)).astype(np.float32) if i % 3 == 0 else None,
+              scale_modifier=float(rng.choice([1.0, 0.6, 1.7])))
+    if i % 6 == 5:   # covariances instead of scales + rotations (the operator accepts exactly one of the two)
+        s, q = cloud.pop("scales").astype(np.float64), cloud.pop("rotations").astype(np.float64)
+        r, x, y, z = q.T
+        Rm = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                       2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                       2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], axis=1).reshape(-1, 3, 3)
+        M = Rm * (s * kw["scale_modifier"])[:, None, :]
+        Sg = M @ M.transpose(0, 2, 1)
+        cloud["cov3D_precomp"] = np.stack([Sg[:, 0, 0], Sg[:, 0, 1], Sg[:, 0, 2], Sg[:, 1, 1], Sg[:, 1, 2], Sg[:, 2, 2]], 1).astype(np.float32)
+    return cloud, cam, (deg if deg is not None else 0), kw, W, H
+
+
+@pytest.mark.parametrize("i", range(30))
+def test_argument_sweep_against_the_oracle(oracle, i):
+    cloud, cam, deg, kw, W, H = _sweep_case(i)
+    cot = S.make_cotangent(W, H, seed=3000 + i)
+    o = oracle.run_scene(cloud, cam, sh_degree=deg, cotangent=cot, **kw)
+    h = run_hip(cloud, cam, sh_degree=deg, cotangent=cot, **kw)
+    np.testing.assert_array_equal(h["radii"], o["radii"])
+    c = compare_forward(h["color"], o)
+    assert c["max_err_solid"] <= 1e-4, c
+    assert c["n_fragile"] <= 0.02 * W * H + 16, c
+    acc_err = np.abs(h["accumulation"] - o["accumulation"])[c["solid_mask"]].max() if c["solid_mask"].any() else 0.0
+    assert acc_err <= 1e-4
+    for k, e in compare_grads(h["grads"], o["grads"]).items():
+        assert e <= 1e-3, (i, k, e)

@@ -5,7 +5,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-GRAD_NAMES = ["means3D", "means2D", "sh", "colors_precomp", "opacities", "scales", "rotations"]
+GRAD_NAMES = ["means3D", "means2D", "sh", "colors_precomp", "opacities", "scales", "rotations", "cov3Ds_precomp"]
 
 
 def to_dev(a, device="cuda"):
@@ -83,7 +83,8 @@ def compare_forward(hip_color, oracle_out, atol=1e-4):
     fragile = (ctx.get("frag_alpha") < FRAG_ALPHA) | (ctx.get("frag_T") < FRAG_T)
     solid = ~fragile
     return dict(max_err_solid=float(err[solid].max()) if solid.any() else 0.0, max_err_all=float(err.max()),
-                n_fragile=int(fragile.sum()), n_pixels=int(err.size), n_over_in_fragile=int((err[fragile] > atol).sum()))
+                n_fragile=int(fragile.sum()), n_pixels=int(err.size), n_over_in_fragile=int((err[fragile] > atol).sum()),
+                solid_mask=solid)
 
 
 def compare_grads(hip_grads, oracle_grads):

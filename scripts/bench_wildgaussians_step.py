@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--height", type=int, default=1200)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--in-kernel-sh", action="store_true",
+                    help="SURVEY 8f N3 (caller side): hand the SH features to the operator (shs=) instead of evaluating them in torch")
+    ap.add_argument("--fused-ssim", action="store_true", help="SURVEY 8f N4: wg_fused_ssim.ssim instead of the conv2d-based ssim")
     args = ap.parse_args()
     import wg_scenes as S
     from diff_gaussian_rasterization import GaussianRasterizer
@@ -77,6 +80,7 @@ def main():
     cam = S.make_camera(W, H)
     rs = make_settings(cam, 0, device=dev)
     rast = GaussianRasterizer(rs)
+    rast_sh = GaussianRasterizer(make_settings(cam, 3, device=dev))
     campos = to_dev(cam["campos"], dev)
     prm = {
         "xyz": to_dev(cloud["means3D"], dev), "scales": torch.log(to_dev(cloud["scales"], dev)),
@@ -102,15 +106,25 @@ def main():
         opac = torch.sigmoid(prm["opacities"]) * torch.sqrt(s2.prod(1) / s2f.prod(1))[:, None]
         feats = prm["features"].clamp_max(1.0)
         d = F.normalize(prm["xyz"] - campos[None], dim=1)
-        colors = sh_to_rgb(feats.view(P, 16, 3).transpose(1, 2), d)
         kw = dict(means3D=prm["xyz"], means2D=means2D, opacities=opac, scales=scales, rotations=rot)
-        raw, radii, acc = rast(colors_precomp=colors, **kw)
+        if args.in_kernel_sh:
+            raw, radii, acc = rast_sh(shs=feats.view(P, 16, 3), **kw)
+        else:
+            colors = sh_to_rgb(feats.view(P, 16, 3).transpose(1, 2), d)
+            raw, radii, acc = rast(colors_precomp=colors, **kw)
         inp = torch.cat((feats[:, :3], prm["embeddings"], prm["image_embedding"][None].expand(P, -1)), dim=-1)
         offset, mul = torch.split(mlp(inp) * 0.01, [3, 3], dim=-1)
         toned_f = feats * mul.repeat(1, 16) + torch.cat((offset / C0, torch.zeros(P, 45, device=dev)), dim=-1)
-        toned = sh_to_rgb(toned_f.clamp_max(1.0).view(P, 16, 3).transpose(1, 2), d)
-        img, _, _ = rast(colors_precomp=toned, **kw)
-        loss = 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - ssim_map(raw, gt)).mean()
+        if args.in_kernel_sh:
+            img, _, _ = rast_sh(shs=toned_f.clamp_max(1.0).view(P, 16, 3), **kw)
+        else:
+            toned = sh_to_rgb(toned_f.clamp_max(1.0).view(P, 16, 3).transpose(1, 2), d)
+            img, _, _ = rast(colors_precomp=toned, **kw)
+        if args.fused_ssim:
+            from wg_fused_ssim import ssim as fused_ssim
+            loss = 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - fused_ssim(raw, gt, size_average=False)).mean()
+        else:
+            loss = 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - ssim_map(raw, gt)).mean()
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
@@ -150,7 +164,7 @@ def main():
     torch.cuda.synchronize()
     dop = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"workload": f"WildGaussians-style train step: {P} Gaussians + appearance MLP, {W}x{H}, 2 fwd + 2 bwd raster calls, "
-                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)",
+                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)" + (", SH evaluated in the operator" if args.in_kernel_sh else "") + (", fused SSIM" if args.fused_ssim else ""),
                       "train_step_ms": round(dt * 1e3, 3), "train_steps_per_s": round(1.0 / dt, 2),
                       "rasterizer_only_ms (2 fwd + 2 bwd)": round(dop * 1e3, 3), "rasterizer_share": round(dop / dt, 3),
                       "visible": int((vis[0] > 0).sum().item()), "loss": float(step().item())}))

@@ -29,8 +29,10 @@ SOURCES = {
     "preprocess_bwd.hip": ["-fno-slp-vectorize"],
     "api.hip": [],
     "knn.hip": ["-ffp-contract=off"],  # simple_knn.distCUDA2 replacement (include/wg_knn.h)
+    "ssim.hip": [],                    # fused SSIM map fwd/bwd (include/wg_ssim.h)
 }
-HEADERS = ["wg_common.h", "wg_alpha.h", os.path.join(INCLUDE, "wg_rasterizer.h"), os.path.join(INCLUDE, "wg_knn.h")]
+HEADERS = ["wg_common.h", "wg_alpha.h", "wg_sort.h", os.path.join(INCLUDE, "wg_rasterizer.h"), os.path.join(INCLUDE, "wg_knn.h"),
+           os.path.join(INCLUDE, "wg_ssim.h")]
 
 
 def _newer(target: str, deps) -> bool:

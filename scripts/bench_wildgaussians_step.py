@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--in-kernel-sh", action="store_true",
                     help="SURVEY 8f N3 (caller side): hand the SH features to the operator (shs=) instead of evaluating them in torch")
+    ap.add_argument("--fused-activations", action="store_true", help="SURVEY 8f N3: wg_fused_gaussians.activate instead of the torch ops")
     ap.add_argument("--fused-ssim", action="store_true", help="SURVEY 8f N4: wg_fused_ssim.ssim instead of the conv2d-based ssim")
     args = ap.parse_args()
     import wg_scenes as S
@@ -98,12 +99,16 @@ def main():
 
     def step():
         means2D = torch.zeros_like(prm["xyz"], requires_grad=True)
-        rot = F.normalize(prm["rotations"])
-        raw_s = torch.exp(prm["scales"])
-        s2 = raw_s * raw_s
-        s2f = s2 + filter_3d * filter_3d
-        scales = s2f.sqrt()
-        opac = torch.sigmoid(prm["opacities"]) * torch.sqrt(s2.prod(1) / s2f.prod(1))[:, None]
+        if args.fused_activations:
+            from wg_fused_gaussians import activate
+            opac, scales, rot = activate(prm["opacities"], prm["scales"], prm["rotations"], filter_3d)
+        else:
+            rot = F.normalize(prm["rotations"])
+            raw_s = torch.exp(prm["scales"])
+            s2 = raw_s * raw_s
+            s2f = s2 + filter_3d * filter_3d
+            scales = s2f.sqrt()
+            opac = torch.sigmoid(prm["opacities"]) * torch.sqrt(s2.prod(1) / s2f.prod(1))[:, None]
         feats = prm["features"].clamp_max(1.0)
         d = F.normalize(prm["xyz"] - campos[None], dim=1)
         kw = dict(means3D=prm["xyz"], means2D=means2D, opacities=opac, scales=scales, rotations=rot)
@@ -164,7 +169,7 @@ def main():
     torch.cuda.synchronize()
     dop = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"workload": f"WildGaussians-style train step: {P} Gaussians + appearance MLP, {W}x{H}, 2 fwd + 2 bwd raster calls, "
-                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)" + (", SH evaluated in the operator" if args.in_kernel_sh else "") + (", fused SSIM" if args.fused_ssim else ""),
+                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)" + (", SH evaluated in the operator" if args.in_kernel_sh else "") + (", fused SSIM" if args.fused_ssim else "") + (", fused activations" if args.fused_activations else ""),
                       "train_step_ms": round(dt * 1e3, 3), "train_steps_per_s": round(1.0 / dt, 2),
                       "rasterizer_only_ms (2 fwd + 2 bwd)": round(dop * 1e3, 3), "rasterizer_share": round(dop / dt, 3),
                       "visible": int((vis[0] > 0).sum().item()), "loss": float(step().item())}))

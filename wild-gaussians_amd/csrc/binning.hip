@@ -562,39 +562,50 @@ __global__ void __launch_bounds__(256) tile_front_sort_kernel(const uint32_t* __
 // ---- launch order of the render kernels ---------------------------------------------------------------------------
 // The render kernels run one wave per tile and all ~8k waves are resident at once (<= 8 per SIMD), so the kernel ends
 // when the SIMD with the largest SUM of tile costs ends.  Dealing the tiles of each XCD band in descending cost order
-// gives every SIMD one tile of each size class.  One workgroup per band sorts (cost, tile) in LDS; bands with more than
-// 8192 tiles keep the image order.  Pure scheduling: results do not depend on it.  Used for the backward kernel, whose
+// gives every SIMD one tile of each size class.  One workgroup per band orders its tiles.  Pure scheduling: results do not
+// depend on it.  Used for the backward kernel, whose
 // per-tile cost (tile_last, the walked length) is known exactly from the forward pass: 0.752 -> 0.660 ms.  The forward
 // kernel's only predictor, the list length, did not help (its walked fraction is what varies), so it keeps image order.
-constexpr uint32_t ORDER_MAX = 8192;
-
+// The order only has to be roughly descending, so it is a 256-bin counting sort (bin = cost scaled by the band's maximum; 5
+// barriers) rather than a comparison sort of the band's ~1000 keys (55 barriers: 14 us of pure latency in front of the backward
+// kernel).
 __global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __restrict__ cost, const uint2* __restrict__ ranges,
                                                           uint32_t* __restrict__ order, int tiles) {
-    __shared__ uint64_t keys[ORDER_MAX];
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wmax[16];
     const int q = tiles >> 3, rem = tiles & 7, x = blockIdx.x;
     const uint32_t start = x * q + min(x, rem), cnt = q + (x < rem ? 1 : 0);
-    const uint32_t tid = threadIdx.x;
-    if (cnt > ORDER_MAX) {
-        for (uint32_t i = tid; i < cnt; i += 1024) order[start + i] = start + i;
-        return;
-    }
-    uint32_t np2 = 2;
-    while (np2 < cnt) np2 <<= 1;
-    for (uint32_t i = tid; i < np2; i += 1024) {
-        uint64_t k = ~0ull;
-        if (i < cnt) {
-            const uint32_t c = cost ? cost[start + i] : (ranges[start + i].y - ranges[start + i].x);
-            k = ((uint64_t)(~c) << 32) | i;  // ascending in ~cost == descending in cost; ties by tile index
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto cost_of = [&](uint32_t i) { return cost ? cost[start + i] : (ranges[start + i].y - ranges[start + i].x); };
+    uint32_t m = 0;
+    for (uint32_t i = tid; i < cnt; i += 1024) m = max(m, cost_of(i));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    if (lane == 0) wmax[wave] = m;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    m = 0;
+    for (int w = 0; w < 16; w++) m = max(m, wmax[w]);
+    const float scale = 255.0f / (float)max(m, 1u);
+    auto bin_of = [&](uint32_t c) { return 255u - min(255u, (uint32_t)((float)c * scale)); };  // bin 0 = the most expensive tiles
+    for (uint32_t i = tid; i < cnt; i += 1024) atomicAdd(&hist[bin_of(cost_of(i))], 1u);
+    __syncthreads();
+    if (tid < 64) {  // exclusive scan of the 256 bins: 4 per lane
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = hist[4 * tid + k]; sum += v[k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= (uint32_t)d) incl += up;
         }
-        keys[i] = k;
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { hist[4 * tid + k] = run; run += v[k]; }
     }
     __syncthreads();
-    for (uint32_t k = 2; k <= np2; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < (np2 >> 1); t += 1024) bitonic_ce(keys, t, j, k);
-            __syncthreads();
-        }
-    for (uint32_t i = tid; i < cnt; i += 1024) order[start + i] = start + (uint32_t)keys[i];
+    for (uint32_t i = tid; i < cnt; i += 1024) order[start + atomicAdd(&hist[bin_of(cost_of(i))], 1u)] = start + i;
 }
 
 hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_or_null, uint32_t* order, int tiles, hipStream_t stream) {

@@ -176,9 +176,10 @@ int wg_profile_read(wg_stage_times* out);
 int wg_profile_reset(void);
 const char* wg_stage_name(int stage);
 
-/* Tuning / test switches.  "force_global_sort" (0/1): bin with the rocPRIM global radix sort of 64-bit
- * (tile|depth) keys (the reference's scheme, and the automatic fallback when a tile lists more than 8192
- * instances) instead of the default counting-sort + per-tile LDS sort.  Both give identical results.
+/* Tuning / test switches (process-wide; set them before, not during, calls).  "force_global_sort" (0/1): bin with the
+ * rocPRIM global radix sort of 64-bit (tile|depth) keys (the reference's scheme; the automatic fallback for frames of more than
+ * 36864 tiles, and for lists longer than 8192 when "lazy_sort" is off) instead of the default counting sort by tile + per-tile
+ * register sort.  Both give identical results.
  * "host_mailbox" (1/0, default 1): read num_rendered back through a pinned host mailbox that the device writes and the
  * host polls, instead of a device-to-host copy followed by a stream synchronise.
  * "staged_scatter" (-1 auto / 0 / 1, default auto: on from 1500 instances per tile): lay a workgroup's instances out

@@ -156,15 +156,18 @@ hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& im
 
 // =====================================================================================================
 // Tile-sort path (default).  The (tile | depth) ordering is produced by a counting sort on the tile id
-// followed by an independent sort of each tile's bucket in LDS.  Global atomics on ~10^4 hot counters are
+// followed by an independent sort of each tile's bucket in registers.  Global atomics on ~10^4 hot counters are
 // memory-side operations on MI355X (measured: 7.4M of them cost 0.4-0.6 ms), so the counting sort only ever
 // touches LDS atomics: the Gaussians are cut into BIN_CHUNKS chunks, one workgroup per chunk, and
-//   tile_count_kernel   : chunk_hist[c][t] = #instances of chunk c in tile t        (histogram in LDS)
-//   chunk_scan_kernel   : chunk_hist[c][t] <- sum_{c' < c} chunk_hist[c'][t];  tile_count[t] = column total
-//   tile_scan_kernel    : tile_offset = exclusive_scan(tile_count); ranges; {num_rendered, max_tile_count}
-//   tile_scatter_kernel : cursor[t] (LDS) = tile_offset[t] + chunk_hist[c][t];  bucket_ids[cursor[t]++] = gaussian_id
-//   tile_sort_kernel    : one workgroup per tile sorts its bucket in LDS (bitonic network on 64-bit keys)
-//                         and writes the low words (Gaussian ids) to point_list
+//   tile_count_kernel          : chunk_hist[c][t] = #instances of chunk c in tile t        (histogram in LDS)
+//   chunk_scan_kernel          : chunk_hist[c][t] <- sum_{c' < c} chunk_hist[c'][t];  tile_count[t] = column total
+//   tile_scan_kernel           : tile_offset = exclusive_scan(tile_count); ranges; {num_rendered, max_tile_count}
+//   tile_scatter_kernel        : cursor[t] (LDS) = tile_offset[t] + chunk_hist[c][t];  bucket_ids[cursor[t]++] = gaussian_id
+//   tile_scatter_staged_kernel : the same buckets, laid out tile-major in LDS and written in runs (dense frames)
+//   tile_sort_kernel           : one workgroup per tile sorts its bucket (wg_sort.h: bitonic network on 64-bit keys held
+//                                in registers) and writes the low words (Gaussian ids) to point_list
+//   tile_front_sort_kernel     : when lists are long, only a depth-nearest front of each is extracted and sorted
+//                                (lazy sort; the rest is sorted on demand by render_fwd.hip: render_fixup_kernel)
 // Sorting (depth_bits, id) ascending inside a tile is exactly the order a stable sort of (tile|depth) keys
 // leaves (ties keep ascending Gaussian id, the emission order of duplicateWithKeys), so point_list and
 // ranges are bit-identical to the reference's -- whatever order the LDS atomics happened in.  Traffic per

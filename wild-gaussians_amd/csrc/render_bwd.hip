@@ -135,6 +135,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     }
 
     const uint2 range = ranges[tile];
+    // the ten partial sums live across instances and are cleared after each reduction only: an instance without any
+    // contributing lane (19 % of them) leaves them at zero
+    float acr = 0.f, acg = 0.f, acb = 0.f, sx = 0.f, sy = 0.f, sab = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f, sq = 0.f;
 
     for (int hi = hi0; hi > 0; hi -= BATCH) {
         // lane l stages the instance at list position hi-1-l (back to front, backward.cu:517)
@@ -174,7 +177,6 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             //   dL_dmean2D.y = -o * 0.5H * sum(q v)           dL_dconic.xy = -0.5 o * sum(q dx dy)
             //   dL_dmean2D.z =  o * sum(|q| (0.5W |u| + 0.5H |v|))   dL_dconic.yy = -0.5 o * sum(q dy dy)
             //   dL_dopacity  = sum(q)
-            float acr = 0.f, acg = 0.f, acb = 0.f, sx = 0.f, sy = 0.f, sab = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f, sq = 0.f;
             bool any = false;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
@@ -212,6 +214,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             if (__ballot(any) == 0ull) continue;
             const float total = butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
             if (issue) unsafeAtomicAdd(abase + (size_t)astride * lds_id[j], total * (oscale ? (vidx == 5 ? fabsf(o) : o) * vscale : vscale));
+            acr = acg = acb = sx = sy = sab = sxx = sxy = syy = sq = 0.f;
         }
     }
 }

@@ -32,15 +32,19 @@ __device__ __forceinline__ float dpp_f(float v) {
 // pair_x32: (a, b) -> one register: lanes 0-31 hold a[l] + a[l+32], lanes 32-63 hold b[l-32] + b[l]
 // pair_x16: (a, b) -> one register: even 16-lane rows hold a summed over the row pair, odd rows hold b likewise
 __device__ __forceinline__ float pair_x32(float a, float b) {
-    // (hipcc 7.2 mis-selects "r[0] + r[1]" of __builtin_amdgcn_permlane32_swap as "r[0] + r[0]", so the swap is spelled
-    // in asm; the s_nops are the VALU-write -> permlane-swap and permlane-swap -> VALU-read wait states, which hipcc
-    // does not insert around inline asm.)
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    return a + b;
+    // hipcc 7.2 mis-selects "r[0] + r[1]" of __builtin_amdgcn_permlane32_swap as "r[0] + r[0]"; passing the two results through an
+    // empty asm keeps them apart.  (Spelling the swap itself in asm works too but needs hand-placed s_nops for the
+    // VALU-write -> swap -> VALU-read wait states, which the compiler otherwise fills with useful instructions.)
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    unsigned x = r[0], y = r[1];
+    asm volatile("" : "+v"(x), "+v"(y));
+    return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
 }
 __device__ __forceinline__ float pair_x16(float a, float b) {
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    return a + b;
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    unsigned x = r[0], y = r[1];
+    asm volatile("" : "+v"(x), "+v"(y));
+    return __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y);
 }
 
 // Butterfly reduction of ten per-lane values over the 64 lanes of a wave.  On return lane l holds, in the

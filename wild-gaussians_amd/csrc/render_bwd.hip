@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             }
             if (__ballot(any) == 0ull) continue;
             const float total = butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
-            if (issue) unsafeAtomicAdd(abase + (size_t)astride * lds_id[j], total * (oscale ? (vidx == 5 ? fabsf(o) : o) * vscale : vscale));
+            if (issue) unsafeAtomicAdd(abase + astride * lds_id[j], total * (oscale ? (vidx == 5 ? fabsf(o) : o) * vscale : vscale));  // 4*P < 2^32
             acr = acg = acb = sx = sy = sab = sxx = sxy = syy = sq = 0.f;
         }
     }

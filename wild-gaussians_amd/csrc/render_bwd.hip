@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     const bool issue = owner && !((lane & 2) && (lane & 17));
     // constant factor of this lane's value (see the per-pair sums below); values 3..8 also carry the splat's opacity
     const bool oscale = vidx >= 3 && vidx <= 8;
-    const float vscale = vidx == 3 ? -ddelx_dx : vidx == 4 ? -ddely_dy : (vidx >= 6 && vidx <= 8) ? -0.5f : 1.0f;
+    constexpr float INV_L = 1.0f / WG_LOG2E;  // u, v above carry a factor -log2(e)
+    const float vscale = vidx == 3 ? ddelx_dx * INV_L : vidx == 4 ? ddely_dy * INV_L : vidx == 5 ? INV_L : (vidx >= 6 && vidx <= 8) ? -0.5f : 1.0f;
 
     float pfx[4], pfy[4], T[4], tfb[4], dLr[4], dLg[4], dLb[4], recd[4];
     int last[4];
@@ -150,13 +151,17 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
         uint32_t mymask = 0;
         if (posl >= 0) {
             const uint32_t id = point_list[range.x + posl];
-            const float4 q0 = splats[3 * (size_t)id];
-            const float4 q1 = splats[3 * (size_t)id + 1];
+            float4 q0 = splats[3 * (size_t)id];
+            float4 q1 = splats[3 * (size_t)id + 1];
+            float4 q2 = splats[3 * (size_t)id + 2];
             mymask = strip_mask(q0, q1, sb);
+            scale_conic(q0, q1);
+            q2.z = 2.0f * q0.z;  // 2 ca, 2 cc: the gradient of the exponent, up to the factor 1 / log2(e) applied after the reduction
+            q2.w = 2.0f * q1.x;
             lds_id[lane] = id;
             lds[3 * lane] = q0;
             lds[3 * lane + 1] = q1;
-            lds[3 * lane + 2] = splats[3 * (size_t)id + 2];
+            lds[3 * lane + 2] = q2;
         }
         __syncthreads();
         // the batch's strip masks as wave-uniform 64-bit words (see render_fwd.hip)
@@ -170,9 +175,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             const float4 r1 = lds[3 * j + 1];
             const int pos = hi - 1 - j;  // "contributor" after the decrement at backward.cu:531
             const float4 r0 = lds[3 * j];
-            const SplatCoef sc = make_coef(r0, r1);
+            const SplatCoef sc = coef_of(r0, r1);
             const float o = sc.o;
-            const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
+            const float4 gb = lds[3 * j + 2];  // green, blue, 2 ca, 2 cc
             const float colr = r1.w, colg = gb.x, colb = gb.y;
             // Per-lane partial sums over this lane's (up to four) pixels.  Constant factors of the reference's
             // expressions are applied once, after the wave reduction:
@@ -204,8 +209,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
                     recd[s] += a * diff;
                     const float dLda = diff * Tn + tfb[s] * inv;
                     const float q = e.G * dLda;
-                    const float u = r0.z * e.dx + r0.w * e.dy;
-                    const float v = r1.x * e.dy + r0.w * e.dx;
+                    // -log2(e) * (A dx + B dy) and -log2(e) * (C dy + B dx): the constant goes into vscale
+                    const float u = gb.z * e.dx + r0.w * e.dy;
+                    const float v = gb.w * e.dy + r0.w * e.dx;
                     sq += q;
                     sx += q * u;
                     sy += q * v;

@@ -109,9 +109,13 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
         // correctness.  WGB (legal only when the workgroup IS the wave) keeps the s_barrier-free __syncthreads() of the one-wave
         // kernel anyway: hipcc schedules and allocates the compositing loop measurably better around it (0.325 vs 0.340 ms).
         if (WGB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-        lds[3 * lane] = a0;
-        lds[3 * lane + 1] = a1;
-        lds[3 * lane + 2] = a2;
+        {
+            float4 s0 = a0, s1 = a1;
+            scale_conic(s0, s1);
+            lds[3 * lane] = s0;
+            lds[3 * lane + 1] = s1;
+            lds[3 * lane + 2] = a2;
+        }
         if (WGB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         if (base + BATCH + lane < n) {  // prefetch the next batch under this batch's math
             const uint32_t id = list[base + BATCH + lane];
@@ -130,9 +134,9 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1;
             if (((reach[0] | reach[1] | reach[2] | reach[3]) >> j & 1ull) == 0ull) continue;  // its strips died meanwhile
-            const float4 r0 = lds[3 * j];      // mx, my, conic.x, conic.y
-            const float4 r1 = lds[3 * j + 1];  // conic.z, opacity, -, red
-            const SplatCoef sc = make_coef(r0, r1);
+            const float4 r0 = lds[3 * j];      // mx, my, ca, cb
+            const float4 r1 = lds[3 * j + 1];  // cc, opacity, -, red
+            const SplatCoef sc = coef_of(r0, r1);
             const uint32_t pos = (uint32_t)(pos_begin + base + j + 1);
             const uint32_t alive_before = alive;
 #pragma unroll

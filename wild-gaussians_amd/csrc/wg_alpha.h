@@ -13,14 +13,22 @@ struct SplatCoef {
     float o;           // opacity * mip-filter coef
 };
 
-// record layout (preprocess.hip): r0 = (mx, my, conic.x, conic.y), r1 = (conic.z, opacity, strip mask, red), r2 = (green, blue, -, -)
-__device__ __forceinline__ SplatCoef make_coef(const float4 r0, const float4 r1) {
+// record layout in HBM (preprocess.hip): r0 = (mx, my, conic.x, conic.y), r1 = (conic.z, opacity, -, red), r2 = (green, blue, -, -).
+// The render kernels park it in LDS with the conic already scaled for the exp2 (one lane does that once per staged instance;
+// every wave-instruction of the per-instance loop that is saved there is saved for each visited instance):
+//   r0 = (mx, my, ca, cb), r1 = (cc, opacity, -, red), r2 = (green, blue, 2 ca, 2 cc)   [r2.zw: backward only]
+__device__ __forceinline__ void scale_conic(float4& r0, float4& r1) {
+    r0.z = -0.5f * WG_LOG2E * r0.z;
+    r0.w = -WG_LOG2E * r0.w;
+    r1.x = -0.5f * WG_LOG2E * r1.x;
+}
+__device__ __forceinline__ SplatCoef coef_of(const float4 r0, const float4 r1) {  // from a parked record
     SplatCoef c;
     c.mx = r0.x;
     c.my = r0.y;
-    c.ca = -0.5f * WG_LOG2E * r0.z;
-    c.cb = -WG_LOG2E * r0.w;
-    c.cc = -0.5f * WG_LOG2E * r1.x;
+    c.ca = r0.z;
+    c.cb = r0.w;
+    c.cc = r1.x;
     c.o = r1.y;
     return c;
 }

@@ -146,12 +146,12 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
                 const bool pass = eval_alpha(sc, pfx[s], pfy[s], e);
                 const float alpha = e.alpha;
                 if (((alive >> s) & 1u) && pass) {
-                    const float test_T = T[s] * (1.0f - alpha);
+                    const float w = alpha * T[s];
+                    const float test_T = T[s] - w;  // T (1 - alpha), forward.cu:367, one rounding step apart
                     if (test_T < 0.0001f) {
                         alive &= ~(1u << s);  // done (forward.cu:368-372): this instance is not blended
                     } else {
                         const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
-                        const float w = alpha * T[s];
                         Cr[s] += r1.w * w;
                         Cg[s] += gb.x * w;
                         Cb[s] += gb.y * w;

@@ -228,6 +228,26 @@ def main():
                                     "backward_GBps": round(Bb / (tb * 1e-3) / 1e9, 1) if tb else None,
                                     "forward_kernel_ms": round(tf, 4), "backward_kernel_ms": round(tb, 4)}
 
+        # every stage against the HBM roofline: by algorithmic bytes and, where profiles/pmc_traffic.json was collected on this
+        # workload, by the PMC-measured traffic (the streaming kernels sit at 55-75 % of peak; the render kernels are VALU-bound)
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            pmc = pt["stages"] if args.scale_mult == 1.0 and pt.get("workload") == f"{P} Gaussians, {W}x{H}, {args.colors}" else {}
+        except (OSError, ValueError, KeyError):
+            pmc = {}
+        rows = {}
+        for k, ms in per_stage.items():
+            if ms <= 0 or k == "render_fixup":
+                continue
+            Bk = algorithmic_bytes(k, P, V, int(R), N, tiles, M, args.colors == "sh")
+            row = {"ms": round(ms, 4), "algorithmic_GBps": round(Bk / (ms * 1e-3) / 1e9, 1)}
+            if k in pmc:
+                row["hbm_traffic_GBps"] = round(pmc[k]["hbm_bytes"] / (ms * 1e-3) / 1e9, 1)
+                row["frac_of_peak_by_traffic"] = round(row["hbm_traffic_GBps"] / HBM_PEAK_GBS, 3)
+            rows[k] = row
+        out["stage_rooflines"] = rows
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.forward_only:
         # CPU leg: the oracle (a CPU port of the reference's algorithm) on the same workload, timed on the host
         # cores, and used as the checker for the parity part of the metric.  Never on the measured path.

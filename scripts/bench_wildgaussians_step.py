@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--in-kernel-sh", action="store_true",
                     help="SURVEY 8f N3 (caller side): hand the SH features to the operator (shs=) instead of evaluating them in torch")
     ap.add_argument("--fused-activations", action="store_true", help="SURVEY 8f N3: wg_fused_gaussians.activate instead of the torch ops")
+    ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the foreach implementation")
     ap.add_argument("--fused-ssim", action="store_true", help="SURVEY 8f N4: wg_fused_ssim.ssim instead of the conv2d-based ssim")
     args = ap.parse_args()
     import wg_scenes as S
@@ -94,7 +95,8 @@ def main():
     prm = {k: nn.Parameter(v) for k, v in prm.items()}
     filter_3d = torch.full((P, 1), 1e-3, device=dev)
     mlp = nn.Sequential(nn.Linear(3 + 24 + 32, 128), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 6)).to(dev)
-    opt = torch.optim.Adam([{"params": [p], "lr": 1e-4} for p in prm.values()] + [{"params": mlp.parameters(), "lr": 5e-4}], eps=1e-15)
+    opt = torch.optim.Adam([{"params": [p], "lr": 1e-4} for p in prm.values()] + [{"params": mlp.parameters(), "lr": 5e-4}], eps=1e-15,
+                           **({"fused": True} if args.fused_adam else {}))
     gt = torch.rand(3, H, W, device=dev)
 
     def step():

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Extended run of tests/test_parity_gpu.py's argument sweep (cases beyond the 30 in CI), default and alternative binning paths.
+usage: python scripts/stress_sweep.py [first] [count]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "wild-gaussians_amd")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import wg_scenes as S
+from oracle import oracle
+from diff_gaussian_rasterization import _C
+from tests.wg_testlib import run_hip, compare_forward, compare_grads
+from tests.test_parity_gpu import _sweep_case
+
+first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 100
+oracle.build()
+PATHS = {"default": {}, "lazy_tiny": dict(lazy_min_len=256, lazy_target=40, lazy_cap=64), "staged": dict(staged_scatter=1, staged_scatter_cap=7),
+         "global": dict(force_global_sort=1)}
+RESET = dict(lazy_min_len=2048, lazy_target=820, lazy_cap=2048, staged_scatter=-1, staged_scatter_cap=0, force_global_sort=0)
+bad = 0
+worst = {"fwd": 0.0, "grad": 0.0}
+for i in range(first, first + count):
+    cloud, cam, deg, kw, W, H = _sweep_case(i)
+    cot = S.make_cotangent(W, H, seed=3000 + i)
+    o = oracle.run_scene(cloud, cam, sh_degree=deg, cotangent=cot, **kw)
+    for name, opts in PATHS.items():
+        for k, v in {**RESET, **opts}.items():
+            _C.set_option(k, v)
+        h = run_hip(cloud, cam, sh_degree=deg, cotangent=cot, **kw)
+        c = compare_forward(h["color"], o)
+        g = compare_grads(h["grads"], o["grads"])
+        ok = (h["radii"] == o["radii"]).all() and c["max_err_solid"] <= 1e-4 and max(g.values()) <= 1e-3
+        worst["fwd"] = max(worst["fwd"], c["max_err_solid"]); worst["grad"] = max(worst["grad"], max(g.values()))
+        if not ok:
+            bad += 1
+            print("FAIL case", i, name, "P", cloud["means3D"].shape[0], W, H, "fwd", c["max_err_solid"], "grads", g)
+for k, v in RESET.items():
+    _C.set_option(k, v)
+print(f"cases {first}..{first + count - 1} x {len(PATHS)} paths: {bad} failures; worst fwd err {worst['fwd']:.2e}, worst grad rel err {worst['grad']:.2e}")

@@ -133,7 +133,6 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
         while (todo != 0ull) {
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1;
-            if (((reach[0] | reach[1] | reach[2] | reach[3]) >> j & 1ull) == 0ull) continue;  // its strips died meanwhile
             const float4 r0 = lds[3 * j];      // mx, my, ca, cb
             const float4 r1 = lds[3 * j + 1];  // cc, opacity, -, red
             const SplatCoef sc = coef_of(r0, r1);
@@ -168,6 +167,7 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
                     else reach[s] = 0ull;
                 }
                 if (strips_alive == 0) break;
+                todo &= reach[0] | reach[1] | reach[2] | reach[3];  // instances only dead strips could see are dropped
             }
         }
     }

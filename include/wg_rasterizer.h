@@ -189,8 +189,9 @@ const char* wg_stage_name(int stage);
  * a depth-nearest front of about "lazy_target" (default 820) instances of each long list -- at most "lazy_cap" (default 2048)
  * -- and extend it per tile, in order, only where the forward pass runs past it.  Images, radii, n_contrib and gradients are
  * those of the fully sorted lists; the unsorted tails of the internal lists are simply never read.
- * "depth_codes" (1/0, default 1): with at most 2^24 Gaussians the lazy sort's bucket entries carry a coarse 8-bit depth code
- * above the id, so that the front extraction fetches exact depths only near its bounds; 0 exercises the uncoded path. */
+ * "depth_codes" (1/0, default 1): with at most 2^24 Gaussians the lazy sort's bucket entries carry a coarse depth code (8 to 12
+ * bits, what the ids leave free) above the id, so that the front extraction fetches exact depths only near its bounds; 0
+ * exercises the uncoded path. */
 int wg_set_option(const char* name, int value);
 
 const char* wg_status_string(int status);

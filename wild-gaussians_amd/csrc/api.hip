@@ -226,7 +226,14 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     // list exceeds the register sort and the lazy sort is switched off.
     const bool lazy = wg::g_lazy.enabled && !g_force_global_sort && !huge_frame && max_tile_count > wg::g_lazy.min_len;
     const bool global_sort = g_force_global_sort || huge_frame || (!lazy && max_tile_count > wg::TILE_SORT_MAX);
-    const bool coded = lazy && g_depth_codes && P <= (1 << 24);  // ids fit 24 bits: bucket entries carry a coarse depth code for the front extraction
+    // lazy sort: bucket entries carry a coarse depth code above the id for the front extraction, as wide as the ids allow
+    // (2^20 Gaussians or fewer: 12 bits; up to 2^24: 8 bits; more: none)
+    int code_bits = 0;
+    if (lazy && g_depth_codes && P <= (1 << 24)) {
+        int id_bits = 20;
+        while ((1 << id_bits) < P) id_bits++;
+        code_bits = 32 - id_bits;
+    }
     size_t bin_bytes = required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)num_rendered, global_sort); });
     char* bin_chunk = binning_alloc(bin_bytes, binning_user);
     if (!bin_chunk) return WG_ERR_ALLOC;
@@ -238,8 +245,8 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     }
     if (num_rendered > 0) {
         if (!global_sort) {
-            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, (uint32_t)num_rendered, coded, stream), "tile_scatter");
-            if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, coded, stream), "tile_sort_lazy");
+            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, (uint32_t)num_rendered, code_bits, stream), "tile_scatter");
+            if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, code_bits, stream), "tile_sort_lazy");
             else WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, geom, tiles, max_tile_count, stream), "tile_sort");
         } else {
             if (!huge_frame) WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
@@ -257,7 +264,7 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
              "render_forward");
     if (lazy_render)
         WG_STAGE(WG_STAGE_RENDER_FIXUP,
-                 wg::launch_render_fixup(coded, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, stream),
+                 wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, stream),
                  "render_fixup");
     return num_rendered;
 }

@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
 // atomic removed the kernel still takes 41 of its 52 us: what is left is the rectangle walk's instruction stream.)
 __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4* __restrict__ rects, const float* __restrict__ depths,
                                                            const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ chunk_hist,
-                                                           uint32_t* __restrict__ bucket_ids, int gx, int tiles, int coded) {
+                                                           uint32_t* __restrict__ bucket_ids, int gx, int tiles, int code_bits) {
     extern __shared__ uint32_t cursor[];
     const int tid = threadIdx.x, band = blockIdx.x & 7, chunk = blockIdx.x >> 3;
     const int q = tiles >> 3, rem = tiles & 7;
@@ -350,13 +350,13 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4*
     chunk_bounds(P, chunk, begin, end);
     for (int base = begin; base < end; base += PF * 256) {
         ushort4 r[PF];
-        uint32_t entry[PF];  // Gaussian id, with the coarse depth code on top when ids fit 24 bits (wg_sort.h: depth_code)
+        uint32_t entry[PF];  // Gaussian id, with the coarse depth code above it when the ids leave room (wg_sort.h: depth_code)
 #pragma unroll
         for (int k = 0; k < PF; k++) {
             const int idx = base + k * 256 + tid;
             r[k] = idx < end ? rects[idx] : make_ushort4(0, 0, 0, 0);
             entry[k] = (uint32_t)idx;
-            if (coded && idx < end) entry[k] |= depth_code(__float_as_uint(depths[idx])) << ID_BITS;
+            if (code_bits && idx < end) entry[k] |= depth_code(__float_as_uint(depths[idx]), (uint32_t)code_bits) << (32 - code_bits);
         }
 #pragma unroll
         for (int k = 0; k < PF; k++) {
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4*
 __global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const ushort4* __restrict__ rects, const float* __restrict__ depths,
                                                                   const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ tile_count,
                                                                   const uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ bucket_ids,
-                                                                  int gx, int tiles, int G, int nbmax, uint32_t cap, int coded) {
+                                                                  int gx, int tiles, int G, int nbmax, uint32_t cap, int code_bits) {
     extern __shared__ uint32_t smem[];
     uint32_t* gbase = smem;           // [nbmax] bucket position of this workgroup's first instance of the tile
     uint32_t* lcur = gbase + nbmax;   // [nbmax] cursor: staging-area positions (staged) or bucket positions (direct)
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const 
                     const int idx = gb0 + k * 1024 + tid;
                     r[k] = idx < end ? rects[idx] : make_ushort4(0, 0, 0, 0);
                     entry[k] = (uint32_t)idx;
-                    if (coded && idx < end) entry[k] |= depth_code(__float_as_uint(depths[idx])) << ID_BITS;
+                    if (code_bits && idx < end) entry[k] |= depth_code(__float_as_uint(depths[idx]), (uint32_t)code_bits) << (32 - code_bits);
                 }
 #pragma unroll
                 for (int k = 0; k < PF; k++) {
@@ -656,7 +656,7 @@ int g_staged_scatter = -1;  // wg_set_option("staged_scatter", -1 auto / 0 / 1)
 int g_staged_cap = 0;       // wg_set_option("staged_scatter_cap", n): staging-area entries, 0 = what the LDS budget allows (tests: multi-pass)
 
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
-                               uint32_t num_rendered, bool coded, hipStream_t stream) {
+                               uint32_t num_rendered, int code_bits, hipStream_t stream) {
     if (P <= 0) return hipSuccess;
     // staged scatter for long lists: G chunks per workgroup such that an average share fits the staging area with headroom
     const bool want = g_staged_scatter == 1 || (g_staged_scatter < 0 && tiles > 0 && num_rendered / (uint32_t)tiles >= 1500u);
@@ -676,7 +676,7 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
             hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_staged_kernel), lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(tile_scatter_staged_kernel, dim3(BIN_CHUNKS / G * 8), dim3(1024), lds, stream, P, g.rects, g.depths,
-                               img.tile_offset, img.tile_count, img.chunk_hist, b.bucket_ids, gx, tiles, G, nbmax, cap, coded ? 1 : 0);
+                               img.tile_offset, img.tile_count, img.chunk_hist, b.bucket_ids, gx, tiles, G, nbmax, cap, code_bits);
             return hipGetLastError();
         }
     }
@@ -684,7 +684,7 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
     hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_kernel), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(BIN_CHUNKS * 8), dim3(256), lds, stream, P, g.rects, g.depths, img.tile_offset,
-                       img.chunk_hist, b.bucket_ids, gx, tiles, coded ? 1 : 0);
+                       img.chunk_hist, b.bucket_ids, gx, tiles, code_bits);
     return hipGetLastError();
 }
 
@@ -699,11 +699,11 @@ static hipError_t launch_tile_sort_e(const ImageState& img, const BinningState& 
     return hipGetLastError();
 }
 
-hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, bool coded,
+hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, int code_bits,
                                  hipStream_t stream) {
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(tile_front_sort_kernel, dim3(tiles), dim3(256), 0, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list,
-                       img.seg_end, g_lazy.min_len, g_lazy.target, g_lazy.cap, coded ? CODED_ID_MASK : 0xffffffffu);
+                       img.seg_end, g_lazy.min_len, g_lazy.target, g_lazy.cap, code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu);
     return hipGetLastError();
 }
 

@@ -285,14 +285,14 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     if (tid == 0) tile_state[tile] = 0xffffffffu;
 }
 
-hipError_t launch_render_fixup(bool coded, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
+hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
                                const float* subpixel_offset, const float* background, float* out_color, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(render_fixup_kernel, dim3(tiles), dim3(256), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, b.bucket_ids,
                        g.depths, g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.tile_state, img.final_T,
                        img.n_contrib, img.tile_last, out_color, 1536u < g_lazy.cap ? 1536u : (g_lazy.cap * 3u) / 4u, g_lazy.cap < FRONT_CAP ? g_lazy.cap : FRONT_CAP,
-                       coded ? CODED_ID_MASK : 0xffffffffu);
+                       code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu);
     return hipGetLastError();
 }
 

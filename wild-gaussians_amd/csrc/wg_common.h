@@ -112,9 +112,10 @@ hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& im
 hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, hipStream_t stream);
 extern int g_staged_scatter;
 extern int g_staged_cap;
-// coded: bucket entries carry a coarse depth code in their top byte (wg_sort.h: depth_code); only the lazy sort reads it
+// code_bits > 0: bucket entries carry a coarse depth code of that width above the id (wg_sort.h: depth_code); only the lazy
+// sort reads it
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
-                               uint32_t num_rendered, bool coded, hipStream_t stream);
+                               uint32_t num_rendered, int code_bits, hipStream_t stream);
 struct LazyConfig {
     bool enabled = true;
     uint32_t min_len = 2048;  // tiles listing more than this are front-split instead of sorted in full
@@ -122,8 +123,8 @@ struct LazyConfig {
     uint32_t cap = 2048;      // hard bound of a front (the 2048-key network)
 };
 extern LazyConfig g_lazy;
-hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, bool coded, hipStream_t stream);
-hipError_t launch_render_fixup(bool coded, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
+hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, int code_bits, hipStream_t stream);
+hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
                                const float* subpixel_offset, const float* background, float* out_color, hipStream_t stream);
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
                             hipStream_t stream);

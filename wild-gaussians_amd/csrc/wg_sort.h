@@ -97,7 +97,7 @@ __device__ __forceinline__ void sort_levels(SortCtx<E>& c, uint32_t kmax) {
 
 // One workgroup sorts n <= 256*E instance ids (E keys per thread) read from src (global or LDS) and writes them, ordered by
 // (depth, id), to dst.  src and dst may overlap (every key is in a register before the first store).
-// id_mask strips the coarse depth code bucket entries may carry in their top byte (see depth_code below).
+// id_mask strips the coarse depth code bucket entries may carry above the id (see depth_code below).
 template <int E>
 __device__ __forceinline__ void tile_sort_body(uint64_t* skeys, uint32_t n, const uint32_t* src, const float* __restrict__ depths,
                                                uint32_t* dst, uint32_t id_mask) {
@@ -135,16 +135,18 @@ __device__ __forceinline__ uint64_t depth_key(const float* __restrict__ depths, 
     return ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
 }
 
-// Coarse, monotone 8-bit code of a depth (> 0.2, the near cull): 1/16 of an octave per step, saturating beyond 0.2 * 2^16.
-// With at most 2^24 Gaussians the scatter kernels put it in the top byte of every bucket entry, and the extraction pass below
-// decides most entries from the code alone: the exact depth (a 4-byte gather that costs a 64-byte sector, and misses the L2
-// once the depth array outgrows it) is fetched only for entries whose code equals that of a bound.
-constexpr uint32_t ID_BITS = 24;
-constexpr uint32_t CODED_ID_MASK = (1u << ID_BITS) - 1u;
-__device__ __forceinline__ uint32_t depth_code(uint32_t depth_bits) {
+// Coarse, monotone code of a depth (> 0.2, the near cull) in `cb` bits: 2^(cb-4) steps per octave (8 bits: 1/16 octave per
+// step), saturating beyond 0.2 * 2^16.  When the Gaussian ids leave room (at most 2^24 of them: 8 bits; 2^20: 12 bits) the
+// scatter kernels put it above the id in every bucket entry, and the extraction pass below decides most entries from the code
+// alone: the exact depth (a 4-byte gather that costs a 64-byte sector, and misses the L2 once the depth array outgrows it) is
+// fetched only for entries whose code equals that of a bound.
+__device__ __forceinline__ uint32_t depth_code(uint32_t depth_bits, uint32_t cb) {
     const uint32_t near_bits = 0x3E4CCCCDu;  // 0.2f
-    return depth_bits <= near_bits ? 0u : min(255u, (depth_bits - near_bits) >> 19);
+    if (cb == 0u || depth_bits <= near_bits) return 0u;
+    return min((1u << cb) - 1u, (depth_bits - near_bits) >> (27u - cb));
 }
+__device__ __forceinline__ uint32_t code_bits_of(uint32_t id_mask) { return 32u - (uint32_t)__builtin_popcount(id_mask); }  // 0: plain ids
+constexpr int MIN_ID_BITS = 20, MAX_ID_BITS_CODED = 24;  // code widths 12 .. 8
 
 constexpr uint32_t FRONT_CAP = 2048;  // the 8-keys-per-thread network
 
@@ -161,10 +163,12 @@ struct SelectScratch {  // LDS
 __device__ __forceinline__ uint32_t extract_pass(const uint32_t* __restrict__ bag, uint32_t n, const float* __restrict__ depths, uint64_t lo,
                                                  uint64_t thr, uint32_t cap, uint32_t id_mask, SelectScratch& sc) {
     const uint32_t tid = threadIdx.x;
-    const bool coded = id_mask == CODED_ID_MASK;
+    const uint32_t cb = code_bits_of(id_mask);
+    const bool coded = cb != 0u;
+    const uint32_t code_shift = coded ? 32u - cb : 0u;
     // codes strictly between those of the bounds are inside for sure, codes beyond them outside for sure
-    const int c_lo = lo == 0ull ? -1 : (int)depth_code((uint32_t)(lo >> 32));
-    const int c_hi = thr == ~0ull ? 256 : (int)depth_code((uint32_t)(thr >> 32));
+    const int c_lo = lo == 0ull ? -1 : (int)depth_code((uint32_t)(lo >> 32), cb);
+    const int c_hi = thr == ~0ull ? (1 << 16) : (int)depth_code((uint32_t)(thr >> 32), cb);
     __syncthreads();
     if (tid == 0) sc.count = 0;
     __syncthreads();
@@ -180,7 +184,7 @@ __device__ __forceinline__ uint32_t extract_pass(const uint32_t* __restrict__ ba
             bool valid = false;
             if (i < n) { e = bag[i]; valid = true; }
             id[u] = e & id_mask;
-            const int c = (int)(e >> ID_BITS);
+            const int c = (int)(e >> code_shift);
             const bool sure = valid && coded && c > c_lo && c < c_hi;
             const bool maybe = valid && (!coded || c == c_lo || c == c_hi);
             if (sure) inside |= 1u << u;

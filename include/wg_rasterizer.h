@@ -191,7 +191,7 @@ const char* wg_stage_name(int stage);
  * those of the fully sorted lists; the unsorted tails of the internal lists are simply never read.
  * "depth_codes" (1/0, default 1): with at most 2^24 Gaussians the lazy sort's bucket entries carry a coarse depth code (8 to 12
  * bits, what the ids leave free) above the id, so that the front extraction fetches exact depths only near its bounds; 0
- * exercises the uncoded path. */
+ * exercises the uncoded path, 8..12 force a width (not wider than the ids allow). */
 int wg_set_option(const char* name, int value);
 
 const char* wg_status_string(int status);

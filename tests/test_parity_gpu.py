@@ -430,7 +430,8 @@ def _dense_scene():
 @pytest.mark.parametrize("opts", [dict(lazy_min_len=256, lazy_target=100, lazy_cap=256),   # fronts of ~100, several fix-up rounds
                                   dict(lazy_min_len=256, lazy_target=60, lazy_cap=64),     # cap close to target: re-selections
                                   dict(lazy_min_len=300, lazy_target=2000, lazy_cap=2048),   # target beyond the list: q saturates
-                                  dict(lazy_min_len=256, lazy_target=100, lazy_cap=256, depth_codes=0)])  # entries without depth codes
+                                  dict(lazy_min_len=256, lazy_target=100, lazy_cap=256, depth_codes=0),   # entries without depth codes
+                                  dict(lazy_min_len=256, lazy_target=100, lazy_cap=256, depth_codes=8)])  # 8-bit codes (2^20 < P <= 2^24)
 def test_lazy_sort_gives_the_fully_sorted_results(oracle, lazy_options, opts):
     """With the lazy sort only a depth-nearest front of each long list is sorted, extended where the forward pass runs past it.
     Everything the operator returns must be what the fully sorted lists give: the colour bit for bit (same instance sequence,

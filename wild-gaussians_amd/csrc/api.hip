@@ -69,7 +69,7 @@ Mailbox* get_mailbox() {
     }
     return (g_use_mailbox && m.host) ? &m : nullptr;
 }
-bool g_depth_codes = true;  // wg_set_option("depth_codes", 0): tests of the lazy sort without coded bucket entries (P > 2^24)
+int g_depth_codes = 1;  // wg_set_option("depth_codes", 0 / 1 / 8..12): off (as for P > 2^24) / automatic width / forced width (tests)
 bool g_force_global_sort = false;  // wg_set_option("force_global_sort", 1): exercise the fallback binning path
 
 struct StageScope {
@@ -233,6 +233,7 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
         int id_bits = 20;
         while ((1 << id_bits) < P) id_bits++;
         code_bits = 32 - id_bits;
+        if (g_depth_codes >= 8 && g_depth_codes <= code_bits) code_bits = g_depth_codes;  // a narrower code than the ids allow
     }
     size_t bin_bytes = required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)num_rendered, global_sort); });
     char* bin_chunk = binning_alloc(bin_bytes, binning_user);
@@ -362,7 +363,11 @@ int wg_set_option(const char* name, int value) {
     if (!name) return WG_ERR_INVALID_ARGUMENT;
     if (std::strcmp(name, "force_global_sort") == 0) { g_force_global_sort = value != 0; return WG_OK; }
     if (std::strcmp(name, "host_mailbox") == 0) { g_use_mailbox = value != 0; return WG_OK; }
-    if (std::strcmp(name, "depth_codes") == 0) { g_depth_codes = value != 0; return WG_OK; }
+    if (std::strcmp(name, "depth_codes") == 0) {
+        if (value != 0 && value != 1 && (value < 8 || value > 12)) return WG_ERR_INVALID_ARGUMENT;
+        g_depth_codes = value;
+        return WG_OK;
+    }
     if (std::strcmp(name, "staged_scatter_cap") == 0) { wg::g_staged_cap = value > 0 ? value : 0; return WG_OK; }
     if (std::strcmp(name, "staged_scatter") == 0) { wg::g_staged_scatter = value < 0 ? -1 : (value != 0); return WG_OK; }
     if (std::strcmp(name, "lazy_sort") == 0) { wg::g_lazy.enabled = value != 0; return WG_OK; }

@@ -185,7 +185,7 @@ const char* wg_stage_name(int stage);
  * "staged_scatter" (-1 auto / 0 / 1, default auto: on from 1500 instances per tile): lay a workgroup's instances out
  * tile-major in LDS and copy them to the tile buckets in runs, instead of one 4-byte store per instance.  Same buckets.
  * ("staged_scatter_cap", n > 0, shrinks the staging area to n entries so that tests reach the multi-pass path; 0 = automatic.)
- * "lazy_sort" (1/0, default 1): when some tile lists more than "lazy_min_len" (256..2048, default 2048) instances, sort only
+ * "lazy_sort" (1/0, default 1): when some tile lists more than 5/4 of "lazy_min_len" (256..2048, default 1024) instances, sort only
  * a depth-nearest front of about "lazy_target" (default 820) instances of each long list -- at most "lazy_cap" (default 2048)
  * -- and extend it per tile, in order, only where the forward pass runs past it.  Images, radii, n_contrib and gradients are
  * those of the fully sorted lists; the unsorted tails of the internal lists are simply never read.

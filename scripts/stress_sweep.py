@@ -15,7 +15,7 @@ first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) 
 oracle.build()
 PATHS = {"default": {}, "lazy_tiny": dict(lazy_min_len=256, lazy_target=40, lazy_cap=64), "staged": dict(staged_scatter=1, staged_scatter_cap=7),
          "global": dict(force_global_sort=1)}
-RESET = dict(lazy_min_len=2048, lazy_target=820, lazy_cap=2048, staged_scatter=-1, staged_scatter_cap=0, force_global_sort=0)
+RESET = dict(lazy_min_len=1024, lazy_target=820, lazy_cap=2048, staged_scatter=-1, staged_scatter_cap=0, force_global_sort=0)
 bad = 0
 flips = 0
 worst = {"fwd": 0.0, "grad": 0.0}

@@ -417,7 +417,7 @@ def lazy_options():
         for k, v in kw.items():
             _C.set_option(k, v)
     yield set_
-    set_(lazy_sort=1, lazy_min_len=2048, lazy_target=820, lazy_cap=2048, depth_codes=1)
+    set_(lazy_sort=1, lazy_min_len=1024, lazy_target=820, lazy_cap=2048, depth_codes=1)
 
 
 def _dense_scene():

@@ -224,7 +224,7 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     // Longest per-tile list decides the binning path: full register sort of every tile, lazy front sort when lists are long,
     // global radix sort (the reference's scheme) when forced, when the frame is too large for the LDS histogram, or when a
     // list exceeds the register sort and the lazy sort is switched off.
-    const bool lazy = wg::g_lazy.enabled && !g_force_global_sort && !huge_frame && max_tile_count > wg::g_lazy.min_len;
+    const bool lazy = wg::g_lazy.enabled && !g_force_global_sort && !huge_frame && max_tile_count > wg::g_lazy.min_len + wg::g_lazy.min_len / 4;
     const bool global_sort = g_force_global_sort || huge_frame || (!lazy && max_tile_count > wg::TILE_SORT_MAX);
     // lazy sort: bucket entries carry a coarse depth code above the id for the front extraction, as wide as the ids allow
     // (2^20 Gaussians or fewer: 12 bits; up to 2^24: 8 bits; more: none)

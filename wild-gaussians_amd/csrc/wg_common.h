@@ -118,7 +118,9 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
                                uint32_t num_rendered, int code_bits, hipStream_t stream);
 struct LazyConfig {
     bool enabled = true;
-    uint32_t min_len = 2048;  // tiles listing more than this are front-split instead of sorted in full
+    uint32_t min_len = 1024;  // tiles listing more than this are front-split instead of sorted in full (the lazy path as a whole is
+                              // taken when the longest list exceeds 5/4 of it: below, a few lists on the 2048-key network cost less
+                              // than coded bucket entries and the fix-up launch)
     uint32_t target = 820;    // aimed front length of the first round (the 1024-key network)
     uint32_t cap = 2048;      // hard bound of a front (the 2048-key network)
 };

@@ -489,8 +489,9 @@ def test_lazy_sort_at_default_thresholds_on_a_dense_frame(oracle, lazy_options):
     assert torch.equal(lz["views"]["image"]["n_contrib"], full["views"]["image"]["n_contrib"])
 
 
+@pytest.mark.parametrize("lists", [False, True])
 @pytest.mark.parametrize("cap", [0, 24, 3])
-def test_staged_scatter_fills_the_same_buckets(oracle, lazy_options, cap):
+def test_staged_scatter_fills_the_same_buckets(oracle, lazy_options, cap, lists):
     """The staged (LDS tile-major, run-wise) scatter of dense frames, with a staging area large enough (0 = automatic), forced
     into several passes per workgroup (24 entries) and smaller than single tile runs (3: those go by direct stores)."""
     from diff_gaussian_rasterization import _C
@@ -499,11 +500,13 @@ def test_staged_scatter_fills_the_same_buckets(oracle, lazy_options, cap):
     try:
         _C.set_option("staged_scatter", 1)
         _C.set_option("staged_scatter_cap", cap)
+        _C.set_option("band_list_min_p", 1 if lists else 2000000)   # per-band candidate lists (the large-P path) or chunk scans
         lazy_options(lazy_sort=0)   # full sort: the whole point_list is comparable
         h = run_hip_native(cloud, cam, sh_degree=1)
     finally:
         _C.set_option("staged_scatter", -1)
         _C.set_option("staged_scatter_cap", 0)
+        _C.set_option("band_list_min_p", 2000000)
     assert h["num_rendered"] == o["num_rendered"]
     np.testing.assert_array_equal(h["views"]["binning"]["point_list"].cpu().numpy().view(np.uint32), o["ctx"].get("point_list"))
     assert compare_forward(h["color"].cpu().numpy(), o)["max_err_solid"] <= 1e-4

@@ -363,6 +363,7 @@ int wg_set_option(const char* name, int value) {
     if (!name) return WG_ERR_INVALID_ARGUMENT;
     if (std::strcmp(name, "force_global_sort") == 0) { g_force_global_sort = value != 0; return WG_OK; }
     if (std::strcmp(name, "host_mailbox") == 0) { g_use_mailbox = value != 0; return WG_OK; }
+    if (std::strcmp(name, "band_list_min_p") == 0) { wg::g_band_list_min_p = value > 0 ? value : 1; return WG_OK; }
     if (std::strcmp(name, "depth_codes") == 0) {
         if (value != 0 && value != 1 && (value < 8 || value > 12)) return WG_ERR_INVALID_ARGUMENT;
         g_depth_codes = value;

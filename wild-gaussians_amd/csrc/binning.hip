@@ -39,6 +39,10 @@ size_t query_sort_temp_bytes(size_t R) {
     return bytes;
 }
 
+int g_band_list_min_p = 2000000;
+// chunk-local indices are 16-bit: lists exist for g_band_list_min_p <= P <= 65536 * BIN_CHUNKS
+static bool band_lists_for(size_t P) { return P >= (size_t)g_band_list_min_p && (P + BIN_CHUNKS - 1) / BIN_CHUNKS <= 65536; }
+
 GeometryState GeometryState::fromChunk(char*& chunk, size_t P) {
     GeometryState g;
     const size_t Pa = P ? P : 1;
@@ -50,6 +54,10 @@ GeometryState GeometryState::fromChunk(char*& chunk, size_t P) {
     carve(chunk, g.rects, Pa);
     carve(chunk, g.tiles_touched, Pa);
     carve(chunk, g.point_offsets, Pa);
+    const bool lists = band_lists_for(P);
+    carve(chunk, g.band_list, lists ? (size_t)BIN_CHUNKS * 8 * ((Pa + BIN_CHUNKS - 1) / BIN_CHUNKS) : 0);
+    carve(chunk, g.band_cnt, lists ? (size_t)BIN_CHUNKS * 8 : 0);
+    if (!lists) g.band_list = nullptr;
     g.scan_temp_bytes = query_scan_temp_bytes(Pa);
     carve(chunk, g.scan_temp, g.scan_temp_bytes);
     return g;
@@ -219,14 +227,28 @@ __device__ __forceinline__ void for_each_tile(bool valid, int x0, int y0, int x1
 
 constexpr int PF = 8;  // rectangles a thread keeps in flight
 
+// XCD band (wg_alpha.h: xcd_tile) that owns tile t
+__device__ __forceinline__ int band_of_tile(int t, int tiles) {
+    const int q = tiles >> 3, rem = tiles & 7, split = rem * (q + 1);
+    return t < split ? t / (q + 1) : rem + (t - split) / max(q, 1);
+}
+
+// With band_list != nullptr (large P) the chunk's Gaussians are also listed per XCD band of tiles they touch (chunk-local 16-bit
+// indices, wave-aggregated append): the staged scatter's (chunk, band) workgroups then read their own candidates instead of
+// scanning the whole chunk once per band and pass (40 scans of 10 M rectangles at 10 M Gaussians / 4K: 2 of its 2.5 ms).
 __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const ushort4* __restrict__ rects, uint32_t* __restrict__ chunk_hist,
-                                                         int gx, int tiles) {
+                                                         uint16_t* __restrict__ band_list, uint32_t* __restrict__ band_cnt, int gx,
+                                                         int tiles) {
     extern __shared__ uint32_t hist[];
-    const int tid = threadIdx.x, chunk = blockIdx.x;
+    __shared__ uint32_t bcnt[8];
+    const int tid = threadIdx.x, chunk = blockIdx.x, lane = tid & 63;
     for (int t = tid; t < tiles; t += BIN_THREADS) hist[t] = 0;
+    if (tid < 8) bcnt[tid] = 0;
     __syncthreads();
     int begin, end;
     chunk_bounds(P, chunk, begin, end);
+    const int per = (P + BIN_CHUNKS - 1) / BIN_CHUNKS;
+    uint16_t* lists = band_list ? band_list + (size_t)chunk * 8 * per : nullptr;
     // uniform trip counts (for_each_tile is convergent); PF rectangles are requested before the first is used, so a thread
     // pays one memory latency per PF Gaussians instead of one each (culled Gaussians carry an all-zero rectangle)
     for (int base = begin; base < end; base += PF * BIN_THREADS) {
@@ -240,12 +262,29 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const us
         for (int k = 0; k < PF; k++) {
             if (base + k * BIN_THREADS >= end) break;
             const bool valid = r[k].z > r[k].x && r[k].w > r[k].y;
+            if (lists) {  // workgroup-uniform
+                const int b_lo = valid ? band_of_tile(r[k].y * gx + r[k].x, tiles) : 8;
+                const int b_hi = valid ? band_of_tile((r[k].w - 1) * gx + r[k].z - 1, tiles) : -1;
+                const uint32_t local = (uint32_t)(base + k * BIN_THREADS + tid - begin);
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const bool in = b >= b_lo && b <= b_hi;
+                    const uint64_t m = __ballot(in);
+                    if (m == 0ull) continue;
+                    const int leader = __builtin_ctzll(m);
+                    uint32_t wbase = 0;
+                    if (lane == leader) wbase = atomicAdd(&bcnt[b], (uint32_t)__builtin_popcountll(m));
+                    wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, leader);
+                    if (in) lists[(size_t)b * per + wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)local;
+                }
+            }
             for_each_tile<16>(valid, r[k].x, r[k].y, r[k].z, r[k].w, 0, [&](int x, int y, int) { atomicAdd(&hist[y * gx + x], 1u); });
         }
     }
     __syncthreads();
     uint32_t* out = chunk_hist + (size_t)chunk * tiles;
     for (int t = tid; t < tiles; t += BIN_THREADS) out[t] = hist[t];
+    if (lists && tid < 8) band_cnt[chunk * 8 + tid] = bcnt[tid];
 }
 
 // Column scan: for each tile, exclusive prefix over the chunks.  Workgroup = 4 waves x 64 tiles; wave w owns a
@@ -380,9 +419,11 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4*
 // consecutive addresses: one write transaction per (workgroup, tile) run.  At ~900 instances per tile the runs are 2 ids long
 // and the direct kernel is as fast (measured), so the host picks this one only for long lists.  Placement inside a bucket is
 // free: the same multiset either way.
+template <bool LISTS>  // a template parameter, not a runtime test: a branch in the prefetch loop makes the compiler wait at every join
 __global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const ushort4* __restrict__ rects, const float* __restrict__ depths,
                                                                   const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ tile_count,
-                                                                  const uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ bucket_ids,
+                                                                  const uint32_t* __restrict__ chunk_hist, const uint16_t* __restrict__ band_list,
+                                                                  const uint32_t* __restrict__ band_cnt, uint32_t* __restrict__ bucket_ids,
                                                                   int gx, int tiles, int G, int nbmax, uint32_t cap, int code_bits) {
     extern __shared__ uint32_t smem[];
     uint32_t* gbase = smem;           // [nbmax] bucket position of this workgroup's first instance of the tile
@@ -429,9 +470,6 @@ __global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const 
     }
     __syncthreads();
 
-    int begin, end, dummy;
-    chunk_bounds(P, c0, begin, dummy);
-    chunk_bounds(P, c1 - 1, dummy, end);
     // The sequence is emitted in passes of as many whole tiles as fit the staging area (one pass when the share is small; a
     // dense frame takes several, re-reading the chunk's rectangles each time).  A single tile whose run alone exceeds the area
     // is stored directly.
@@ -453,28 +491,42 @@ __global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const 
         const int ta = t0 + a, tb = t0 + e;
         const int ya0 = ta / gx, yb0 = (tb - 1) / gx;
         if (pass_total > 0) {
-            for (int gb0 = begin; gb0 < end; gb0 += PF * 1024) {
-                ushort4 r[PF];
-                uint32_t entry[PF];
+            // candidates: the band's list of every chunk of the group (large P), or the chunks themselves
+            const int per = (P + BIN_CHUNKS - 1) / BIN_CHUNKS;
+            for (int c = c0; c < c1; c++) {
+                int cb, ce;
+                chunk_bounds(P, c, cb, ce);
+                const uint16_t* list = LISTS ? band_list + ((size_t)c * 8 + band) * per : nullptr;
+                const int cn = LISTS ? (int)band_cnt[c * 8 + band] : ce - cb;
+                for (int gb0 = 0; gb0 < cn; gb0 += PF * 1024) {
+                    ushort4 r[PF];
+                    uint32_t entry[PF];
+                    int idx[PF];
 #pragma unroll
-                for (int k = 0; k < PF; k++) {
-                    const int idx = gb0 + k * 1024 + tid;
-                    r[k] = idx < end ? rects[idx] : make_ushort4(0, 0, 0, 0);
-                    entry[k] = (uint32_t)idx;
-                    if (code_bits && idx < end) entry[k] |= depth_code(__float_as_uint(depths[idx]), (uint32_t)code_bits) << (32 - code_bits);
-                }
+                    for (int k = 0; k < PF; k++) {
+                        const int i = gb0 + k * 1024 + tid;
+                        idx[k] = i < cn ? cb + (LISTS ? (int)list[i] : i) : -1;
+                    }
 #pragma unroll
-                for (int k = 0; k < PF; k++) {
-                    if (gb0 + k * 1024 >= end) break;
-                    const int ya = max((int)r[k].y, ya0), yb = min((int)r[k].w, yb0 + 1);
-                    for_each_tile<16>(r[k].z > r[k].x && yb > ya, r[k].x, ya, r[k].z, yb, (int)entry[k], [&](int x, int y, int id) {
-                        const int t = y * gx + x;
-                        if (t >= ta && t < tb) {
-                            const uint32_t slot = atomicAdd(&lcur[t - t0], 1u) - base;
-                            if (staged) stage[slot] = (uint32_t)id;
-                            else bucket_ids[gbase[t - t0] + slot] = (uint32_t)id;
-                        }
-                    });
+                    for (int k = 0; k < PF; k++) {
+                        const bool in = idx[k] >= 0;
+                        r[k] = in ? rects[idx[k]] : make_ushort4(0, 0, 0, 0);
+                        entry[k] = in ? (uint32_t)idx[k] : 0u;
+                        if (code_bits && in) entry[k] |= depth_code(__float_as_uint(depths[idx[k]]), (uint32_t)code_bits) << (32 - code_bits);
+                    }
+#pragma unroll
+                    for (int k = 0; k < PF; k++) {
+                        if (gb0 + k * 1024 >= cn) break;
+                        const int ya = max((int)r[k].y, ya0), yb = min((int)r[k].w, yb0 + 1);
+                        for_each_tile<16>(r[k].z > r[k].x && yb > ya, r[k].x, ya, r[k].z, yb, (int)entry[k], [&](int x, int y, int id) {
+                            const int t = y * gx + x;
+                            if (t >= ta && t < tb) {
+                                const uint32_t slot = atomicAdd(&lcur[t - t0], 1u) - base;
+                                if (staged) stage[slot] = (uint32_t)id;
+                                else bucket_ids[gbase[t - t0] + slot] = (uint32_t)id;
+                            }
+                        });
+                    }
                 }
             }
         }
@@ -638,7 +690,8 @@ hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& im
     const size_t lds = (size_t)tiles * sizeof(uint32_t);
     hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_count_kernel), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tile_count_kernel, dim3(BIN_CHUNKS), dim3(BIN_THREADS), lds, stream, P, g.rects, img.chunk_hist, gx, tiles);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(BIN_CHUNKS), dim3(BIN_THREADS), lds, stream, P, g.rects, img.chunk_hist, g.band_list, g.band_cnt,
+                       gx, tiles);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(chunk_scan_kernel, dim3((tiles + 63) / 64), dim3(256), 0, stream, img.chunk_hist, img.tile_count, tiles);
@@ -673,10 +726,20 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
             int G = 4;
             while (G > 1 && share1 * G * 1.5 > (double)cap) G >>= 1;
             const size_t lds = fixed + (size_t)cap * sizeof(uint32_t);
-            hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_staged_kernel), lds);
+            hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_staged_kernel<false>), lds);
+            if (e == hipSuccess) e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_staged_kernel<true>), lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(tile_scatter_staged_kernel, dim3(BIN_CHUNKS / G * 8), dim3(1024), lds, stream, P, g.rects, g.depths,
-                               img.tile_offset, img.tile_count, img.chunk_hist, b.bucket_ids, gx, tiles, G, nbmax, cap, code_bits);
+            // the band lists (large P) replace one scan of the chunk per band and pass by a dependent list -> rectangle load
+            // chain: worth it when a share takes several passes, or when there are few instances per Gaussian to amortise a scan
+            const bool use_lists = g.band_list != nullptr && (share1 * G > (double)cap || (double)num_rendered < 10.0 * (double)P);
+            if (use_lists)
+                hipLaunchKernelGGL(tile_scatter_staged_kernel<true>, dim3(BIN_CHUNKS / G * 8), dim3(1024), lds, stream, P, g.rects, g.depths,
+                                   img.tile_offset, img.tile_count, img.chunk_hist, g.band_list, g.band_cnt, b.bucket_ids, gx, tiles, G, nbmax,
+                                   cap, code_bits);
+            else
+                hipLaunchKernelGGL(tile_scatter_staged_kernel<false>, dim3(BIN_CHUNKS / G * 8), dim3(1024), lds, stream, P, g.rects, g.depths,
+                                   img.tile_offset, img.tile_count, img.chunk_hist, (const uint16_t*)nullptr, (const uint32_t*)nullptr,
+                                   b.bucket_ids, gx, tiles, G, nbmax, cap, code_bits);
             return hipGetLastError();
         }
     }

@@ -370,36 +370,50 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
 // holds its own eighth of the bucket array (< 4 MiB at 1080p) and lines leave it complete.  The band assignment is a
 // speed matter only: any placement gives the same buckets.
 // (Measured and dropped: (i) staging a workgroup's instances tile-major in LDS and writing them out in runs brought the
-// fabric writes down to the 30 MB of payload and was not faster; (ii) per-band candidate lists built by the count kernel, so
-// that a band's workgroup does not scan the whole chunk, saved 2 us for 16 B/Gaussian of lists.  With every store and
-// atomic removed the kernel still takes 41 of its 52 us: what is left is the rectangle walk's instruction stream.)
+// fabric writes down to the 30 MB of payload and was not faster at ~900 instances per tile (it is the kernel for dense
+// frames, below); (ii) per-band candidate lists built by the count kernel, so that a band's workgroup does not scan the whole
+// chunk, saved 2 us at 1 M Gaussians for 16 B/Gaussian of lists -- they are built from 2 M Gaussians on, where the eightfold
+// scan does matter.  With every store and atomic removed the kernel still takes 41 of its 52 us at 1 M: what is left is the
+// rectangle walk's instruction stream.)
+template <bool LISTS>  // candidates from the count kernel's band lists (large P) instead of the whole chunk
 __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4* __restrict__ rects, const float* __restrict__ depths,
                                                            const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ chunk_hist,
+                                                           const uint16_t* __restrict__ band_list, const uint32_t* __restrict__ band_cnt,
                                                            uint32_t* __restrict__ bucket_ids, int gx, int tiles, int code_bits) {
     extern __shared__ uint32_t cursor[];
     const int tid = threadIdx.x, band = blockIdx.x & 7, chunk = blockIdx.x >> 3;
     const int q = tiles >> 3, rem = tiles & 7;
     const int t0 = band * q + min(band, rem), t1 = t0 + q + (band < rem ? 1 : 0);  // this band's tiles [t0, t1)
     if (t0 >= t1) return;
+    int begin, end;
+    chunk_bounds(P, chunk, begin, end);
+    const int per = (P + BIN_CHUNKS - 1) / BIN_CHUNKS;
+    const uint16_t* list = LISTS ? band_list + ((size_t)chunk * 8 + band) * per : nullptr;
+    const int cn = LISTS ? (int)band_cnt[chunk * 8 + band] : end - begin;
+    if (cn == 0) return;
     const uint32_t* hbase = chunk_hist + (size_t)chunk * tiles;
     for (int t = t0 + tid; t < t1; t += 256) cursor[t - t0] = tile_offset[t] + hbase[t];
     __syncthreads();
     const int y0 = t0 / gx, y1 = (t1 - 1) / gx;  // tile rows the band touches (first / last possibly partial)
-    int begin, end;
-    chunk_bounds(P, chunk, begin, end);
-    for (int base = begin; base < end; base += PF * 256) {
+    for (int base = 0; base < cn; base += PF * 256) {
         ushort4 r[PF];
         uint32_t entry[PF];  // Gaussian id, with the coarse depth code above it when the ids leave room (wg_sort.h: depth_code)
+        int idx[PF];
 #pragma unroll
         for (int k = 0; k < PF; k++) {
-            const int idx = base + k * 256 + tid;
-            r[k] = idx < end ? rects[idx] : make_ushort4(0, 0, 0, 0);
-            entry[k] = (uint32_t)idx;
-            if (code_bits && idx < end) entry[k] |= depth_code(__float_as_uint(depths[idx]), (uint32_t)code_bits) << (32 - code_bits);
+            const int i = base + k * 256 + tid;
+            idx[k] = i < cn ? begin + (LISTS ? (int)list[i] : i) : -1;
         }
 #pragma unroll
         for (int k = 0; k < PF; k++) {
-            if (base + k * 256 >= end) break;
+            const bool in = idx[k] >= 0;
+            r[k] = in ? rects[idx[k]] : make_ushort4(0, 0, 0, 0);
+            entry[k] = in ? (uint32_t)idx[k] : 0u;
+            if (code_bits && in) entry[k] |= depth_code(__float_as_uint(depths[idx[k]]), (uint32_t)code_bits) << (32 - code_bits);
+        }
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            if (base + k * 256 >= cn) break;
             const int ya = max((int)r[k].y, y0), yb = min((int)r[k].w, y1 + 1);
             for_each_tile<16>(r[k].z > r[k].x && yb > ya, r[k].x, ya, r[k].z, yb, (int)entry[k], [&](int x, int y, int id) {
                 const int t = y * gx + x;
@@ -744,10 +758,15 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
         }
     }
     const size_t lds = (size_t)(tiles / 8 + 1) * sizeof(uint32_t);
-    hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_kernel), lds);
+    hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_kernel<false>), lds);
+    if (e == hipSuccess) e = ensure_lds(reinterpret_cast<const void*>(tile_scatter_kernel<true>), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(BIN_CHUNKS * 8), dim3(256), lds, stream, P, g.rects, g.depths, img.tile_offset,
-                       img.chunk_hist, b.bucket_ids, gx, tiles, code_bits);
+    if (g.band_list != nullptr)
+        hipLaunchKernelGGL(tile_scatter_kernel<true>, dim3(BIN_CHUNKS * 8), dim3(256), lds, stream, P, g.rects, g.depths, img.tile_offset,
+                           img.chunk_hist, g.band_list, g.band_cnt, b.bucket_ids, gx, tiles, code_bits);
+    else
+        hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(BIN_CHUNKS * 8), dim3(256), lds, stream, P, g.rects, g.depths, img.tile_offset,
+                           img.chunk_hist, (const uint16_t*)nullptr, (const uint32_t*)nullptr, b.bucket_ids, gx, tiles, code_bits);
     return hipGetLastError();
 }
 

@@ -184,7 +184,7 @@ const char* wg_stage_name(int stage);
  * host polls, instead of a device-to-host copy followed by a stream synchronise.
  * "staged_scatter" (-1 auto / 0 / 1, default auto: on from 1500 instances per tile): lay a workgroup's instances out
  * tile-major in LDS and copy them to the tile buckets in runs, instead of one 4-byte store per instance.  Same buckets.
- * From "band_list_min_p" Gaussians (default 2000000) it reads per-XCD-band candidate lists written by the counting kernel
+ * From "band_list_min_p" Gaussians (default 2000000) both scatter kernels read per-XCD-band candidate lists written by the counting kernel
  * (16 B per Gaussian more geometry scratch) instead of scanning whole chunks; set between frames only.
  * ("staged_scatter_cap", n > 0, shrinks the staging area to n entries so that tests reach the multi-pass path; 0 = automatic.)
  * "lazy_sort" (1/0, default 1): when some tile lists more than 5/4 of "lazy_min_len" (256..2048, default 1024) instances, sort only

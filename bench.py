@@ -278,6 +278,23 @@ def main():
                          "num_rendered_equal": bool(int(R) == o["num_rendered"])}
         out["speedup_vs_cpu_baseline"] = round(iters_per_s / (1.0 / t_cpu), 1)
 
+        # Same leg, second baseline: the reference's OWN kernels on this GPU -- its CUDA sources compiled for gfx950 with hipcc
+        # (oracle/ref_hip -> oracle/_ref/*.so, prebuilt; test infrastructure) -- timed on the same workload and compared with the
+        # product's outputs at full size.  In a subprocess with a timeout: whatever happens there cannot touch the numbers above.
+        ref_lib = os.path.join(ROOT, "oracle", "_ref", "libref_hip_rasterizer.so")
+        if os.path.exists(ref_lib):
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_hip_bench.py"), "--gaussians", str(P), "--width", str(W),
+                                    "--height", str(H), "--colors", args.colors, "--scale-mult", str(args.scale_mult)],
+                                   capture_output=True, text=True, timeout=240)
+                ref = json.loads(r.stdout.strip().splitlines()[-1])
+                out["reference_on_this_gpu"] = ref
+                out["speedup_vs_reference_on_this_gpu"] = {"train": round(iters_per_s / ref["train_iters_per_s"], 2),
+                                                           "forward": round(fwd_fps / ref["forward_fps"], 2)}
+            except Exception as ex:  # noqa: BLE001 -- a reported extra, never a reason to lose the bench line
+                out["reference_on_this_gpu"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -2,7 +2,7 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
 product path (wild-gaussians_amd/) never does.  See the header of oracle/wg_oracle.c for what the
-oracle restates and for its "parity unpinned" status.
+oracle restates and how it is pinned (against outputs of the reference itself: tests/test_reference_golden.py).
 
 The call surface mirrors the reference's native module
 (submodules/diff-gaussian-rasterization/rasterize_points.h:18-71): ``rasterize_gaussians``,

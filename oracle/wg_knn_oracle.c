@@ -9,7 +9,10 @@
  * count as neighbours at distance 0.
  *
  * wgo_knn_bruteforce() is an independent O(P^2) statement of the same quantity used to cross-check the restatement.
- * PARITY STATUS: "parity unpinned" -- the reference ships no test or golden vector for this function either.
+ * PARITY STATUS: PINNED against outputs of the reference itself -- simple_knn.cu compiles for gfx950 with hipcc where it
+ * lies (oracle/ref_hip/Makefile); run on an MI355X it produced tests/golden/ref_hip_knn_golden.npz, and tests/test_knn.py
+ * holds this restatement to it bit for bit (-ffp-contract=off build of the reference; <= 1e-6 relative against its
+ * default-contraction build, which differs from the other by an ulp in 5-10 % of the points).
  * Build: -ffp-contract=off (see oracle/Makefile).  Only tests/ may load this library.
  */
 #include <float.h>

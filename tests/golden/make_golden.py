@@ -20,7 +20,8 @@ This script imports wildgaussians.method (with inert stand-ins for the packages 
 installed here: omegaconf, plyfile, and the two CUDA extensions, none of which are exercised),
 evaluates those functions on seeded inputs and stores inputs + outputs as small .npz fixtures.
 tests/test_oracle.py checks the CPU oracle against them.  The splatting/compositing arithmetic itself
-has no second statement anywhere in the reference, hence "parity unpinned" for that part.
+has no second statement anywhere in the reference; that part is pinned by running the reference's CUDA sources themselves
+(hipcc build) on a GPU box: tests/golden/make_golden_ref_hip.py.
 """
 import os
 import sys

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""The reference's OWN kernels on this GPU, beside ours: time oracle/_ref/libref_hip_rasterizer.so (hipcc build of the
+reference's CUDA sources, oracle/ref_hip/) on a bench.py workload and compare its outputs with the product's at full size.
+
+    python tests/ref_hip_bench.py [--gaussians 1000000 --width 1920 --height 1080 --colors sh --steps 20 --warmup 3]
+
+Prints one JSON line.  bench.py runs it as a subprocess (with a timeout) inside its baseline leg; it is a checker and a
+reported baseline, never part of the product path.  Needs a GPU and the prebuilt .so (no /root/reference at run time).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "wild-gaussians_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--colors", choices=["sh", "precomp"], default="sh")
+    ap.add_argument("--scale-mult", type=float, default=1.0)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--variant", default="default")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    import wg_scenes as S
+    from oracle.ref_hip import ref_hip
+    from tests.wg_testlib import run_hip, rel_err
+
+    W, H, P = args.width, args.height, args.gaussians
+    deg = 3 if args.colors == "sh" else None
+    cloud = S.make_cloud(P, W, H, sh_degree=deg, seed=0, scale_mult=args.scale_mult)
+    cam = S.make_camera(W, H)
+    cot_np = S.make_cotangent(W, H)
+    s = ref_hip.Session(cloud, cam, sh_degree=deg if deg is not None else 0, variant=args.variant)
+    cot = torch.from_numpy(cot_np).cuda()
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def step():
+        s.forward(copy_image_state=False)
+        s.backward(cot)
+
+    for _ in range(args.warmup):
+        step()
+    ms_step = timed(step, args.steps)
+    ms_fwd = timed(lambda: s.forward(copy_image_state=False), args.steps)
+    out = {"what": "reference CUDA sources compiled for gfx950 with hipcc (oracle/ref_hip), same workload, same GPU",
+           "variant": args.variant, "gaussians": P, "width": W, "height": H, "colors": args.colors,
+           "train_ms": round(ms_step, 3), "train_iters_per_s": round(1e3 / ms_step, 2),
+           "forward_ms": round(ms_fwd, 3), "forward_fps": round(1e3 / ms_fwd, 2), "num_rendered": int(s.num_rendered)}
+    if not args.no_parity:
+        s.forward()
+        s.backward(cot)
+        torch.cuda.synchronize()
+        ref_color = s.color.cpu().numpy()
+        ref_radii = s.radii.cpu().numpy()
+        ref_T = s.final_T.cpu().numpy().reshape(H, W)
+        ref_g = {k: v.cpu().numpy() for k, v in s.g.items()}
+        del s
+        h = run_hip(cloud, cam, sh_degree=deg if deg is not None else 0, cotangent=cot_np)
+        err = np.abs(h["color"].astype(np.float64) - ref_color).max(axis=0)
+        out["product_vs_reference"] = {
+            "color_max_abs": float(err.max()), "color_p9999_abs": float(np.quantile(err, 0.9999)),
+            "pixels_over_1e-4": int((err > 1e-4).sum()), "pixels": int(err.size),
+            "accumulation_max_abs": float(np.abs(h["accumulation"].reshape(H, W) - (1.0 - ref_T)).max()),
+            "radii_mismatch": int((h["radii"] != ref_radii).sum()),
+            "grad_max_rel_err": {k: float(f"{rel_err(g.reshape(ref_g[k].shape), ref_g[k]):.3e}") for k, g in h["grads"].items() if k in ref_g},
+        }
+        out["product_vs_reference"]["grad_max_rel_err_worst"] = max(out["product_vs_reference"]["grad_max_rel_err"].values())
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

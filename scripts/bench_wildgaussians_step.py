@@ -71,6 +71,9 @@ def main():
                     help="SURVEY 8f N3 (caller side): hand the SH features to the operator (shs=) instead of evaluating them in torch")
     ap.add_argument("--fused-activations", action="store_true", help="SURVEY 8f N3: wg_fused_gaussians.activate instead of the torch ops")
     ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the foreach implementation")
+    ap.add_argument("--densification-stats", choices=["off", "torch", "fused"], default="off",
+                    help="the loop's per-Gaussian bookkeeping after backward (method.py:1995-1998, 1470-1477): torch statements, or "
+                         "SURVEY 8f N4 wg_fused_gaussians.add_densification_stats")
     ap.add_argument("--fused-ssim", action="store_true", help="SURVEY 8f N4: wg_fused_ssim.ssim instead of the conv2d-based ssim")
     args = ap.parse_args()
     import wg_scenes as S
@@ -98,6 +101,8 @@ def main():
     opt = torch.optim.Adam([{"params": [p], "lr": 1e-4} for p in prm.values()] + [{"params": mlp.parameters(), "lr": 5e-4}], eps=1e-15,
                            **({"fused": True} if args.fused_adam else {}))
     gt = torch.rand(3, H, W, device=dev)
+    zP = lambda: torch.zeros(P, 1, device=dev)
+    stats = dict(xyz_grad=zP(), denom=zP(), max_radii2D=torch.zeros(P, device=dev), accum_abs=zP(), accum_abs_max=zP())
 
     def step():
         means2D = torch.zeros_like(prm["xyz"], requires_grad=True)
@@ -134,6 +139,18 @@ def main():
             loss = 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - ssim_map(raw, gt)).mean()
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if args.densification_stats == "torch":
+            with torch.no_grad():
+                vf, g = radii > 0, means2D.grad
+                stats["max_radii2D"][vf] = torch.max(stats["max_radii2D"][vf], radii[vf])
+                stats["xyz_grad"][vf] += torch.norm(g[vf, :2], dim=-1, keepdim=True)
+                stats["accum_abs"][vf] += torch.norm(g[vf, 2:], dim=-1, keepdim=True)
+                stats["accum_abs_max"][vf] = torch.max(stats["accum_abs_max"][vf], torch.norm(g[vf, 2:], dim=-1, keepdim=True))
+                stats["denom"][vf] += 1
+        elif args.densification_stats == "fused":
+            from wg_fused_gaussians import add_densification_stats
+            add_densification_stats(radii, means2D.grad, stats["xyz_grad"], stats["denom"], stats["max_radii2D"], stats["accum_abs"],
+                                    stats["accum_abs_max"])
         opt.step()
         return loss
 
@@ -171,7 +188,7 @@ def main():
     torch.cuda.synchronize()
     dop = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"workload": f"WildGaussians-style train step: {P} Gaussians + appearance MLP, {W}x{H}, 2 fwd + 2 bwd raster calls, "
-                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)" + (", SH evaluated in the operator" if args.in_kernel_sh else "") + (", fused SSIM" if args.fused_ssim else "") + (", fused activations" if args.fused_activations else ""),
+                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)" + (", SH evaluated in the operator" if args.in_kernel_sh else "") + (", fused SSIM" if args.fused_ssim else "") + (", fused activations" if args.fused_activations else "") + ("" if args.densification_stats == "off" else f", densification statistics ({args.densification_stats})"),
                       "train_step_ms": round(dt * 1e3, 3), "train_steps_per_s": round(1.0 / dt, 2),
                       "rasterizer_only_ms (2 fwd + 2 bwd)": round(dop * 1e3, 3), "rasterizer_share": round(dop / dt, 3),
                       "visible": int((vis[0] > 0).sum().item()), "loss": float(step().item())}))

@@ -31,9 +31,10 @@ SOURCES = {
     "knn.hip": ["-ffp-contract=off"],  # simple_knn.distCUDA2 replacement (include/wg_knn.h)
     "ssim.hip": [],                    # fused SSIM map fwd/bwd (include/wg_ssim.h)
     "activations.hip": [],             # fused activations + 3-D filter fwd/bwd (include/wg_activations.h)
+    "densify.hip": [],                 # fused densification statistics (include/wg_densify.h)
 }
 HEADERS = ["wg_common.h", "wg_alpha.h", "wg_sort.h", os.path.join(INCLUDE, "wg_rasterizer.h"), os.path.join(INCLUDE, "wg_knn.h"),
-           os.path.join(INCLUDE, "wg_ssim.h"), os.path.join(INCLUDE, "wg_activations.h")]
+           os.path.join(INCLUDE, "wg_ssim.h"), os.path.join(INCLUDE, "wg_activations.h"), os.path.join(INCLUDE, "wg_densify.h")]
 
 
 def _newer(target: str, deps) -> bool:

@@ -12,6 +12,14 @@ with `raw_opacities` [P,1] logits, `raw_scales` [P,3] log-scales, `raw_rotations
 
 One HIP kernel forward, one backward (include/wg_activations.h, csrc/activations.hip); gradients flow to the three raw
 parameters.  No CPU path: float32 tensors on a HIP device.
+
+SURVEY.md 8f N4, the per-Gaussian bookkeeping after the backward pass (method.py:1995-1998, :1470-1477), in place, one kernel,
+no host synchronisation (the torch code runs six boolean-mask index operations, each with a nonzero()):
+
+    from wg_fused_gaussians import add_densification_stats
+    add_densification_stats(radii, viewspace_points.grad, model.xyz_grad, model.denom, max_radii2D=model.max_radii2D,
+                            xyz_gradient_accum_abs=model.xyz_gradient_accum_abs,
+                            xyz_gradient_accum_abs_max=model.xyz_gradient_accum_abs_max)
 """
 from __future__ import annotations
 
@@ -27,6 +35,8 @@ _lib.wg_activations_forward.restype = _i
 _lib.wg_activations_forward.argtypes = [_i] + [_vp] * 8
 _lib.wg_activations_backward.restype = _i
 _lib.wg_activations_backward.argtypes = [_i] + [_vp] * 11
+_lib.wg_densification_stats.restype = _i
+_lib.wg_densification_stats.argtypes = [_i] + [_vp] * 8
 
 
 def _prep(t, cols, name):
@@ -71,3 +81,32 @@ class _Activate(torch.autograd.Function):
 def activate(raw_opacities, raw_scales, raw_rotations, filter_3D):
     """-> (opacities [like raw_opacities], scales [like raw_scales], rotations [like raw_rotations])."""
     return _Activate.apply(raw_opacities, raw_scales, raw_rotations, filter_3D)
+
+
+def add_densification_stats(radii, viewspace_grad, xyz_grad, denom, max_radii2D=None, xyz_gradient_accum_abs=None,
+                            xyz_gradient_accum_abs_max=None):
+    """In place, for every Gaussian with radii > 0 (the loop's visibility_filter): xyz_grad += |grad[:, :2]|, denom += 1,
+    max_radii2D = max(max_radii2D, radii) and, when the two GOF buffers are given, xyz_gradient_accum_abs += |grad[:, 2]|,
+    xyz_gradient_accum_abs_max = max(., |grad[:, 2]|).  `radii` int32 [P], `viewspace_grad` float32 [P, 3], the rest float32 with
+    P elements ([P] or [P, 1]), all contiguous on one HIP device.  (A NaN gradient does not propagate into the two max buffers.)"""
+    P = radii.numel()
+    if not (radii.is_cuda and radii.dtype == torch.int32 and radii.is_contiguous()):
+        raise RuntimeError("wg_fused_gaussians: radii must be a contiguous int32 tensor on a HIP device (there is no CPU path)")
+    if (xyz_gradient_accum_abs is None) != (xyz_gradient_accum_abs_max is None):
+        raise RuntimeError("wg_fused_gaussians: pass both GOF buffers or neither")
+    g = _prep(viewspace_grad, 3, "viewspace_grad")
+    if g.numel() != 3 * P:
+        raise RuntimeError("wg_fused_gaussians: viewspace_grad must be [P, 3]")
+    bufs = []
+    for name, t in (("xyz_grad", xyz_grad), ("xyz_gradient_accum_abs", xyz_gradient_accum_abs),
+                    ("xyz_gradient_accum_abs_max", xyz_gradient_accum_abs_max), ("denom", denom), ("max_radii2D", max_radii2D)):
+        if t is None:
+            bufs.append(None)
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == P):
+            raise RuntimeError(f"wg_fused_gaussians: {name} must be a contiguous float32 tensor of {P} elements on the HIP device")
+        bufs.append(t.data_ptr())
+    stream = torch.cuda.current_stream(radii.device).cuda_stream
+    with torch.cuda.device(radii.device):
+        _native._check(_lib.wg_densification_stats(P, radii.data_ptr(), g.data_ptr(), bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], stream),
+                       "wg_densification_stats")

@@ -60,7 +60,8 @@ size_t wg_binning_buffer_size(int num_rendered);
 /*
  * Rasterizer::forward (rasterizer.h:33-59, rasterizer_impl.cu:198-340).
  * Returns num_rendered (>= 0) = number of (tile, Gaussian) instances, or a negative wg_status.
- * out_color: float[3*H*W] planar CHW.  radii: int[P] or NULL.  One host<->device rendezvous (the read-back
+ * out_color: float[3*H*W] planar CHW.  radii: int[P] or NULL.  subpixel_offset: float[H*W*2] or NULL (beyond the reference:
+ * NULL = all zero, nothing is read; the same in wg_rasterize_backward).  One host<->device rendezvous (the read-back
  * of num_rendered that sizes the binning buffer, as rasterizer_impl.cu:284): the host waits until the first
  * three kernels have run, but work queued on the stream before the call is only waited for, never flushed twice.
  */

@@ -587,3 +587,31 @@ def test_argument_sweep_on_the_alternative_binning_paths(oracle, lazy_options, p
     assert c["max_err_solid"] <= 1e-4, c
     for k, e in compare_grads(h["grads"], o["grads"]).items():
         assert e <= 1e-3, (i, k, e)
+
+
+@pytest.mark.gpu
+def test_absent_subpixel_offsets_equal_a_tensor_of_zeros():
+    """SURVEY 8f N3 (the caller's per-call allocations, method.py:1527): subpixel_offset=None in the settings means no offsets --
+    nothing allocated, memset or read -- and gives bit for bit what the reference's torch.zeros((H, W, 2)) gives."""
+    import wg_scenes as S
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from tests.wg_testlib import make_settings, to_dev
+    W, H, P = 200, 120, 6000
+    cam, cloud = S.make_camera(W, H), S.make_cloud(P, W, H, sh_degree=2, seed=9, scale_mult=5.0)
+    cot = to_dev(S.make_cotangent(W, H))
+    outs = []
+    for absent in (False, True):
+        rs = make_settings(cam, 2)
+        if absent:
+            rs = rs._replace(subpixel_offset=None)
+        t = {k: to_dev(v).requires_grad_(True) for k, v in cloud.items()}
+        m2 = torch.zeros(P, 3, device="cuda", requires_grad=True)
+        color, radii, acc = GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], shs=t["shs"],
+                                                   scales=t["scales"], rotations=t["rotations"])
+        color.backward(cot)
+        outs.append([color.detach(), radii, acc.detach(), m2.grad] + [t[k].grad for k in ("means3D", "opacities", "shs", "scales", "rotations")])
+    for i, (a, b) in enumerate(zip(*outs)):
+        if i < 3:  # image, radii, accumulation: bit-exact
+            assert torch.equal(a, b)
+        else:      # gradients: the order of the atomic adds differs from run to run
+            assert (a - b).abs().max() <= 1e-6 * b.abs().max()

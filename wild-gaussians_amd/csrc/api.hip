@@ -136,7 +136,7 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!geometry_alloc || !binning_alloc || !image_alloc) return WG_ERR_INVALID_ARGUMENT;
     if (P < 0 || width <= 0 || height <= 0 || D < 0 || D > 3) return WG_ERR_INVALID_ARGUMENT;
-    if (!background || !out_color || !viewmatrix || !projmatrix || !subpixel_offset) return WG_ERR_INVALID_ARGUMENT;
+    if (!background || !out_color || !viewmatrix || !projmatrix) return WG_ERR_INVALID_ARGUMENT;  // subpixel_offset may be null (= zeros)
     if (P > 0) {
         if (!means3D || !opacities) return WG_ERR_INVALID_ARGUMENT;
         // exactly one colour source / one covariance source (GaussianRasterizer.forward, __init__.py:212-216)
@@ -282,7 +282,7 @@ int wg_rasterize_backward(int P, int D, int M, int R, const float* background, i
     (void)colors_precomp;  // colours were copied into the splat records by the forward pass
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return WG_ERR_INVALID_ARGUMENT;
     if (P == 0) return WG_OK;
-    if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background || !subpixel_offset) return WG_ERR_INVALID_ARGUMENT;
+    if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background) return WG_ERR_INVALID_ARGUMENT;
     if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D) return WG_ERR_INVALID_ARGUMENT;
     if (shs != nullptr && (!dL_dsh || !campos)) return WG_ERR_INVALID_ARGUMENT;
     if (scales != nullptr && (!rotations || !dL_dscale || !dL_drot)) return WG_ERR_INVALID_ARGUMENT;

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
         T[s] = 0.f; last[s] = 0; dLr[s] = dLg[s] = dLb[s] = 0.f;
         if (inside) {
             const size_t pix = (size_t)W * py + px;
-            off = subpixel_offset[pix];
+            if (subpixel_offset) off = subpixel_offset[pix];
             T[s] = final_T[pix];
             last[s] = (int)n_contrib[pix];
             dLr[s] = dL_dpix[pix];

@@ -51,7 +51,7 @@ __device__ void fwd_init(FwdTile& st, int W, int H, int gx, int tile, int lane, 
         st.last[s] = 0;
         if (inside) {
             const size_t pix = (size_t)W * py + st.px;
-            off = subpixel_offset[pix];
+            if (subpixel_offset) off = subpixel_offset[pix];
             st.alive |= 1u << s;
             if (resume) {  // parked state: T < 0 marks a pixel that already hit the T < 1e-4 stop
                 const float t = final_T[pix];

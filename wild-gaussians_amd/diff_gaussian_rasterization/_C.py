@@ -137,6 +137,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     background, colors, opacity = _f32(background, device), _f32(colors, device), _f32(opacity, device)
     scales, rotations, cov3D_precomp = _f32(scales, device), _f32(rotations, device), _f32(cov3D_precomp, device)
     viewmatrix, projmatrix, campos = _f32(viewmatrix, device), _f32(projmatrix, device), _f32(campos, device)
+    if subpixel_offset is None:  # opt-in beyond the reference: no offsets, nothing allocated or read
+        subpixel_offset = torch.Tensor([])
     subpixel_offset, sh = _f32(subpixel_offset, device), _f32(sh, device)
     M = sh.size(1) if sh.numel() != 0 else 0  # rasterize_points.cu:85-89
 
@@ -181,6 +183,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         background, colors = _f32(background, device), _f32(colors, device)
         scales, rotations, cov3D_precomp = _f32(scales, device), _f32(rotations, device), _f32(cov3D_precomp, device)
         viewmatrix, projmatrix, campos = _f32(viewmatrix, device), _f32(projmatrix, device), _f32(campos, device)
+        if subpixel_offset is None:
+            subpixel_offset = torch.Tensor([])
         subpixel_offset, dL_dout_color = _f32(subpixel_offset, device), _f32(dL_dout_color, device)
         radii = radii if radii.is_contiguous() else radii.contiguous()
         with torch.cuda.device(device):

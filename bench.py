@@ -28,6 +28,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+# secondary ceiling of the two render kernels ("report, not judged"): a SIMD issues one wave64 VALU instruction per 4
+# cycles, 256 CUs x 4 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions/s
+VALU_ISSUE_PEAK_G = 256 * 4 * 2.4 / 4
 
 
 def algorithmic_bytes(stage: str, P: int, V: int, R: int, N: int, tiles: int, M: int, sh: bool) -> float:
@@ -206,17 +209,23 @@ def main():
         ach = B / (per_stage[dom] * 1e-3) / 1e9 if per_stage[dom] > 0 else 0.0
         # HBM traffic per launch from PMC counters: taken in separate rocprofv3 --pmc passes (scripts/profile_gpu.sh) and
         # committed as profiles/pmc_traffic.json; used only when it was collected on this very workload
-        traffic = None
+        traffic, valu = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pt = json.load(f)
             if args.scale_mult == 1.0 and pt.get("workload") == f"{P} Gaussians, {W}x{H}, {args.colors}" and dom in pt["stages"]:
                 traffic = pt["stages"][dom]["hbm_bytes"]
+                valu = pt["stages"][dom].get("SQ_INSTS_VALU")
         except (OSError, ValueError, KeyError):
             pass
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": B, "avg_launch_ms": round(per_stage[dom], 4)}
+        if valu and per_stage[dom] > 0:
+            # what actually bounds this kernel: VALU issue.  SQ_INSTS_VALU per launch (PMC pass) / this run's time.
+            g = valu / (per_stage[dom] * 1e-3) / 1e9
+            out["roofline"]["valu_issue"] = {"wave_instructions_per_launch": valu, "achieved": round(g, 1), "peak": round(VALU_ISSUE_PEAK_G, 1),
+                                             "unit": "G wave-instr/s", "frac": round(g / VALU_ISSUE_PEAK_G, 3)}
         # whole forward / backward pipelines against the same roofline, for context
         fwd_names = ["preprocess", "scan", "duplicate_keys", "sort", "tile_ranges", "render_forward"]
         bwd_names = ["render_backward", "preprocess_backward"]
@@ -245,6 +254,8 @@ def main():
             if k in pmc:
                 row["hbm_traffic_GBps"] = round(pmc[k]["hbm_bytes"] / (ms * 1e-3) / 1e9, 1)
                 row["frac_of_peak_by_traffic"] = round(row["hbm_traffic_GBps"] / HBM_PEAK_GBS, 3)
+                if pmc[k].get("SQ_INSTS_VALU"):
+                    row["frac_of_valu_issue_peak"] = round(pmc[k]["SQ_INSTS_VALU"] / (ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_G, 3)
             rows[k] = row
         out["stage_rooflines"] = rows
 

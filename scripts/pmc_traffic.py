@@ -14,13 +14,15 @@ STAGE_OF = {"preprocess_kernel": "preprocess", "tile_count_kernel": "scan", "chu
             "render_backward_kernel": "render_backward", "preprocess_backward_kernel": "preprocess_backward"}
 vals = {}
 for line in open(sys.argv[1]):
-    m = re.match(r"(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*\d+\s+per_dispatch=\s*(\d+)", line)
+    m = re.match(r"(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU|SQ_INSTS_SALU|SQ_INSTS_LDS)\s+dispatches=\s*\d+\s+per_dispatch=\s*(\d+)", line)
     if not m:
         continue
     name = re.sub(r"^void ", "", m.group(1)).split("(")[0].replace("wg::", "").split("<")[0]
     st = STAGE_OF.get(name)
     if st:
-        vals.setdefault(st, {"FETCH_SIZE_KiB": 0, "WRITE_SIZE_KiB": 0})[m.group(2) + "_KiB"] += int(m.group(3))
+        key = m.group(2) + "_KiB" if m.group(2).endswith("_SIZE") else m.group(2)  # SQ_INSTS_*: wave-instructions per launch
+        d = vals.setdefault(st, {"FETCH_SIZE_KiB": 0, "WRITE_SIZE_KiB": 0})
+        d[key] = d.get(key, 0) + int(m.group(3))
 out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving; WRITE_SIZE as reported)",
        "stages": {k: dict(v, hbm_bytes=(2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024) for k, v in vals.items()}}
 print(json.dumps(out, indent=1))

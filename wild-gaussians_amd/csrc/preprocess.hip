@@ -10,6 +10,7 @@
 // ~70 B written per Gaussian, no reuse, so the work is laid out one Gaussian per lane with the
 // per-Gaussian outputs packed into one 48-byte record that the render kernels gather in one go.
 #include "wg_common.h"
+#include "wg_alpha.h"
 
 #pragma clang fp contract(off)
 
@@ -240,7 +241,8 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
         float4* rec = g.splats + 3 * (size_t)idx;
         rec[0] = make_float4(pixx, pixy, conx, cony);
         rec[1] = make_float4(conz, opacity * coef, 0.f, cr);  // .z is reserved: the render kernels park a strip mask there
-        rec[2] = make_float4(cg, cb, 0.f, 0.f);
+        const float2 ext = splat_extent(conx, cony, conz, opacity * coef);  // the render kernels' strip tests (wg_alpha.h)
+        rec[2] = make_float4(cg, cb, ext.x, ext.y);
     }
     // always written (all-zero for a culled Gaussian): the binning kernels read the rectangle only
     g.rects[idx] = vis ? make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy)

@@ -104,7 +104,7 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
 
     for (int base = 0; base < n && strips_alive != 0; base += BATCH) {
         const int cnt = min(BATCH, n - base);
-        const uint32_t mymask = lane < cnt ? strip_mask(a0, a1, sb) : 0u;
+        const uint32_t mymask = lane < cnt ? strip_mask(a0, a2, sb) : 0u;
         // The wave is the staging area's only user and its LDS operations execute in issue order, so no barrier is needed for
         // correctness.  WGB (legal only when the workgroup IS the wave) keeps the s_barrier-free __syncthreads() of the one-wave
         // kernel anyway: hipcc schedules and allocates the compositing loop measurably better around it (0.325 vs 0.340 ms).

@@ -91,20 +91,21 @@ struct FwdTile {
     int px, py0;
 };
 
-// Conservative per-(splat, strip) reachability mask.  A pixel can only pass alpha >= 1/255 when
-// power >= -ln(255*o), i.e. inside the ellipse d^T Q d <= 2 ln(255 o); the mask tests that ellipse's axis-aligned
-// bounding box (inflated by 0.1% + 0.01 px so float rounding can never exclude a pixel the exact test would keep)
-// against each strip's sample-position box.  Splats with an indefinite conic keep all strips.
-__device__ __forceinline__ uint32_t strip_mask(const float4 r0, const float4 r1, const StripBounds& sb) {
-    const float o = r1.y, A = r0.z, B = r0.w, C = r1.x;
-    if (!(o * 1.001f >= (1.0f / 255.0f))) return 0u;
+// Conservative per-(splat, strip) reachability.  A pixel can only pass alpha >= 1/255 when power >= -ln(255*o), i.e. inside the
+// ellipse d^T Q d <= 2 ln(255 o); splat_extent() is that ellipse's axis-aligned half-extent (inflated by 0.1% + 0.01 px so float
+// rounding can never exclude a pixel the exact test would keep), computed once per Gaussian by the preprocess kernel and kept in
+// the record's two spare floats (r2.z, r2.w); strip_mask() tests the box against each strip's sample-position box while staging.
+// A splat below the 1/255 cut everywhere gets -inf (no strip), one with an indefinite conic +inf (all strips).
+__device__ __forceinline__ float2 splat_extent(float A, float B, float C, float o) {
+    if (!(o * 1.001f >= (1.0f / 255.0f))) return make_float2(-__builtin_huge_valf(), -__builtin_huge_valf());
     const float det = A * C - B * B;
-    if (!(det > 0.0f) || !(A > 0.0f) || !(C > 0.0f)) return 0xFu;
+    if (!(det > 0.0f) || !(A > 0.0f) || !(C > 0.0f)) return make_float2(__builtin_huge_valf(), __builtin_huge_valf());
     const float tau2 = 2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(255.0f * o) * 1.002f + 0.002f;  // 2 ln(255 o), inflated
     const float idet = 1.0f / det;
-    const float ex = __builtin_sqrtf(fmaxf(tau2 * C * idet, 0.0f)) + 0.01f;
-    const float ey = __builtin_sqrtf(fmaxf(tau2 * A * idet, 0.0f)) + 0.01f;
-    const float mx = r0.x, my = r0.y;
+    return make_float2(__builtin_sqrtf(fmaxf(tau2 * C * idet, 0.0f)) + 0.01f, __builtin_sqrtf(fmaxf(tau2 * A * idet, 0.0f)) + 0.01f);
+}
+__device__ __forceinline__ uint32_t strip_mask(const float4 r0, const float4 r2, const StripBounds& sb) {
+    const float mx = r0.x, my = r0.y, ex = r2.z, ey = r2.w;
     uint32_t m = 0;
 #pragma unroll
     for (int s = 0; s < 4; s++)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """One case of the argument sweep against the float32 AND the float64 oracle (is a deviation a threshold flip of a fragile pixel?).
-usage: python scripts/debug_sweep_case.py <case>"""
+usage: python tests/tools/debug_sweep_case.py <case>"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "wild-gaussians_amd")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import wg_scenes as S

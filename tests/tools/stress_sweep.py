@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Extended run of tests/test_parity_gpu.py's argument sweep (cases beyond the 30 in CI), default and alternative binning paths.
-usage: python scripts/stress_sweep.py [first] [count]"""
+usage: python tests/tools/stress_sweep.py [first] [count]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "wild-gaussians_amd")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import wg_scenes as S
@@ -32,7 +32,7 @@ for i in range(first, first + count):
         ok = (h["radii"] == o["radii"]).all() and c["max_err_solid"] <= 1e-4 and max(g.values()) <= 1e-3
         worst["fwd"] = max(worst["fwd"], c["max_err_solid"]); worst["grad"] = max(worst["grad"], max(g.values()))
         if not ok and c["max_err_solid"] <= 1e-4 and c["n_over_in_fragile"] > 0 and (h["radii"] == o["radii"]).all():
-            flips += 1  # a fragile pixel took the other side of a threshold (exp rounding): see scripts/debug_sweep_case.py
+            flips += 1  # a fragile pixel took the other side of a threshold (exp rounding): see tests/tools/debug_sweep_case.py
             print("fragile flip: case", i, name, "worst grad rel err", max(g.values()))
         elif not ok:
             bad += 1

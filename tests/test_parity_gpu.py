@@ -615,3 +615,41 @@ def test_absent_subpixel_offsets_equal_a_tensor_of_zeros():
             assert torch.equal(a, b)
         else:      # gradients: the order of the atomic adds differs from run to run
             assert (a - b).abs().max() <= 1e-6 * b.abs().max()
+
+
+@pytest.mark.gpu
+def test_scratch_buffers_are_released_without_the_cyclic_collector():
+    """The allocator callbacks handed to the C-ABI must not keep the scratch tensors in a reference cycle: a training loop would
+    otherwise hold tens of steps' worth of dead geometry / binning / image buffers until Python's cyclic GC happens to run, and
+    the caching allocator would cover them with fresh device allocations (host stalls of 10-100 ms in the timed loop)."""
+    import gc
+    import wg_scenes as S
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from tests.wg_testlib import make_settings, to_dev
+    W, H, P = 640, 360, 100_000
+    cam, cloud = S.make_camera(W, H), S.make_cloud(P, W, H, sh_degree=1, seed=5, scale_mult=2.0)
+    rast = GaussianRasterizer(make_settings(cam, 1))
+    t = {k: to_dev(v).requires_grad_(True) for k, v in cloud.items()}
+    cot = to_dev(S.make_cotangent(W, H))
+
+    def step():
+        m2 = torch.zeros(P, 3, device="cuda", requires_grad=True)
+        for v in t.values():
+            v.grad = None
+        color, _, _ = rast(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+        color.backward(cot)
+
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        grown = torch.cuda.memory_allocated() - base
+    finally:
+        gc.enable()
+    assert grown < 4 * 2**20, f"{grown / 2**20:.1f} MiB of device memory held by garbage after 20 steps"

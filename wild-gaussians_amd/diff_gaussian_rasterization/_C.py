@@ -114,6 +114,13 @@ class _Scratch:
         self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self.tensor.data_ptr()
 
+    def take(self) -> torch.Tensor:
+        """Hand the tensor over and break the self -> callback -> bound method -> self cycle: with the cycle left in place the
+        buffer would stay allocated until Python's cyclic collector runs, some tens of steps later -- hundreds of MB of dead
+        scratch per step for the caching allocator to cover with fresh (slow, synchronising) device allocations."""
+        t, self.tensor, self.callback = self.tensor, None, None
+        return t
+
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width, sh, degree,
@@ -128,7 +135,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     geom, binning, img = _Scratch(device), _Scratch(device), _Scratch(device)
     if P == 0:  # rasterize_points.cu:83: nothing is launched, the image stays zero
         return (0, torch.zeros((3, H, W), dtype=torch.float32, device=device), torch.zeros((0,), dtype=torch.int32, device=device),
-                geom.tensor, binning.tensor, img.tensor)
+                geom.take(), binning.take(), img.take())
     # both outputs are fully written by the kernels (every pixel, every Gaussian): no need for the reference's zero fill
     out_color = torch.empty((3, H, W), dtype=torch.float32, device=device)
     radii = torch.empty((P,), dtype=torch.int32, device=device)
@@ -142,15 +149,18 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     subpixel_offset, sh = _f32(subpixel_offset, device), _f32(sh, device)
     M = sh.size(1) if sh.numel() != 0 else 0  # rasterize_points.cu:85-89
 
-    with torch.cuda.device(device):
-        rendered = _lib.wg_rasterize_forward(
-            geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
-            _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
-            _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-            float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
-            int(bool(debug)), _stream(device))
+    try:
+        with torch.cuda.device(device):
+            rendered = _lib.wg_rasterize_forward(
+                geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
+                _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
+                _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
+                int(bool(debug)), _stream(device))
+    finally:
+        buffers = (geom.take(), binning.take(), img.take())
     _check(rendered, "wg_rasterize_forward")
-    return rendered, out_color, radii, geom.tensor, binning.tensor, img.tensor
+    return (rendered, out_color, radii) + buffers
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,

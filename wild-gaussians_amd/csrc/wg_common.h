@@ -29,7 +29,7 @@ struct GeometryState {
     uint32_t* tiles_touched;
     uint32_t* point_offsets;
     uint16_t* band_list;  // large P only (g_band_list_min_p): [BIN_CHUNKS][8][chunk size] chunk-local indices of the Gaussians touching
-    uint32_t* band_cnt;   // each XCD band of tiles, and their counts [BIN_CHUNKS][8]; candidates of the staged scatter
+    uint32_t* band_cnt;   // each XCD band of tiles, and their counts [BIN_CHUNKS][8]; the candidates of both scatter kernels
     char* scan_temp;
     size_t scan_temp_bytes;
     static GeometryState fromChunk(char*& chunk, size_t P);
@@ -80,7 +80,7 @@ struct BinningState {
 
 constexpr uint32_t TILE_SORT_MAX = 8192;  // longest per-tile list the register sort handles (32 keys per thread)
 constexpr int BIN_CHUNKS = 512;           // Gaussian chunks (= workgroups) of the LDS counting sort
-extern int g_band_list_min_p;  // default 2 000 000: from here on the staged scatter reads per-band candidate lists instead of whole
+extern int g_band_list_min_p;  // default 2 000 000: from here on the scatter kernels read per-band candidate lists instead of whole
                                // chunks (wg_set_option("band_list_min_p"); it sizes the geometry buffer: set it between frames only)
 constexpr int BIN_MAX_TILES = 36864;      // tiles*4 B must fit one workgroup's LDS (144 KiB): up to 4K frames
 

@@ -653,3 +653,23 @@ def test_scratch_buffers_are_released_without_the_cyclic_collector():
     finally:
         gc.enable()
     assert grown < 4 * 2**20, f"{grown / 2**20:.1f} MiB of device memory held by garbage after 20 steps"
+
+
+@pytest.mark.gpu
+def test_backward_through_accumulation_only_gives_zero_gradients():
+    """radii and accumulation take no gradient (reference __init__.py:117 ignores both incoming gradients): a loss built on
+    the accumulation alone back-propagates zeros, as it does through the reference's Function."""
+    import wg_scenes as S
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from tests.wg_testlib import make_settings, to_dev
+    W, H, P = 96, 64, 500
+    cam, cloud = S.make_camera(W, H), S.make_cloud(P, W, H, sh_degree=0, seed=3, scale_mult=6.0)
+    t = {k: to_dev(v).requires_grad_(True) for k, v in cloud.items()}
+    m2 = torch.zeros(P, 3, device="cuda", requires_grad=True)
+    color, radii, acc = GaussianRasterizer(make_settings(cam, 0))(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], shs=t["shs"],
+                                                                  scales=t["scales"], rotations=t["rotations"])
+    assert not radii.requires_grad and acc.sum() > 0
+    acc.sum().backward()
+    for k, v in t.items():
+        assert v.grad is not None and float(v.grad.abs().max()) == 0.0, k
+    assert float(m2.grad.abs().max()) == 0.0

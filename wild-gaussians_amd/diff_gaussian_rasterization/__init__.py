@@ -82,6 +82,9 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        # radii and accumulation take no gradient (reference backward signature (ctx, grad_out_color, _, _), :117): do not let
+        # autograd materialise P- and H*W-sized zero tensors for them on every backward pass
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf)
 
         accumulation = None
@@ -96,6 +99,8 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _grad_radii, _grad_accumulation):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf = ctx.saved_tensors
+        if grad_out_color is None:  # the image itself took no gradient (only radii / accumulation were used downstream)
+            grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
         native_args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                        rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset, grad_out_color, sh,
                        rs.sh_degree, rs.campos, geom_buf, ctx.num_rendered, binning_buf, img_buf, rs.debug)

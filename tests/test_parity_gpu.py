@@ -8,6 +8,8 @@ take different branches when a decision sits within ~1e-6 of its threshold, whic
 ~4e-3.  The oracle records each pixel's distance to its nearest decision (frag_alpha / frag_T); pixels with a safety
 margin ("solid", >99% of the image) must meet 1e-4, the remaining "fragile" pixels are counted and bounded.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -673,3 +675,30 @@ def test_backward_through_accumulation_only_gives_zero_gradients():
     for k, v in t.items():
         assert v.grad is not None and float(v.grad.abs().max()) == 0.0, k
     assert float(m2.grad.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_bench_flow_with_two_ranks(tmp_path):
+    """bench.py's N > 1 path end to end (rendezvous, per-rank cameras, the loss all-reduce every step, barrier-bracketed timing,
+    max over ranks, one JSON line from rank 0).  The GPU box has one device, where RCCL cannot host two ranks: WG_DIST_BACKEND=gloo
+    lets both ranks share it; everything but the collective's transport is the code the 8-GPU run executes."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WG_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--gaussians", "200000", "--width", "640", "--height", "360"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["config"]["views_per_step"] == 2 and d["value"] > 0 and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) <= 1e-2 * d["value"]  # whole-job rate: both ranks' steps over the slowest rank's time

@@ -24,14 +24,20 @@ def init(backend: str | None = None) -> tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if backend is None:  # WG_DIST_BACKEND=gloo: exercise the N > 1 flow of bench.py where RCCL cannot run (ranks sharing one GPU)
+            backend = os.environ.get("WG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local_rank %= torch.cuda.device_count()
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
+        local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
     return rank, local_rank, world
+
+
+def _host_side() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo"
 
 
 def views_for_rank(num_views: int, rank: int, world: int) -> List[int]:
@@ -47,7 +53,12 @@ def view_cameras(num_views: int, width: int, height: int, yaw_step_deg: float = 
 def allreduce_loss(loss: torch.Tensor) -> torch.Tensor:
     """SUM all-reduce of a 1-element fp32 tensor: 4 bytes on the wire per step, latency-bound."""
     if dist.is_available() and dist.is_initialized():
-        dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+        if _host_side() and loss.is_cuda:  # gloo (tests): reduce a host copy
+            host = loss.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            loss.copy_(host)
+        else:
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM)
     return loss
 
 
@@ -57,14 +68,14 @@ def barrier():
 
 
 def max_over_ranks(value: float, device) -> float:
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if _host_side() else device)
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def sum_over_ranks(value: float, device) -> float:
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if _host_side() else device)
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())

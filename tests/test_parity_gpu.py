@@ -702,3 +702,39 @@ def test_bench_flow_with_two_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
     assert d["config"]["views_per_step"] == 2 and d["value"] > 0 and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) <= 1e-2 * d["value"]  # whole-job rate: both ranks' steps over the slowest rank's time
+
+
+def test_input_layouts_and_partial_gradients():
+    """What a caller can legitimately hand over: non-contiguous views, float64 / float16 tensors (converted, as .contiguous()
+    .data<float>() would demand in the reference), inputs that need no gradient, no_grad calls; and what it cannot: host tensors."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    W, H, P = 128, 80, 1500
+    cam, cloud = S.make_camera(W, H), S.make_cloud(P, W, H, sh_degree=1, seed=21, scale_mult=5.0)
+    rast = GaussianRasterizer(make_settings(cam, 1))
+    t = {k: to_dev(v) for k, v in cloud.items()}
+    m2 = torch.zeros(P, 3, device="cuda")
+    kw = dict(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    with torch.no_grad():
+        ref, ref_r, ref_a = rast(**kw)
+    assert not ref.requires_grad
+    # non-contiguous views of wider buffers, and a float64 input
+    wide = torch.zeros(P, 7, device="cuda")
+    wide[:, 2:5] = t["means3D"]
+    sh_t = t["shs"].permute(1, 0, 2).contiguous().permute(1, 0, 2)  # same values, strides of a transposed buffer
+    assert not wide[:, 2:5].is_contiguous() and not sh_t.is_contiguous()
+    out, r, a = rast(**dict(kw, means3D=wide[:, 2:5], shs=sh_t, scales=t["scales"].double(), opacities=t["opacities"].double()))
+    assert torch.equal(out, ref) and torch.equal(r, ref_r) and torch.equal(a, ref_a)
+    # only some inputs take a gradient: the others get None, the values of the wanted ones do not depend on who else asked
+    cot = to_dev(S.make_cotangent(W, H))
+    full = {k: v.clone().requires_grad_(True) for k, v in t.items()}
+    c, _, _ = rast(means3D=full["means3D"], means2D=m2.clone().requires_grad_(True), opacities=full["opacities"], shs=full["shs"],
+                   scales=full["scales"], rotations=full["rotations"])
+    c.backward(cot)
+    part_sh = t["shs"].clone().requires_grad_(True)
+    c2, _, _ = rast(**dict(kw, shs=part_sh))
+    c2.backward(cot)
+    assert t["means3D"].grad is None and t["scales"].grad is None
+    assert (part_sh.grad - full["shs"].grad).abs().max() <= 1e-6 * full["shs"].grad.abs().max()
+    # host tensors: a clear error, never a silent CPU path
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        rast(**{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in kw.items()})

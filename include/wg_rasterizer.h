@@ -132,6 +132,45 @@ int wg_rasterize_backward(int P, int D, int M, int R,
                           int debug,
                           void* stream);
 
+/*
+ * Beyond the reference ("the appearance MLP output feeds SH eval directly"): an optional per-Gaussian affine
+ * on the SH coefficients, applied inside the preprocess kernel and differentiated inside the preprocess-backward kernel:
+ *
+ *     x = min(shs[i][k][c], pre_clamp_max);   t = x * mul[i][c] + (k == 0 ? offset[i][c] : 0);   used = min(t, post_clamp_max)
+ *
+ * (separate multiply and add, so that the values equal what the PyTorch chain it replaces computes:
+ * `(features.clamp_max(1) * mul.repeat(1, 16) + cat(offset / C0, 0)).clamp_max(1)`, wildgaussians/method.py:890-900, 1590-1595,
+ * with `offset` here = the caller's offset / C0).  INFINITY switches a clamp off; mul / offset may be NULL (1 / 0).
+ * The *_toned entry points take the same arguments as the plain ones plus this block; tone == NULL is the plain call.
+ * Backward: dL_dsh is then the gradient w.r.t. the RAW coefficients, and dL_dmul / dL_doffset ([P,3], overwritten, zeros for
+ * culled Gaussians) receive the gradients of the two affine inputs.  Only with SH colours (shs != NULL).
+ */
+typedef struct wg_sh_tone {
+    const float* mul;      /* [P,3] or NULL */
+    const float* offset;   /* [P,3] or NULL */
+    float pre_clamp_max;
+    float post_clamp_max;
+    float* dL_dmul;        /* backward only; required when mul != NULL */
+    float* dL_doffset;     /* backward only; required when offset != NULL */
+} wg_sh_tone;
+
+int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
+                               wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                               int height, const float* means3D, const float* shs, const float* colors_precomp,
+                               const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                               float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
+                               float* out_color, int* radii, int debug, void* stream, const wg_sh_tone* tone);
+
+int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                                const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                                const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
+                                const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
+                                char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                                float* dL_drot, int debug, void* stream, const wg_sh_tone* tone);
+
 /* Rasterizer::markVisible (rasterizer.h:26-31, rasterizer_impl.cu:141-153). present: unsigned char[P]. */
 int wg_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     unsigned char* present, void* stream);

@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--densification-stats", choices=["off", "torch", "fused"], default="off",
                     help="the loop's per-Gaussian bookkeeping after backward (method.py:1995-1998, 1470-1477): torch statements, or "
                          "SURVEY 8f N4 wg_fused_gaussians.add_densification_stats")
+    ap.add_argument("--in-kernel-tone", action="store_true",
+                    help="SURVEY 8f N3: the appearance toning (clamp, * mul, + offset / C0, clamp; method.py:890-900, 1590-1595) inside the "
+                         "preprocess kernels (sh_mul / sh_offset / sh_*_clamp_max) instead of P x 48 torch tensors; implies --in-kernel-sh")
     ap.add_argument("--fused-ssim", action="store_true", help="SURVEY 8f N4: wg_fused_ssim.ssim instead of the conv2d-based ssim")
     args = ap.parse_args()
     import wg_scenes as S
@@ -116,9 +119,16 @@ def main():
             s2f = s2 + filter_3d * filter_3d
             scales = s2f.sqrt()
             opac = torch.sigmoid(prm["opacities"]) * torch.sqrt(s2.prod(1) / s2f.prod(1))[:, None]
+        kw = dict(means3D=prm["xyz"], means2D=means2D, opacities=opac, scales=scales, rotations=rot)
+        if args.in_kernel_tone:
+            shs = prm["features"].view(P, 16, 3)
+            raw, radii, acc = rast_sh(shs=shs, sh_pre_clamp_max=1.0, **kw)
+            inp = torch.cat((prm["features"][:, :3].clamp_max(1.0), prm["embeddings"], prm["image_embedding"][None].expand(P, -1)), dim=-1)
+            offset, mul = torch.split(mlp(inp) * 0.01, [3, 3], dim=-1)
+            img, _, _ = rast_sh(shs=shs, sh_mul=mul, sh_offset=offset / C0, sh_pre_clamp_max=1.0, sh_post_clamp_max=1.0, **kw)
+            return finish(img, raw, radii, means2D)
         feats = prm["features"].clamp_max(1.0)
         d = F.normalize(prm["xyz"] - campos[None], dim=1)
-        kw = dict(means3D=prm["xyz"], means2D=means2D, opacities=opac, scales=scales, rotations=rot)
         if args.in_kernel_sh:
             raw, radii, acc = rast_sh(shs=feats.view(P, 16, 3), **kw)
         else:
@@ -132,6 +142,9 @@ def main():
         else:
             toned = sh_to_rgb(toned_f.clamp_max(1.0).view(P, 16, 3).transpose(1, 2), d)
             img, _, _ = rast(colors_precomp=toned, **kw)
+        return finish(img, raw, radii, means2D)
+
+    def finish(img, raw, radii, means2D):
         if args.fused_ssim:
             from wg_fused_ssim import ssim as fused_ssim
             loss = 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - fused_ssim(raw, gt, size_average=False)).mean()
@@ -188,7 +201,7 @@ def main():
     torch.cuda.synchronize()
     dop = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"workload": f"WildGaussians-style train step: {P} Gaussians + appearance MLP, {W}x{H}, 2 fwd + 2 bwd raster calls, "
-                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)" + (", SH evaluated in the operator" if args.in_kernel_sh else "") + (", fused SSIM" if args.fused_ssim else "") + (", fused activations" if args.fused_activations else "") + ("" if args.densification_stats == "off" else f", densification statistics ({args.densification_stats})"),
+                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)" + (", SH evaluated in the operator" if args.in_kernel_sh or args.in_kernel_tone else "") + (", appearance toning in the operator" if args.in_kernel_tone else "") + (", fused SSIM" if args.fused_ssim else "") + (", fused activations" if args.fused_activations else "") + ("" if args.densification_stats == "off" else f", densification statistics ({args.densification_stats})"),
                       "train_step_ms": round(dt * 1e3, 3), "train_steps_per_s": round(1.0 / dt, 2),
                       "rasterizer_only_ms (2 fwd + 2 bwd)": round(dop * 1e3, 3), "rasterizer_share": round(dop / dt, 3),
                       "visible": int((vis[0] > 0).sum().item()), "loss": float(step().item())}))

@@ -126,6 +126,17 @@ size_t wg_binning_buffer_size(int R) {  // upper bound over both binning paths
     return required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)(R > 0 ? R : 0), true); });
 }
 
+static wg::ShTone device_tone(const wg_sh_tone* t) {
+    wg::ShTone d;
+    if (t != nullptr) {
+        d.enabled = 1;
+        d.mul = t->mul; d.offset = t->offset;
+        d.pre_clamp = t->pre_clamp_max; d.post_clamp = t->post_clamp_max;
+        d.dL_dmul = t->dL_dmul; d.dL_doffset = t->dL_doffset;
+    }
+    return d;
+}
+
 int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
                          wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
                          int height, const float* means3D, const float* shs, const float* colors_precomp,
@@ -133,7 +144,21 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
                          const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                          float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
                          float* out_color, int* radii, int debug, void* stream_) {
+    return wg_rasterize_forward_toned(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
+                                      width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                      cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, subpixel_offset,
+                                      prefiltered, out_color, radii, debug, stream_, nullptr);
+}
+
+int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
+                               wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                               int height, const float* means3D, const float* shs, const float* colors_precomp,
+                               const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                               float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
+                               float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (tone != nullptr && shs == nullptr && P > 0) return WG_ERR_INVALID_ARGUMENT;  // the tone acts on SH coefficients
     if (!geometry_alloc || !binning_alloc || !image_alloc) return WG_ERR_INVALID_ARGUMENT;
     if (P < 0 || width <= 0 || height <= 0 || D < 0 || D > 3) return WG_ERR_INVALID_ARGUMENT;
     if (!background || !out_color || !viewmatrix || !projmatrix) return WG_ERR_INVALID_ARGUMENT;  // subpixel_offset may be null (= zeros)
@@ -163,6 +188,7 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     fp.focal_y = height / (2.0f * tan_fovy);  // rasterizer_impl.cu:224-225
     fp.focal_x = width / (2.0f * tan_fovx);
     fp.kernel_size = kernel_size; fp.prefiltered = prefiltered;
+    fp.tone = device_tone(tone);
 
     int num_rendered = 0;
     uint32_t max_tile_count = 0;
@@ -278,7 +304,25 @@ int wg_rasterize_backward(int P, int D, int M, int R, const float* background, i
                           char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                           float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                           float* dL_drot, int debug, void* stream_) {
+    return wg_rasterize_backward_toned(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
+                                       cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, subpixel_offset, radii,
+                                       geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+                                       dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream_, nullptr);
+}
+
+int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                                const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                                const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
+                                const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
+                                char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                                float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (tone != nullptr && P > 0) {
+        if (shs == nullptr) return WG_ERR_INVALID_ARGUMENT;
+        if ((tone->mul != nullptr && tone->dL_dmul == nullptr) || (tone->offset != nullptr && tone->dL_doffset == nullptr)) return WG_ERR_INVALID_ARGUMENT;
+    }
     (void)colors_precomp;  // colours were copied into the splat records by the forward pass
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return WG_ERR_INVALID_ARGUMENT;
     if (P == 0) return WG_OK;
@@ -310,6 +354,7 @@ int wg_rasterize_backward(int P, int D, int M, int R, const float* background, i
     bp.focal_y = height / (2.0f * tan_fovy);
     bp.focal_x = width / (2.0f * tan_fovx);
     bp.kernel_size = kernel_size; bp.radii = radii;
+    bp.tone = device_tone(tone);
     WG_STAGE(WG_STAGE_PREPROCESS_BACKWARD, wg::launch_preprocess_backward(bp, geom, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                             dL_dscale, dL_drot, stream),
              "preprocess_backward");

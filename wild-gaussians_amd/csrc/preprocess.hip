@@ -49,7 +49,7 @@ __device__ __forceinline__ float sh_channel(int deg, const float* sh, float x, f
 // lane stride.  The values, and the order of the arithmetic on them, are unchanged.
 constexpr int SH_PITCH4 = 13;
 
-template <bool FAST_SH, bool PRECOMP>
+template <bool FAST_SH, bool PRECOMP, bool TONE>
 __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometryState g, int* __restrict__ radii_out) {
     __shared__ float4 stage[FAST_SH ? 64 * SH_PITCH4 : 1];
     const int lane = threadIdx.x;
@@ -223,6 +223,29 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
                     const float4 v = stage[lane * SH_PITCH4 + q];
                     sh[4 * q] = v.x; sh[4 * q + 1] = v.y; sh[4 * q + 2] = v.z; sh[4 * q + 3] = v.w;
                 }
+                if (TONE) {
+                    float m[3], o[3], xin, t;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        m[ch] = p.tone.mul ? p.tone.mul[3 * idx + ch] : 1.0f;
+                        o[ch] = p.tone.offset ? p.tone.offset[3 * idx + ch] : 0.0f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 48; e++) sh[e] = tone_value(sh[e], m[e % 3], e < 3 ? o[e] : 0.0f, p.tone.pre_clamp, p.tone.post_clamp, xin, t);
+                }
+                cr = sh_channel(p.D, sh + 0, dx, dy, dz);
+                cg = sh_channel(p.D, sh + 1, dx, dy, dz);
+                cb = sh_channel(p.D, sh + 2, dx, dy, dz);
+            } else if (TONE) {  // generic layout (M != 16 or unaligned): the (D+1)^2 <= 16 coefficients the evaluation reads
+                const float* src = p.shs + (size_t)idx * p.M * 3;
+                float sh[48], xin, t;
+                const int used = 3 * (p.D + 1) * (p.D + 1);
+                for (int e = 0; e < 48; e++) {
+                    const int ch = e % 3;
+                    const float m = p.tone.mul ? p.tone.mul[3 * idx + ch] : 1.0f;
+                    const float o = (e < 3 && p.tone.offset) ? p.tone.offset[3 * idx + ch] : 0.0f;
+                    sh[e] = e < used ? tone_value(src[e], m, o, p.tone.pre_clamp, p.tone.post_clamp, xin, t) : 0.0f;
+                }
                 cr = sh_channel(p.D, sh + 0, dx, dy, dz);
                 cg = sh_channel(p.D, sh + 1, dx, dy, dz);
                 cb = sh_channel(p.D, sh + 2, dx, dy, dz);
@@ -266,10 +289,18 @@ hipError_t launch_preprocess(const FwdParams& p, const GeometryState& g, int* ra
     const bool fast = p.shs != nullptr && p.colors_precomp == nullptr && p.M == 16 && (reinterpret_cast<uintptr_t>(p.shs) % 16 == 0);
     const bool pre = p.cov3D_precomp != nullptr;
     const dim3 grid((p.P + 63) / 64), block(64);
-    if (fast && !pre) hipLaunchKernelGGL((preprocess_kernel<true, false>), grid, block, 0, stream, p, g, radii_out);
-    else if (fast) hipLaunchKernelGGL((preprocess_kernel<true, true>), grid, block, 0, stream, p, g, radii_out);
-    else if (!pre) hipLaunchKernelGGL((preprocess_kernel<false, false>), grid, block, 0, stream, p, g, radii_out);
-    else hipLaunchKernelGGL((preprocess_kernel<false, true>), grid, block, 0, stream, p, g, radii_out);
+    const bool tone = p.tone.enabled && p.shs != nullptr && p.colors_precomp == nullptr;
+#define WG_LAUNCH(F, C, T) hipLaunchKernelGGL((preprocess_kernel<F, C, T>), grid, block, 0, stream, p, g, radii_out)
+    if (tone) {
+        if (fast && !pre) WG_LAUNCH(true, false, true);
+        else if (fast) WG_LAUNCH(true, true, true);
+        else if (!pre) WG_LAUNCH(false, false, true);
+        else WG_LAUNCH(false, true, true);
+    } else if (fast && !pre) WG_LAUNCH(true, false, false);
+    else if (fast) WG_LAUNCH(true, true, false);
+    else if (!pre) WG_LAUNCH(false, false, false);
+    else WG_LAUNCH(false, true, false);
+#undef WG_LAUNCH
     return hipGetLastError();
 }
 

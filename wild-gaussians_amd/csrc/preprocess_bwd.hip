@@ -58,7 +58,7 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
 
 // Load schedule: the memory counter retires in issue order, so every per-Gaussian input is requested first, the
 // 12 KiB SH block second (into registers), and only the SH part of the arithmetic -- placed last -- waits for it.
-template <bool FAST_SH, bool HAS_SCALES>
+template <bool FAST_SH, bool HAS_SCALES, bool TONE>
 __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     BwdParams p, const float4* __restrict__ splats, const unsigned char* __restrict__ clamped,
     const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
@@ -276,6 +276,7 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     }
 
     // ------------------------------------------------------------------ SH backward, backward.cu:20-139
+    float tdm[3] = {0.f, 0.f, 0.f}, tdo[3] = {0.f, 0.f, 0.f};  // TONE: dL/dmul, dL/doffset of this Gaussian
     float dsh[FAST_SH ? 48 : 1];
     if (FAST_SH) {
 #pragma unroll
@@ -289,6 +290,16 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
         sh_basis(p.D, ox * ilen, oy * ilen, oz * ilen, B, Dx, Dy, Dz);
         const float dRGB[3] = {(cl & 1) ? 0.f : dcol0, (cl & 2) ? 0.f : dcol1, (cl & 4) ? 0.f : dcol2};
         float ddx = 0.f, ddy = 0.f, ddz = 0.f;  // dL_ddir
+        // TONE (wg_common.h: ShTone): the evaluation saw min(min(raw, pre) * mul + offset[k == 0], post); chain rule back to the raw
+        // coefficients, the multiplier and the offset (clamp_max passes the gradient where x <= max, as torch does)
+        float tm[3] = {1.f, 1.f, 1.f}, to[3] = {0.f, 0.f, 0.f};
+        if (TONE) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                if (p.tone.mul) tm[ch] = p.tone.mul[3 * idx + ch];
+                if (p.tone.offset) to[ch] = p.tone.offset[3 * idx + ch];
+            }
+        }
         if (FAST_SH) {
             float sh[48];
 #pragma unroll
@@ -300,8 +311,18 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
             for (int k = 0; k < 16; k++)
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    dsh[3 * k + ch] = B[k] * dRGB[ch];
-                    const float w = sh[3 * k + ch] * dRGB[ch];
+                    float g = B[k] * dRGB[ch], val = sh[3 * k + ch];
+                    if (TONE) {
+                        float xin, t;
+                        const float raw = val;
+                        val = tone_value(raw, tm[ch], k == 0 ? to[ch] : 0.0f, p.tone.pre_clamp, p.tone.post_clamp, xin, t);
+                        g = (t <= p.tone.post_clamp) ? g : 0.0f;
+                        tdm[ch] += g * xin;
+                        if (k == 0) tdo[ch] = g;
+                        g = (raw <= p.tone.pre_clamp) ? g * tm[ch] : 0.0f;
+                    }
+                    dsh[3 * k + ch] = g;
+                    const float w = val * dRGB[ch];
                     ddx += Dx[k] * w;
                     ddy += Dy[k] * w;
                     ddz += Dz[k] * w;
@@ -314,8 +335,18 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
                 for (int ch = 0; ch < 3; ch++) {
                     float bk = 0.f, dxk = 0.f, dyk = 0.f, dzk = 0.f;
                     if (k < ncoef && k < 16) { bk = B[k]; dxk = Dx[k]; dyk = Dy[k]; dzk = Dz[k]; }
-                    d[3 * k + ch] = bk * dRGB[ch];
-                    const float w = sh[3 * k + ch] * dRGB[ch];
+                    float g = bk * dRGB[ch], val = sh[3 * k + ch];
+                    if (TONE) {
+                        float xin, t;
+                        const float raw = val;
+                        val = tone_value(raw, tm[ch], k == 0 ? to[ch] : 0.0f, p.tone.pre_clamp, p.tone.post_clamp, xin, t);
+                        g = (t <= p.tone.post_clamp) ? g : 0.0f;
+                        tdm[ch] += g * xin;
+                        if (k == 0) tdo[ch] = g;
+                        g = (raw <= p.tone.pre_clamp) ? g * tm[ch] : 0.0f;
+                    }
+                    d[3 * k + ch] = g;
+                    const float w = val * dRGB[ch];
                     ddx += dxk * w;
                     ddy += dyk * w;
                     ddz += dzk * w;
@@ -336,6 +367,13 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
         if (!FAST_SH && p.shs != nullptr && !vis) {
             float* d = dL_dsh + (size_t)idx * p.M * 3;
             for (int k = 0; k < p.M * 3; k++) d[k] = 0.f;
+        }
+        if (TONE) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                if (p.tone.dL_dmul) p.tone.dL_dmul[3 * idx + ch] = tdm[ch];
+                if (p.tone.dL_doffset) p.tone.dL_doffset[3 * idx + ch] = tdo[ch];
+            }
         }
     }
     if (FAST_SH) {
@@ -363,13 +401,19 @@ hipError_t launch_preprocess_backward(const BwdParams& p, const GeometryState& g
     const bool fast = p.shs != nullptr && p.M == 16 && (reinterpret_cast<uintptr_t>(p.shs) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(dL_dsh) % 16 == 0);
     const bool sc = p.scales != nullptr;
-#define WG_LAUNCH(F, S)                                                                                                              \
-    hipLaunchKernelGGL((preprocess_backward_kernel<F, S>), grid, block, 0, stream, p, g.splats, g.clamped, dL_dmean2D, dL_dconic, \
+    const bool tone = p.tone.enabled && p.shs != nullptr;
+#define WG_LAUNCH(F, S, T)                                                                                                           \
+    hipLaunchKernelGGL((preprocess_backward_kernel<F, S, T>), grid, block, 0, stream, p, g.splats, g.clamped, dL_dmean2D, dL_dconic, \
                        dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot)
-    if (fast && sc) WG_LAUNCH(true, true);
-    else if (fast) WG_LAUNCH(true, false);
-    else if (sc) WG_LAUNCH(false, true);
-    else WG_LAUNCH(false, false);
+    if (tone) {
+        if (fast && sc) WG_LAUNCH(true, true, true);
+        else if (fast) WG_LAUNCH(true, false, true);
+        else if (sc) WG_LAUNCH(false, true, true);
+        else WG_LAUNCH(false, false, true);
+    } else if (fast && sc) WG_LAUNCH(true, true, false);
+    else if (fast) WG_LAUNCH(true, false, false);
+    else if (sc) WG_LAUNCH(false, true, false);
+    else WG_LAUNCH(false, false, false);
 #undef WG_LAUNCH
     return hipGetLastError();
 }

@@ -87,6 +87,25 @@ constexpr int BIN_MAX_TILES = 36864;      // tiles*4 B must fit one workgroup's 
 size_t query_scan_temp_bytes(size_t P);
 size_t query_sort_temp_bytes(size_t R);
 
+// Optional per-Gaussian affine on the SH coefficients before their evaluation (include/wg_rasterizer.h: wg_sh_tone):
+//   x = min(sh[k][c], pre_clamp);  t = x * mul[c] + (k == 0 ? offset[c] : 0);  used value = min(t, post_clamp)
+// evaluated with separate multiply and add (what the PyTorch elementwise chain it replaces rounds to).  enabled == 0: untouched.
+struct ShTone {
+    int enabled = 0;
+    const float* mul = nullptr;     // [P,3] or null (= 1)
+    const float* offset = nullptr;  // [P,3] or null (= 0)
+    float pre_clamp = 0.f, post_clamp = 0.f;
+    float* dL_dmul = nullptr;       // backward: [P,3] each, written for every Gaussian (zeros when culled)
+    float* dL_doffset = nullptr;
+};
+
+// the used value and, for the backward pass, what it was made of
+__device__ __forceinline__ float tone_value(float raw, float m, float o, float pre, float post, float& xin, float& t) {
+    xin = fminf(raw, pre);
+    t = __fadd_rn(__fmul_rn(xin, m), o);
+    return fminf(t, post);
+}
+
 struct FwdParams {
     int P, D, M, W, H, gx, gy;
     const float* means3D;
@@ -102,6 +121,7 @@ struct FwdParams {
     const float* cam_pos;
     float tan_fovx, tan_fovy, focal_x, focal_y, kernel_size;
     int prefiltered;
+    ShTone tone;
 };
 
 // kernels / stages (each launches on `stream`, returns hipGetLastError())
@@ -155,6 +175,7 @@ struct BwdParams {
     const float* campos;
     float tan_fovx, tan_fovy, focal_x, focal_y, kernel_size;
     const int* radii;
+    ShTone tone;
 };
 hipError_t launch_preprocess_backward(const BwdParams& p, const GeometryState& g, const float* dL_dmean2D,
                                       const float* dL_dconic, float* dL_dopacity, const float* dL_dcolor,

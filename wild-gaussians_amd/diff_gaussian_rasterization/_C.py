@@ -39,6 +39,16 @@ _lib.wg_rasterize_forward.argtypes = [_ALLOC_FN, _vp, _ALLOC_FN, _vp, _ALLOC_FN,
 _lib.wg_rasterize_backward.restype = _i
 _lib.wg_rasterize_backward.argtypes = [_i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _f,
                                        _vp, _vp, _vp, _vp, _vp, _vp] + [_vp] * 9 + [_i, _vp]
+
+
+class _ShTone(C.Structure):  # include/wg_rasterizer.h: wg_sh_tone
+    _fields_ = [("mul", _vp), ("offset", _vp), ("pre_clamp_max", _f), ("post_clamp_max", _f), ("dL_dmul", _vp), ("dL_doffset", _vp)]
+
+
+_lib.wg_rasterize_forward_toned.restype = _i
+_lib.wg_rasterize_forward_toned.argtypes = _lib.wg_rasterize_forward.argtypes + [C.POINTER(_ShTone)]
+_lib.wg_rasterize_backward_toned.restype = _i
+_lib.wg_rasterize_backward_toned.argtypes = _lib.wg_rasterize_backward.argtypes + [C.POINTER(_ShTone)]
 _lib.wg_mark_visible.restype = _i
 _lib.wg_mark_visible.argtypes = [_i, _vp, _vp, _vp, _vp, _vp]
 for _name in ("wg_geometry_buffer_size", "wg_binning_buffer_size"):
@@ -122,9 +132,29 @@ class _Scratch:
         return t
 
 
+def _tone_block(sh_tone, device, P, grads=None):
+    """sh_tone = (mul [P,3] or None, offset [P,3] or None, pre_clamp_max or None, post_clamp_max or None) -> (_ShTone, keep-alive).
+    Beyond the reference: see wg_sh_tone in include/wg_rasterizer.h."""
+    mul, offset, pre, post = sh_tone
+    keep = []
+    t = _ShTone()
+    for name, v in (("mul", mul), ("offset", offset)):
+        if v is not None:
+            v = _f32(v, device)
+            if v.numel() != 3 * P:
+                raise RuntimeError(f"sh_{name} must have 3 * P elements")
+            keep.append(v)
+            setattr(t, name, v.data_ptr())
+    t.pre_clamp_max = float("inf") if pre is None else float(pre)
+    t.post_clamp_max = float("inf") if post is None else float(post)
+    if grads is not None:
+        t.dL_dmul, t.dL_doffset = (None if g is None else g.data_ptr() for g in grads)
+    return t, keep
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width, sh, degree,
-                        campos, prefiltered, debug):
+                        campos, prefiltered, debug, sh_tone=None):
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:59-61
     if not means3D.is_cuda:
@@ -149,14 +179,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     subpixel_offset, sh = _f32(subpixel_offset, device), _f32(sh, device)
     M = sh.size(1) if sh.numel() != 0 else 0  # rasterize_points.cu:85-89
 
+    tone, _keep = (None, None) if sh_tone is None else _tone_block(sh_tone, device, P)
     try:
         with torch.cuda.device(device):
-            rendered = _lib.wg_rasterize_forward(
+            rendered = _lib.wg_rasterize_forward_toned(
                 geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
                 _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
                 _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
                 float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
-                int(bool(debug)), _stream(device))
+                int(bool(debug)), _stream(device), None if tone is None else C.byref(tone))
     finally:
         buffers = (geom.take(), binning.take(), img.take())
     _check(rendered, "wg_rasterize_forward")
@@ -165,7 +196,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, dL_dout_color, sh,
-                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, sh_tone=None):
+    """With sh_tone (see rasterize_gaussians) two more tensors are appended to the result: dL_dsh_mul, dL_dsh_offset (None where the
+    input was None), and dL_dsh is the gradient w.r.t. the raw coefficients."""
     device = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -187,6 +220,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dsh = alloc((P, M, 3), dtype=torch.float32, device=device)
     dL_dscales = (alloc if have_scales else torch.zeros)((P, 3), dtype=torch.float32, device=device)
     dL_drotations = (alloc if have_scales else torch.zeros)((P, 4), dtype=torch.float32, device=device)
+    tone_grads = None
+    if sh_tone is not None:
+        tone_grads = tuple(None if v is None else alloc((P, 3), dtype=torch.float32, device=device) for v in sh_tone[:2])
 
     if P != 0:
         means3D = _f32(means3D, device)
@@ -197,17 +233,19 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             subpixel_offset = torch.Tensor([])
         subpixel_offset, dL_dout_color = _f32(subpixel_offset, device), _f32(dL_dout_color, device)
         radii = radii if radii.is_contiguous() else radii.contiguous()
+        tone, _keep = (None, None) if sh_tone is None else _tone_block(sh_tone, device, P, tone_grads)
         with torch.cuda.device(device):
-            status = _lib.wg_rasterize_backward(
+            status = _lib.wg_rasterize_backward_toned(
                 P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
                 float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
                 float(tan_fovx), float(tan_fovy), float(kernel_size), _ptr(subpixel_offset), _ptr(radii),
                 geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL_dout_color),
                 dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
                 dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(), dL_drotations.data_ptr(),
-                int(bool(debug)), _stream(device))
+                int(bool(debug)), _stream(device), None if tone is None else C.byref(tone))
         _check(status, "wg_rasterize_backward")
-    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+    out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    return out if sh_tone is None else out + tone_grads
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

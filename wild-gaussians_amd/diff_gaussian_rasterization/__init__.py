@@ -72,11 +72,20 @@ def _accumulation_from_image_state(img_buffer: torch.Tensor, height: int, width:
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None):
         rs = raster_settings
         native_args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset,
                        rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        # beyond the reference (opt-in, see GaussianRasterizer.forward): per-Gaussian affine + clamps on the SH coefficients in-kernel
+        ctx.sh_tone = None
+        if sh_mul is not None or sh_offset is not None or sh_pre_clamp_max is not None or sh_post_clamp_max is not None:
+            if sh.numel() == 0:
+                raise Exception("sh_mul / sh_offset / sh_*_clamp_max act on SH coefficients: provide shs, not colors_precomp")
+            ctx.sh_tone = (None if sh_mul is None else sh_mul.detach(), None if sh_offset is None else sh_offset.detach(),
+                           sh_pre_clamp_max, sh_post_clamp_max)
+            native_args = native_args + (ctx.sh_tone,)
         num_rendered, color, radii, geom_buf, binning_buf, img_buf = _call_native(
             _C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
 
@@ -104,15 +113,24 @@ class _RasterizeGaussians(torch.autograd.Function):
         native_args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                        rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset, grad_out_color, sh,
                        rs.sh_degree, rs.campos, geom_buf, ctx.num_rendered, binning_buf, img_buf, rs.debug)
-        (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations) = _call_native(
-            _C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
-        # order of forward()'s inputs; None for raster_settings
-        return g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3Ds, None
+        g_mul = g_offset = None
+        if ctx.sh_tone is None:
+            (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations) = _call_native(
+                _C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
+        else:
+            (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations, g_mul, g_offset) = _call_native(
+                _C.rasterize_gaussians_backward, native_args + (ctx.sh_tone,), rs.debug, "snapshot_bw.dump", "backward")
+            mul, offset = ctx.sh_tone[:2]
+            g_mul = None if mul is None else g_mul.view(mul.shape)
+            g_offset = None if offset is None else g_offset.view(offset.shape)
+        # order of forward()'s inputs; None for raster_settings and the two clamp constants
+        return g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3Ds, None, g_mul, g_offset, None, None
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                        sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings)
+                                     raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max)
 
 
 class GaussianRasterizer(nn.Module):
@@ -128,7 +146,14 @@ class GaussianRasterizer(nn.Module):
 
     def forward(self, means3D, means2D, opacities, shs: Optional[torch.Tensor] = None,
                 colors_precomp: Optional[torch.Tensor] = None, scales: Optional[torch.Tensor] = None,
-                rotations: Optional[torch.Tensor] = None, cov3D_precomp: Optional[torch.Tensor] = None):
+                rotations: Optional[torch.Tensor] = None, cov3D_precomp: Optional[torch.Tensor] = None, *,
+                sh_mul: Optional[torch.Tensor] = None, sh_offset: Optional[torch.Tensor] = None,
+                sh_pre_clamp_max: Optional[float] = None, sh_post_clamp_max: Optional[float] = None):
+        """The reference's signature (diff_gaussian_rasterization/__init__.py:208-241) plus four keyword-only opt-ins (SURVEY.md 8f
+        N3): with `shs`, the kernels evaluate `min(min(shs, sh_pre_clamp_max) * sh_mul[:, None, :] + [k == 0] * sh_offset[:, None, :],
+        sh_post_clamp_max)` instead of `shs` -- WildGaussians' appearance toning (method.py:890-900, 1590-1595: pass the clamped
+        features' raw tensor, `mul`, `offset / C0`, and 1.0 for both clamps) without the P x 48 intermediate tensors -- and return
+        gradients for `shs` (raw), `sh_mul` and `sh_offset` ([P, 3] each)."""
         if (shs is None) == (colors_precomp is None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
         has_scale_rot = scales is not None or rotations is not None
@@ -144,4 +169,4 @@ class GaussianRasterizer(nn.Module):
             _absent() if scales is None else scales,
             _absent() if rotations is None else rotations,
             _absent() if cov3D_precomp is None else cov3D_precomp,
-            self.raster_settings)
+            self.raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max)

@@ -188,14 +188,13 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
     fp.focal_y = height / (2.0f * tan_fovy);  // rasterizer_impl.cu:224-225
     fp.focal_x = width / (2.0f * tan_fovx);
     fp.kernel_size = kernel_size; fp.prefiltered = prefiltered;
-    fp.tone = device_tone(tone);
 
     int num_rendered = 0;
     uint32_t max_tile_count = 0;
     bool huge_frame = false;
     Mailbox* mbox = nullptr;
     if (P > 0) {
-        WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, geom, radii, stream), "preprocess");
+        WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, device_tone(tone), geom, radii, stream), "preprocess");
         if (tiles <= wg::BIN_MAX_TILES) {
             WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_count(P, geom, img, gx, tiles, stream), "tile_count");
             mbox = debug ? nullptr : get_mailbox();
@@ -354,8 +353,7 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     bp.focal_y = height / (2.0f * tan_fovy);
     bp.focal_x = width / (2.0f * tan_fovx);
     bp.kernel_size = kernel_size; bp.radii = radii;
-    bp.tone = device_tone(tone);
-    WG_STAGE(WG_STAGE_PREPROCESS_BACKWARD, wg::launch_preprocess_backward(bp, geom, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+    WG_STAGE(WG_STAGE_PREPROCESS_BACKWARD, wg::launch_preprocess_backward(bp, device_tone(tone), geom, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                             dL_dscale, dL_drot, stream),
              "preprocess_backward");
     return WG_OK;

@@ -50,7 +50,7 @@ __device__ __forceinline__ float sh_channel(int deg, const float* sh, float x, f
 constexpr int SH_PITCH4 = 13;
 
 template <bool FAST_SH, bool PRECOMP, bool TONE>
-__global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometryState g, int* __restrict__ radii_out) {
+__global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometryState g, int* __restrict__ radii_out, ToneArg<TONE> tone) {
     __shared__ float4 stage[FAST_SH ? 64 * SH_PITCH4 : 1];
     const int lane = threadIdx.x;
     const int base = blockIdx.x * 64;
@@ -223,28 +223,28 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
                     const float4 v = stage[lane * SH_PITCH4 + q];
                     sh[4 * q] = v.x; sh[4 * q + 1] = v.y; sh[4 * q + 2] = v.z; sh[4 * q + 3] = v.w;
                 }
-                if (TONE) {
+                if constexpr (TONE) {
                     float m[3], o[3], xin, t;
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
-                        m[ch] = p.tone.mul ? p.tone.mul[3 * idx + ch] : 1.0f;
-                        o[ch] = p.tone.offset ? p.tone.offset[3 * idx + ch] : 0.0f;
+                        m[ch] = tone.mul ? tone.mul[3 * idx + ch] : 1.0f;
+                        o[ch] = tone.offset ? tone.offset[3 * idx + ch] : 0.0f;
                     }
 #pragma unroll
-                    for (int e = 0; e < 48; e++) sh[e] = tone_value(sh[e], m[e % 3], e < 3 ? o[e] : 0.0f, p.tone.pre_clamp, p.tone.post_clamp, xin, t);
+                    for (int e = 0; e < 48; e++) sh[e] = tone_value(sh[e], m[e % 3], e < 3 ? o[e] : 0.0f, tone.pre_clamp, tone.post_clamp, xin, t);
                 }
                 cr = sh_channel(p.D, sh + 0, dx, dy, dz);
                 cg = sh_channel(p.D, sh + 1, dx, dy, dz);
                 cb = sh_channel(p.D, sh + 2, dx, dy, dz);
-            } else if (TONE) {  // generic layout (M != 16 or unaligned): the (D+1)^2 <= 16 coefficients the evaluation reads
+            } else if constexpr (TONE) {  // generic layout (M != 16 or unaligned): the (D+1)^2 <= 16 coefficients the evaluation reads
                 const float* src = p.shs + (size_t)idx * p.M * 3;
                 float sh[48], xin, t;
                 const int used = 3 * (p.D + 1) * (p.D + 1);
                 for (int e = 0; e < 48; e++) {
                     const int ch = e % 3;
-                    const float m = p.tone.mul ? p.tone.mul[3 * idx + ch] : 1.0f;
-                    const float o = (e < 3 && p.tone.offset) ? p.tone.offset[3 * idx + ch] : 0.0f;
-                    sh[e] = e < used ? tone_value(src[e], m, o, p.tone.pre_clamp, p.tone.post_clamp, xin, t) : 0.0f;
+                    const float m = tone.mul ? tone.mul[3 * idx + ch] : 1.0f;
+                    const float o = (e < 3 && tone.offset) ? tone.offset[3 * idx + ch] : 0.0f;
+                    sh[e] = e < used ? tone_value(src[e], m, o, tone.pre_clamp, tone.post_clamp, xin, t) : 0.0f;
                 }
                 cr = sh_channel(p.D, sh + 0, dx, dy, dz);
                 cg = sh_channel(p.D, sh + 1, dx, dy, dz);
@@ -284,23 +284,25 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* _
     present[idx] = !(vz <= 0.2f);  // auxiliary.h:154
 }
 
-hipError_t launch_preprocess(const FwdParams& p, const GeometryState& g, int* radii_out, hipStream_t stream) {
+hipError_t launch_preprocess(const FwdParams& p, const ShTone& tone_in, const GeometryState& g, int* radii_out, hipStream_t stream) {
     if (p.P <= 0) return hipSuccess;
     const bool fast = p.shs != nullptr && p.colors_precomp == nullptr && p.M == 16 && (reinterpret_cast<uintptr_t>(p.shs) % 16 == 0);
     const bool pre = p.cov3D_precomp != nullptr;
     const dim3 grid((p.P + 63) / 64), block(64);
-    const bool tone = p.tone.enabled && p.shs != nullptr && p.colors_precomp == nullptr;
-#define WG_LAUNCH(F, C, T) hipLaunchKernelGGL((preprocess_kernel<F, C, T>), grid, block, 0, stream, p, g, radii_out)
+    const bool tone = tone_in.enabled && p.shs != nullptr && p.colors_precomp == nullptr;
+#define WG_LAUNCH(F, C) hipLaunchKernelGGL((preprocess_kernel<F, C, false>), grid, block, 0, stream, p, g, radii_out, NoTone{})
+#define WG_LAUNCH_TONE(F, C) hipLaunchKernelGGL((preprocess_kernel<F, C, true>), grid, block, 0, stream, p, g, radii_out, tone_in)
     if (tone) {
-        if (fast && !pre) WG_LAUNCH(true, false, true);
-        else if (fast) WG_LAUNCH(true, true, true);
-        else if (!pre) WG_LAUNCH(false, false, true);
-        else WG_LAUNCH(false, true, true);
-    } else if (fast && !pre) WG_LAUNCH(true, false, false);
-    else if (fast) WG_LAUNCH(true, true, false);
-    else if (!pre) WG_LAUNCH(false, false, false);
-    else WG_LAUNCH(false, true, false);
+        if (fast && !pre) WG_LAUNCH_TONE(true, false);
+        else if (fast) WG_LAUNCH_TONE(true, true);
+        else if (!pre) WG_LAUNCH_TONE(false, false);
+        else WG_LAUNCH_TONE(false, true);
+    } else if (fast && !pre) WG_LAUNCH(true, false);
+    else if (fast) WG_LAUNCH(true, true);
+    else if (!pre) WG_LAUNCH(false, false);
+    else WG_LAUNCH(false, true);
 #undef WG_LAUNCH
+#undef WG_LAUNCH_TONE
     return hipGetLastError();
 }
 

@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     BwdParams p, const float4* __restrict__ splats, const unsigned char* __restrict__ clamped,
     const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
     const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
-    float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot) {
+    float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, ToneArg<TONE> tone) {
     __shared__ float4 stage[FAST_SH ? 64 * SH_PITCH4 : 1];
     const int lane = threadIdx.x;
     const int base = blockIdx.x * 64;
@@ -293,11 +293,11 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
         // TONE (wg_common.h: ShTone): the evaluation saw min(min(raw, pre) * mul + offset[k == 0], post); chain rule back to the raw
         // coefficients, the multiplier and the offset (clamp_max passes the gradient where x <= max, as torch does)
         float tm[3] = {1.f, 1.f, 1.f}, to[3] = {0.f, 0.f, 0.f};
-        if (TONE) {
+        if constexpr (TONE) {
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                if (p.tone.mul) tm[ch] = p.tone.mul[3 * idx + ch];
-                if (p.tone.offset) to[ch] = p.tone.offset[3 * idx + ch];
+                if (tone.mul) tm[ch] = tone.mul[3 * idx + ch];
+                if (tone.offset) to[ch] = tone.offset[3 * idx + ch];
             }
         }
         if (FAST_SH) {
@@ -312,14 +312,14 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
                     float g = B[k] * dRGB[ch], val = sh[3 * k + ch];
-                    if (TONE) {
+                    if constexpr (TONE) {
                         float xin, t;
                         const float raw = val;
-                        val = tone_value(raw, tm[ch], k == 0 ? to[ch] : 0.0f, p.tone.pre_clamp, p.tone.post_clamp, xin, t);
-                        g = (t <= p.tone.post_clamp) ? g : 0.0f;
+                        val = tone_value(raw, tm[ch], k == 0 ? to[ch] : 0.0f, tone.pre_clamp, tone.post_clamp, xin, t);
+                        g = (t <= tone.post_clamp) ? g : 0.0f;
                         tdm[ch] += g * xin;
                         if (k == 0) tdo[ch] = g;
-                        g = (raw <= p.tone.pre_clamp) ? g * tm[ch] : 0.0f;
+                        g = (raw <= tone.pre_clamp) ? g * tm[ch] : 0.0f;
                     }
                     dsh[3 * k + ch] = g;
                     const float w = val * dRGB[ch];
@@ -336,14 +336,14 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
                     float bk = 0.f, dxk = 0.f, dyk = 0.f, dzk = 0.f;
                     if (k < ncoef && k < 16) { bk = B[k]; dxk = Dx[k]; dyk = Dy[k]; dzk = Dz[k]; }
                     float g = bk * dRGB[ch], val = sh[3 * k + ch];
-                    if (TONE) {
+                    if constexpr (TONE) {
                         float xin, t;
                         const float raw = val;
-                        val = tone_value(raw, tm[ch], k == 0 ? to[ch] : 0.0f, p.tone.pre_clamp, p.tone.post_clamp, xin, t);
-                        g = (t <= p.tone.post_clamp) ? g : 0.0f;
+                        val = tone_value(raw, tm[ch], k == 0 ? to[ch] : 0.0f, tone.pre_clamp, tone.post_clamp, xin, t);
+                        g = (t <= tone.post_clamp) ? g : 0.0f;
                         tdm[ch] += g * xin;
                         if (k == 0) tdo[ch] = g;
-                        g = (raw <= p.tone.pre_clamp) ? g * tm[ch] : 0.0f;
+                        g = (raw <= tone.pre_clamp) ? g * tm[ch] : 0.0f;
                     }
                     d[3 * k + ch] = g;
                     const float w = val * dRGB[ch];
@@ -368,11 +368,11 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
             float* d = dL_dsh + (size_t)idx * p.M * 3;
             for (int k = 0; k < p.M * 3; k++) d[k] = 0.f;
         }
-        if (TONE) {
+        if constexpr (TONE) {
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                if (p.tone.dL_dmul) p.tone.dL_dmul[3 * idx + ch] = tdm[ch];
-                if (p.tone.dL_doffset) p.tone.dL_doffset[3 * idx + ch] = tdo[ch];
+                if (tone.dL_dmul) tone.dL_dmul[3 * idx + ch] = tdm[ch];
+                if (tone.dL_doffset) tone.dL_doffset[3 * idx + ch] = tdo[ch];
             }
         }
     }
@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     }
 }
 
-hipError_t launch_preprocess_backward(const BwdParams& p, const GeometryState& g, const float* dL_dmean2D,
+hipError_t launch_preprocess_backward(const BwdParams& p, const ShTone& tone_in, const GeometryState& g, const float* dL_dmean2D,
                                       const float* dL_dconic, float* dL_dopacity, const float* dL_dcolor,
                                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                                       float* dL_drot, hipStream_t stream) {
@@ -401,20 +401,24 @@ hipError_t launch_preprocess_backward(const BwdParams& p, const GeometryState& g
     const bool fast = p.shs != nullptr && p.M == 16 && (reinterpret_cast<uintptr_t>(p.shs) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(dL_dsh) % 16 == 0);
     const bool sc = p.scales != nullptr;
-    const bool tone = p.tone.enabled && p.shs != nullptr;
-#define WG_LAUNCH(F, S, T)                                                                                                           \
-    hipLaunchKernelGGL((preprocess_backward_kernel<F, S, T>), grid, block, 0, stream, p, g.splats, g.clamped, dL_dmean2D, dL_dconic, \
-                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot)
+    const bool tone = tone_in.enabled && p.shs != nullptr;
+#define WG_LAUNCH(F, S)                                                                                                                  \
+    hipLaunchKernelGGL((preprocess_backward_kernel<F, S, false>), grid, block, 0, stream, p, g.splats, g.clamped, dL_dmean2D, dL_dconic, \
+                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, NoTone{})
+#define WG_LAUNCH_TONE(F, S)                                                                                                            \
+    hipLaunchKernelGGL((preprocess_backward_kernel<F, S, true>), grid, block, 0, stream, p, g.splats, g.clamped, dL_dmean2D, dL_dconic, \
+                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, tone_in)
     if (tone) {
-        if (fast && sc) WG_LAUNCH(true, true, true);
-        else if (fast) WG_LAUNCH(true, false, true);
-        else if (sc) WG_LAUNCH(false, true, true);
-        else WG_LAUNCH(false, false, true);
-    } else if (fast && sc) WG_LAUNCH(true, true, false);
-    else if (fast) WG_LAUNCH(true, false, false);
-    else if (sc) WG_LAUNCH(false, true, false);
-    else WG_LAUNCH(false, false, false);
+        if (fast && sc) WG_LAUNCH_TONE(true, true);
+        else if (fast) WG_LAUNCH_TONE(true, false);
+        else if (sc) WG_LAUNCH_TONE(false, true);
+        else WG_LAUNCH_TONE(false, false);
+    } else if (fast && sc) WG_LAUNCH(true, true);
+    else if (fast) WG_LAUNCH(true, false);
+    else if (sc) WG_LAUNCH(false, true);
+    else WG_LAUNCH(false, false);
 #undef WG_LAUNCH
+#undef WG_LAUNCH_TONE
     return hipGetLastError();
 }
 

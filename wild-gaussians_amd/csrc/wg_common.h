@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <type_traits>
 #include "../../include/wg_rasterizer.h"
 
 namespace wg {
@@ -106,6 +107,11 @@ __device__ __forceinline__ float tone_value(float raw, float m, float o, float p
     return fminf(t, post);
 }
 
+// kernel argument of the TONE instantiations only: the plain kernels keep the argument block (and the code) they had
+struct NoTone {};
+template <bool TONE>
+using ToneArg = typename std::conditional<TONE, ShTone, NoTone>::type;
+
 struct FwdParams {
     int P, D, M, W, H, gx, gy;
     const float* means3D;
@@ -121,11 +127,10 @@ struct FwdParams {
     const float* cam_pos;
     float tan_fovx, tan_fovy, focal_x, focal_y, kernel_size;
     int prefiltered;
-    ShTone tone;
 };
 
 // kernels / stages (each launches on `stream`, returns hipGetLastError())
-hipError_t launch_preprocess(const FwdParams& p, const GeometryState& g, int* radii_out, hipStream_t stream);
+hipError_t launch_preprocess(const FwdParams& p, const ShTone& tone, const GeometryState& g, int* radii_out, hipStream_t stream);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t stream);
 hipError_t run_scan(const GeometryState& g, int P, hipStream_t stream);
 hipError_t launch_duplicate_keys(int P, const GeometryState& g, const BinningState& b, int gx, hipStream_t stream);
@@ -175,9 +180,8 @@ struct BwdParams {
     const float* campos;
     float tan_fovx, tan_fovy, focal_x, focal_y, kernel_size;
     const int* radii;
-    ShTone tone;
 };
-hipError_t launch_preprocess_backward(const BwdParams& p, const GeometryState& g, const float* dL_dmean2D,
+hipError_t launch_preprocess_backward(const BwdParams& p, const ShTone& tone, const GeometryState& g, const float* dL_dmean2D,
                                       const float* dL_dconic, float* dL_dopacity, const float* dL_dcolor,
                                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                                       float* dL_drot, hipStream_t stream);

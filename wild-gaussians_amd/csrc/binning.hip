@@ -287,28 +287,35 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const us
     if (lists && tid < 8) band_cnt[chunk * 8 + tid] = bcnt[tid];
 }
 
-// Column scan: for each tile, exclusive prefix over the chunks.  Workgroup = 4 waves x 64 tiles; wave w owns a
-// quarter of the chunks, lane = tile (loads are 256-byte coalesced rows of chunk_hist).
-__global__ void __launch_bounds__(256) chunk_scan_kernel(uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ tile_count, int tiles) {
-    __shared__ uint32_t part[4][64];
+// Column scan: for each tile, exclusive prefix over the chunks.  Workgroup = 16 waves x 64 tiles; wave w owns a sixteenth of the
+// chunks, lane = tile (loads are 256-byte coalesced rows of chunk_hist).  The kernel is a chain of dependent row loads per
+// wave, so it is cut into many short chains (32 rows each, 8 loads in flight) rather than few long ones.
+constexpr int SCAN_WAVES = 16;
+__global__ void __launch_bounds__(64 * SCAN_WAVES) chunk_scan_kernel(uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ tile_count, int tiles) {
+    __shared__ uint32_t part[SCAN_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + lane;
-    constexpr int Q = BIN_CHUNKS / 4;
+    constexpr int Q = BIN_CHUNKS / SCAN_WAVES;
+    static_assert(Q % 8 == 0, "row batches of 8");
+    uint32_t v[Q];
     uint32_t sum = 0;
-    if (t < tiles)
-        for (int c = wave * Q; c < (wave + 1) * Q; c++) sum += chunk_hist[(size_t)c * tiles + t];
+    if (t < tiles) {
+#pragma unroll
+        for (int c = 0; c < Q; c++) v[c] = chunk_hist[(size_t)(wave * Q + c) * tiles + t];
+#pragma unroll
+        for (int c = 0; c < Q; c++) sum += v[c];
+    }
     part[wave][lane] = sum;
     __syncthreads();
     uint32_t run = 0;
     for (int w = 0; w < wave; w++) run += part[w][lane];
     if (t < tiles) {
-        for (int c = wave * Q; c < (wave + 1) * Q; c++) {
-            const size_t i = (size_t)c * tiles + t;
-            const uint32_t v = chunk_hist[i];
-            chunk_hist[i] = run;
-            run += v;
+#pragma unroll
+        for (int c = 0; c < Q; c++) {
+            chunk_hist[(size_t)(wave * Q + c) * tiles + t] = run;
+            run += v[c];
         }
-        if (wave == 3) tile_count[t] = run;
+        if (wave == SCAN_WAVES - 1) tile_count[t] = run;
     }
 }
 
@@ -708,7 +715,7 @@ hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& im
                        gx, tiles);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(chunk_scan_kernel, dim3((tiles + 63) / 64), dim3(256), 0, stream, img.chunk_hist, img.tile_count, tiles);
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3((tiles + 63) / 64), dim3(64 * SCAN_WAVES), 0, stream, img.chunk_hist, img.tile_count, tiles);
     return hipGetLastError();
 }
 

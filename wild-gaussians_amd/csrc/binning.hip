@@ -319,19 +319,25 @@ __global__ void __launch_bounds__(64 * SCAN_WAVES) chunk_scan_kernel(uint32_t* _
     }
 }
 
+// PER = tiles per thread, a compile-time bound so that a thread's counts are loaded together (the kernel is one workgroup on a
+// critical path: its duration is its chain of memory round trips) and kept in registers for the second pass.
+template <int PER>
 __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
                                                          uint2* __restrict__ ranges, BinStats* __restrict__ stats, int tiles,
                                                          HostMailbox* mailbox, uint32_t seq) {
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t wave_max[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (tiles + 1023) / 1024;
+    const int per = (tiles + 1023) / 1024;  // <= PER
     const int begin = tid * per, end = min(tiles, begin + per);
+    uint32_t cnt[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) cnt[k] = (k < per && begin + k < end) ? tile_count[begin + k] : 0u;
     uint32_t local = 0, lmax = 0;
-    for (int i = begin; i < end; i++) {
-        const uint32_t c = tile_count[i];
-        local += c;
-        lmax = max(lmax, c);
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        local += cnt[k];
+        lmax = max(lmax, cnt[k]);
     }
     // inclusive scan of `local` across the 1024 threads: wave scan, then scan of wave totals
     uint32_t incl = local;
@@ -351,14 +357,7 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
         total += wave_sum[w];
         gmax = max(gmax, wave_max[w]);
     }
-    uint32_t run = wave_base + incl - local;  // exclusive prefix of this thread's first tile
-    for (int i = begin; i < end; i++) {
-        const uint32_t c = tile_count[i];
-        tile_offset[i] = run;
-        ranges[i] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u);  // empty tiles stay (0,0) as after the reference's memset
-        run += c;
-    }
-    if (tid == 0) {
+    if (tid == 0) {  // first: the two numbers the host is waiting for (it launches the next kernels behind this one)
         tile_offset[tiles] = total;
         stats->num_rendered = total;
         stats->max_tile_count = gmax;
@@ -366,6 +365,16 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
             mailbox->num_rendered = total;
             mailbox->max_tile_count = gmax;
             __hip_atomic_store(&mailbox->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    uint32_t run = wave_base + incl - local;  // exclusive prefix of this thread's first tile
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        if (k < per && begin + k < end) {
+            const uint32_t c = cnt[k];
+            tile_offset[begin + k] = run;
+            ranges[begin + k] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u);  // empty tiles stay (0,0) as after the reference's memset
+            run += c;
         }
     }
 }
@@ -720,8 +729,13 @@ hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& im
 }
 
 hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, hipStream_t stream) {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges, img.stats, tiles,
-                       mailbox_dev, seq);
+    // BIN_MAX_TILES / 1024 = 36 tiles per thread at most; 8 covers 1080p (8160 tiles)
+    if (tiles <= 8 * 1024)
+        hipLaunchKernelGGL(tile_scan_kernel<8>, dim3(1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges, img.stats, tiles,
+                           mailbox_dev, seq);
+    else
+        hipLaunchKernelGGL((tile_scan_kernel<BIN_MAX_TILES / 1024>), dim3(1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges,
+                           img.stats, tiles, mailbox_dev, seq);
     return hipGetLastError();
 }
 

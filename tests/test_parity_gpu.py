@@ -290,6 +290,23 @@ def test_frame_with_more_tiles_than_the_lds_histogram_holds(oracle):
     assert c["max_err_solid"] <= 1e-4, c
 
 
+def test_frame_between_1080p_and_the_lds_limit(oracle):
+    """8192 < tiles <= 36864 (1440p .. 4K): the LDS binning path with more than eight tiles per thread in the tile scan."""
+    W, H, P = 2560, 1440, 30000  # 160 x 90 = 14400 tiles
+    cam = S.make_camera(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=None, seed=18, scale_mult=6.0)
+    cot = S.make_cotangent(W, H, seed=19)
+    o = oracle.run_scene(cloud, cam, sh_degree=0, cotangent=cot)
+    n = run_hip_native(cloud, cam, sh_degree=0)
+    assert n["num_rendered"] == o["num_rendered"]
+    np.testing.assert_array_equal(n["views"]["binning"]["point_list"].cpu().numpy().view(np.uint32), o["ctx"].get("point_list"))
+    np.testing.assert_array_equal(n["views"]["image"]["ranges"].cpu().numpy().view(np.uint32), o["ctx"].get("ranges"))
+    h = run_hip(cloud, cam, sh_degree=0, cotangent=cot)
+    assert (h["radii"] == o["radii"]).all()
+    assert compare_forward(h["color"], o)["max_err_solid"] <= 1e-4
+    assert max(compare_grads(h["grads"], o["grads"]).values()) <= 1e-3
+
+
 def test_huge_splats_cover_every_tile(oracle):
     """A few screen-filling Gaussians (rect = whole grid) mixed with small ones; saturating centre pixels."""
     W, H = 200, 136

@@ -579,11 +579,12 @@ def test_argument_sweep_against_the_oracle(oracle, i):
         assert e <= 1e-3, (i, k, e)
 
 
-@pytest.mark.parametrize("path", ["lazy_tiny_fronts", "staged_multi_pass", "global_sort"])
+@pytest.mark.parametrize("path", ["lazy_tiny_fronts", "staged_multi_pass", "global_sort", "band_lists"])
 @pytest.mark.parametrize("i", [0, 3, 5, 9, 14, 20, 23, 27])
 def test_argument_sweep_on_the_alternative_binning_paths(oracle, lazy_options, path, i):
     """The same sweep cases through the paths the defaults would not take at these sizes: lazy front sort with tiny fronts
-    (several fix-up rounds per tile), staged scatter forced into several passes, rocPRIM global sort."""
+    (several fix-up rounds per tile), staged scatter forced into several passes, rocPRIM global sort, the direct scatter reading
+    per-band candidate lists (the large-P path, forced on)."""
     from diff_gaussian_rasterization import _C
     cloud, cam, deg, kw, W, H = _sweep_case(i)
     cot = S.make_cotangent(W, H, seed=3000 + i)
@@ -594,6 +595,9 @@ def test_argument_sweep_on_the_alternative_binning_paths(oracle, lazy_options, p
         elif path == "staged_multi_pass":
             _C.set_option("staged_scatter", 1)
             _C.set_option("staged_scatter_cap", 7)
+        elif path == "band_lists":
+            _C.set_option("band_list_min_p", 1)
+            _C.set_option("staged_scatter", 0)
         else:
             _C.set_option("force_global_sort", 1)
         h = run_hip(cloud, cam, sh_degree=deg, cotangent=cot, **kw)
@@ -601,6 +605,7 @@ def test_argument_sweep_on_the_alternative_binning_paths(oracle, lazy_options, p
         _C.set_option("staged_scatter", -1)
         _C.set_option("staged_scatter_cap", 0)
         _C.set_option("force_global_sort", 0)
+        _C.set_option("band_list_min_p", 2000000)
     np.testing.assert_array_equal(h["radii"], o["radii"])
     c = compare_forward(h["color"], o)
     assert c["max_err_solid"] <= 1e-4, c

@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--in-kernel-tone", action="store_true",
                     help="SURVEY 8f N3: the appearance toning (clamp, * mul, + offset / C0, clamp; method.py:890-900, 1590-1595) inside the "
                          "preprocess kernels (sh_mul / sh_offset / sh_*_clamp_max) instead of P x 48 torch tensors; implies --in-kernel-sh")
+    ap.add_argument("--tall-linear", action="store_true",
+                    help="wg_fused_gaussians.tall_linear for the appearance MLP's three layers (weight gradients as a batched product over "
+                         "row chunks: plain PyTorch, a BLAS kernel-selection workaround for 3 M-row reductions)")
     ap.add_argument("--fused-ssim", action="store_true", help="SURVEY 8f N4: wg_fused_ssim.ssim instead of the conv2d-based ssim")
     args = ap.parse_args()
     import wg_scenes as S
@@ -103,6 +106,16 @@ def main():
     mlp = nn.Sequential(nn.Linear(3 + 24 + 32, 128), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 6)).to(dev)
     opt = torch.optim.Adam([{"params": [p], "lr": 1e-4} for p in prm.values()] + [{"params": mlp.parameters(), "lr": 5e-4}], eps=1e-15,
                            **({"fused": True} if args.fused_adam else {}))
+    if args.tall_linear:
+        from wg_fused_gaussians import tall_linear
+        layers = [m for m in mlp if isinstance(m, nn.Linear)]
+
+        def mlp_fn(x):
+            h = torch.relu(tall_linear(x, layers[0].weight, layers[0].bias))
+            h = torch.relu(tall_linear(h, layers[1].weight, layers[1].bias))
+            return tall_linear(h, layers[2].weight, layers[2].bias)
+    else:
+        mlp_fn = mlp
     gt = torch.rand(3, H, W, device=dev)
     zP = lambda: torch.zeros(P, 1, device=dev)
     stats = dict(xyz_grad=zP(), denom=zP(), max_radii2D=torch.zeros(P, device=dev), accum_abs=zP(), accum_abs_max=zP())
@@ -124,7 +137,7 @@ def main():
             shs = prm["features"].view(P, 16, 3)
             raw, radii, acc = rast_sh(shs=shs, sh_pre_clamp_max=1.0, **kw)
             inp = torch.cat((prm["features"][:, :3].clamp_max(1.0), prm["embeddings"], prm["image_embedding"][None].expand(P, -1)), dim=-1)
-            offset, mul = torch.split(mlp(inp) * 0.01, [3, 3], dim=-1)
+            offset, mul = torch.split(mlp_fn(inp) * 0.01, [3, 3], dim=-1)
             img, _, _ = rast_sh(shs=shs, sh_mul=mul, sh_offset=offset / C0, sh_pre_clamp_max=1.0, sh_post_clamp_max=1.0, **kw)
             return finish(img, raw, radii, means2D)
         feats = prm["features"].clamp_max(1.0)
@@ -135,7 +148,7 @@ def main():
             colors = sh_to_rgb(feats.view(P, 16, 3).transpose(1, 2), d)
             raw, radii, acc = rast(colors_precomp=colors, **kw)
         inp = torch.cat((feats[:, :3], prm["embeddings"], prm["image_embedding"][None].expand(P, -1)), dim=-1)
-        offset, mul = torch.split(mlp(inp) * 0.01, [3, 3], dim=-1)
+        offset, mul = torch.split(mlp_fn(inp) * 0.01, [3, 3], dim=-1)
         toned_f = feats * mul.repeat(1, 16) + torch.cat((offset / C0, torch.zeros(P, 45, device=dev)), dim=-1)
         if args.in_kernel_sh:
             img, _, _ = rast_sh(shs=toned_f.clamp_max(1.0).view(P, 16, 3), **kw)

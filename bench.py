@@ -50,6 +50,25 @@ def algorithmic_bytes(stage: str, P: int, V: int, R: int, N: int, tiles: int, M:
     return float(table[stage])
 
 
+def self_launch(n: int):
+    """`python bench.py --gpus N` without a launcher: replace this process by `torch.distributed.run` with N ranks of the same
+    command line (one process per GPU, rendezvous on 127.0.0.1, a free port).  With fewer than N devices visible (the 1-GPU test
+    box) the ranks share devices, which RCCL refuses: the collective transport falls back to gloo there and the JSON line says so."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    if torch.cuda.is_available() and torch.cuda.device_count() < n and "WG_DIST_BACKEND" not in env:
+        env["WG_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (parity + CPU timing)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events in the timed region")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)   # does not return
 
     import wg_scenes as S
     import wg_viewparallel as VP
@@ -74,7 +95,8 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the rasterizer has no CPU path")
     rank, local_rank, world = VP.init()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         f"or without a launcher (bench.py starts its own ranks)")
     device = torch.device("cuda", local_rank)
 
     W, H, P = args.width, args.height, args.gaussians
@@ -111,13 +133,17 @@ def main():
         with torch.no_grad():
             return call()[0]
 
-    def timed(fn, steps):
+    t_train_local = [0.0]
+
+    def timed(fn, steps, keep=None):
         VP.barrier()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
         torch.cuda.synchronize(device)
+        if keep is not None:
+            keep[0] = time.perf_counter() - t0   # this rank's own time, before waiting for the others
         VP.barrier()
         return VP.max_over_ranks(time.perf_counter() - t0, device)
 
@@ -128,7 +154,7 @@ def main():
     torch.cuda.synchronize(device)
     # timed region: exactly K steps, no instrumentation inside (recording a HIP event costs ~15 us on this stack, and a
     # step would carry 16 of them)
-    t_train = timed(train_step, args.steps)
+    t_train = timed(train_step, args.steps, keep=t_train_local)
     # per-stage durations: the same K steps once more with a pair of HIP events recorded around every stage, on the stream
     # the kernels are launched on (wg_profile_* in the C-ABI library)
     stages = {}
@@ -171,6 +197,10 @@ def main():
         walked = int(tile_last.sum().item())
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
 
+    # who took part: an all-gather of (rank, device index, this rank's own ms/step) over the job's collective backend
+    my_ms = 1000.0 * t_train_local[0] / args.steps
+    ranks_seen = VP.gather_over_ranks([float(rank), float(local_rank), my_ms], device)
+
     iters_per_s = world * args.steps / t_train
     fwd_fps = world * args.steps / t_fwd
     out = {
@@ -184,6 +214,10 @@ def main():
         "ms_per_step": round(1000.0 * t_train / args.steps, 4),
         "higher_is_better": True,
         "scaling": "weak",
+        "collective_backend": VP.backend_name(),
+        "rccl_ranks_seen": sorted(int(r[0]) for r in ranks_seen),
+        "per_rank_ms_per_step": {str(int(r[0])): round(r[2], 4) for r in ranks_seen},
+        "per_rank_device": {str(int(r[0])): int(r[1]) for r in ranks_seen},
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",

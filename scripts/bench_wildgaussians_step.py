@@ -60,6 +60,53 @@ def ssim_map(a, b):  # 11x11 Gaussian window, sigma 1.5, per channel
     return ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s1 + s2 + c2))
 
 
+def real_caller(args):
+    """BASELINE config 3 with the reference's real caller: K `train_iteration` steps, unchanged call pattern."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "real_caller"))
+    import harness
+    P, W, H = args.gaussians, args.width, args.height
+    m, wg = harness.make_method(P, W, H, n_cams=args.cameras, cloud_shapes="bench", gt="random")
+    wg.model.active_sh_degree.fill_(3)   # the state a trained model is in (oneupSHdegree every 1000 iterations, method.py:1896)
+    losses = []
+    for i in range(args.warmup):
+        losses.append(wg.train_iteration(i)["loss"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        losses.append(wg.train_iteration(i)["loss"])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    # the operator's share: replay the two rasterizer calls of one step (tapped inputs) forward + backward, alone
+    cam = wg.train_cameras[0]
+    with harness.RasterizerTap(m) as tap:
+        wg.model._render_internal(cam, config=wg.config, embedding=wg.model.get_embedding(0), kernel_size=wg.config.kernel_size)
+    calls = tap.calls
+    rast = m.GaussianRasterizer(raster_settings=calls[0]["settings"])
+    cot = torch.randn(3, H, W, device="cuda") / (3 * H * W)
+
+    def op_only():
+        outs = []
+        for c in calls:
+            kw = {k: (v.clone().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in c["kwargs"].items()}
+            outs.append(rast(**kw)[0])
+        sum(outs).backward(cot)
+    for _ in range(3):
+        op_only()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        op_only()
+    torch.cuda.synchronize()
+    dop = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"workload": f"REAL caller: wildgaussians/method.py WildGaussians.train_iteration unchanged (staged copy, sha256-verified), "
+                                  f"{P} Gaussians + appearance MLP, {W}x{H}, {args.cameras} cameras, default.yml with uncertainty_mode=disabled, "
+                                  "num_sky_gaussians=0, active SH degree 3",
+                      "train_step_ms": round(dt * 1e3, 3), "train_steps_per_s": round(1.0 / dt, 2),
+                      "rasterizer_only_ms (2 fwd + 2 bwd, incl. input clones)": round(dop * 1e3, 3), "rasterizer_share": round(dop / dt, 3),
+                      "rasterizer_calls_per_step": len(calls), "visible": int((calls[0]["out"][1] > 0).sum().item()),
+                      "num_gaussians": int(len(wg.model.xyz)), "loss_first": losses[0], "loss_last": losses[-1]}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gaussians", type=int, default=3_000_000)
@@ -81,7 +128,13 @@ def main():
                     help="wg_fused_gaussians.tall_linear for the appearance MLP's three layers (weight gradients as a batched product over "
                          "row chunks: plain PyTorch, a BLAS kernel-selection workaround for 3 M-row reductions)")
     ap.add_argument("--fused-ssim", action="store_true", help="SURVEY 8f N4: wg_fused_ssim.ssim instead of the conv2d-based ssim")
+    ap.add_argument("--real-caller", action="store_true",
+                    help="run the reference's OWN `WildGaussians.train_iteration` (method.py:1880-2024, staged unchanged by "
+                         "tests/real_caller/stage_reference_caller.py) instead of the restated step; none of the opt-ins apply")
+    ap.add_argument("--cameras", type=int, default=4)
     args = ap.parse_args()
+    if args.real_caller:
+        return real_caller(args)
     import wg_scenes as S
     from diff_gaussian_rasterization import GaussianRasterizer
     from tests.wg_testlib import make_settings, to_dev

@@ -178,6 +178,8 @@ def _vp_worker(rank, world, port, q):
     loss = VP.allreduce_loss(torch.tensor([local], dtype=torch.float32))
     VP.barrier()
     slowest = VP.max_over_ranks(float(r + 1), torch.device("cpu"))
+    seen = VP.gather_over_ranks([float(r), 10.0 * r], torch.device("cpu"))
+    assert seen == [[0.0, 0.0], [1.0, 10.0]] and VP.backend_name() == "gloo"
     q.put((r, float(loss.item()), local, slowest))
     torch.distributed.destroy_process_group()
 
@@ -203,6 +205,26 @@ def test_view_parallel_loss_allreduce_world2_gloo(oracle):
         assert abs(total - serial) <= 1e-5 * abs(serial) + 1e-9
         assert slowest == 2.0
     assert abs(sum(l for _, _, l, _ in res) - serial) <= 1e-5 * abs(serial) + 1e-9
+
+
+def test_bench_self_launch_builds_the_launcher_command(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE re-executes itself under torch.distributed.run with N ranks on 127.0.0.1."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_execve(exe, argv, env):
+        seen.update(exe=exe, argv=argv, env=env)
+        raise SystemExit(0)
+    monkeypatch.setattr(os, "execve", fake_execve)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit):
+        bench.main()
+    a = seen["argv"]
+    assert a[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in a and a[a.index("--nproc-per-node") + 1] == "4"
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and a[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert a[-5] == os.path.join(ROOT, "bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
 def test_bench_byte_model():

@@ -712,9 +712,9 @@ def test_bench_flow_with_two_ranks(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, WG_DIST_BACKEND="gloo")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+    # the driver's own form: no launcher, bench.py starts its ranks itself (and, finding one device for two ranks, picks gloo)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "WG_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
                         "--gaussians", "200000", "--width", "640", "--height", "360"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -723,6 +723,9 @@ def test_bench_flow_with_two_ranks(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
     assert d["config"]["views_per_step"] == 2 and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["rccl_ranks_seen"] == [0, 1] and set(d["per_rank_ms_per_step"]) == {"0", "1"}
+    assert d["collective_backend"] == ("gloo" if torch.cuda.device_count() < 2 else "nccl")
+    assert max(d["per_rank_ms_per_step"].values()) <= d["ms_per_step"] * 1.001
     assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) <= 1e-2 * d["value"]  # whole-job rate: both ranks' steps over the slowest rank's time
 
 

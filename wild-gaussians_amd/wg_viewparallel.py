@@ -79,3 +79,18 @@ def sum_over_ranks(value: float, device) -> float:
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_over_ranks(values, device):
+    """All-gather of a short float vector: one row per rank (bench.py's "who took part" record)."""
+    t = torch.tensor(values, dtype=torch.float64, device="cpu" if _host_side() else device)
+    if dist.is_available() and dist.is_initialized():
+        out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, t)
+        return [o.cpu().tolist() for o in out]
+    return [t.cpu().tolist()]
+
+
+def backend_name() -> str:
+    """"nccl" is RCCL on ROCm; "none" for a single process."""
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else "none"

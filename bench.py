@@ -50,6 +50,52 @@ def algorithmic_bytes(stage: str, P: int, V: int, R: int, N: int, tiles: int, M:
     return float(table[stage])
 
 
+def design_bytes(stage: str, P: int, V: int, R: int, N: int, tiles: int, M: int, sh: bool, walked: int) -> float:
+    """Bytes THIS design's kernel of the stage has to move at least once: the 48-byte splat record, 4-byte bucket
+    entries, only the instances the compositing walks actually reach (`walked` = sum of tile_last).  Every datum counted once per
+    kernel, so this can never exceed what the HBM delivers; the PMC traffic is at or above it."""
+    c_in = 12 * M if sh else 12
+    hist = 512 * tiles * 4   # chunk x tile histograms of the LDS counting sort (BIN_CHUNKS = 512)
+    table = {
+        "preprocess": P * (44 + c_in) + 8 * P + V * (4 + 48 + 8 + 24),
+        "scan": 8 * P + 3 * hist + 16 * tiles,            # rects in; histograms written, column-scanned in place, read by the tile scan
+        "duplicate_keys": 8 * P + hist + 4 * R,           # rects + chunk bases in; one 4-byte bucket entry per instance out
+        "sort": 4 * R + 4 * V + 4 * R,                    # bucket in, one depth per visible Gaussian, point_list out
+        "tile_ranges": 8 * tiles,
+        "render_forward": 4 * walked + 48 * V + 28 * N + 12 * tiles,
+        "render_backward": 4 * walked + 48 * V + 28 * N + 40 * V,   # + one 10-float accumulator update per visible Gaussian
+        "preprocess_backward": V * (100 + 40) + V * 90 + P * (12 + 12 + 16 + 4) + (24 * M * V if sh else 0),
+    }
+    return float(table[stage])
+
+
+def kernel_source_sha() -> str:
+    """Hash of every kernel source + the build flags: stamps profiles/pmc_traffic.json to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "wild-gaussians_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../build.py"]:
+        if f.endswith((".hip", ".h", ".py")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(workload_key: str):
+    """PMC HBM traffic per stage (separate rocprofv3 --pmc passes, scripts/profile_gpu.sh), only when it was collected on this very
+    workload AND on these very kernel sources; otherwise {} and the reason."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pt = json.load(f)
+    except (OSError, ValueError):
+        return {}, "profiles/pmc_traffic.json missing"
+    if pt.get("workload") != workload_key:
+        return {}, f"pmc_traffic.json is for another workload ({pt.get('workload')})"
+    if pt.get("kernel_source_sha") != kernel_source_sha():
+        return {}, f"pmc_traffic.json is stale: measured on kernel sources {pt.get('kernel_source_sha')}, these are {kernel_source_sha()}"
+    return pt.get("stages", {}), f"pmc passes of {pt.get('collected', '?')} on kernel sources {pt.get('kernel_source_sha')}"
+
+
 def self_launch(n: int):
     """`python bench.py --gpus N` without a launcher: replace this process by `torch.distributed.run` with N ranks of the same
     command line (one process per GPU, rendezvous on 127.0.0.1, a free port).  With fewer than N devices visible (the 1-GPU test
@@ -82,6 +128,8 @@ def main():
     ap.add_argument("--forward-only", action="store_true", help="stress mode: time only the forward pass (e.g. 10M Gaussians @ 4K)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (parity + CPU timing)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events in the timed region")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="wg_set_option(NAME, VALUE) before the run (A/B of library options, e.g. grad_record=0); recorded in the JSON line")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)   # does not return
@@ -93,6 +141,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the rasterizer has no CPU path")
+    for kv in args.option:
+        k, v = kv.split("=", 1)
+        _C.set_option(k, int(v))
     rank, local_rank, world = VP.init()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
@@ -202,10 +253,13 @@ def main():
     ranks_seen = VP.gather_over_ranks([float(rank), float(local_rank), my_ms], device)
 
     iters_per_s = world * args.steps / t_train
+    pl = f"{P // 1_000_000}M" if P % 1_000_000 == 0 and P >= 1_000_000 else (f"{P // 1000}k" if P % 1000 == 0 else str(P))
+    size_label = f"{pl} Gaussians @{'1080p' if (W, H) == (1920, 1080) else '4K' if (W, H) == (3840, 2160) else f'{W}x{H}'}" + \
+                 ("" if args.scale_mult == 1.0 else f", scales x{args.scale_mult:g}")
     fwd_fps = world * args.steps / t_fwd
     out = {
-        "metric": ("forward_fps (forward only)" if args.forward_only else
-                   "train_iters_per_s (fwd+bwd of the rasterizer, 1M Gaussians @1080p)"),
+        "metric": (f"forward_fps (forward only, {size_label})" if args.forward_only else
+                   f"train_iters_per_s (fwd+bwd of the rasterizer, {size_label})"),
         "value": round(iters_per_s, 3),
         "unit": "iter/s",
         "n_gpus": world,
@@ -231,6 +285,8 @@ def main():
         "step_ms_quantiles": step_q,
         "forward_ms_quantiles": fwd_q,
         "workload_stats": {"P": P, "V": V, "R": int(R), "N": N, "tiles": tiles, "instances_walked": walked},
+        "library": {"version": _C.version(), "path": os.path.relpath(_C._LIB_PATH, ROOT), "options": args.option,
+                    "kernel_source_sha": kernel_source_sha()},
     }
 
     if stages:
@@ -239,61 +295,62 @@ def main():
         out["stages_note"] = ("HIP-event pairs around each stage over a second timed pass of the same K steps "
                               f"({round(1000.0 * t_train_profiled / args.steps, 4)} ms/step with the events in)")
         dom = max(stages, key=lambda k: stages[k][0])
-        B = algorithmic_bytes(dom, P, V, int(R), N, tiles, M, args.colors == "sh")
-        ach = B / (per_stage[dom] * 1e-3) / 1e9 if per_stage[dom] > 0 else 0.0
-        # HBM traffic per launch from PMC counters: taken in separate rocprofv3 --pmc passes (scripts/profile_gpu.sh) and
-        # committed as profiles/pmc_traffic.json; used only when it was collected on this very workload
-        traffic, valu = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pt = json.load(f)
-            if args.scale_mult == 1.0 and pt.get("workload") == f"{P} Gaussians, {W}x{H}, {args.colors}" and dom in pt["stages"]:
-                traffic = pt["stages"][dom]["hbm_bytes"]
-                valu = pt["stages"][dom].get("SQ_INSTS_VALU")
-        except (OSError, ValueError, KeyError):
-            pass
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "algorithmic_bytes_per_launch": B, "avg_launch_ms": round(per_stage[dom], 4)}
-        if valu and per_stage[dom] > 0:
+        is_sh = args.colors == "sh"
+        kw = dict(P=P, V=V, R=int(R), N=N, tiles=tiles, M=M, sh=is_sh)
+        pmc, pmc_note = load_pmc(f"{P} Gaussians, {W}x{H}, {args.colors}" + ("" if args.scale_mult == 1.0 else f", scales x{args.scale_mult:g}"))
+
+        # Three byte counts per stage, each divided by the stage's HIP-event time of THIS run:
+        #   hbm_traffic     PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950 correction), when stamped to these sources
+        #   design          what this design's kernel must move at least once (walked instances, 48-B records): <= peak by construction
+        #   survey_8d       SURVEY 8(d)'s formula of the REFERENCE scheme (R-based, 6 radix passes...): an equivalent rate, which
+        #                   exceeds the peak wherever this design avoids the reference's traffic -- reported, never called a fraction
+        def row_of(k):
+            ms = per_stage[k]
+            t = ms * 1e-3
+            row = {"ms": round(ms, 4), "design_GBps": round(design_bytes(k, walked=walked, **kw) / t / 1e9, 1),
+                   "reference_scheme_equiv_GBps": round(algorithmic_bytes(k, **kw) / t / 1e9, 1)}
+            row["frac_of_peak_by_design_bytes"] = round(row["design_GBps"] / HBM_PEAK_GBS, 4)
+            if k in pmc:
+                row["hbm_traffic_GBps"] = round(pmc[k]["hbm_bytes"] / t / 1e9, 1)
+                row["frac_of_peak_by_traffic"] = round(row["hbm_traffic_GBps"] / HBM_PEAK_GBS, 4)
+                if pmc[k].get("SQ_INSTS_VALU"):
+                    row["frac_of_valu_issue_peak"] = round(pmc[k]["SQ_INSTS_VALU"] / t / 1e9 / VALU_ISSUE_PEAK_G, 3)
+            return row
+        rows = {k: row_of(k) for k, ms in per_stage.items() if ms > 0 and k != "render_fixup"}
+        out["stage_rooflines"] = rows
+        out["stage_rooflines_note"] = pmc_note
+
+        d = rows[dom]
+        by_traffic = "hbm_traffic_GBps" in d
+        ach = d["hbm_traffic_GBps"] if by_traffic else d["design_GBps"]
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 4),
+                           "frac_basis": "pmc hbm traffic / event time" if by_traffic else "design bytes / event time (no valid PMC pass for these sources)",
+                           "traffic": pmc[dom]["hbm_bytes"] if by_traffic else None,
+                           "design_bytes_per_launch": design_bytes(dom, walked=walked, **kw),
+                           "frac_by_design_bytes": d["frac_of_peak_by_design_bytes"],
+                           "survey_8d_bytes_per_launch": algorithmic_bytes(dom, **kw),
+                           "survey_8d_equiv_GBps": d["reference_scheme_equiv_GBps"],
+                           "avg_launch_ms": round(per_stage[dom], 4)}
+        if "frac_of_valu_issue_peak" in d:
             # what actually bounds this kernel: VALU issue.  SQ_INSTS_VALU per launch (PMC pass) / this run's time.
-            g = valu / (per_stage[dom] * 1e-3) / 1e9
-            out["roofline"]["valu_issue"] = {"wave_instructions_per_launch": valu, "achieved": round(g, 1), "peak": round(VALU_ISSUE_PEAK_G, 1),
-                                             "unit": "G wave-instr/s", "frac": round(g / VALU_ISSUE_PEAK_G, 3),
+            out["roofline"]["valu_issue"] = {"wave_instructions_per_launch": pmc[dom]["SQ_INSTS_VALU"], "peak": round(VALU_ISSUE_PEAK_G, 1),
+                                             "unit": "G wave-instr/s", "frac": d["frac_of_valu_issue_peak"],
                                              "note": "SQ_INSTS_VALU counts every VALU issue; a few kinds (readlane, DPP moves) take fewer than 4 "
                                                      "cycles, so a kernel at the ceiling can read above 1"}
         # whole forward / backward pipelines against the same roofline, for context
         fwd_names = ["preprocess", "scan", "duplicate_keys", "sort", "tile_ranges", "render_forward"]
         bwd_names = ["render_backward", "preprocess_backward"]
-        Bf = sum(algorithmic_bytes(k, P, V, int(R), N, tiles, M, args.colors == "sh") for k in fwd_names)
-        Bb = sum(algorithmic_bytes(k, P, V, int(R), N, tiles, M, args.colors == "sh") for k in bwd_names)
         tf = sum(per_stage[k] for k in fwd_names)
         tb = sum(per_stage[k] for k in bwd_names)
-        out["pipeline_roofline"] = {"forward_GBps": round(Bf / (tf * 1e-3) / 1e9, 1) if tf else None,
-                                    "backward_GBps": round(Bb / (tb * 1e-3) / 1e9, 1) if tb else None,
-                                    "forward_kernel_ms": round(tf, 4), "backward_kernel_ms": round(tb, 4)}
-
-        # every stage against the HBM roofline: by algorithmic bytes and, where profiles/pmc_traffic.json was collected on this
-        # workload, by the PMC-measured traffic (the streaming kernels sit at 55-75 % of peak; the render kernels are VALU-bound)
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pt = json.load(f)
-            pmc = pt["stages"] if args.scale_mult == 1.0 and pt.get("workload") == f"{P} Gaussians, {W}x{H}, {args.colors}" else {}
-        except (OSError, ValueError, KeyError):
-            pmc = {}
-        rows = {}
-        for k, ms in per_stage.items():
-            if ms <= 0 or k == "render_fixup":
-                continue
-            Bk = algorithmic_bytes(k, P, V, int(R), N, tiles, M, args.colors == "sh")
-            row = {"ms": round(ms, 4), "algorithmic_GBps": round(Bk / (ms * 1e-3) / 1e9, 1)}
-            if k in pmc:
-                row["hbm_traffic_GBps"] = round(pmc[k]["hbm_bytes"] / (ms * 1e-3) / 1e9, 1)
-                row["frac_of_peak_by_traffic"] = round(row["hbm_traffic_GBps"] / HBM_PEAK_GBS, 3)
-                if pmc[k].get("SQ_INSTS_VALU"):
-                    row["frac_of_valu_issue_peak"] = round(pmc[k]["SQ_INSTS_VALU"] / (ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK_G, 3)
-            rows[k] = row
-        out["stage_rooflines"] = rows
+        pipe = {"forward_kernel_ms": round(tf, 4), "backward_kernel_ms": round(tb, 4)}
+        for nm, names, tt in (("forward", fwd_names, tf), ("backward", bwd_names, tb)):
+            if tt > 0:
+                pipe[nm + "_design_GBps"] = round(sum(design_bytes(k, walked=walked, **kw) for k in names) / (tt * 1e-3) / 1e9, 1)
+                pipe[nm + "_reference_scheme_equiv_GBps"] = round(sum(algorithmic_bytes(k, **kw) for k in names) / (tt * 1e-3) / 1e9, 1)
+                if all(k in pmc for k in names if per_stage[k] > 0 and k != "tile_ranges"):
+                    pipe[nm + "_hbm_traffic_GBps"] = round(sum(pmc[k]["hbm_bytes"] for k in names if k in pmc) / (tt * 1e-3) / 1e9, 1)
+        out["pipeline_roofline"] = pipe
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.forward_only:
         # CPU leg: the oracle (a CPU port of the reference's algorithm) on the same workload, timed on the host

@@ -93,9 +93,13 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user,
 
 /*
  * Rasterizer::backward (rasterizer.h:61-88, rasterizer_impl.cu:344-443).
- * The reference requires all nine gradient outputs zero-filled by the caller (rasterize_points.cu:157-165).  Here only
- * the four accumulation targets of the per-tile pass -- dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor -- must be
- * zero on entry; dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot are fully overwritten (zeros for culled Gaussians).
+ * The reference requires all nine gradient outputs zero-filled by the caller (rasterize_points.cu:157-165).  Here, by default
+ * (option "grad_record" = 1), ALL nine are fully overwritten (zeros for culled Gaussians): the per-tile pass accumulates into a
+ * 64-byte record per Gaussian inside geom_buffer, which this call clears itself, and the per-Gaussian kernel writes dL_dmean2D,
+ * dL_dconic, dL_dopacity and dL_dcolor from it -- a caller following the reference's protocol (zeroed buffers) gets the same
+ * values.  dL_dconic (an intermediate of the reference) and, with SH colours, dL_dcolor (the gradient of the evaluated RGB, an
+ * intermediate there) may then be NULL: they are not written.  With "grad_record" = 0 those four ARE the accumulation targets,
+ * none may be NULL and all must be zero on entry.
  * dL_dconic is float[P*4], 16-byte aligned (2x2 per Gaussian; [0],[1],[3] used), dL_dmean2D float[P*3]
  * (x, y in NDC-scaled units, z = abs-gradient, backward.cu:590-595).  dL_dsh may be NULL when M == 0.
  */
@@ -235,6 +239,9 @@ const char* wg_stage_name(int stage);
  * bits, what the ids leave free) above the id, so that the front extraction fetches exact depths only near its bounds; 0
  * exercises the uncoded path, 8..12 force a width (not wider than the ids allow). */
 int wg_set_option(const char* name, int value);
+/* Current value of an option ("grad_record", "force_global_sort", "host_mailbox", "lazy_sort", "depth_codes"); -1 = unknown name.
+ * "grad_record" (1/0, default 1): see wg_rasterize_backward. */
+int wg_get_option(const char* name);
 
 const char* wg_status_string(int status);
 const char* wg_last_hip_error(void);

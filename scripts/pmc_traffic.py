@@ -6,11 +6,18 @@ FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read,
 byte count; WRITE_SIZE (and narrow / gather access patterns) are uncalibrated and taken as reported.
 usage: pmc_traffic.py pmc_summary.txt "<workload string>" > profiles/pmc_traffic.json"""
 import json
+import os
 import re
+import subprocess
 import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 STAGE_OF = {"preprocess_kernel": "preprocess", "tile_count_kernel": "scan", "chunk_scan_kernel": "scan", "tile_scan_kernel": "scan",
-            "tile_scatter_kernel": "duplicate_keys", "tile_sort_kernel": "sort", "render_forward_kernel": "render_forward",
+            "tile_scatter_kernel": "duplicate_keys", "tile_scatter_staged_kernel": "duplicate_keys", "tile_sort_kernel": "sort",
+            "tile_front_sort_kernel": "sort", "render_fixup_kernel": "render_fixup", "tile_order_kernel": "tile_ranges", "render_forward_kernel": "render_forward",
             "render_backward_kernel": "render_backward", "preprocess_backward_kernel": "preprocess_backward"}
 vals = {}
 for line in open(sys.argv[1]):
@@ -23,6 +30,11 @@ for line in open(sys.argv[1]):
         key = m.group(2) + "_KiB" if m.group(2).endswith("_SIZE") else m.group(2)  # SQ_INSTS_*: wave-instructions per launch
         d = vals.setdefault(st, {"FETCH_SIZE_KiB": 0, "WRITE_SIZE_KiB": 0})
         d[key] = d.get(key, 0) + int(m.group(3))
-out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving; WRITE_SIZE as reported)",
+try:
+    import bench
+    src_sha = bench.kernel_source_sha()
+except Exception:  # noqa: BLE001
+    src_sha = None
+out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "kernel_source_sha": src_sha, "collected": time.strftime("%Y-%m-%d"), "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving; WRITE_SIZE as reported)",
        "stages": {k: dict(v, hbm_bytes=(2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024) for k, v in vals.items()}}
 print(json.dumps(out, indent=1))

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): kernel trace + PMC passes for bench.py, summaries into gpurun_out/<tag>/.
-# usage: scripts/profile_gpu.sh <tag> [extra bench args]
+# usage: [WORKLOAD="<P> Gaussians, <W>x<H>, <sh|precomp>[, scales x<m>]"] scripts/profile_gpu.sh <tag> [extra bench args]
+# WORKLOAD is the key bench.py looks profiles/pmc_traffic.json up by (default: the headline scene).
 set -u
 TAG=${1:-prof}; shift || true
 cd /tmp && export TMPDIR=/tmp
@@ -23,4 +24,4 @@ for CS in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_B
 done
 rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4
 cat $OUT/kernel_trace_summary.txt | cut -c1-150 | head -16
-python scripts/pmc_traffic.py $OUT/pmc_summary.txt "1000000 Gaussians, 1920x1080, sh" > $OUT/pmc_traffic.json; cat $OUT/pmc_traffic.json
+python scripts/pmc_traffic.py $OUT/pmc_summary.txt "${WORKLOAD:-1000000 Gaussians, 1920x1080, sh}" > $OUT/pmc_traffic.json; head -c 600 $OUT/pmc_traffic.json

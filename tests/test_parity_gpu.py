@@ -100,8 +100,8 @@ def test_forward_rgb_parity(oracle, name):
     c = compare_forward(h["color"], o)
     assert c["max_err_solid"] <= 1e-4, c
     assert c["n_fragile"] <= 0.01 * c["n_pixels"], c           # the margin thresholds leave >= 99% of pixels strict
-    assert c["n_over_in_fragile"] <= max(3, 2e-4 * c["n_pixels"]), c  # and only a handful of those actually flip
-    assert c["max_err_all"] <= 2e-2, c
+    assert c["n_over_in_fragile"] <= max(3, 1e-5 * c["n_pixels"]), c  # and only a handful of those actually flip (observed: ~2 ppm)
+    assert c["max_err_all"] <= 5e-3, c                                # a flipped decision moves a pixel by at most ~4e-3
     # accumulation = 1 - final_T
     acc_ref = 1.0 - o["ctx"].get("final_T")
     ok = np.abs(h["accumulation"] - acc_ref) <= 1e-4
@@ -136,7 +136,8 @@ def test_config2_500k_1080p_sh3_fwd_bwd(oracle):
     np.testing.assert_array_equal(h["radii"], o["radii"])
     c = compare_forward(h["color"], o)
     assert c["max_err_solid"] <= 1e-4, c
-    assert c["n_over_in_fragile"] <= 2e-4 * c["n_pixels"], c
+    assert c["n_over_in_fragile"] <= max(3, 1e-5 * c["n_pixels"]), c
+    assert c["max_err_all"] <= 5e-3, c
     errs = compare_grads(h["grads"], o["grads"])
     for k, e in errs.items():
         assert e <= 1e-3, (k, e, errs)
@@ -763,3 +764,85 @@ def test_input_layouts_and_partial_gradients():
     # host tensors: a clear error, never a silent CPU path
     with pytest.raises(RuntimeError, match="no CPU path"):
         rast(**{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in kw.items()})
+
+
+@pytest.fixture()
+def record_option():
+    from diff_gaussian_rasterization import _C
+    yield _C
+    _C.set_option("grad_record", 1)
+
+
+def test_gradient_record_and_in_place_accumulation_agree(oracle, record_option):
+    """wg_set_option("grad_record"): the per-tile backward accumulating into one 48-byte record per Gaussian (default; the
+    per-Gaussian kernel applies the factors and writes the four arrays) against accumulating into the arrays themselves."""
+    _C = record_option
+    W, H, P = 400, 240, 20000
+    cam, cot = S.make_camera(W, H), S.make_cotangent(W, H)
+    for deg, sm in ((2, 2.0), (None, 5.0)):
+        cloud = S.make_cloud(P, W, H, sh_degree=deg, seed=5, scale_mult=sm)
+        assert _C.get_option("grad_record") == 1
+        a = run_hip(cloud, cam, sh_degree=deg or 0, cotangent=cot, bg=np.array([0.3, 0.1, 0.6], np.float32))
+        _C.set_option("grad_record", 0)
+        b = run_hip(cloud, cam, sh_degree=deg or 0, cotangent=cot, bg=np.array([0.3, 0.1, 0.6], np.float32))
+        _C.set_option("grad_record", 1)
+        assert set(a["grads"]) == set(b["grads"])
+        for k in a["grads"]:
+            assert rel_err(a["grads"][k], b["grads"][k]) <= 2e-6, k
+        o = oracle.run_scene(cloud, cam, sh_degree=deg or 0, cotangent=cot, bg=np.array([0.3, 0.1, 0.6], np.float32))
+        for k, e in compare_grads(a["grads"], o["grads"]).items():
+            assert e <= 1e-3, (k, e)
+
+
+def test_c_abi_backward_overwrites_its_outputs_and_returns_the_intermediates_on_request(oracle):
+    """include/wg_rasterizer.h: with the gradient record every output of wg_rasterize_backward is overwritten (buffers full of
+    garbage on entry give the same result), and dL_dconic -- the reference's intermediate, backward.cu:598-600 -- is written when
+    asked for; values against the oracle's."""
+    import ctypes as C
+    from diff_gaussian_rasterization import _C
+    W, H, P = 320, 200, 6000
+    cam, cot = S.make_camera(W, H), S.make_cotangent(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=None, seed=9, scale_mult=4.0)
+    o = oracle.run_scene(cloud, cam, sh_degree=0, cotangent=cot)
+    n = run_hip_native(cloud, cam, sh_degree=0)
+    gb, bb, ib = n["buffers"]
+    t = {k: to_dev(v) for k, v in cloud.items()}
+    rs = make_settings(cam, 0)
+    junk = lambda *shape: torch.full(shape, 7.5, device="cuda")
+    g2d, gcon, gop, gcol, g3d, gcov, gsc, grot = junk(P, 3), junk(P, 4), junk(P, 1), junk(P, 3), junk(P, 3), junk(P, 6), junk(P, 3), junk(P, 4)
+    dp = lambda x: C.c_void_p(x.data_ptr())
+    st = _C._lib.wg_rasterize_backward(
+        P, 0, 0, int(n["num_rendered"]), dp(rs.bg), W, H, dp(t["means3D"]), None, dp(t["colors_precomp"]), dp(t["scales"]), 1.0,
+        dp(t["rotations"]), None, dp(rs.viewmatrix), dp(rs.projmatrix), dp(rs.campos), rs.tanfovx, rs.tanfovy, rs.kernel_size,
+        dp(rs.subpixel_offset), dp(n["radii"]), gb.data_ptr(), bb.data_ptr(), ib.data_ptr(), dp(to_dev(cot)), dp(g2d), dp(gcon), dp(gop),
+        dp(gcol), dp(g3d), dp(gcov), None, dp(gsc), dp(grot), 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0
+    torch.cuda.synchronize()
+    got = dict(means2D=g2d, opacities=gop, colors_precomp=gcol, means3D=g3d, scales=gsc, rotations=grot, cov3Ds_precomp=gcov)
+    errs = compare_grads({k: v.cpu().numpy() for k, v in got.items()}, o["grads"])
+    for k, e in errs.items():
+        assert e <= 1e-3, (k, e)
+    conic = gcon.cpu().numpy().reshape(P, 4)
+    ref = np.asarray(o["grads"]["conic"]).reshape(P, 4)
+    assert rel_err(conic[:, [0, 1, 3]], ref[:, [0, 1, 3]]) <= 1e-3 and not conic[:, 2].any()
+    # a NULL campos with precomputed colours is legal (forward.cu:33 reads it only for SH): same image
+    e = torch.Tensor([])
+    R2, col2, _r, _g, _b, _i = _C.rasterize_gaussians(rs.bg, t["means3D"], t["colors_precomp"], t["opacities"], t["scales"], t["rotations"], 1.0, e,
+                                                     rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset, H, W,
+                                                     e, 0, e, False, False)
+    assert R2 == n["num_rendered"] and torch.equal(col2, n["color"])
+
+
+def test_backward_run_to_run_spread_is_at_rounding_level():
+    """The per-tile backward adds each (tile, Gaussian) instance's wave-reduced sums with float atomics (as the reference adds each
+    pixel's, backward.cu:568-603), so the order of a Gaussian's ~8 tile contributions varies between runs.  Statement: two runs of
+    the same step differ by no more than 2e-6 of an array's largest magnitude; everything else (forward, radii, n_contrib) is
+    bit-identical."""
+    W, H, P = 960, 540, 150_000
+    cam, cot = S.make_camera(W, H), S.make_cotangent(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=3, seed=2, scale_mult=2.0)
+    a = run_hip(cloud, cam, sh_degree=3, cotangent=cot)
+    b = run_hip(cloud, cam, sh_degree=3, cotangent=cot)
+    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["radii"], b["radii"])
+    for k in a["grads"]:
+        assert rel_err(a["grads"][k], b["grads"][k]) <= 2e-6, k

@@ -136,9 +136,50 @@ def test_product_beside_the_reference_build_at_sizes_the_cpu_oracle_is_slow_for(
     print({"radii_mismatch": int((h["radii"] != r["radii"]).sum()), "pixels_over_1e-4": int((err > 1e-4).sum()), "max": float(err.max()),
            "p9999": float(np.quantile(err, 0.9999)), "acc_max": float(acc_err.max()),
            "grads": {k: _rel(g, r["grads"][k]) for k, g in h["grads"].items()}})
-    assert (h["radii"] != r["radii"]).sum() <= 5 + P // 50_000
-    assert (err > 1e-4).sum() <= 5 + err.size // 100_000, (int((err > 1e-4).sum()), float(err.max()))
+    # observed on these three scenes (default-contraction build of the reference): <= 2 radii per million Gaussians, <= 2 ppm pixels
+    assert (h["radii"] != r["radii"]).sum() <= 2 + P // 200_000
+    assert (err > 1e-4).sum() <= max(3, err.size // 100_000), (int((err > 1e-4).sum()), float(err.max()))
+    assert err.max() <= 5e-3
     assert np.quantile(err, 0.9999) <= 1e-5
     assert np.quantile(acc_err, 0.9999) <= 1e-5
     for k, g in h["grads"].items():
         assert _rel(g, r["grads"][k]) <= 1e-3, (k, _rel(g, r["grads"][k]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,W,H,colors,scale_mult,label", [
+    (3_000_000, 1600, 1200, "precomp", 1.0, "config 3 size: 3 M Gaussians, 1600x1200, precomputed colours (forward + backward)"),
+    (2_000_000, 3840, 2160, "sh", 1.5, "config-5-shaped: 4K, 32 400 tiles -> LDS binning, lazy front sort"),
+    (2_000_000, 4096, 2400, "sh", 1.5, "38 400 tiles > BIN_MAX_TILES -> the global-sort binning path"),
+])
+def test_full_size_frames_beside_the_reference_build_without_contraction(P, W, H, colors, scale_mult, label):
+    """BASELINE configs 3 and 5 shapes against oracle/_ref's -ffp-contract=off build (the arithmetic the reference's sources spell,
+    which the preprocess kernel restates): radii and num_rendered BIT-EXACT, image within 1e-4 except threshold flips
+    (<= max(3, 1e-5 N) pixels, none above 5e-3), config 3 also every gradient within 1e-3."""
+    import torch
+    from oracle.ref_hip import ref_hip
+    if not ref_hip.available("nofma"):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    import wg_scenes as S
+    from tests.wg_testlib import run_hip, run_hip_native
+    deg = 3 if colors == "sh" else None
+    d = deg if deg is not None else 0
+    cloud = S.make_cloud(P, W, H, sh_degree=deg, seed=0, scale_mult=scale_mult)
+    cam = S.make_camera(W, H)
+    backward = colors == "precomp"
+    cot = S.make_cotangent(W, H, seed=4) if backward else None
+    r = ref_hip.run_scene(cloud, cam, sh_degree=d, cotangent=cot, variant="nofma")
+    torch.cuda.empty_cache()
+    h = run_hip(cloud, cam, sh_degree=d, cotangent=cot)
+    n = run_hip_native(cloud, cam, sh_degree=d)
+    assert int(n["num_rendered"]) == int(r["num_rendered"])
+    assert np.array_equal(h["radii"], r["radii"])
+    err = np.abs(h["color"].astype(np.float64) - r["color"]).max(axis=0)
+    nflip = int((err > 1e-4).sum())
+    print({"case": label, "num_rendered": int(r["num_rendered"]), "pixels_over_1e-4": nflip, "max": float(err.max())})
+    assert nflip <= max(3, int(1e-5 * err.size)) and err.max() <= 5e-3, (nflip, float(err.max()))
+    ncon = n["views"]["image"]["n_contrib"].cpu().numpy().reshape(H, W).astype(np.int64)
+    assert (ncon != r["n_contrib"].astype(np.int64)).sum() <= max(3, int(1e-5 * err.size))
+    if backward:
+        for k, g in h["grads"].items():
+            assert _rel(g, r["grads"][k]) <= 1e-3, (k, _rel(g, r["grads"][k]))

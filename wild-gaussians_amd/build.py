@@ -18,6 +18,13 @@ OBJ = os.path.join(HERE, "build")
 OUT = os.path.join(HERE, "diff_gaussian_rasterization", "libwg_rasterizer.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
+# A/B builds of kernel variants (scripts/ab_variants.sh): WG_BUILD_VARIANT=<name> WG_EXTRA_FLAGS="-DWG_...=0" puts objects and the
+# library under build/<name>/; load it with WG_RASTERIZER_LIB=<path> (diff_gaussian_rasterization/_C.py).
+VARIANT = os.environ.get("WG_BUILD_VARIANT", "")
+EXTRA = os.environ.get("WG_EXTRA_FLAGS", "").split()
+if VARIANT:
+    OBJ = os.path.join(OBJ, VARIANT)
+    OUT = os.path.join(OBJ, "libwg_rasterizer.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + INCLUDE, "-I" + CSRC]
 # per-file extra flags: the preprocess kernel must not fuse multiply-adds (integer outputs bit-exact vs oracle)
@@ -54,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            jobs.append([HIPCC] + COMMON + extra + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + COMMON + extra + EXTRA + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

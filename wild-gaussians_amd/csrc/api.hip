@@ -69,6 +69,7 @@ Mailbox* get_mailbox() {
     }
     return (g_use_mailbox && m.host) ? &m : nullptr;
 }
+int g_grad_record = 1;   // wg_set_option("grad_record", 0): the per-tile backward accumulates into the four arrays themselves (A/B)
 int g_depth_codes = 1;  // wg_set_option("depth_codes", 0 / 1 / 8..12): off (as for P > 2^24) / automatic width / forced width (tests)
 bool g_force_global_sort = false;  // wg_set_option("force_global_sort", 1): exercise the fallback binning path
 
@@ -203,6 +204,7 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
         } else {
             huge_frame = true;  // tile histogram does not fit LDS: count through the per-Gaussian prefix sum instead
             WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
+            WG_STAGE(WG_STAGE_SCAN, wg::launch_scan_overflow_check(geom, P, &img.stats->max_tile_count, stream), "scan_overflow_check");
         }
         // the one host sync of the forward pass (rasterizer_impl.cu:284): sizes the binning buffer
         wg::BinStats st{};
@@ -230,12 +232,16 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
             e = hipMemcpyAsync(&st, img.stats, sizeof(st), hipMemcpyDeviceToHost, stream);
         } else {
             e = hipMemcpyAsync(&st.num_rendered, geom.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-            st.max_tile_count = 0xffffffffu;
+            if (e == hipSuccess) e = hipMemcpyAsync(&st.max_tile_count, &img.stats->max_tile_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
         }
         if (e != hipSuccess) return hip_fail(e, "num_rendered readback");
         if (!have_stats) {
             e = hipStreamSynchronize(stream);
             if (e != hipSuccess) return hip_fail(e, "num_rendered readback sync");
+        }
+        if (huge_frame) {  // here max_tile_count carried the scan's overflow flag; the longest list itself is unknown on this path
+            if (st.max_tile_count != 0u) return WG_ERR_OVERFLOW;
+            st.max_tile_count = 0xffffffffu;
         }
         if (st.num_rendered > 0x7fffffffu) return WG_ERR_OVERFLOW;
         num_rendered = (int)st.num_rendered;
@@ -326,7 +332,11 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return WG_ERR_INVALID_ARGUMENT;
     if (P == 0) return WG_OK;
     if (!geom_buffer || !binning_buffer || !image_buffer || !dL_dpix || !background) return WG_ERR_INVALID_ARGUMENT;
-    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D) return WG_ERR_INVALID_ARGUMENT;
+    if (!dL_dmean2D || !dL_dopacity || !dL_dmean3D || !dL_dcov3D) return WG_ERR_INVALID_ARGUMENT;
+    // dL_dconic (always an intermediate) and, with SH colours, dL_dcolor (the gradient of the evaluated RGB, an intermediate there)
+    // may be NULL with the gradient record: nobody reads them.  Without the record they are accumulation targets.
+    if (!g_grad_record && (!dL_dconic || !dL_dcolor)) return WG_ERR_INVALID_ARGUMENT;
+    if (!dL_dcolor && shs == nullptr) return WG_ERR_INVALID_ARGUMENT;
     if (shs != nullptr && (!dL_dsh || !campos)) return WG_ERR_INVALID_ARGUMENT;
     if (scales != nullptr && (!rotations || !dL_dscale || !dL_drot)) return WG_ERR_INVALID_ARGUMENT;
     if (scales == nullptr && cov3D_precomp == nullptr) return WG_ERR_INVALID_ARGUMENT;
@@ -337,10 +347,19 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     wg::ImageState img = wg::ImageState::fromChunk(image_buffer, (size_t)width * height, (size_t)gx * gy);
     if (radii == nullptr) radii = geom.radii;  // rasterizer_impl.cu:381-384
 
+    // grad_record (default): the per-tile pass accumulates into one 64-byte record per Gaussian inside the geometry buffer, cleared
+    // here; the per-Gaussian kernel then WRITES the four arrays (they need no clearing by the caller).  Off: the arrays are the
+    // accumulation targets and must arrive zeroed, as the reference demands of its caller (rasterize_points.cu:157-165).
+    const bool record = g_grad_record != 0;
+    if (record) {
+        StageScope scope_(WG_STAGE_RENDER_BACKWARD, stream);
+        hipError_t e = hipMemsetAsync(geom.grad_rec, 0, (size_t)P * wg::GRAD_REC_FLOATS * sizeof(float), stream);
+        if (e != hipSuccess) return hip_fail(e, "gradient record memset");
+    }
     if (R > 0) {
         WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_order(img.tile_last, nullptr, img.order_bwd, gx * gy, stream), "tile_order");
         WG_STAGE(WG_STAGE_RENDER_BACKWARD, wg::launch_render_backward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, dL_dpix,
-                                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, stream),
+                                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, stream),
                  "render_backward");
     }
 
@@ -354,7 +373,7 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     bp.focal_x = width / (2.0f * tan_fovx);
     bp.kernel_size = kernel_size; bp.radii = radii;
     WG_STAGE(WG_STAGE_PREPROCESS_BACKWARD, wg::launch_preprocess_backward(bp, device_tone(tone), geom, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
-                                            dL_dscale, dL_drot, stream),
+                                            dL_dscale, dL_drot, record, stream),
              "preprocess_backward");
     return WG_OK;
 }
@@ -406,6 +425,7 @@ int wg_set_option(const char* name, int value) {
     if (!name) return WG_ERR_INVALID_ARGUMENT;
     if (std::strcmp(name, "force_global_sort") == 0) { g_force_global_sort = value != 0; return WG_OK; }
     if (std::strcmp(name, "host_mailbox") == 0) { g_use_mailbox = value != 0; return WG_OK; }
+    if (std::strcmp(name, "grad_record") == 0) { g_grad_record = value != 0; return WG_OK; }
     if (std::strcmp(name, "band_list_min_p") == 0) { wg::g_band_list_min_p = value > 0 ? value : 1; return WG_OK; }
     if (std::strcmp(name, "depth_codes") == 0) {
         if (value != 0 && value != 1 && (value < 8 || value > 12)) return WG_ERR_INVALID_ARGUMENT;
@@ -424,6 +444,16 @@ int wg_set_option(const char* name, int value) {
         return WG_OK;
     }
     return WG_ERR_INVALID_ARGUMENT;
+}
+
+int wg_get_option(const char* name) {
+    if (!name) return -1;
+    if (std::strcmp(name, "grad_record") == 0) return g_grad_record;
+    if (std::strcmp(name, "force_global_sort") == 0) return g_force_global_sort ? 1 : 0;
+    if (std::strcmp(name, "host_mailbox") == 0) return g_use_mailbox ? 1 : 0;
+    if (std::strcmp(name, "lazy_sort") == 0) return wg::g_lazy.enabled ? 1 : 0;
+    if (std::strcmp(name, "depth_codes") == 0) return g_depth_codes;
+    return -1;
 }
 
 int wg_profile_enable(int enable) {

@@ -58,6 +58,7 @@ GeometryState GeometryState::fromChunk(char*& chunk, size_t P) {
     carve(chunk, g.band_list, lists ? (size_t)BIN_CHUNKS * 8 * ((Pa + BIN_CHUNKS - 1) / BIN_CHUNKS) : 0);
     carve(chunk, g.band_cnt, lists ? (size_t)BIN_CHUNKS * 8 : 0);
     if (!lists) g.band_list = nullptr;
+    carve(chunk, g.grad_rec, Pa * GRAD_REC_FLOATS);
     g.scan_temp_bytes = query_scan_temp_bytes(Pa);
     carve(chunk, g.scan_temp, g.scan_temp_bytes);
     return g;
@@ -98,6 +99,21 @@ BinningState BinningState::fromChunk(char*& chunk, size_t R, bool global_sort) {
 hipError_t run_scan(const GeometryState& g, int P, hipStream_t stream) {
     size_t bytes = g.scan_temp_bytes;
     return rocprim::inclusive_scan(g.scan_temp, bytes, g.tiles_touched, g.point_offsets, (size_t)P, rocprim::plus<uint32_t>(), stream);
+}
+
+// An inclusive scan of non-negative counts that wrapped around 2^32 is not monotone any more: flag it (huge-frame path only).
+__global__ void __launch_bounds__(256) scan_overflow_kernel(int P, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                            uint32_t* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t prev = i ? offsets[i - 1] : 0u;
+    if (offsets[i] < prev || offsets[i] - prev != counts[i]) *flag = 1u;
+}
+hipError_t launch_scan_overflow_check(const GeometryState& g, int P, uint32_t* flag, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(scan_overflow_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, g.point_offsets, g.tiles_touched, flag);
+    return hipGetLastError();
 }
 
 // One lane per Gaussian; each visible Gaussian writes its run of (key, id) pairs.  Consecutive lanes own
@@ -327,7 +343,12 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
                                                          HostMailbox* mailbox, uint32_t seq) {
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t wave_max[16];
+    __shared__ uint32_t wave_ovf[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The instance total is a 32-bit sum (the reference's is a 32-bit int, rasterizer_impl.cu:280-284, and overflows silently).
+    // Every addition below is checked for wrap-around: if none wraps, every partial sum is exact, so a total of 2^32 or more
+    // always trips the flag; the kernel then reports 0xffffffff and the host returns WG_ERR_OVERFLOW before any buffer is sized.
+    bool ovf = false;
     const int per = (tiles + 1023) / 1024;  // <= PER
     const int begin = tid * per, end = min(tiles, begin + per);
     uint32_t cnt[PER];
@@ -337,6 +358,7 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         local += cnt[k];
+        ovf |= local < cnt[k];
         lmax = max(lmax, cnt[k]);
     }
     // inclusive scan of `local` across the 1024 threads: wave scan, then scan of wave totals
@@ -344,19 +366,27 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += up;
+        if (lane >= d) {
+            incl += up;
+            ovf |= incl < up;
+        }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, m));
     if (lane == 63) wave_sum[wave] = incl;
     if (lane == 0) wave_max[wave] = lmax;
+    const uint64_t any_ovf = __ballot(ovf);
+    if (lane == 0) wave_ovf[wave] = any_ovf != 0ull ? 1u : 0u;
     __syncthreads();
-    uint32_t wave_base = 0, total = 0, gmax = 0;
+    uint32_t wave_base = 0, total = 0, gmax = 0, tovf = 0;
     for (int w = 0; w < 16; w++) {
         if (w < wave) wave_base += wave_sum[w];
         total += wave_sum[w];
+        tovf |= (total < wave_sum[w]) ? 1u : 0u;
+        tovf |= wave_ovf[w];
         gmax = max(gmax, wave_max[w]);
     }
+    if (tovf) total = 0xffffffffu;
     if (tid == 0) {  // first: the two numbers the host is waiting for (it launches the next kernels behind this one)
         tile_offset[tiles] = total;
         stats->num_rendered = total;

@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
         vm[i] = p.viewmatrix[i];
         pm[i] = p.projmatrix[i];
     }
-    const float camx = p.cam_pos[0], camy = p.cam_pos[1], camz = p.cam_pos[2];
+    // the camera position only enters through the SH view direction (forward.cu:33): absent (null) with precomputed colours
+    float camx = 0.f, camy = 0.f, camz = 0.f;
+    if (p.colors_precomp == nullptr) { camx = p.cam_pos[0]; camy = p.cam_pos[1]; camz = p.cam_pos[2]; }  // wave-uniform, scalar loads
     // Geometry inputs first, SH block second: the memory counter retires loads in issue order, so whatever the geometry
     // waits for has to be issued ahead of the twelve SH loads for those to stay in flight behind it.
     float px = p.means3D[3 * ld], py = p.means3D[3 * ld + 1], pz = p.means3D[3 * ld + 2];

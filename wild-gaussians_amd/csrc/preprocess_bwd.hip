@@ -58,11 +58,13 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
 
 // Load schedule: the memory counter retires in issue order, so every per-Gaussian input is requested first, the
 // 12 KiB SH block second (into registers), and only the SH part of the arithmetic -- placed last -- waits for it.
-template <bool FAST_SH, bool HAS_SCALES, bool TONE>
+// RECORD: the per-tile pass left its raw sums in grad_rec (wg_common.h: GRAD_REC_*); this kernel applies the per-Gaussian factors
+// and WRITES dL_dmean2D / dL_dconic / dL_dopacity / dL_dcolor for every Gaussian.  !RECORD: those four arrive accumulated.
+template <bool FAST_SH, bool HAS_SCALES, bool TONE, bool RECORD>
 __global__ void __launch_bounds__(64) preprocess_backward_kernel(
-    BwdParams p, const float4* __restrict__ splats, const unsigned char* __restrict__ clamped,
-    const float* __restrict__ dL_dmean2D, const float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
-    const float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
+    BwdParams p, const float4* __restrict__ splats, const unsigned char* __restrict__ clamped, const float4* __restrict__ grad_rec,
+    float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
+    float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
     float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, ToneArg<TONE> tone) {
     __shared__ float4 stage[FAST_SH ? 64 * SH_PITCH4 : 1];
     const int lane = threadIdx.x;
@@ -77,19 +79,31 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
         vm[i] = p.viewmatrix[i];
         proj[i] = p.projmatrix[i];
     }
-    const float camx = p.campos[0], camy = p.campos[1], camz = p.campos[2];
+    // the camera position only enters through the SH view direction: absent (null) with precomputed colours, as in the reference
+    float camx = 0.f, camy = 0.f, camz = 0.f;
+    if (p.shs != nullptr) { camx = p.campos[0]; camy = p.campos[1]; camz = p.campos[2]; }
 
     // (non-const: they are operands of the ordering fence below, which keeps the compiler from sinking the loads)
     int radius = p.radii[ld];
     float mx = p.means3D[3 * ld], my = p.means3D[3 * ld + 1], mz = p.means3D[3 * ld + 2];
     const float* cv = p.cov3D + 6 * (size_t)ld;
     float v0 = cv[0], v1 = cv[1], v2 = cv[2], v3 = cv[3], v4 = cv[4], v5 = cv[5];
-    float4 dconic = reinterpret_cast<const float4*>(dL_dconic)[ld];
+    float4 dconic;
     float combined_opacity = splats[3 * (size_t)ld + 1].y;
-    float dLdo_in = dL_dopacity[ld];
-    float g2x = dL_dmean2D[3 * ld], g2y = dL_dmean2D[3 * ld + 1];
+    float dLdo_in, g2x, g2y, g2abs = 0.f, dcol0, dcol1, dcol2;
+    if (RECORD) {
+        const float4 r0 = grad_rec[3 * (size_t)ld], r1 = grad_rec[3 * (size_t)ld + 1], r2 = grad_rec[3 * (size_t)ld + 2];
+        dcol0 = r0.x; dcol1 = r0.y; dcol2 = r0.z;
+        g2x = r0.w; g2y = r1.x; g2abs = r1.y;                       // raw sums: scaled below, once the loads have landed
+        dconic = make_float4(r1.z, r1.w, 0.f, r2.x);
+        dLdo_in = r2.y;
+    } else {
+        dconic = reinterpret_cast<const float4*>(dL_dconic)[ld];
+        dLdo_in = dL_dopacity[ld];
+        g2x = dL_dmean2D[3 * ld]; g2y = dL_dmean2D[3 * ld + 1];
+        dcol0 = dL_dcolor[3 * ld]; dcol1 = dL_dcolor[3 * ld + 1]; dcol2 = dL_dcolor[3 * ld + 2];
+    }
     int cl = clamped[ld];
-    float dcol0 = dL_dcolor[3 * ld], dcol1 = dL_dcolor[3 * ld + 1], dcol2 = dL_dcolor[3 * ld + 2];
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     float sc0 = 0.f, sc1 = 0.f, sc2 = 0.f;
     if (HAS_SCALES) {
@@ -110,11 +124,25 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     // nothing below moves above the SH loads, none of the loads above sinks below them
     asm volatile(""
                  : "+v"(mx), "+v"(my), "+v"(mz), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(dconic.x), "+v"(dconic.y),
-                   "+v"(dconic.w), "+v"(combined_opacity), "+v"(dLdo_in), "+v"(g2x), "+v"(g2y), "+v"(cl), "+v"(dcol0), "+v"(dcol1),
+                   "+v"(dconic.w), "+v"(combined_opacity), "+v"(dLdo_in), "+v"(g2x), "+v"(g2y), "+v"(g2abs), "+v"(cl), "+v"(dcol0), "+v"(dcol1),
                    "+v"(dcol2), "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w), "+v"(sc0), "+v"(sc1), "+v"(sc2), "+v"(radius)
                  :
                  : "memory");
     const bool vis = in && radius > 0;
+    if (RECORD) {
+        // the factors the per-tile pass leaves out (render_bwd.hip): mean2D.x = o * 0.5W / log2e * sum(q u'), .y likewise with 0.5H,
+        // .z = |o| / log2e * sum(...), conic = -0.5 o * sum(q d d), colour and opacity as summed.  A culled Gaussian's record is
+        // zero but its splat record (hence o) was never written: everything is forced to zero there.
+        constexpr float INV_L = 1.0f / 1.4426950408889634f;
+        const float o = vis ? combined_opacity : 0.f;
+        g2x = vis ? g2x * (o * (0.5f * p.W * INV_L)) : 0.f;
+        g2y = vis ? g2y * (o * (0.5f * p.H * INV_L)) : 0.f;
+        g2abs = vis ? g2abs * (fabsf(o) * INV_L) : 0.f;
+        dconic.x = vis ? dconic.x * (o * -0.5f) : 0.f;
+        dconic.y = vis ? dconic.y * (o * -0.5f) : 0.f;
+        dconic.w = vis ? dconic.w * (o * -0.5f) : 0.f;
+        if (!vis) { dcol0 = dcol1 = dcol2 = 0.f; dLdo_in = 0.f; }
+    }
 
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float gmx = 0.f, gmy = 0.f, gmz = 0.f;
@@ -252,7 +280,15 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     if (in) {
         float* o = dL_dcov3D + 6 * (size_t)idx;
         o[0] = dcov[0]; o[1] = dcov[1]; o[2] = dcov[2]; o[3] = dcov[3]; o[4] = dcov[4]; o[5] = dcov[5];
-        if (write_dLdo) dL_dopacity[idx] = dLdo_out;
+        if (RECORD) {
+            dL_dopacity[idx] = write_dLdo ? dLdo_out : dLdo_in;
+            dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = g2abs;
+            // the reference's intermediates: only a caller that wants them passes the pointers (wg_rasterizer.h)
+            if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[idx] = dconic;
+            if (dL_dcolor) { dL_dcolor[3 * idx] = dcol0; dL_dcolor[3 * idx + 1] = dcol1; dL_dcolor[3 * idx + 2] = dcol2; }
+        } else if (write_dLdo) {
+            dL_dopacity[idx] = dLdo_out;
+        }
         if (HAS_SCALES) {
             dL_dscale[3 * idx] = dsc[0];
             dL_dscale[3 * idx + 1] = dsc[1];
@@ -392,33 +428,31 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     }
 }
 
-hipError_t launch_preprocess_backward(const BwdParams& p, const ShTone& tone_in, const GeometryState& g, const float* dL_dmean2D,
-                                      const float* dL_dconic, float* dL_dopacity, const float* dL_dcolor,
+hipError_t launch_preprocess_backward(const BwdParams& p, const ShTone& tone_in, const GeometryState& g, float* dL_dmean2D,
+                                      float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                                      float* dL_drot, hipStream_t stream) {
+                                      float* dL_drot, bool record, hipStream_t stream) {
     if (p.P <= 0) return hipSuccess;
     const dim3 grid((p.P + 63) / 64), block(64);
     const bool fast = p.shs != nullptr && p.M == 16 && (reinterpret_cast<uintptr_t>(p.shs) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(dL_dsh) % 16 == 0);
     const bool sc = p.scales != nullptr;
     const bool tone = tone_in.enabled && p.shs != nullptr;
-#define WG_LAUNCH(F, S)                                                                                                                  \
-    hipLaunchKernelGGL((preprocess_backward_kernel<F, S, false>), grid, block, 0, stream, p, g.splats, g.clamped, dL_dmean2D, dL_dconic, \
-                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, NoTone{})
-#define WG_LAUNCH_TONE(F, S)                                                                                                            \
-    hipLaunchKernelGGL((preprocess_backward_kernel<F, S, true>), grid, block, 0, stream, p, g.splats, g.clamped, dL_dmean2D, dL_dconic, \
-                       dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, tone_in)
-    if (tone) {
-        if (fast && sc) WG_LAUNCH_TONE(true, true);
-        else if (fast) WG_LAUNCH_TONE(true, false);
-        else if (sc) WG_LAUNCH_TONE(false, true);
-        else WG_LAUNCH_TONE(false, false);
-    } else if (fast && sc) WG_LAUNCH(true, true);
+    const float4* rec = reinterpret_cast<const float4*>(g.grad_rec);
+#define WG_ARGS p, g.splats, g.clamped, rec, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot
+#define WG_LAUNCH(F, S)                                                                                                              \
+    do {                                                                                                                             \
+        if (tone && record) hipLaunchKernelGGL((preprocess_backward_kernel<F, S, true, true>), grid, block, 0, stream, WG_ARGS, tone_in);   \
+        else if (tone) hipLaunchKernelGGL((preprocess_backward_kernel<F, S, true, false>), grid, block, 0, stream, WG_ARGS, tone_in);       \
+        else if (record) hipLaunchKernelGGL((preprocess_backward_kernel<F, S, false, true>), grid, block, 0, stream, WG_ARGS, NoTone{});    \
+        else hipLaunchKernelGGL((preprocess_backward_kernel<F, S, false, false>), grid, block, 0, stream, WG_ARGS, NoTone{});               \
+    } while (0)
+    if (fast && sc) WG_LAUNCH(true, true);
     else if (fast) WG_LAUNCH(true, false);
     else if (sc) WG_LAUNCH(false, true);
     else WG_LAUNCH(false, false);
 #undef WG_LAUNCH
-#undef WG_LAUNCH_TONE
+#undef WG_ARGS
     return hipGetLastError();
 }
 

@@ -73,22 +73,26 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
     return y;
 }
 
+// RECORD (default, wg_set_option("grad_record")): the ten reduced values of an instance go, unscaled, to ONE 48-byte gradient
+// record of its Gaussian (grad_rec[12 id + k], k = the value's index; wg_common.h: GRAD_REC_*) -- one L2 line per instance (two for
+// a quarter of the records) instead of partial lines of four arrays, and the per-Gaussian factors (opacity, 0.5 W,
+// -0.5, 1 / log2 e) are applied once per Gaussian by the preprocess backward kernel, which also writes the caller-visible
+// dL_dmean2D / dL_dconic / dL_dopacity / dL_dcolor.  !RECORD: the arrays themselves are the accumulation targets (as in the
+// reference, backward.cu:568-603), factors applied per instance.
+template <bool RECORD>
 __global__ void __launch_bounds__(64) render_backward_kernel(
     int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_last,
     const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
-    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor) {
+    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ grad_rec) {
     __shared__ float4 lds[BATCH * 3];
-    __shared__ uint32_t lds_id[BATCH];
 
     const int tile = (int)order[xcd_tile(blockIdx.x, tiles)];
     const int hi0 = (int)tile_last[tile];
     if (hi0 == 0) return;
     const int lane = threadIdx.x;
     const int tx = tile % gx, ty = tile / gx;
-    const int px = tx * TILE_X + (lane & 15);
-    const int py0 = ty * TILE_Y + (lane >> 4);
     const size_t plane = (size_t)W * H;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
@@ -99,7 +103,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     const bool owner = (lane & 12) == 0;  // lanes with bits 2,3 clear: one lane per value (two spare for value 8/9 copies)
     float* abase;
     uint32_t astride;
-    if (vidx < 3) { abase = dL_dcolor + vidx; astride = 3; }
+    if (RECORD) { abase = grad_rec + vidx; astride = GRAD_REC_FLOATS; }
+    else if (vidx < 3) { abase = dL_dcolor + vidx; astride = 3; }
     else if (vidx < 6) { abase = dL_dmean2D + (vidx - 3); astride = 3; }
     else if (vidx < 9) { abase = dL_dconic + (vidx == 8 ? 3 : vidx - 6); astride = 4; }
     else { abase = dL_dopacity; astride = 1; }
@@ -115,7 +120,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     StripBounds sb;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        const int py = py0 + 4 * s;
+        const int px = tx * TILE_X + strip_x(lane, s), py = ty * TILE_Y + strip_y(lane, s);
         const bool inside = px < W && py < H;
         float2 off = make_float2(0.f, 0.f);
         T[s] = 0.f; last[s] = 0; dLr[s] = dLg[s] = dLb[s] = 0.f;
@@ -158,7 +163,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             scale_conic(q0, q1);
             q2.z = 2.0f * q0.z;  // 2 ca, 2 cc: the gradient of the exponent, up to the factor 1 / log2(e) applied after the reduction
             q2.w = 2.0f * q1.x;
-            lds_id[lane] = id;
+            q1.z = __uint_as_float(id);  // the record's spare float carries the Gaussian id to the reduction (no second LDS array,
+                                         // no LDS round trip on the reduction path)
             lds[3 * lane] = q0;
             lds[3 * lane + 1] = q1;
             lds[3 * lane + 2] = q2;
@@ -223,7 +229,11 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             }
             if (__ballot(any) == 0ull) continue;
             const float total = butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
-            if (issue) unsafeAtomicAdd(abase + astride * lds_id[j], total * (oscale ? (vidx == 5 ? fabsf(o) : o) * vscale : vscale));  // 4*P < 2^32
+            if (RECORD) {
+                if (issue) unsafeAtomicAdd(abase + (size_t)__float_as_uint(r1.z) * GRAD_REC_FLOATS, total);  // 64-bit: shift-adds, no quarter-rate 32-bit multiply
+            } else {
+                if (issue) unsafeAtomicAdd(abase + astride * __float_as_uint(r1.z), total * (oscale ? (vidx == 5 ? fabsf(o) : o) * vscale : vscale));  // 4*P < 2^32
+            }
             acr = acg = acb = sx = sy = sab = sxx = sxy = syy = sq = 0.f;
         }
     }
@@ -232,12 +242,16 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                   const GeometryState& g, const float* subpixel_offset, const float* background,
                                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                  float* dL_dcolor, hipStream_t stream) {
+                                  float* dL_dcolor, bool record, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(render_backward_kernel, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.order_bwd, img.ranges, b.point_list, g.splats,
-                       reinterpret_cast<const float2*>(subpixel_offset), background, img.final_T, img.n_contrib, img.tile_last,
-                       dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+#define WG_LAUNCH(REC)                                                                                                                      \
+    hipLaunchKernelGGL(render_backward_kernel<REC>, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.order_bwd, img.ranges, b.point_list, \
+                       g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.final_T, img.n_contrib, img.tile_last,   \
+                       dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, g.grad_rec)
+    if (record) WG_LAUNCH(true);
+    else WG_LAUNCH(false);
+#undef WG_LAUNCH
     return hipGetLastError();
 }
 

@@ -1,8 +1,8 @@
 // K8: per-tile front-to-back alpha compositing for gfx950.  Replaces renderCUDA (forward.cu:273-395).
 //
 // Mapping (wave64-first, not a 16x16-thread CUDA block):
-//   * one 64-lane wave per 16x16 tile; lane l owns column x = l & 15 and rows (l >> 4) + 4*s for the
-//     four 16x4 strips s = 0..3, i.e. 4 pixels per lane.  No workgroup barrier is ever needed (the
+//   * one 64-lane wave per 16x16 tile; lane l owns one pixel in each of the tile's four strips s = 0..3 (the 8x8 quadrants:
+//     x = 8 (s & 1) + (l & 7), y = 8 (s >> 1) + (l >> 3); wg_alpha.h: strip_x / strip_y), i.e. 4 pixels per lane.  No workgroup barrier is ever needed (the
 //     workgroup IS the wave), the per-instance LDS broadcast read is amortised over 256 pixel
 //     evaluations, and each lane carries 4 independent dependency chains (ILP hides v_exp latency).
 //   * the tile's sorted instance list is consumed in batches of 64: lane l gathers instance l's 48-byte
@@ -30,6 +30,14 @@ namespace wg {
 
 constexpr int BATCH = 64;
 
+// code-shape switches of the compositing loop (A/B builds: wild-gaussians_amd/build.py WG_EXTRA_FLAGS; numbers in DESIGN.md)
+#ifndef WG_FWD_HOIST_GB
+#define WG_FWD_HOIST_GB 1
+#endif
+#ifndef WG_FWD_FLAT_STOP
+#define WG_FWD_FLAT_STOP 0
+#endif
+
 // ---- the per-tile walk, as device functions shared by render_forward_kernel and the lazy-sort fix-up kernel (binning.hip) ----
 // One wave owns a tile.  The walk is resumable: it composites list positions [pos_begin, pos_end) and can be continued
 // later from the state parked in the output buffers (fwd_store with complete == false / fwd_init with resume == true).
@@ -37,20 +45,20 @@ constexpr int BATCH = 64;
 __device__ void fwd_init(FwdTile& st, int W, int H, int gx, int tile, int lane, const float2* __restrict__ subpixel_offset, bool resume,
                          const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ out_color) {
     const int tx = tile % gx, ty = tile / gx;
-    st.px = tx * TILE_X + (lane & 15);
-    st.py0 = ty * TILE_Y + (lane >> 4);
+    st.x0 = tx * TILE_X;
+    st.y0 = ty * TILE_Y;
     st.alive = 0;
     const size_t plane = (size_t)W * H;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        const int py = st.py0 + 4 * s;
-        const bool inside = st.px < W && py < H;
+        const int px = st.x0 + strip_x(lane, s), py = st.y0 + strip_y(lane, s);
+        const bool inside = px < W && py < H;
         float2 off = make_float2(0.f, 0.f);
         st.T[s] = 1.0f;
         st.Cr[s] = st.Cg[s] = st.Cb[s] = 0.f;
         st.last[s] = 0;
         if (inside) {
-            const size_t pix = (size_t)W * py + st.px;
+            const size_t pix = (size_t)W * py + px;
             if (subpixel_offset) off = subpixel_offset[pix];
             st.alive |= 1u << s;
             if (resume) {  // parked state: T < 0 marks a pixel that already hit the T < 1e-4 stop
@@ -63,7 +71,7 @@ __device__ void fwd_init(FwdTile& st, int W, int H, int gx, int tile, int lane, 
                 st.Cb[s] = out_color[2 * plane + pix];
             }
         }
-        st.pfx[s] = (float)st.px + off.x;
+        st.pfx[s] = (float)px + off.x;
         st.pfy[s] = (float)py + off.y;
         const float inf = __builtin_huge_valf();
         st.sb.x0[s] = wave_min_uniform(inside ? st.pfx[s] : inf);
@@ -136,6 +144,9 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
             const float4 r0 = lds[3 * j];      // mx, my, ca, cb
             const float4 r1 = lds[3 * j + 1];  // cc, opacity, -, red
             const SplatCoef sc = coef_of(r0, r1);
+#if WG_FWD_HOIST_GB
+            const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);  // green, blue: requested with the rest of the record
+#endif
             const uint32_t pos = (uint32_t)(pos_begin + base + j + 1);
             const uint32_t alive_before = alive;
 #pragma unroll
@@ -147,16 +158,33 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
                 if (((alive >> s) & 1u) && pass) {
                     const float w = alpha * T[s];
                     const float test_T = T[s] - w;  // T (1 - alpha), forward.cu:367, one rounding step apart
+#if WG_FWD_FLAT_STOP
+                    // the stop (forward.cu:368-372: the instance is not blended, the pixel is done) as selects, not a nested branch
+                    const bool keep = !(test_T < 0.0001f);
+                    const float wk = keep ? w : 0.0f;
+#if !WG_FWD_HOIST_GB
+                    const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
+#endif
+                    Cr[s] += r1.w * wk;
+                    Cg[s] += gb.x * wk;
+                    Cb[s] += gb.y * wk;
+                    T[s] = keep ? test_T : T[s];
+                    last[s] = keep ? pos : last[s];
+                    alive = keep ? alive : (alive & ~(1u << s));
+#else
                     if (test_T < 0.0001f) {
                         alive &= ~(1u << s);  // done (forward.cu:368-372): this instance is not blended
                     } else {
+#if !WG_FWD_HOIST_GB
                         const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
+#endif
                         Cr[s] += r1.w * w;
                         Cg[s] += gb.x * w;
                         Cb[s] += gb.y * w;
                         T[s] = test_T;
                         last[s] = pos;
                     }
+#endif
                 }
             }
             if (__ballot(alive != alive_before) != 0ull) {  // some pixel saturated: refresh the strip liveness
@@ -189,9 +217,9 @@ __device__ void fwd_store(const FwdTile& st, bool complete, int W, int H, int ti
     const float bg0 = complete ? bg[0] : 0.f, bg1 = complete ? bg[1] : 0.f, bg2 = complete ? bg[2] : 0.f;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        const int py = st.py0 + 4 * s;
-        if (st.px < W && py < H) {
-            const size_t pix = (size_t)W * py + st.px;
+        const int px = st.x0 + strip_x(lane, s), py = st.y0 + strip_y(lane, s);
+        if (px < W && py < H) {
+            const size_t pix = (size_t)W * py + px;
             final_T[pix] = (complete || ((st.alive >> s) & 1u)) ? st.T[s] : -st.T[s];
             n_contrib[pix] = st.last[s];
             out_color[pix] = st.Cr[s] + st.T[s] * bg0;

@@ -31,10 +31,17 @@ struct GeometryState {
     uint32_t* point_offsets;
     uint16_t* band_list;  // large P only (g_band_list_min_p): [BIN_CHUNKS][8][chunk size] chunk-local indices of the Gaussians touching
     uint32_t* band_cnt;   // each XCD band of tiles, and their counts [BIN_CHUNKS][8]; the candidates of both scatter kernels
+    float* grad_rec;      // backward only: one 64-byte gradient record per Gaussian (GRAD_REC_*), cleared at the start of every backward
     char* scan_temp;
     size_t scan_temp_bytes;
     static GeometryState fromChunk(char*& chunk, size_t P);
 };
+
+// Gradient record of the per-tile backward pass (render_bwd.hip, RECORD): 12 floats = 48 bytes per Gaussian (three float4; a
+// record lies within one 128-byte L2 line in 6 of 8 cases, in two otherwise), holding the raw wave-reduced sums
+//   [0..2] sum(w dL_c)  [3] sum(q u)  [4] sum(q v)  [5] sum(|q| (0.5W|u| + 0.5H|v|))  [6..8] sum(q dx dx), sum(q dx dy), sum(q dy dy)
+//   [9] sum(q)  [10..11] unused.   preprocess_bwd.hip turns them into the reference's four arrays.
+constexpr int GRAD_REC_FLOATS = 12;
 
 struct BinStats {  // read back by the host once per forward (the reference's num_rendered sync point)
     uint32_t num_rendered;
@@ -133,6 +140,7 @@ struct FwdParams {
 hipError_t launch_preprocess(const FwdParams& p, const ShTone& tone, const GeometryState& g, int* radii_out, hipStream_t stream);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t stream);
 hipError_t run_scan(const GeometryState& g, int P, hipStream_t stream);
+hipError_t launch_scan_overflow_check(const GeometryState& g, int P, uint32_t* flag, hipStream_t stream);  // *flag = 1: the 32-bit scan wrapped
 hipError_t launch_duplicate_keys(int P, const GeometryState& g, const BinningState& b, int gx, hipStream_t stream);
 hipError_t run_sort(const BinningState& b, int R, int end_bit, hipStream_t stream);
 hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& img, int tiles, hipStream_t stream);
@@ -165,7 +173,7 @@ hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState&
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                   const GeometryState& g, const float* subpixel_offset, const float* background,
                                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                  float* dL_dcolor, hipStream_t stream);
+                                  float* dL_dcolor, bool record, hipStream_t stream);
 
 struct BwdParams {
     int P, D, M, W, H;
@@ -181,10 +189,11 @@ struct BwdParams {
     float tan_fovx, tan_fovy, focal_x, focal_y, kernel_size;
     const int* radii;
 };
-hipError_t launch_preprocess_backward(const BwdParams& p, const ShTone& tone, const GeometryState& g, const float* dL_dmean2D,
-                                      const float* dL_dconic, float* dL_dopacity, const float* dL_dcolor,
+// record: the four arrays are OUTPUTS computed from g.grad_rec (see GRAD_REC_*); otherwise inputs accumulated by the per-tile pass
+hipError_t launch_preprocess_backward(const BwdParams& p, const ShTone& tone, const GeometryState& g, float* dL_dmean2D,
+                                      float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                                      float* dL_drot, hipStream_t stream);
+                                      float* dL_drot, bool record, hipStream_t stream);
 
 uint32_t higher_msb(uint32_t n);
 

@@ -59,6 +59,8 @@ _lib.wg_image_buffer_size.argtypes = [_i, _i]
 for _name in ("wg_status_string",):
     getattr(_lib, _name).restype = C.c_char_p
     getattr(_lib, _name).argtypes = [_i]
+_lib.wg_get_option.restype = _i
+_lib.wg_get_option.argtypes = [C.c_char_p]
 for _name in ("wg_last_hip_error", "wg_version"):
     getattr(_lib, _name).restype = C.c_char_p
     getattr(_lib, _name).argtypes = []
@@ -208,11 +210,20 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     # The reference zero-fills nine gradient tensors per call (rasterize_points.cu:157-165).  Here only the four
     # accumulation targets of the per-tile pass need clearing -- they share one allocation, hence one memset -- and
     # everything else is fully written by the per-Gaussian kernel (zeros for culled Gaussians).
-    acc = torch.zeros((P * 11,), dtype=torch.float32, device=device)
-    dL_dconic = acc[0:4 * P].view(P, 2, 2)
-    dL_dmeans2D = acc[4 * P:7 * P].view(P, 3)
-    dL_dcolors = acc[7 * P:10 * P].view(P, 3)
-    dL_dopacity = acc[10 * P:11 * P].view(P, 1)
+    # With the gradient record (the default, include/wg_rasterizer.h) the library clears its own accumulator and these four are
+    # plain outputs too.
+    record = P != 0 and _lib.wg_get_option(b"grad_record") == 1
+    if record:
+        dL_dconic = None   # the reference's intermediate: not returned (rasterize_points.cu:201), so not requested
+        dL_dmeans2D = torch.empty((P, 3), dtype=torch.float32, device=device)
+        dL_dopacity = torch.empty((P, 1), dtype=torch.float32, device=device)
+        dL_dcolors = torch.empty((P, 3), dtype=torch.float32, device=device)
+    else:
+        acc = torch.zeros((P * 11,), dtype=torch.float32, device=device)
+        dL_dconic = acc[0:4 * P].view(P, 2, 2)
+        dL_dmeans2D = acc[4 * P:7 * P].view(P, 3)
+        dL_dcolors = acc[7 * P:10 * P].view(P, 3)
+        dL_dopacity = acc[10 * P:11 * P].view(P, 1)
     have_scales = scales.numel() != 0
     alloc = torch.empty if P != 0 else torch.zeros
     dL_dmeans3D = alloc((P, 3), dtype=torch.float32, device=device)
@@ -240,7 +251,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
                 float(tan_fovx), float(tan_fovy), float(kernel_size), _ptr(subpixel_offset), _ptr(radii),
                 geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL_dout_color),
-                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                dL_dmeans2D.data_ptr(), None if dL_dconic is None else dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
                 dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(), dL_drotations.data_ptr(),
                 int(bool(debug)), _stream(device), None if tone is None else C.byref(tone))
         _check(status, "wg_rasterize_backward")
@@ -311,6 +322,11 @@ _lib.wg_set_option.argtypes = [C.c_char_p, _i]
 def set_option(name: str, value: int) -> None:
     """wg_set_option: e.g. set_option("force_global_sort", 1) selects the rocPRIM global-sort binning path."""
     _check(_lib.wg_set_option(name.encode(), int(value)), f"wg_set_option({name})")
+
+
+def get_option(name: str) -> int:
+    """wg_get_option: current value of a library option (-1: unknown name)."""
+    return int(_lib.wg_get_option(name.encode()))
 
 
 def version() -> str:

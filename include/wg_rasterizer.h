@@ -238,9 +238,15 @@ const char* wg_stage_name(int stage);
  * "depth_codes" (1/0, default 1): with at most 2^24 Gaussians the lazy sort's bucket entries carry a coarse depth code (8 to 12
  * bits, what the ids leave free) above the id, so that the front extraction fetches exact depths only near its bounds; 0
  * exercises the uncoded path, 8..12 force a width (not wider than the ids allow). */
+/* "roctx" (0/1, default 0; WG_ROCTX=1 in the environment switches it on from the first call): a roctx range around every stage
+ * ("wg:K1 preprocess" ... "wg:K10-K11 preprocess_backward"), for `rocprofv3 --marker-trace --kernel-trace`.  The marker library is
+ * dlopen()ed on demand; WG_ERR_INVALID_ARGUMENT if none is found. */
 int wg_set_option(const char* name, int value);
-/* Current value of an option ("grad_record", "force_global_sort", "host_mailbox", "lazy_sort", "depth_codes"); -1 = unknown name.
- * "grad_record" (1/0, default 1): see wg_rasterize_backward. */
+/* Current value of an option (every name above except the two test-only caps); -1 = unknown name.
+ * "grad_record" (1/0, default 1): see wg_rasterize_backward.
+ * Thread safety: options are process-wide; wg_set_option may be called from any host thread at any time -- every forward /
+ * backward call copies the whole set once at its start and works from that copy (a call never sees half of an update, and the
+ * scratch layout never depends on an option read twice).  The per-stage profiler keeps its events per device. */
 int wg_get_option(const char* name);
 
 const char* wg_status_string(int status);

@@ -36,6 +36,43 @@ C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.37317633259
       -0.5900435899266435]
 
 
+class _TallLinear(torch.autograd.Function):
+    """(Measurement scaffolding for the CALLER's appearance MLP -- out of this repository's scope, kept out of the package.)
+    y = x W^T + b for a very tall x (millions of rows, <= a few hundred columns).  Plain PyTorch -- no kernel of this repository
+    -- around one observation on MI355X: the weight gradient x^T dy is a product with a reduction as long as x is tall, for which
+    the BLAS picks 32x32 tiles (26 TFLOP/s fp32 at 3 M rows); cut into row chunks and issued as ONE batched product of
+    [C, in, rows/C] x [C, rows/C, out] followed by a sum over C, the same arithmetic runs several times faster."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, chunks):
+        ctx.save_for_backward(x, weight)
+        ctx.chunks = chunks
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gy @ weight
+        if ctx.needs_input_grad[1]:
+            n, c = x.shape[0], max(1, min(ctx.chunks, x.shape[0]))
+            rows = (n // c) * c
+            gw = torch.bmm(x[:rows].view(c, rows // c, -1).transpose(1, 2), gy[:rows].view(c, rows // c, -1)).sum(0).t()
+            if rows < n:
+                gw = gw + gy[rows:].t() @ x[rows:]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb, None
+
+
+def tall_linear(x, weight, bias=None, chunks=256):
+    """Drop-in for `torch.nn.functional.linear(x, weight, bias)` when x has millions of rows (the appearance MLP over all Gaussians,
+    wildgaussians/method.py:882-900): same forward, the weight gradient computed as a batched product over `chunks` row blocks."""
+    return _TallLinear.apply(x, weight, bias, chunks)
+
+
 def sh_to_rgb(sh, d):  # sh [P,3,16], d [P,3] unit directions; real SH basis up to degree 3
     x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
     xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
@@ -125,9 +162,12 @@ def main():
                     help="SURVEY 8f N3: the appearance toning (clamp, * mul, + offset / C0, clamp; method.py:890-900, 1590-1595) inside the "
                          "preprocess kernels (sh_mul / sh_offset / sh_*_clamp_max) instead of P x 48 torch tensors; implies --in-kernel-sh")
     ap.add_argument("--tall-linear", action="store_true",
-                    help="wg_fused_gaussians.tall_linear for the appearance MLP's three layers (weight gradients as a batched product over "
+                    help="tall_linear (defined in this script) for the appearance MLP's three layers (weight gradients as a batched product over "
                          "row chunks: plain PyTorch, a BLAS kernel-selection workaround for 3 M-row reductions)")
     ap.add_argument("--fused-ssim", action="store_true", help="SURVEY 8f N4: wg_fused_ssim.ssim instead of the conv2d-based ssim")
+    ap.add_argument("--fused-loss", action="store_true",
+                    help="SURVEY 8f N4: wg_fused_ssim.l1_ssim_loss -- the whole (1 - l) L1 + l DSSIM image loss (method.py:1948-1965) in two "
+                         "launches each way instead of the L1 / mean / SSIM statement chain")
     ap.add_argument("--real-caller", action="store_true",
                     help="run the reference's OWN `WildGaussians.train_iteration` (method.py:1880-2024, staged unchanged by "
                          "tests/real_caller/stage_reference_caller.py) instead of the restated step; none of the opt-ins apply")
@@ -160,7 +200,6 @@ def main():
     opt = torch.optim.Adam([{"params": [p], "lr": 1e-4} for p in prm.values()] + [{"params": mlp.parameters(), "lr": 5e-4}], eps=1e-15,
                            **({"fused": True} if args.fused_adam else {}))
     if args.tall_linear:
-        from wg_fused_gaussians import tall_linear
         layers = [m for m in mlp if isinstance(m, nn.Linear)]
 
         def mlp_fn(x):
@@ -211,7 +250,10 @@ def main():
         return finish(img, raw, radii, means2D)
 
     def finish(img, raw, radii, means2D):
-        if args.fused_ssim:
+        if args.fused_loss:
+            from wg_fused_ssim import l1_ssim_loss
+            loss = l1_ssim_loss(img, raw, gt, 0.2)
+        elif args.fused_ssim:
             from wg_fused_ssim import ssim as fused_ssim
             loss = 0.8 * (img - gt).abs().mean() + 0.2 * (1.0 - fused_ssim(raw, gt, size_average=False)).mean()
         else:
@@ -267,7 +309,7 @@ def main():
     torch.cuda.synchronize()
     dop = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"workload": f"WildGaussians-style train step: {P} Gaussians + appearance MLP, {W}x{H}, 2 fwd + 2 bwd raster calls, "
-                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)" + (", SH evaluated in the operator" if args.in_kernel_sh or args.in_kernel_tone else "") + (", appearance toning in the operator" if args.in_kernel_tone else "") + (", fused SSIM" if args.fused_ssim else "") + (", fused activations" if args.fused_activations else "") + ("" if args.densification_stats == "off" else f", densification statistics ({args.densification_stats})"),
+                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)" + (", SH evaluated in the operator" if args.in_kernel_sh or args.in_kernel_tone else "") + (", appearance toning in the operator" if args.in_kernel_tone else "") + (", fused L1+DSSIM loss" if args.fused_loss else ", fused SSIM" if args.fused_ssim else "") + (", fused activations" if args.fused_activations else "") + ("" if args.densification_stats == "off" else f", densification statistics ({args.densification_stats})"),
                       "train_step_ms": round(dt * 1e3, 3), "train_steps_per_s": round(1.0 / dt, 2),
                       "rasterizer_only_ms (2 fwd + 2 bwd)": round(dop * 1e3, 3), "rasterizer_share": round(dop / dt, 3),
                       "visible": int((vis[0] > 0).sum().item()), "loss": float(step().item())}))

@@ -15,7 +15,7 @@ import wg_scenes as S
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "wg_rasterizer.h")
-LIB = os.path.join(ROOT, "wild-gaussians_amd", "diff_gaussian_rasterization", "libwg_rasterizer.so")
+LIB = os.environ.get("WG_RASTERIZER_LIB") or os.path.join(ROOT, "wild-gaussians_amd", "diff_gaussian_rasterization", "libwg_rasterizer.so")
 
 
 @pytest.fixture(scope="module")
@@ -35,6 +35,18 @@ def test_library_exports_every_declared_symbol(lib):
             "wg_binning_buffer_size", "wg_image_buffer_size", "wg_set_option", "wg_profile_enable"} <= names
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in wg_rasterizer.h but not exported"
+
+
+def test_options_round_trip_and_roctx_is_optional(lib):
+    lib.wg_set_option.restype, lib.wg_set_option.argtypes = C.c_int, [C.c_char_p, C.c_int]
+    lib.wg_get_option.restype, lib.wg_get_option.argtypes = C.c_int, [C.c_char_p]
+    assert lib.wg_get_option(b"grad_record") == 1 and lib.wg_get_option(b"no_such_option") == -1
+    assert lib.wg_set_option(b"grad_record", 0) == 0 and lib.wg_get_option(b"grad_record") == 0
+    assert lib.wg_set_option(b"grad_record", 1) == 0
+    assert lib.wg_set_option(b"no_such_option", 1) == -1
+    r = lib.wg_set_option(b"roctx", 1)   # the marker library is looked up at run time: present in a ROCm image, optional elsewhere
+    assert r in (0, -1) and lib.wg_get_option(b"roctx") == (1 if r == 0 else 0)
+    assert lib.wg_set_option(b"roctx", 0) == 0 and lib.wg_get_option(b"roctx") == 0
 
 
 def test_scratch_sizes(lib):

@@ -127,6 +127,10 @@ def test_binning_invariants(oracle):
     depth_bits = (keys & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.float32)
     np.testing.assert_array_equal(depth_bits, ctx.get("depths")[pl])
     assert oracle.get_higher_msb(8160) == 13 and oracle.get_higher_msb(256) == 9 and oracle.get_higher_msb(32400) == 15
+    # the product computes it as 32 - clz(n) (csrc/binning.hip: higher_msb): the same function as the reference's bisection
+    rng = np.random.default_rng(0)
+    for n in list(range(0, 70000)) + [int(x) for x in rng.integers(0, 2 ** 32, size=20000)] + [2 ** k + d for k in range(1, 32) for d in (-1, 0, 1)]:
+        assert oracle.get_higher_msb(n) == max(1, int(n).bit_length()), n
 
 
 def test_empty_and_culled_inputs(oracle):

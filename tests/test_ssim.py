@@ -83,15 +83,67 @@ def test_fused_ssim_full_frame_properties():
         ssim(x.cpu(), y.cpu())  # no CPU path
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 64, 96), (3, 33, 47), (3, 120, 200)])
+@pytest.mark.parametrize("mode", ["two_images", "one_image", "with_mult"])
+def test_fused_l1_ssim_loss_matches_the_reference_statements(shape, mode):
+    """wg_fused_ssim.l1_ssim_loss against the loss statements of the reference's train step (method.py:1948-1965) written with the
+    torch restatement of ssim(): value, the two logged parts, and both image gradients."""
+    from wg_fused_ssim import l1_ssim_loss
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(sum(shape) + len(mode))
+    lam = 0.2
+    gt = torch.rand(shape, generator=g).to(dev)
+    toned = (gt.cpu() * 0.6 + 0.4 * torch.rand(shape, generator=g)).to(dev).requires_grad_(True)
+    raw = (gt.cpu() * 0.5 + 0.5 * torch.rand(shape, generator=g)).to(dev).requires_grad_(True)
+    mult = (torch.rand((1,) + shape[1:], generator=g) * 2.0).to(dev) if mode == "with_mult" else None
+    if mode == "one_image":
+        raw = toned
+    t2, r2 = toned.detach().clone().requires_grad_(True), None
+    r2 = t2 if mode == "one_image" else raw.detach().clone().requires_grad_(True)
+    loss, l1m, ssm = l1_ssim_loss(toned, raw, gt, lam, loss_mult=mult, return_parts=True)
+    lm = 1.0 if mult is None else mult
+    Ll1 = F.l1_loss(t2, gt, reduction="none")
+    ssim_value = ref_ssim(r2[None], gt[None], size_average=False)[0]
+    ref = (1.0 - lam) * (Ll1 * lm).mean() + lam * ((1.0 - ssim_value) * lm).mean()
+    assert abs(loss.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    assert abs(l1m.item() - (Ll1 * lm).mean().item()) <= 2e-6 and not l1m.requires_grad
+    assert abs(ssm.item() - (1.0 - ((1.0 - ssim_value) * lm).mean().item())) <= 2e-5
+    (loss * 3.0).backward()
+    (ref * 3.0).backward()
+    for a, b in ((toned, t2),) + (() if mode == "one_image" else ((raw, r2),)):
+        err = (a.grad - b.grad).abs().max().item() / (b.grad.abs().max().item() + 1e-12)
+        assert err <= 1e-4, (mode, err)
+    # bit-reproducible value (fixed summation order) and the constants are refused as differentiable inputs
+    again = l1_ssim_loss(toned, raw, gt, lam, loss_mult=mult)
+    assert again.item() == loss.item()
+    with pytest.raises(RuntimeError):
+        l1_ssim_loss(toned, raw, gt.clone().requires_grad_(True), lam)
+
+
+@pytest.mark.gpu
+def test_fused_ssim_refuses_a_differentiable_second_image_and_runs_without_gradients():
+    from wg_fused_ssim import ssim
+    dev = torch.device("cuda", 0)
+    x, y = torch.rand(3, 40, 50, device=dev), torch.rand(3, 40, 50, device=dev)
+    with pytest.raises(RuntimeError):
+        ssim(x, y.clone().requires_grad_(True))
+    with torch.no_grad():
+        v = ssim(x.clone().requires_grad_(True), y)
+    assert not v.requires_grad and 0.0 < v.item() < 1.0
+
+
 def test_c_abi_exports_the_ssim_entry_points():
     import ctypes as C
     lib = C.CDLL(os.path.join(ROOT, "wild-gaussians_amd", "diff_gaussian_rasterization", "libwg_rasterizer.so"))
     hdr = open(os.path.join(ROOT, "include", "wg_ssim.h")).read()
     import re
-    names = set(re.findall(r"\b(wg_ssim_\w+)\s*\(", hdr))
-    assert names == {"wg_ssim_forward", "wg_ssim_backward"}
+    names = set(re.findall(r"\b(wg_(?:l1_)?ssim_\w+)\s*\(", hdr))
+    assert names == {"wg_ssim_forward", "wg_ssim_backward", "wg_l1_ssim_loss_forward", "wg_l1_ssim_loss_backward", "wg_l1_ssim_loss_scratch_floats"}
     for n in names:
         assert hasattr(lib, n)
     lib.wg_ssim_forward.restype = C.c_int
     lib.wg_ssim_forward.argtypes = [C.c_int] * 3 + [C.c_void_p] * 7
     assert lib.wg_ssim_forward(3, 0, 4, None, None, None, None, None, None, None) == -1  # rejected before any device work
+    lib.wg_l1_ssim_loss_scratch_floats.restype = C.c_size_t
+    assert lib.wg_l1_ssim_loss_scratch_floats(3, 1200, 1600) == 2 * 50 * 75 * 3 and lib.wg_l1_ssim_loss_scratch_floats(0, 4, 4) == 0

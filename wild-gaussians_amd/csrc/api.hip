@@ -2,10 +2,14 @@
 // ::markVisible do in the reference (rasterizer_impl.cu:141-153, 198-340, 344-443).
 #include "wg_common.h"
 
+#include <dlfcn.h>
+
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -23,12 +27,18 @@ int hip_fail(hipError_t e, const char* where) {
 struct StageProfiler {
     bool enabled = false;
     std::mutex mu;
-    struct Rec { int stage; hipEvent_t a, b; };
+    struct Rec { int stage; hipEvent_t a, b; int dev; };
     std::vector<Rec> pending;
-    std::vector<hipEvent_t> pool;
+    std::map<int, std::vector<hipEvent_t>> pool;  // per device: an event belongs to the device it was created on
     wg_stage_times totals{};
-    hipEvent_t get() {
-        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    static int device() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return d;
+    }
+    hipEvent_t get(int dev) {
+        auto& p = pool[dev];
+        if (!p.empty()) { hipEvent_t e = p.back(); p.pop_back(); return e; }
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
         return e;
@@ -48,7 +58,14 @@ struct Mailbox {
     }
 };
 thread_local Mailbox t_mailbox;
-bool g_use_mailbox = true;  // wg_set_option("host_mailbox", 0) restores the copy + synchronise read-back
+
+// the options (wg_common.h: Options): written by wg_set_option under the mutex, copied once per call
+std::mutex g_opt_mu;
+wg::Options g_opt;
+wg::Options options_snapshot() {
+    std::lock_guard<std::mutex> l(g_opt_mu);
+    return g_opt;
+}
 
 Mailbox* get_mailbox() {
     Mailbox& m = t_mailbox;
@@ -67,25 +84,50 @@ Mailbox* get_mailbox() {
         }
         (void)hipGetLastError();
     }
-    return (g_use_mailbox && m.host) ? &m : nullptr;
+    return m.host ? &m : nullptr;
 }
-int g_grad_record = 1;   // wg_set_option("grad_record", 0): the per-tile backward accumulates into the four arrays themselves (A/B)
-int g_depth_codes = 1;  // wg_set_option("depth_codes", 0 / 1 / 8..12): off (as for P > 2^24) / automatic width / forced width (tests)
-bool g_force_global_sort = false;  // wg_set_option("force_global_sort", 1): exercise the fallback binning path
+
+// roctx ranges around every stage (wg_set_option("roctx", 1) or WG_ROCTX=1 in the environment): `rocprofv3 --marker-trace
+// --kernel-trace` then shows K1...K11 as named host ranges above the kernels they launch.  The marker library is looked up at run
+// time (librocprofiler-sdk-roctx.so, else libroctx64.so), so the rasterizer has no link-time dependency on a profiler.
+struct Roctx {
+    int state = 0;  // 0 = not tried, 1 = available, -1 = unavailable
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool enabled = false;
+    bool load() {
+        if (state == 0) {
+            state = -1;
+            for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+                void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (!h) continue;
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) { state = 1; break; }
+            }
+        }
+        return state == 1;
+    }
+};
+Roctx g_roctx;
+const char* stage_label(int stage);
 
 struct StageScope {
-    int stage; hipStream_t stream; hipEvent_t a = nullptr, b = nullptr; bool on;
+    int stage; hipStream_t stream; hipEvent_t a = nullptr, b = nullptr; bool on; bool marked = false; int dev = 0;
     StageScope(int s, hipStream_t st) : stage(s), stream(st), on(g_prof.enabled) {
+        if (g_roctx.enabled) { g_roctx.push(stage_label(s)); marked = true; }
         if (!on) return;
         std::lock_guard<std::mutex> l(g_prof.mu);
-        a = g_prof.get(); b = g_prof.get();
+        dev = StageProfiler::device();
+        a = g_prof.get(dev); b = g_prof.get(dev);
         if (a) (void)hipEventRecord(a, stream);
     }
     ~StageScope() {
+        if (marked) g_roctx.pop();
         if (!on || !a || !b) return;
         (void)hipEventRecord(b, stream);
         std::lock_guard<std::mutex> l(g_prof.mu);
-        g_prof.pending.push_back({stage, a, b});
+        g_prof.pending.push_back({stage, a, b, dev});
     }
 };
 
@@ -104,6 +146,20 @@ struct StageScope {
         }                                                                        \
     } while (0)
 
+const char* stage_label(int stage) {
+    static const char* names[WG_STAGE_COUNT] = {"wg:K1 preprocess", "wg:K2-K3 scan", "wg:K4 duplicate_keys", "wg:K5 sort", "wg:K6-K7 tile_ranges",
+                                                "wg:K8 render_forward", "wg:K9 render_backward", "wg:K10-K11 preprocess_backward",
+                                                "wg:K8 render_fixup"};
+    return (stage >= 0 && stage < WG_STAGE_COUNT) ? names[stage] : "wg:?";
+}
+
+struct RoctxEnv {  // WG_ROCTX=1: ranges on from the first call, without touching the caller
+    RoctxEnv() {
+        const char* e = std::getenv("WG_ROCTX");
+        if (e && e[0] == '1') g_roctx.enabled = g_roctx.load();
+    }
+} g_roctx_env;
+
 template <typename F>
 size_t required_bytes(F carve_fn) {
     char* p = nullptr;
@@ -116,7 +172,9 @@ size_t required_bytes(F carve_fn) {
 extern "C" {
 
 size_t wg_geometry_buffer_size(int P) {
-    return required_bytes([&](char*& c) { wg::GeometryState::fromChunk(c, (size_t)(P > 0 ? P : 0)); });
+    const size_t p = (size_t)(P > 0 ? P : 0);
+    const bool lists = p >= (size_t)options_snapshot().band_list_min_p;
+    return required_bytes([&](char*& c) { wg::GeometryState::fromChunk(c, p, lists); });
 }
 size_t wg_image_buffer_size(int width, int height) {
     const size_t N = (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0);
@@ -159,6 +217,7 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
                                float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
                                float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const wg::Options opt = options_snapshot();
     if (tone != nullptr && shs == nullptr && P > 0) return WG_ERR_INVALID_ARGUMENT;  // the tone acts on SH coefficients
     if (!geometry_alloc || !binning_alloc || !image_alloc) return WG_ERR_INVALID_ARGUMENT;
     if (P < 0 || width <= 0 || height <= 0 || D < 0 || D > 3) return WG_ERR_INVALID_ARGUMENT;
@@ -174,10 +233,11 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
     const int gx = (width + wg::TILE_X - 1) / wg::TILE_X, gy = (height + wg::TILE_Y - 1) / wg::TILE_Y;
     const int tiles = gx * gy;
 
-    char* geom_chunk = geometry_alloc(wg_geometry_buffer_size(P), geometry_user);
+    const bool band_lists = (size_t)P >= (size_t)opt.band_list_min_p;  // size and carving from the same snapshot
+    char* geom_chunk = geometry_alloc(required_bytes([&](char*& c) { wg::GeometryState::fromChunk(c, (size_t)P, band_lists); }), geometry_user);
     char* img_chunk = image_alloc(wg_image_buffer_size(width, height), image_user);
     if (!geom_chunk || !img_chunk) return WG_ERR_ALLOC;
-    wg::GeometryState geom = wg::GeometryState::fromChunk(geom_chunk, (size_t)P);
+    wg::GeometryState geom = wg::GeometryState::fromChunk(geom_chunk, (size_t)P, band_lists);
     wg::ImageState img = wg::ImageState::fromChunk(img_chunk, (size_t)width * height, (size_t)tiles);
 
     wg::FwdParams fp;
@@ -198,7 +258,7 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
         WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, device_tone(tone), geom, radii, stream), "preprocess");
         if (tiles <= wg::BIN_MAX_TILES) {
             WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_count(P, geom, img, gx, tiles, stream), "tile_count");
-            mbox = debug ? nullptr : get_mailbox();
+            mbox = (debug || !opt.use_mailbox) ? nullptr : get_mailbox();
             if (mbox) mbox->seq += 1;
             WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, mbox ? mbox->dev : nullptr, mbox ? mbox->seq : 0, stream), "tile_scan");
         } else {
@@ -255,11 +315,12 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
     // Longest per-tile list decides the binning path: full register sort of every tile, lazy front sort when lists are long,
     // global radix sort (the reference's scheme) when forced, when the frame is too large for the LDS histogram, or when a
     // list exceeds the register sort and the lazy sort is switched off.
-    const bool lazy = wg::g_lazy.enabled && !g_force_global_sort && !huge_frame && max_tile_count > wg::g_lazy.min_len + wg::g_lazy.min_len / 4;
-    const bool global_sort = g_force_global_sort || huge_frame || (!lazy && max_tile_count > wg::TILE_SORT_MAX);
+    const bool lazy = opt.lazy.enabled && !opt.force_global_sort && !huge_frame && max_tile_count > opt.lazy.min_len + opt.lazy.min_len / 4;
+    const bool global_sort = opt.force_global_sort || huge_frame || (!lazy && max_tile_count > wg::TILE_SORT_MAX);
     // lazy sort: bucket entries carry a coarse depth code above the id for the front extraction, as wide as the ids allow
     // (2^20 Gaussians or fewer: 12 bits; up to 2^24: 8 bits; more: none)
     int code_bits = 0;
+    const int g_depth_codes = opt.depth_codes;
     if (lazy && g_depth_codes && P <= (1 << 24)) {
         int id_bits = 20;
         while ((1 << id_bits) < P) id_bits++;
@@ -277,8 +338,8 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
     }
     if (num_rendered > 0) {
         if (!global_sort) {
-            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, (uint32_t)num_rendered, code_bits, stream), "tile_scatter");
-            if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, code_bits, stream), "tile_sort_lazy");
+            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, (uint32_t)num_rendered, code_bits, opt.staged_scatter, opt.staged_cap, stream), "tile_scatter");
+            if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, code_bits, opt.lazy, stream), "tile_sort_lazy");
             else WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, geom, tiles, max_tile_count, stream), "tile_sort");
         } else {
             if (!huge_frame) WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
@@ -296,7 +357,7 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
              "render_forward");
     if (lazy_render)
         WG_STAGE(WG_STAGE_RENDER_FIXUP,
-                 wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, stream),
+                 wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, stream),
                  "render_fixup");
     return num_rendered;
 }
@@ -324,6 +385,8 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
                                 float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                                 float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const wg::Options opt = options_snapshot();
+    const int g_grad_record = opt.grad_record;
     if (tone != nullptr && P > 0) {
         if (shs == nullptr) return WG_ERR_INVALID_ARGUMENT;
         if ((tone->mul != nullptr && tone->dL_dmul == nullptr) || (tone->offset != nullptr && tone->dL_doffset == nullptr)) return WG_ERR_INVALID_ARGUMENT;
@@ -342,7 +405,7 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     if (scales == nullptr && cov3D_precomp == nullptr) return WG_ERR_INVALID_ARGUMENT;
 
     const int gx = (width + wg::TILE_X - 1) / wg::TILE_X, gy = (height + wg::TILE_Y - 1) / wg::TILE_Y;
-    wg::GeometryState geom = wg::GeometryState::fromChunk(geom_buffer, (size_t)P);
+    wg::GeometryState geom = wg::GeometryState::fromChunk(geom_buffer, (size_t)P, false);  // the band lists (carved last) are not needed
     wg::BinningState bin = wg::BinningState::fromChunk(binning_buffer, (size_t)R, false);  // only point_list is used
     wg::ImageState img = wg::ImageState::fromChunk(image_buffer, (size_t)width * height, (size_t)gx * gy);
     if (radii == nullptr) radii = geom.radii;  // rasterizer_impl.cu:381-384
@@ -392,7 +455,7 @@ int wg_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
 
 int wg_view_geometry(char* geom_buffer, int P, wg_geometry_view* out) {
     if (!geom_buffer || !out || P < 0) return WG_ERR_INVALID_ARGUMENT;
-    wg::GeometryState g = wg::GeometryState::fromChunk(geom_buffer, (size_t)P);
+    wg::GeometryState g = wg::GeometryState::fromChunk(geom_buffer, (size_t)P, false);
     out->depths = g.depths;
     out->radii = g.radii;
     out->splats = reinterpret_cast<const float*>(g.splats);
@@ -423,24 +486,31 @@ int wg_view_image(char* image_buffer, int width, int height, wg_image_view* out)
 
 int wg_set_option(const char* name, int value) {
     if (!name) return WG_ERR_INVALID_ARGUMENT;
-    if (std::strcmp(name, "force_global_sort") == 0) { g_force_global_sort = value != 0; return WG_OK; }
-    if (std::strcmp(name, "host_mailbox") == 0) { g_use_mailbox = value != 0; return WG_OK; }
-    if (std::strcmp(name, "grad_record") == 0) { g_grad_record = value != 0; return WG_OK; }
-    if (std::strcmp(name, "band_list_min_p") == 0) { wg::g_band_list_min_p = value > 0 ? value : 1; return WG_OK; }
-    if (std::strcmp(name, "depth_codes") == 0) {
-        if (value != 0 && value != 1 && (value < 8 || value > 12)) return WG_ERR_INVALID_ARGUMENT;
-        g_depth_codes = value;
+    if (std::strcmp(name, "roctx") == 0) {  // WG_ERR_INVALID_ARGUMENT when no marker library can be loaded
+        if (value != 0 && !g_roctx.load()) return WG_ERR_INVALID_ARGUMENT;
+        g_roctx.enabled = value != 0;
         return WG_OK;
     }
-    if (std::strcmp(name, "staged_scatter_cap") == 0) { wg::g_staged_cap = value > 0 ? value : 0; return WG_OK; }
-    if (std::strcmp(name, "staged_scatter") == 0) { wg::g_staged_scatter = value < 0 ? -1 : (value != 0); return WG_OK; }
-    if (std::strcmp(name, "lazy_sort") == 0) { wg::g_lazy.enabled = value != 0; return WG_OK; }
+    std::lock_guard<std::mutex> l(g_opt_mu);
+    wg::Options& o = g_opt;
+    if (std::strcmp(name, "force_global_sort") == 0) { o.force_global_sort = value != 0; return WG_OK; }
+    if (std::strcmp(name, "host_mailbox") == 0) { o.use_mailbox = value != 0; return WG_OK; }
+    if (std::strcmp(name, "grad_record") == 0) { o.grad_record = value != 0; return WG_OK; }
+    if (std::strcmp(name, "band_list_min_p") == 0) { o.band_list_min_p = value > 0 ? value : 1; return WG_OK; }
+    if (std::strcmp(name, "depth_codes") == 0) {
+        if (value != 0 && value != 1 && (value < 8 || value > 12)) return WG_ERR_INVALID_ARGUMENT;
+        o.depth_codes = value;
+        return WG_OK;
+    }
+    if (std::strcmp(name, "staged_scatter_cap") == 0) { o.staged_cap = value > 0 ? value : 0; return WG_OK; }
+    if (std::strcmp(name, "staged_scatter") == 0) { o.staged_scatter = value < 0 ? -1 : (value != 0); return WG_OK; }
+    if (std::strcmp(name, "lazy_sort") == 0) { o.lazy.enabled = value != 0; return WG_OK; }
     if (std::strcmp(name, "lazy_min_len") == 0 || std::strcmp(name, "lazy_target") == 0 || std::strcmp(name, "lazy_cap") == 0) {
         // min_len >= 256 (the selection samples 256 entries) and min_len, cap <= 2048 (the 8-keys-per-thread network)
         if (value < 1 || value > 2048) return WG_ERR_INVALID_ARGUMENT;
-        if (name[5] == 'm') { if (value < 256) return WG_ERR_INVALID_ARGUMENT; wg::g_lazy.min_len = (uint32_t)value; }
-        else if (name[5] == 't') wg::g_lazy.target = (uint32_t)value;
-        else wg::g_lazy.cap = (uint32_t)value;
+        if (name[5] == 'm') { if (value < 256) return WG_ERR_INVALID_ARGUMENT; o.lazy.min_len = (uint32_t)value; }
+        else if (name[5] == 't') o.lazy.target = (uint32_t)value;
+        else o.lazy.cap = (uint32_t)value;
         return WG_OK;
     }
     return WG_ERR_INVALID_ARGUMENT;
@@ -448,11 +518,18 @@ int wg_set_option(const char* name, int value) {
 
 int wg_get_option(const char* name) {
     if (!name) return -1;
-    if (std::strcmp(name, "grad_record") == 0) return g_grad_record;
-    if (std::strcmp(name, "force_global_sort") == 0) return g_force_global_sort ? 1 : 0;
-    if (std::strcmp(name, "host_mailbox") == 0) return g_use_mailbox ? 1 : 0;
-    if (std::strcmp(name, "lazy_sort") == 0) return wg::g_lazy.enabled ? 1 : 0;
-    if (std::strcmp(name, "depth_codes") == 0) return g_depth_codes;
+    if (std::strcmp(name, "roctx") == 0) return g_roctx.enabled ? 1 : 0;
+    const wg::Options o = options_snapshot();
+    if (std::strcmp(name, "grad_record") == 0) return o.grad_record;
+    if (std::strcmp(name, "force_global_sort") == 0) return o.force_global_sort ? 1 : 0;
+    if (std::strcmp(name, "host_mailbox") == 0) return o.use_mailbox ? 1 : 0;
+    if (std::strcmp(name, "lazy_sort") == 0) return o.lazy.enabled ? 1 : 0;
+    if (std::strcmp(name, "depth_codes") == 0) return o.depth_codes;
+    if (std::strcmp(name, "band_list_min_p") == 0) return o.band_list_min_p;
+    if (std::strcmp(name, "staged_scatter") == 0) return o.staged_scatter;
+    if (std::strcmp(name, "lazy_min_len") == 0) return (int)o.lazy.min_len;
+    if (std::strcmp(name, "lazy_target") == 0) return (int)o.lazy.target;
+    if (std::strcmp(name, "lazy_cap") == 0) return (int)o.lazy.cap;
     return -1;
 }
 
@@ -463,7 +540,7 @@ int wg_profile_enable(int enable) {
 
 int wg_profile_reset(void) {
     std::lock_guard<std::mutex> l(g_prof.mu);
-    for (auto& r : g_prof.pending) { g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b); }
+    for (auto& r : g_prof.pending) { g_prof.pool[r.dev].push_back(r.a); g_prof.pool[r.dev].push_back(r.b); }
     g_prof.pending.clear();
     g_prof.totals = wg_stage_times{};
     return WG_OK;
@@ -480,8 +557,8 @@ int wg_profile_read(wg_stage_times* out) {
         if (e != hipSuccess) return hip_fail(e, "profile event elapsed");
         g_prof.totals.total_ms[r.stage] += ms;
         g_prof.totals.launches[r.stage] += 1;
-        g_prof.pool.push_back(r.a);
-        g_prof.pool.push_back(r.b);
+        g_prof.pool[r.dev].push_back(r.a);
+        g_prof.pool[r.dev].push_back(r.b);
     }
     g_prof.pending.clear();
     *out = g_prof.totals;

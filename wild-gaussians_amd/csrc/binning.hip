@@ -1,7 +1,11 @@
-// Tile binning for gfx950: prefix sum of tiles_touched, (tile|depth) key emission, rocPRIM radix sort,
-// per-tile range extraction.  Replaces cub::DeviceScan::InclusiveSum, duplicateWithKeys,
-// cub::DeviceRadixSort::SortPairs and identifyTileRanges (rasterizer_impl.cu:70-138, 280, 306-321)
-// and the scratch carving of rasterizer_impl.cu:155-194.  Integer work: results are bit-exact.
+// Tile binning for gfx950.  Replaces cub::DeviceScan::InclusiveSum, duplicateWithKeys, cub::DeviceRadixSort::SortPairs and
+// identifyTileRanges (rasterizer_impl.cu:70-138, 280, 306-321) and the scratch carving of rasterizer_impl.cu:155-194.
+// Default path: an LDS-only counting sort of the instances by tile (per-chunk tile histograms, column scan, tile scan, scatter of
+// 4-byte Gaussian ids into tile buckets) followed by a per-tile register-resident bitonic sort on (depth, id) -- in full, or of a
+// depth-nearest front only when lists are long (lazy sort, extended on demand by render_fwd.hip's fix-up kernel).  The
+// reference's own scheme -- per-Gaussian prefix sum, (tile|depth) key emission, rocPRIM 64-bit radix sort, range extraction --
+// is kept as the fallback for frames whose tile histogram does not fit LDS (> 36 864 tiles) and for tests.
+// Integer work: point_list / ranges / num_rendered are bit-exact on every path.
 #include <cstring>
 #include <cstdlib>
 #include <map>
@@ -14,17 +18,10 @@
 
 namespace wg {
 
-uint32_t higher_msb(uint32_t n) {  // number of bits needed for values < n, as rasterizer_impl.cu:35-50 computes it
-    uint32_t msb = sizeof(n) * 4;
-    uint32_t step = msb;
-    while (step > 1) {
-        step /= 2;
-        if (n >> msb) msb += step;
-        else msb -= step;
-    }
-    if (n >> msb) msb++;
-    return msb;
-}
+// Number of low key bits the global radix sort has to cover for tile ids < n: the reference's getHigherMsb(n)
+// (rasterizer_impl.cu:35-50, a 5-step bisection) equals the position of n's highest set bit, i.e. floor(log2 n) + 1, for every
+// n >= 1, and 1 for n == 0 (tests/test_oracle.py holds the literal restatement of the bisection to exactly this formula).
+uint32_t higher_msb(uint32_t n) { return n <= 1u ? 1u : 32u - (uint32_t)__builtin_clz(n); }
 
 size_t query_scan_temp_bytes(size_t P) {
     size_t bytes = 0;
@@ -39,11 +36,10 @@ size_t query_sort_temp_bytes(size_t R) {
     return bytes;
 }
 
-int g_band_list_min_p = 2000000;
-// chunk-local indices are 16-bit: lists exist for g_band_list_min_p <= P <= 65536 * BIN_CHUNKS
-static bool band_lists_for(size_t P) { return P >= (size_t)g_band_list_min_p && (P + BIN_CHUNKS - 1) / BIN_CHUNKS <= 65536; }
+// chunk-local indices are 16-bit: lists can exist up to P = 65536 * BIN_CHUNKS (and are wanted from Options::band_list_min_p on)
+bool GeometryState::band_lists_possible(size_t P) { return (P + BIN_CHUNKS - 1) / BIN_CHUNKS <= 65536; }
 
-GeometryState GeometryState::fromChunk(char*& chunk, size_t P) {
+GeometryState GeometryState::fromChunk(char*& chunk, size_t P, bool lists) {
     GeometryState g;
     const size_t Pa = P ? P : 1;
     carve(chunk, g.depths, Pa);
@@ -54,13 +50,13 @@ GeometryState GeometryState::fromChunk(char*& chunk, size_t P) {
     carve(chunk, g.rects, Pa);
     carve(chunk, g.tiles_touched, Pa);
     carve(chunk, g.point_offsets, Pa);
-    const bool lists = band_lists_for(P);
-    carve(chunk, g.band_list, lists ? (size_t)BIN_CHUNKS * 8 * ((Pa + BIN_CHUNKS - 1) / BIN_CHUNKS) : 0);
-    carve(chunk, g.band_cnt, lists ? (size_t)BIN_CHUNKS * 8 : 0);
-    if (!lists) g.band_list = nullptr;
     carve(chunk, g.grad_rec, Pa * GRAD_REC_FLOATS);
     g.scan_temp_bytes = query_scan_temp_bytes(Pa);
     carve(chunk, g.scan_temp, g.scan_temp_bytes);
+    lists = lists && band_lists_possible(P);
+    carve(chunk, g.band_list, lists ? (size_t)BIN_CHUNKS * 8 * ((Pa + BIN_CHUNKS - 1) / BIN_CHUNKS) : 0);
+    carve(chunk, g.band_cnt, lists ? (size_t)BIN_CHUNKS * 8 : 0);
+    if (!lists) g.band_list = nullptr;
     return g;
 }
 
@@ -643,7 +639,6 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restri
 // Tiles listing at most min_len instances are sorted in full.  Of a longer list only a front of about `target` depth-nearest
 // instances is extracted (wg_sort.h: extract_front) and sorted into point_list; seg_end[tile] tells the forward pass how far
 // the list is in order.  The tile's bucket is left as it is.
-LazyConfig g_lazy;
 
 // One workgroup per tile: extract (long list) or take (short list) the ids, sort them in registers, write point_list.
 __global__ void __launch_bounds__(256) tile_front_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bucket_ids,
@@ -770,11 +765,8 @@ hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailb
 }
 
 
-int g_staged_scatter = -1;  // wg_set_option("staged_scatter", -1 auto / 0 / 1)
-int g_staged_cap = 0;       // wg_set_option("staged_scatter_cap", n): staging-area entries, 0 = what the LDS budget allows (tests: multi-pass)
-
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
-                               uint32_t num_rendered, int code_bits, hipStream_t stream) {
+                               uint32_t num_rendered, int code_bits, int g_staged_scatter, int g_staged_cap, hipStream_t stream) {
     if (P <= 0) return hipSuccess;
     // staged scatter for long lists: G chunks per workgroup such that an average share fits the staging area with headroom
     const bool want = g_staged_scatter == 1 || (g_staged_scatter < 0 && tiles > 0 && num_rendered / (uint32_t)tiles >= 1500u);
@@ -833,7 +825,7 @@ static hipError_t launch_tile_sort_e(const ImageState& img, const BinningState& 
 }
 
 hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, int code_bits,
-                                 hipStream_t stream) {
+                                 const LazyConfig& g_lazy, hipStream_t stream) {
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(tile_front_sort_kernel, dim3(tiles), dim3(256), 0, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list,
                        img.seg_end, g_lazy.min_len, g_lazy.target, g_lazy.cap, code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu);

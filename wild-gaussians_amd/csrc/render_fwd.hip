@@ -314,7 +314,8 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
 }
 
 hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
-                               const float* subpixel_offset, const float* background, float* out_color, hipStream_t stream) {
+                               const float* subpixel_offset, const float* background, float* out_color, const LazyConfig& g_lazy,
+                               hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(render_fixup_kernel, dim3(tiles), dim3(256), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, b.bucket_ids,

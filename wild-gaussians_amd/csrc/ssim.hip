@@ -10,6 +10,7 @@
 // The backward pass is the same separable convolution applied to dL_dmap * (the three derivative maps).
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <stddef.h>
 #include "wg_ssim.h"
 #include "wg_rasterizer.h"
 
@@ -22,11 +23,19 @@ struct SsimTaps {
     float w[SS_K];
 };
 
+// LOSS (include/wg_ssim.h: wg_l1_ssim_loss_*): instead of writing the SSIM map, the workgroup sums (1 - ssim) * mult and
+// |img_l1 - img2| * mult over its tile (img2 = the ground truth) and leaves the two partial sums in partials[2 * block]; a second
+// tiny kernel adds the partials in block order (deterministic) and forms the reference's loss (method.py:1948-1965).
+template <bool LOSS>
 __global__ void __launch_bounds__(256) ssim_forward_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                                                            float* __restrict__ ssim_map, float* __restrict__ dm_dmu1,
-                                                           float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12, SsimTaps taps) {
+                                                           float* __restrict__ dm_dsigma1_sq, float* __restrict__ dm_dsigma12, SsimTaps taps,
+                                                           const float* __restrict__ img_l1, const float* __restrict__ mult,
+                                                           float* __restrict__ partials) {
     __shared__ float sx[SS_HH][SS_HW + 1], sy[SS_HH][SS_HW + 1];
     __shared__ float hs[5][SS_HH][SS_TW + 1];
+    __shared__ float red[2][4];
+    float acc_s = 0.f, acc_l = 0.f;
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * SS_TW, y0 = blockIdx.y * SS_TH;
     const size_t plane = (size_t)blockIdx.z * H * W;
@@ -66,7 +75,14 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(int H, int W, const f
         const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
         const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cc = mu1_sq + mu2_sq + C1, D = s1 + s2 + C2;
         const size_t o = plane + (size_t)gy * W + gx;
-        ssim_map[o] = (A * B) / (Cc * D);
+        const float m = (A * B) / (Cc * D);
+        if (LOSS) {
+            const float wgt = mult ? mult[(size_t)gy * W + gx] : 1.0f;
+            acc_s += (1.0f - m) * wgt;
+            acc_l += fabsf(img_l1[o] - sy[ly + SS_R][lx + SS_R]) * wgt;
+        } else {
+            ssim_map[o] = m;
+        }
         if (dm_dmu1) {
             // total derivative w.r.t. mu1, including sigma1_sq = E[xx] - mu1^2 and sigma12 = E[xy] - mu1*mu2
             const float iCD = 1.f / (Cc * D);
@@ -75,13 +91,56 @@ __global__ void __launch_bounds__(256) ssim_forward_kernel(int H, int W, const f
             dm_dsigma12[o] = 2.f * A * iCD;
         }
     }
+    if (LOSS) {  // workgroup sum in a fixed order: lanes (xor butterfly), then the four waves
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            acc_s += __shfl_xor(acc_s, d);
+            acc_l += __shfl_xor(acc_l, d);
+        }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = acc_s; red[1][tid >> 6] = acc_l; }
+        __syncthreads();
+        if (tid == 0) {
+            const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            partials[2 * b] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            partials[2 * b + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        }
+    }
+}
+
+// loss_out = { (1 - lambda) * l1_mean + lambda * dssim_mean, l1_mean, ssim_mean } from the per-workgroup partial sums
+__global__ void __launch_bounds__(1024) l1_ssim_finish_kernel(const float* __restrict__ partials, int nblocks, float inv_count, float lambda,
+                                                              float* __restrict__ loss_out) {
+    __shared__ double red[2][16];
+    double s = 0.0, l = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 1024) { s += partials[2 * i]; l += partials[2 * i + 1]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s += __shfl_xor(s, d);
+        l += __shfl_xor(l, d);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = l; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = 0.0; l = 0.0;
+        for (int w = 0; w < 16; w++) { s += red[0][w]; l += red[1][w]; }
+        const float dssim = (float)(s * inv_count), l1 = (float)(l * inv_count);
+        loss_out[0] = (1.0f - lambda) * l1 + lambda * dssim;
+        loss_out[1] = l1;
+        loss_out[2] = 1.0f - dssim;   // mean SSIM when mult == 1 (what the reference logs, method.py:1972)
+    }
 }
 
 // dL_dimg1(q) = sum_p w(p - q) g(p) [ dm_dmu1(p) + 2 img1(q) dm_dsigma1_sq(p) + img2(q) dm_dsigma12(p) ]
+// LOSS: dL_dmap is not a tensor but  -lambda * inv_count * (*dL_dloss) * mult[pixel]  (the loss is lambda * mean((1 - ssim) mult)),
+// and the L1 branch's gradient  (1 - lambda) * inv_count * (*dL_dloss) * mult * sign(img_l1 - img2)  is written alongside.
+template <bool LOSS>
 __global__ void __launch_bounds__(256) ssim_backward_kernel(int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
                                                             const float* __restrict__ dL_dmap, const float* __restrict__ dm_dmu1,
                                                             const float* __restrict__ dm_dsigma1_sq, const float* __restrict__ dm_dsigma12,
-                                                            float* __restrict__ dL_dimg1, SsimTaps taps) {
+                                                            float* __restrict__ dL_dimg1, SsimTaps taps, const float* __restrict__ img_l1,
+                                                            const float* __restrict__ mult, const float* __restrict__ dL_dloss, float lambda,
+                                                            float inv_count, float* __restrict__ dL_dimg_l1) {
+    const float gl = LOSS ? dL_dloss[0] * inv_count : 0.f;
     __shared__ float t[3][SS_HH][SS_HW + 1];
     __shared__ float hs[3][SS_HH][SS_TW + 1];
     const int tid = threadIdx.x;
@@ -93,7 +152,7 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(int H, int W, const 
         float a = 0.f, b = 0.f, c = 0.f;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
             const size_t o = plane + (size_t)gy * W + gx;
-            const float g = dL_dmap[o];
+            const float g = LOSS ? -lambda * gl * (mult ? mult[(size_t)gy * W + gx] : 1.0f) : dL_dmap[o];
             a = g * dm_dmu1[o]; b = g * dm_dsigma1_sq[o]; c = g * dm_dsigma12[o];
         }
         t[0][ly][lx] = a; t[1][ly][lx] = b; t[2][ly][lx] = c;
@@ -121,7 +180,20 @@ __global__ void __launch_bounds__(256) ssim_backward_kernel(int H, int W, const 
             a += w * hs[0][ly + k][lx]; b += w * hs[1][ly + k][lx]; c += w * hs[2][ly + k][lx];
         }
         const size_t o = plane + (size_t)gy * W + gx;
-        dL_dimg1[o] = a + 2.f * img1[o] * b + img2[o] * c;
+        const float gt = img2[o];
+        const float gs = a + 2.f * img1[o] * b + gt * c;
+        if (LOSS) {
+            const float d = img_l1[o] - gt;
+            const float gl1 = (1.0f - lambda) * gl * (mult ? mult[(size_t)gy * W + gx] : 1.0f) * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+            if (dL_dimg_l1 == dL_dimg1) {  // one image feeds both terms: a single gradient
+                dL_dimg1[o] = gs + gl1;
+            } else {
+                dL_dimg1[o] = gs;
+                dL_dimg_l1[o] = gl1;
+            }
+        } else {
+            dL_dimg1[o] = gs;
+        }
     }
 }
 
@@ -145,8 +217,8 @@ int wg_ssim_forward(int C, int H, int W, const float* img1, const float* img2, f
     if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !ssim_map) return WG_ERR_INVALID_ARGUMENT;
     if ((dm_dmu1 != nullptr) != (dm_dsigma1_sq != nullptr) || (dm_dmu1 != nullptr) != (dm_dsigma12 != nullptr)) return WG_ERR_INVALID_ARGUMENT;
     const dim3 grid((W + wg::SS_TW - 1) / wg::SS_TW, (H + wg::SS_TH - 1) / wg::SS_TH, C);
-    hipLaunchKernelGGL(wg::ssim_forward_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), H, W, img1, img2, ssim_map,
-                       dm_dmu1, dm_dsigma1_sq, dm_dsigma12, wg::make_taps());
+    hipLaunchKernelGGL(wg::ssim_forward_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), H, W, img1, img2, ssim_map,
+                       dm_dmu1, dm_dsigma1_sq, dm_dsigma12, wg::make_taps(), (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     return hipGetLastError() == hipSuccess ? WG_OK : WG_ERR_HIP;
 }
 
@@ -155,8 +227,42 @@ int wg_ssim_backward(int C, int H, int W, const float* img1, const float* img2, 
     if (C <= 0 || H <= 0 || W <= 0 || !img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 || !dL_dimg1)
         return WG_ERR_INVALID_ARGUMENT;
     const dim3 grid((W + wg::SS_TW - 1) / wg::SS_TW, (H + wg::SS_TH - 1) / wg::SS_TH, C);
-    hipLaunchKernelGGL(wg::ssim_backward_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), H, W, img1, img2, dL_dmap,
-                       dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, wg::make_taps());
+    hipLaunchKernelGGL(wg::ssim_backward_kernel<false>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), H, W, img1, img2, dL_dmap,
+                       dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg1, wg::make_taps(), (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, 0.f, 0.f, (float*)nullptr);
+    return hipGetLastError() == hipSuccess ? WG_OK : WG_ERR_HIP;
+}
+
+size_t wg_l1_ssim_loss_scratch_floats(int C, int H, int W) {
+    if (C <= 0 || H <= 0 || W <= 0) return 0;
+    return 2 * (size_t)((W + wg::SS_TW - 1) / wg::SS_TW) * (size_t)((H + wg::SS_TH - 1) / wg::SS_TH) * (size_t)C;
+}
+
+int wg_l1_ssim_loss_forward(int C, int H, int W, const float* img_l1, const float* img_ssim, const float* gt, const float* mult,
+                            float lambda, float* scratch, float* loss_out, float* dm_dmu1, float* dm_dsigma1_sq, float* dm_dsigma12,
+                            void* stream) {
+    if (C <= 0 || H <= 0 || W <= 0 || !img_l1 || !img_ssim || !gt || !scratch || !loss_out) return WG_ERR_INVALID_ARGUMENT;
+    if ((dm_dmu1 != nullptr) != (dm_dsigma1_sq != nullptr) || (dm_dmu1 != nullptr) != (dm_dsigma12 != nullptr)) return WG_ERR_INVALID_ARGUMENT;
+    const dim3 grid((W + wg::SS_TW - 1) / wg::SS_TW, (H + wg::SS_TH - 1) / wg::SS_TH, C);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(wg::ssim_forward_kernel<true>, grid, dim3(256), 0, st, H, W, img_ssim, gt, (float*)nullptr, dm_dmu1, dm_dsigma1_sq,
+                       dm_dsigma12, wg::make_taps(), img_l1, mult, scratch);
+    hipLaunchKernelGGL(wg::l1_ssim_finish_kernel, dim3(1), dim3(1024), 0, st, scratch, (int)(grid.x * grid.y * grid.z),
+                       1.0f / ((float)C * (float)H * (float)W), lambda, loss_out);
+    return hipGetLastError() == hipSuccess ? WG_OK : WG_ERR_HIP;
+}
+
+int wg_l1_ssim_loss_backward(int C, int H, int W, const float* img_l1, const float* img_ssim, const float* gt, const float* mult,
+                             float lambda, const float* dL_dloss, const float* dm_dmu1, const float* dm_dsigma1_sq,
+                             const float* dm_dsigma12, float* dL_dimg_l1, float* dL_dimg_ssim, void* stream) {
+    if (C <= 0 || H <= 0 || W <= 0 || !img_l1 || !img_ssim || !gt || !dL_dloss || !dm_dmu1 || !dm_dsigma1_sq || !dm_dsigma12 ||
+        !dL_dimg_l1 || !dL_dimg_ssim)
+        return WG_ERR_INVALID_ARGUMENT;
+    if ((img_l1 == img_ssim) != (dL_dimg_l1 == dL_dimg_ssim)) return WG_ERR_INVALID_ARGUMENT;  // one image <-> one gradient
+    const dim3 grid((W + wg::SS_TW - 1) / wg::SS_TW, (H + wg::SS_TH - 1) / wg::SS_TH, C);
+    hipLaunchKernelGGL(wg::ssim_backward_kernel<true>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), H, W, img_ssim, gt,
+                       (const float*)nullptr, dm_dmu1, dm_dsigma1_sq, dm_dsigma12, dL_dimg_ssim, wg::make_taps(), img_l1, mult, dL_dloss, lambda,
+                       1.0f / ((float)C * (float)H * (float)W), dL_dimg_l1);
     return hipGetLastError() == hipSuccess ? WG_OK : WG_ERR_HIP;
 }
 

@@ -34,7 +34,10 @@ struct GeometryState {
     float* grad_rec;      // backward only: one 64-byte gradient record per Gaussian (GRAD_REC_*), cleared at the start of every backward
     char* scan_temp;
     size_t scan_temp_bytes;
-    static GeometryState fromChunk(char*& chunk, size_t P);
+    // band_lists: whether the two band-list arrays exist.  They are carved LAST, so that everything the backward pass and the
+    // views address has the same offset either way (the decision is the forward call's alone, taken from its option snapshot).
+    static GeometryState fromChunk(char*& chunk, size_t P, bool band_lists);
+    static bool band_lists_possible(size_t P);  // chunk-local indices are 16-bit
 };
 
 // Gradient record of the per-tile backward pass (render_bwd.hip, RECORD): 12 floats = 48 bytes per Gaussian (three float4; a
@@ -88,8 +91,6 @@ struct BinningState {
 
 constexpr uint32_t TILE_SORT_MAX = 8192;  // longest per-tile list the register sort handles (32 keys per thread)
 constexpr int BIN_CHUNKS = 512;           // Gaussian chunks (= workgroups) of the LDS counting sort
-extern int g_band_list_min_p;  // default 2 000 000: from here on the scatter kernels read per-band candidate lists instead of whole
-                               // chunks (wg_set_option("band_list_min_p"); it sizes the geometry buffer: set it between frames only)
 constexpr int BIN_MAX_TILES = 36864;      // tiles*4 B must fit one workgroup's LDS (144 KiB): up to 4K frames
 
 size_t query_scan_temp_bytes(size_t P);
@@ -147,12 +148,10 @@ hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& im
 hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_or_null, uint32_t* order, int tiles, hipStream_t stream);
 hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, hipStream_t stream);
 hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, hipStream_t stream);
-extern int g_staged_scatter;
-extern int g_staged_cap;
 // code_bits > 0: bucket entries carry a coarse depth code of that width above the id (wg_sort.h: depth_code); only the lazy
 // sort reads it
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
-                               uint32_t num_rendered, int code_bits, hipStream_t stream);
+                               uint32_t num_rendered, int code_bits, int staged_scatter, int staged_cap, hipStream_t stream);
 struct LazyConfig {
     bool enabled = true;
     uint32_t min_len = 1024;  // tiles listing more than this are front-split instead of sorted in full (the lazy path as a whole is
@@ -161,10 +160,23 @@ struct LazyConfig {
     uint32_t target = 820;    // aimed front length of the first round (the 1024-key network)
     uint32_t cap = 2048;      // hard bound of a front (the 2048-key network)
 };
-extern LazyConfig g_lazy;
-hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, int code_bits, hipStream_t stream);
+// Every option wg_set_option() can change (include/wg_rasterizer.h).  The library keeps one instance behind a mutex; each C-ABI call
+// takes ONE copy at its start and hands it down, so a call sees a consistent set whatever other host threads set meanwhile.
+struct Options {
+    LazyConfig lazy;
+    int staged_scatter = -1;          // -1 auto / 0 / 1
+    int staged_cap = 0;               // staging-area entries, 0 = what the LDS budget allows (tests: multi-pass)
+    int band_list_min_p = 2000000;    // from here on the scatter kernels read per-band candidate lists instead of whole chunks
+    int depth_codes = 1;              // 0 / 1 / 8..12: off (as for P > 2^24) / automatic width / forced width (tests)
+    int grad_record = 1;              // 0: the per-tile backward accumulates into the four arrays themselves (A/B)
+    bool force_global_sort = false;   // exercise the fallback binning path
+    bool use_mailbox = true;          // 0 restores the copy + synchronise read-back
+};
+hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, int code_bits,
+                                 const LazyConfig& lazy, hipStream_t stream);
 hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
-                               const float* subpixel_offset, const float* background, float* out_color, hipStream_t stream);
+                               const float* subpixel_offset, const float* background, float* out_color, const LazyConfig& lazy,
+                               hipStream_t stream);
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
                             hipStream_t stream);
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,

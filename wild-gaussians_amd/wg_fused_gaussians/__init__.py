@@ -110,39 +110,3 @@ def add_densification_stats(radii, viewspace_grad, xyz_grad, denom, max_radii2D=
     with torch.cuda.device(radii.device):
         _native._check(_lib.wg_densification_stats(P, radii.data_ptr(), g.data_ptr(), bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], stream),
                        "wg_densification_stats")
-
-
-class _TallLinear(torch.autograd.Function):
-    """y = x W^T + b for a very tall x (millions of rows, <= a few hundred columns).  Plain PyTorch -- no kernel of this repository
-    -- around one observation on MI355X: the weight gradient x^T dy is a product with a reduction as long as x is tall, for which
-    the BLAS picks 32x32 tiles (26 TFLOP/s fp32 at 3 M rows); cut into row chunks and issued as ONE batched product of
-    [C, in, rows/C] x [C, rows/C, out] followed by a sum over C, the same arithmetic runs several times faster."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, chunks):
-        ctx.save_for_backward(x, weight)
-        ctx.chunks = chunks
-        ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = gy @ weight
-        if ctx.needs_input_grad[1]:
-            n, c = x.shape[0], max(1, min(ctx.chunks, x.shape[0]))
-            rows = (n // c) * c
-            gw = torch.bmm(x[:rows].view(c, rows // c, -1).transpose(1, 2), gy[:rows].view(c, rows // c, -1)).sum(0).t()
-            if rows < n:
-                gw = gw + gy[rows:].t() @ x[rows:]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum(0)
-        return gx, gw, gb, None
-
-
-def tall_linear(x, weight, bias=None, chunks=256):
-    """Drop-in for `torch.nn.functional.linear(x, weight, bias)` when x has millions of rows (the appearance MLP over all Gaussians,
-    wildgaussians/method.py:882-900): same forward, the weight gradient computed as a batched product over `chunks` row blocks."""
-    return _TallLinear.apply(x, weight, bias, chunks)

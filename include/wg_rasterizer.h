@@ -199,6 +199,8 @@ typedef struct wg_image_view {
     const uint32_t* n_contrib;  /* [H*W] */
     const uint32_t* ranges;     /* [tiles*2] (start,end) */
     const uint32_t* tile_last;  /* [tiles] max n_contrib over the tile's pixels */
+    const uint32_t* tile_near;  /* [tiles] near / far split: near instances of the tile (meaningful only when the split was attempted) */
+    const uint32_t* split;      /* [2] {depth-code threshold of the split, 0xffffffff = off; 1 = some tile needed its far instances} */
 } wg_image_view;
 
 int wg_view_geometry(char* geom_buffer, int P, wg_geometry_view* out);
@@ -238,6 +240,12 @@ const char* wg_stage_name(int stage);
  * "depth_codes" (1/0, default 1): with at most 2^24 Gaussians the lazy sort's bucket entries carry a coarse depth code (8 to 12
  * bits, what the ids leave free) above the id, so that the front extraction fetches exact depths only near its bounds; 0
  * exercises the uncoded path, 8..12 force a width (not wider than the ids allow). */
+/* "near_split" (-1 automatic / 0 off / 1 whenever possible, default -1): dense frames of large scenes (from "band_list_min_p"
+ * Gaussians on, at 1500 or more instances per tile) first bin, scatter and front-sort only the NEAR instances -- those of the
+ * Gaussians below a frame-wide depth-code threshold picked on the device so that about "near_per_tile" (0 = 2.5 x "lazy_target")
+ * instances per tile qualify -- and scatter the far ones afterwards only into tiles whose pixels are still accumulating when their
+ * near instances are used up.  num_rendered, radii, images, n_contrib and gradients are those of the full binning.
+ */
 /* "roctx" (0/1, default 0; WG_ROCTX=1 in the environment switches it on from the first call): a roctx range around every stage
  * ("wg:K1 preprocess" ... "wg:K10-K11 preprocess_backward"), for `rocprofv3 --marker-trace --kernel-trace`.  The marker library is
  * dlopen()ed on demand; WG_ERR_INVALID_ARGUMENT if none is found. */

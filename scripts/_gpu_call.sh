@@ -1,15 +1,12 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r2c5; mkdir -p $O
-timeout 600 python -m pytest tests/test_ssim.py -m gpu -q --tb=short 2>&1 | tail -40 > $O/pytest_ssim.log; tail -30 $O/pytest_ssim.log
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
-timeout 900 scripts/asan_pass.sh $O/asan_pass.log; tail -12 $O/asan_pass.log
-WG_ROCTX=1 timeout 600 rocprofv3 --marker-trace --kernel-trace --stats -d $O/mk -o m -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile > $O/mk.log 2>&1
-python - <<'PY' > gpurun_out/r2c5/roctx_marker_summary.txt 2>&1
-import sqlite3, glob
-db = sqlite3.connect(glob.glob("gpurun_out/r2c5/mk/*results.db")[0])
-print(list(db.execute("select count(*) from regions")))
-for r in db.execute("select category, name, count(*), avg(duration)/1e3 from regions group by category, name order by count(*) desc limit 40"):
-    print(r)
-PY
-cat $O/roctx_marker_summary.txt | head -45; ls $O/mk; rm -rf $O/mk
-timeout 300 python bench.py --steps 200 --warmup 30 --no-cpu-baseline | tail -1 | cut -c1-400
+O=gpurun_out/r2c7; mkdir -p $O
+B="python bench.py --no-cpu-baseline"
+run() { n=$1; shift; timeout 600 $B "$@" > $O/bench_$n.log 2>&1; tail -1 $O/bench_$n.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$n', d['value'], d['forward_fps'], d['stages_ms'])" || tail -5 $O/bench_$n.log; }
+# MFMA reduction variant: parity, then time
+WG_RASTERIZER_LIB=$PWD/wild-gaussians_amd/build/bwd_mfma/libwg_rasterizer.so timeout 600 python -m pytest tests/test_parity_gpu.py -m gpu -x -q -k "backward_gradient_parity or gradient_record" 2>&1 | tail -3
+WG_RASTERIZER_LIB=$PWD/wild-gaussians_amd/build/bwd_mfma/libwg_rasterizer.so run bwd_mfma --steps 200 --warmup 30
+run bwd_butterfly --steps 200 --warmup 30
+run x4_auto_hint --steps 100 --warmup 10 --scale-mult 4
+run x2_auto_hint --steps 100 --warmup 10 --scale-mult 2
+run c5_npt1000 --steps 30 --warmup 5 --gaussians 10000000 --width 3840 --height 2160 --forward-only --option near_per_tile=1000
+run c5_npt1400 --steps 30 --warmup 5 --gaussians 10000000 --width 3840 --height 2160 --forward-only --option near_per_tile=1400

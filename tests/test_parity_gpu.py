@@ -437,7 +437,8 @@ def lazy_options():
         for k, v in kw.items():
             _C.set_option(k, v)
     yield set_
-    set_(lazy_sort=1, lazy_min_len=1024, lazy_target=820, lazy_cap=2048, depth_codes=1)
+    set_(lazy_sort=1, lazy_min_len=1024, lazy_target=820, lazy_cap=2048, depth_codes=1, near_split=-1, near_per_tile=0, band_list_min_p=2000000,
+         staged_scatter=-1, staged_scatter_cap=0)
 
 
 def _dense_scene():
@@ -485,6 +486,58 @@ def test_lazy_sort_gives_the_fully_sorted_results(oracle, lazy_options, opts):
     assert compare_forward(hh["color"], oo)["max_err_solid"] <= 1e-4
     for k, e in compare_grads(hh["grads"], oo["grads"]).items():
         assert e <= 1e-3, (k, e)
+
+
+@pytest.mark.parametrize("extra", [dict(), dict(band_list_min_p=1), dict(staged_scatter=1, staged_scatter_cap=24), dict(depth_codes=0)])
+@pytest.mark.parametrize("npt", [30, 150, 500])
+def test_near_far_split_gives_the_fully_sorted_results(oracle, lazy_options, npt, extra):
+    """Near / far split (wg_set_option "near_split"): only the instances of Gaussians below a frame-wide depth-code threshold are
+    binned, scattered and front-sorted at first; tiles still accumulating when those run out get their far instances afterwards.
+    With ~1000 instances per tile and pixels stopping after ~220, 30 near instances per tile send nearly every tile to the far
+    phase, 500 only the odd one.  Everything the operator returns equals the full binning's, bit for bit."""
+    cloud, cam, W, H = _dense_scene()
+    o = oracle.run_scene(cloud, cam, sh_degree=1)
+    rg = o["ctx"].get("ranges")
+    lazy_options(lazy_sort=0, near_split=0)
+    full = run_hip_native(cloud, cam, sh_degree=1)
+    lazy_options(lazy_sort=1, near_split=1, near_per_tile=npt, lazy_min_len=256, lazy_target=100, lazy_cap=256, **extra)
+    lz = run_hip_native(cloud, cam, sh_degree=1)
+    sp = lz["views"]["image"]["split"].cpu().numpy().view(np.uint32)
+    near = lz["views"]["image"]["tile_near"].cpu().numpy().astype(np.int64)
+    n = (rg[:, 1] - rg[:, 0]).astype(np.int64)
+    assert sp[0] != 0xffffffff and (near <= n).all() and near.sum() < 0.8 * n.sum()   # the split was on and did prune
+    assert abs(near.sum() / max(1, (n > 0).sum()) - npt) <= 0.5 * npt + 20                # about npt near instances per tile
+    if npt == 30:
+        assert sp[1] == 1   # far phase taken
+    assert lz["num_rendered"] == full["num_rendered"]
+    assert torch.equal(lz["color"], full["color"]) and torch.equal(lz["radii"], full["radii"])
+    for k in ("final_T", "n_contrib", "tile_last", "ranges"):
+        assert torch.equal(lz["views"]["image"][k], full["views"]["image"][k]), k
+    pl = lz["views"]["binning"]["point_list"].cpu().numpy().view(np.uint32)
+    ref = o["ctx"].get("point_list")
+    tl = lz["views"]["image"]["tile_last"].cpu().numpy()
+    for t in range(rg.shape[0]):
+        b, w = int(rg[t, 0]), int(tl[t])
+        np.testing.assert_array_equal(pl[b:b + w], ref[b:b + w])
+    cot = S.make_cotangent(W, H)
+    oo = oracle.run_scene(cloud, cam, sh_degree=1, cotangent=cot)
+    hh = run_hip(cloud, cam, sh_degree=1, cotangent=cot)
+    assert compare_forward(hh["color"], oo)["max_err_solid"] <= 1e-4
+    for k, e in compare_grads(hh["grads"], oo["grads"]).items():
+        assert e <= 1e-3, (k, e)
+
+
+def test_near_far_split_stays_off_on_frames_that_are_not_dense(lazy_options):
+    """Automatic mode: attempted from band_list_min_p Gaussians on, but switched off on the device below 1500 instances per tile."""
+    W, H, P = 640, 360, 60000
+    cam, cloud = S.make_camera(W, H), S.make_cloud(P, W, H, sh_degree=0, seed=3, scale_mult=2.0)
+    lazy_options(near_split=0)
+    a = run_hip_native(cloud, cam, sh_degree=0)
+    lazy_options(near_split=-1, band_list_min_p=1)
+    b = run_hip_native(cloud, cam, sh_degree=0)
+    assert int(b["views"]["image"]["split"].cpu().numpy().view(np.uint32)[0]) == 0xffffffff
+    assert torch.equal(a["color"], b["color"]) and a["num_rendered"] == b["num_rendered"]
+    assert torch.equal(a["views"]["binning"]["point_list"], b["views"]["binning"]["point_list"])
 
 
 def test_lazy_sort_at_default_thresholds_on_a_dense_frame(oracle, lazy_options):

@@ -4,6 +4,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -58,6 +59,7 @@ struct Mailbox {
     }
 };
 thread_local Mailbox t_mailbox;
+thread_local uint32_t t_last_instances_per_tile = 0;  // density of this thread's previous frame: the near / far split's "try it" hint
 
 // the options (wg_common.h: Options): written by wg_set_option under the mutex, copied once per call
 std::mutex g_opt_mu;
@@ -254,13 +256,25 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
     uint32_t max_tile_count = 0;
     bool huge_frame = false;
     Mailbox* mbox = nullptr;
+    // Near / far split of dense frames (binning.hip): attempted from band_list_min_p Gaussians on (or whenever forced), on the LDS
+    // binning path with the lazy sort available; whether it is ACTIVE for this frame is decided on the device (dense enough?) and
+    // comes back with the instance count.
+    const uint32_t near_per_tile = opt.near_per_tile > 0 ? (uint32_t)opt.near_per_tile : (opt.lazy.target * 5u) / 2u;
+    // Automatic mode attempts it for large scenes and whenever this host thread's previous frame was dense (a performance hint only:
+    // the threshold pass costs ~15 us, the results are the same either way).
+    const bool try_split = P > 0 && tiles <= wg::BIN_MAX_TILES && opt.lazy.enabled && !opt.force_global_sort && opt.near_split != 0 &&
+                           wg::GeometryState::band_lists_possible((size_t)P) &&
+                           (opt.near_split == 1 || P >= opt.band_list_min_p || t_last_instances_per_tile >= 1500u);
+    bool split_active = false;
     if (P > 0) {
         WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, device_tone(tone), geom, radii, stream), "preprocess");
         if (tiles <= wg::BIN_MAX_TILES) {
-            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_count(P, geom, img, gx, tiles, stream), "tile_count");
+            if (try_split)
+                WG_STAGE(WG_STAGE_SCAN, wg::launch_split_threshold(P, geom, img, tiles, opt.near_split == 1, near_per_tile, stream), "split_threshold");
+            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_count(P, geom, img, gx, tiles, try_split, stream), "tile_count");
             mbox = (debug || !opt.use_mailbox) ? nullptr : get_mailbox();
             if (mbox) mbox->seq += 1;
-            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, mbox ? mbox->dev : nullptr, mbox ? mbox->seq : 0, stream), "tile_scan");
+            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, mbox ? mbox->dev : nullptr, mbox ? mbox->seq : 0, try_split, stream), "tile_scan");
         } else {
             huge_frame = true;  // tile histogram does not fit LDS: count through the per-Gaussian prefix sum instead
             WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
@@ -283,6 +297,7 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
                 std::atomic_thread_fence(std::memory_order_acquire);
                 st.num_rendered = mbox->host->num_rendered;
                 st.max_tile_count = mbox->host->max_tile_count;
+                st.split_active = mbox->host->split_active;
                 have_stats = true;
             }
         }
@@ -306,6 +321,8 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
         if (st.num_rendered > 0x7fffffffu) return WG_ERR_OVERFLOW;
         num_rendered = (int)st.num_rendered;
         max_tile_count = st.max_tile_count;
+        split_active = try_split && !huge_frame && st.split_active != 0u;
+        t_last_instances_per_tile = tiles > 0 ? st.num_rendered / (uint32_t)tiles : 0u;
     } else {
         hipError_t e = hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream);
         if (e != hipSuccess) return hip_fail(e, "ranges memset");
@@ -315,7 +332,9 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
     // Longest per-tile list decides the binning path: full register sort of every tile, lazy front sort when lists are long,
     // global radix sort (the reference's scheme) when forced, when the frame is too large for the LDS histogram, or when a
     // list exceeds the register sort and the lazy sort is switched off.
-    const bool lazy = opt.lazy.enabled && !opt.force_global_sort && !huge_frame && max_tile_count > opt.lazy.min_len + opt.lazy.min_len / 4;
+    // (an active split implies the lazy path: its buckets only hold the near instances at first)
+    const bool lazy = split_active ||
+                      (opt.lazy.enabled && !opt.force_global_sort && !huge_frame && max_tile_count > opt.lazy.min_len + opt.lazy.min_len / 4);
     const bool global_sort = opt.force_global_sort || huge_frame || (!lazy && max_tile_count > wg::TILE_SORT_MAX);
     // lazy sort: bucket entries carry a coarse depth code above the id for the front extraction, as wide as the ids allow
     // (2^20 Gaussians or fewer: 12 bits; up to 2^24: 8 bits; more: none)
@@ -338,8 +357,11 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
     }
     if (num_rendered > 0) {
         if (!global_sort) {
-            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, (uint32_t)num_rendered, code_bits, opt.staged_scatter, opt.staged_cap, stream), "tile_scatter");
-            if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, code_bits, opt.lazy, stream), "tile_sort_lazy");
+            // what the scatter will emit, for the sizing of its staging passes: everything, or about near_per_tile per tile
+            uint32_t emit = (uint32_t)num_rendered;
+            if (split_active) emit = (uint32_t)std::min<uint64_t>(emit, (uint64_t)near_per_tile * (uint64_t)tiles * 5u / 4u);
+            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, emit, code_bits, opt.staged_scatter, opt.staged_cap, try_split, stream), "tile_scatter");
+            if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, code_bits, opt.lazy, try_split, stream), "tile_sort_lazy");
             else WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, geom, tiles, max_tile_count, stream), "tile_sort");
         } else {
             if (!huge_frame) WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
@@ -355,10 +377,17 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
     WG_STAGE(WG_STAGE_RENDER_FORWARD,
              wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, lazy_render, stream),
              "render_forward");
-    if (lazy_render)
+    if (lazy_render) {
         WG_STAGE(WG_STAGE_RENDER_FIXUP,
-                 wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, stream),
+                 wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, try_split, 0, stream),
                  "render_fixup");
+        if (split_active) {  // both return at once unless some tile ran out of near instances with pixels still accumulating
+            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter_far(P, geom, img, bin, gx, tiles, code_bits, stream), "tile_scatter_far");
+            WG_STAGE(WG_STAGE_RENDER_FIXUP,
+                     wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, true, 1, stream),
+                     "render_fixup_far");
+        }
+    }
     return num_rendered;
 }
 
@@ -481,6 +510,8 @@ int wg_view_image(char* image_buffer, int width, int height, wg_image_view* out)
     out->n_contrib = img.n_contrib;
     out->ranges = reinterpret_cast<const uint32_t*>(img.ranges);
     out->tile_last = img.tile_last;
+    out->tile_near = img.tile_near;
+    out->split = reinterpret_cast<const uint32_t*>(img.split);
     return WG_OK;
 }
 
@@ -497,6 +528,8 @@ int wg_set_option(const char* name, int value) {
     if (std::strcmp(name, "host_mailbox") == 0) { o.use_mailbox = value != 0; return WG_OK; }
     if (std::strcmp(name, "grad_record") == 0) { o.grad_record = value != 0; return WG_OK; }
     if (std::strcmp(name, "band_list_min_p") == 0) { o.band_list_min_p = value > 0 ? value : 1; return WG_OK; }
+    if (std::strcmp(name, "near_split") == 0) { o.near_split = value < 0 ? -1 : (value != 0); return WG_OK; }
+    if (std::strcmp(name, "near_per_tile") == 0) { o.near_per_tile = value > 0 ? value : 0; return WG_OK; }
     if (std::strcmp(name, "depth_codes") == 0) {
         if (value != 0 && value != 1 && (value < 8 || value > 12)) return WG_ERR_INVALID_ARGUMENT;
         o.depth_codes = value;
@@ -527,6 +560,8 @@ int wg_get_option(const char* name) {
     if (std::strcmp(name, "depth_codes") == 0) return o.depth_codes;
     if (std::strcmp(name, "band_list_min_p") == 0) return o.band_list_min_p;
     if (std::strcmp(name, "staged_scatter") == 0) return o.staged_scatter;
+    if (std::strcmp(name, "near_split") == 0) return o.near_split;
+    if (std::strcmp(name, "near_per_tile") == 0) return o.near_per_tile;
     if (std::strcmp(name, "lazy_min_len") == 0) return (int)o.lazy.min_len;
     if (std::strcmp(name, "lazy_target") == 0) return (int)o.lazy.target;
     if (std::strcmp(name, "lazy_cap") == 0) return (int)o.lazy.cap;

@@ -73,6 +73,10 @@ ImageState ImageState::fromChunk(char*& chunk, size_t N, size_t tiles) {
     carve(chunk, img.seg_end, tiles ? tiles : 1);
     carve(chunk, img.tile_state, tiles ? tiles : 1);
     carve(chunk, img.stats, 1);
+    carve(chunk, img.tile_near, tiles ? tiles : 1);
+    carve(chunk, img.far_cursor, tiles ? tiles : 1);
+    carve(chunk, img.code_hist, SPLIT_BINS);
+    carve(chunk, img.split, 1);
     return img;
 }
 
@@ -248,12 +252,17 @@ __device__ __forceinline__ int band_of_tile(int t, int tiles) {
 // With band_list != nullptr (large P) the chunk's Gaussians are also listed per XCD band of tiles they touch (chunk-local 16-bit
 // indices, wave-aggregated append): the staged scatter's (chunk, band) workgroups then read their own candidates instead of
 // scanning the whole chunk once per band and pass (40 scans of 10 M rectangles at 10 M Gaussians / 4K: 2 of its 2.5 ms).
+// With an active near / far split (split != nullptr and a real threshold in it) a histogram word counts two things at once: the
+// chunk's instances in the tile in its upper half, the near ones among them in its lower half (a chunk holds fewer than 65536
+// Gaussians whenever the split is attempted, so neither half can overflow).
 __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const ushort4* __restrict__ rects, uint32_t* __restrict__ chunk_hist,
                                                          uint16_t* __restrict__ band_list, uint32_t* __restrict__ band_cnt, int gx,
-                                                         int tiles) {
+                                                         int tiles, const float* __restrict__ depths, const SplitState* __restrict__ split) {
     extern __shared__ uint32_t hist[];
     __shared__ uint32_t bcnt[8];
     const int tid = threadIdx.x, chunk = blockIdx.x, lane = tid & 63;
+    const uint32_t near_code = split ? split->near_code : SPLIT_OFF;
+    const bool packed = near_code != SPLIT_OFF;  // workgroup-uniform
     for (int t = tid; t < tiles; t += BIN_THREADS) hist[t] = 0;
     if (tid < 8) bcnt[tid] = 0;
     __syncthreads();
@@ -265,10 +274,13 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const us
     // pays one memory latency per PF Gaussians instead of one each (culled Gaussians carry an all-zero rectangle)
     for (int base = begin; base < end; base += PF * BIN_THREADS) {
         ushort4 r[PF];
+        uint32_t inc[PF];  // what one instance adds to a histogram word
 #pragma unroll
         for (int k = 0; k < PF; k++) {
             const int idx = base + k * BIN_THREADS + tid;
             r[k] = idx < end ? rects[idx] : make_ushort4(0, 0, 0, 0);
+            inc[k] = 1u;
+            if (packed) inc[k] = (idx < end && depth_code(__float_as_uint(depths[idx]), SPLIT_BITS) <= near_code) ? 0x10001u : 0x10000u;
         }
 #pragma unroll
         for (int k = 0; k < PF; k++) {
@@ -290,7 +302,7 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const us
                     if (in) lists[(size_t)b * per + wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)local;
                 }
             }
-            for_each_tile<16>(valid, r[k].x, r[k].y, r[k].z, r[k].w, 0, [&](int x, int y, int) { atomicAdd(&hist[y * gx + x], 1u); });
+            for_each_tile<16>(valid, r[k].x, r[k].y, r[k].z, r[k].w, (int)inc[k], [&](int x, int y, int add) { atomicAdd(&hist[y * gx + x], (uint32_t)add); });
         }
     }
     __syncthreads();
@@ -303,21 +315,31 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const us
 // chunks, lane = tile (loads are 256-byte coalesced rows of chunk_hist).  The kernel is a chain of dependent row loads per
 // wave, so it is cut into many short chains (32 rows each, 8 loads in flight) rather than few long ones.
 constexpr int SCAN_WAVES = 16;
-__global__ void __launch_bounds__(64 * SCAN_WAVES) chunk_scan_kernel(uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ tile_count, int tiles) {
+// With an active split the words are (total << 16 | near) per chunk: the prefix written back is that of the NEAR counts (the bucket
+// positions of the near scatter), tile_count gets the totals, tile_near the near totals.
+__global__ void __launch_bounds__(64 * SCAN_WAVES) chunk_scan_kernel(uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ tile_count, int tiles,
+                                                                     uint32_t* __restrict__ tile_near, const SplitState* __restrict__ split) {
     __shared__ uint32_t part[SCAN_WAVES][64];
+    __shared__ uint32_t part_tot[SCAN_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + lane;
     constexpr int Q = BIN_CHUNKS / SCAN_WAVES;
     static_assert(Q % 8 == 0, "row batches of 8");
+    const bool packed = split && split->near_code != SPLIT_OFF;  // uniform
     uint32_t v[Q];
-    uint32_t sum = 0;
+    uint32_t sum = 0, tot = 0;
     if (t < tiles) {
 #pragma unroll
         for (int c = 0; c < Q; c++) v[c] = chunk_hist[(size_t)(wave * Q + c) * tiles + t];
+        if (packed) {
+#pragma unroll
+            for (int c = 0; c < Q; c++) { tot += v[c] >> 16; v[c] &= 0xffffu; }
+        }
 #pragma unroll
         for (int c = 0; c < Q; c++) sum += v[c];
     }
     part[wave][lane] = sum;
+    if (packed) part_tot[wave][lane] = tot;
     __syncthreads();
     uint32_t run = 0;
     for (int w = 0; w < wave; w++) run += part[w][lane];
@@ -327,7 +349,15 @@ __global__ void __launch_bounds__(64 * SCAN_WAVES) chunk_scan_kernel(uint32_t* _
             chunk_hist[(size_t)(wave * Q + c) * tiles + t] = run;
             run += v[c];
         }
-        if (wave == SCAN_WAVES - 1) tile_count[t] = run;
+        if (wave == SCAN_WAVES - 1) {
+            uint32_t total = run;
+            if (packed) {
+                total = 0;
+                for (int w = 0; w < SCAN_WAVES; w++) total += part_tot[w][lane];
+            }
+            tile_count[t] = total;
+            if (tile_near) tile_near[t] = run;
+        }
     }
 }
 
@@ -336,7 +366,7 @@ __global__ void __launch_bounds__(64 * SCAN_WAVES) chunk_scan_kernel(uint32_t* _
 template <int PER>
 __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
                                                          uint2* __restrict__ ranges, BinStats* __restrict__ stats, int tiles,
-                                                         HostMailbox* mailbox, uint32_t seq) {
+                                                         HostMailbox* mailbox, uint32_t seq, const SplitState* __restrict__ split) {
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t wave_max[16];
     __shared__ uint32_t wave_ovf[16];
@@ -385,11 +415,14 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
     if (tovf) total = 0xffffffffu;
     if (tid == 0) {  // first: the two numbers the host is waiting for (it launches the next kernels behind this one)
         tile_offset[tiles] = total;
+        const uint32_t active = (split && split->near_code != SPLIT_OFF) ? 1u : 0u;
         stats->num_rendered = total;
         stats->max_tile_count = gmax;
+        stats->split_active = active;
         if (mailbox) {
             mailbox->num_rendered = total;
             mailbox->max_tile_count = gmax;
+            mailbox->split_active = active;
             __hip_atomic_store(&mailbox->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -421,9 +454,12 @@ template <bool LISTS>  // candidates from the count kernel's band lists (large P
 __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4* __restrict__ rects, const float* __restrict__ depths,
                                                            const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ chunk_hist,
                                                            const uint16_t* __restrict__ band_list, const uint32_t* __restrict__ band_cnt,
-                                                           uint32_t* __restrict__ bucket_ids, int gx, int tiles, int code_bits) {
+                                                           uint32_t* __restrict__ bucket_ids, int gx, int tiles, int code_bits,
+                                                           const SplitState* __restrict__ split) {
     extern __shared__ uint32_t cursor[];
     const int tid = threadIdx.x, band = blockIdx.x & 7, chunk = blockIdx.x >> 3;
+    const uint32_t near_code = split ? split->near_code : SPLIT_OFF;
+    const bool near_only = near_code != SPLIT_OFF;  // active split: only the near Gaussians are scattered (chunk_hist holds their prefix)
     const int q = tiles >> 3, rem = tiles & 7;
     const int t0 = band * q + min(band, rem), t1 = t0 + q + (band < rem ? 1 : 0);  // this band's tiles [t0, t1)
     if (t0 >= t1) return;
@@ -451,7 +487,11 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4*
             const bool in = idx[k] >= 0;
             r[k] = in ? rects[idx[k]] : make_ushort4(0, 0, 0, 0);
             entry[k] = in ? (uint32_t)idx[k] : 0u;
-            if (code_bits && in) entry[k] |= depth_code(__float_as_uint(depths[idx[k]]), (uint32_t)code_bits) << (32 - code_bits);
+            if ((code_bits || near_only) && in) {
+                const uint32_t db = __float_as_uint(depths[idx[k]]);
+                if (code_bits) entry[k] |= depth_code(db, (uint32_t)code_bits) << (32 - code_bits);
+                if (near_only && depth_code(db, SPLIT_BITS) > near_code) r[k] = make_ushort4(0, 0, 0, 0);  // a far Gaussian: nothing to emit now
+            }
         }
 #pragma unroll
         for (int k = 0; k < PF; k++) {
@@ -480,8 +520,12 @@ __global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const 
                                                                   const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ tile_count,
                                                                   const uint32_t* __restrict__ chunk_hist, const uint16_t* __restrict__ band_list,
                                                                   const uint32_t* __restrict__ band_cnt, uint32_t* __restrict__ bucket_ids,
-                                                                  int gx, int tiles, int G, int nbmax, uint32_t cap, int code_bits) {
+                                                                  int gx, int tiles, int G, int nbmax, uint32_t cap, int code_bits,
+                                                                  const SplitState* __restrict__ split) {
     extern __shared__ uint32_t smem[];
+    // active split: only near Gaussians are emitted; chunk_hist holds the prefix of the near counts and `tile_count` is tile_near
+    const uint32_t near_code = split ? split->near_code : SPLIT_OFF;
+    const bool near_only = near_code != SPLIT_OFF;
     uint32_t* gbase = smem;           // [nbmax] bucket position of this workgroup's first instance of the tile
     uint32_t* lcur = gbase + nbmax;   // [nbmax] cursor: staging-area positions (staged) or bucket positions (direct)
     uint32_t* wsum = lcur + nbmax;    // [16]
@@ -568,7 +612,11 @@ __global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const 
                         const bool in = idx[k] >= 0;
                         r[k] = in ? rects[idx[k]] : make_ushort4(0, 0, 0, 0);
                         entry[k] = in ? (uint32_t)idx[k] : 0u;
-                        if (code_bits && in) entry[k] |= depth_code(__float_as_uint(depths[idx[k]]), (uint32_t)code_bits) << (32 - code_bits);
+                        if ((code_bits || near_only) && in) {
+                            const uint32_t db = __float_as_uint(depths[idx[k]]);
+                            if (code_bits) entry[k] |= depth_code(db, (uint32_t)code_bits) << (32 - code_bits);
+                            if (near_only && depth_code(db, SPLIT_BITS) > near_code) r[k] = make_ushort4(0, 0, 0, 0);
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < PF; k++) {
@@ -598,6 +646,138 @@ __global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const 
         }
         a = e;
     }
+}
+
+// ---- near / far split ---------------------------------------------------------------------------------------------------
+// Far scatter: after the first fix-up phase, the tiles whose pixels are still accumulating with every near instance consumed
+// (tile_state != 0xffffffff) get the instances of the far Gaussians, appended behind the near ones through a per-tile global
+// cursor (the slow kind of atomic, but this is the rare path).  Every workgroup leaves at once when no tile asked.
+template <bool LISTS>
+__global__ void __launch_bounds__(256) tile_scatter_far_kernel(int P, const ushort4* __restrict__ rects, const float* __restrict__ depths,
+                                                               const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ tile_near,
+                                                               const uint32_t* __restrict__ tile_state, uint32_t* __restrict__ far_cursor,
+                                                               const uint16_t* __restrict__ band_list, const uint32_t* __restrict__ band_cnt,
+                                                               uint32_t* __restrict__ bucket_ids, int gx, int tiles, int code_bits,
+                                                               const SplitState* __restrict__ split) {
+    if (split->need_far == 0u || split->near_code == SPLIT_OFF) return;
+    const uint32_t near_code = split->near_code;
+    const int tid = threadIdx.x, band = blockIdx.x & 7, chunk = blockIdx.x >> 3;
+    const int q = tiles >> 3, rem = tiles & 7;
+    const int t0 = band * q + min(band, rem), t1 = t0 + q + (band < rem ? 1 : 0);
+    if (t0 >= t1) return;
+    int begin, end;
+    chunk_bounds(P, chunk, begin, end);
+    const int per = (P + BIN_CHUNKS - 1) / BIN_CHUNKS;
+    const uint16_t* list = LISTS ? band_list + ((size_t)chunk * 8 + band) * per : nullptr;
+    const int cn = LISTS ? (int)band_cnt[chunk * 8 + band] : end - begin;
+    const int y0 = t0 / gx, y1 = (t1 - 1) / gx;
+    for (int base = 0; base < cn; base += 256) {  // uniform trip count: for_each_tile is convergent
+        const int i = base + tid;
+        const int idx = i < cn ? begin + (LISTS ? (int)list[i] : i) : -1;
+        ushort4 r = make_ushort4(0, 0, 0, 0);
+        uint32_t entry = 0u;
+        if (idx >= 0) {
+            const uint32_t db = __float_as_uint(depths[idx]);
+            if (depth_code(db, SPLIT_BITS) > near_code) {
+                r = rects[idx];
+                entry = (uint32_t)idx;
+                if (code_bits) entry |= depth_code(db, (uint32_t)code_bits) << (32 - code_bits);
+            }
+        }
+        const int ya = max((int)r.y, y0), yb = min((int)r.w, y1 + 1);
+        for_each_tile<16>(r.z > r.x && yb > ya, r.x, ya, r.z, yb, (int)entry, [&](int x, int y, int id) {
+            const int t = y * gx + x;
+            if (t >= t0 && t < t1 && tile_state[t] != 0xffffffffu)
+                bucket_ids[tile_offset[t] + tile_near[t] + atomicAdd(&far_cursor[t], 1u)] = (uint32_t)id;
+        });
+    }
+}
+
+// Threshold selection, two small kernels.  (1) histogram of the visible Gaussians' SPLIT_BITS-bit depth codes, each weighted by the
+// number of tiles it touches (= its instances), per workgroup in LDS, then added to the global bins; (2) one workgroup scans the
+// bins and takes the first code at which the running instance count reaches near_per_tile * tiles -- or switches the split off
+// when the frame is not dense (fewer than dense_avg instances per tile, unless forced) or the threshold would keep everything.
+__global__ void __launch_bounds__(1024) split_hist_kernel(int P, const float* __restrict__ depths, const uint32_t* __restrict__ tiles_touched,
+                                                          uint32_t* __restrict__ code_hist) {
+    __shared__ uint32_t h[SPLIT_BINS];
+    for (uint32_t i = threadIdx.x; i < SPLIT_BINS; i += 1024) h[i] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * 1024 + threadIdx.x; i < P; i += gridDim.x * 1024) {
+        const uint32_t w = tiles_touched[i];
+        if (w) atomicAdd(&h[depth_code(__float_as_uint(depths[i]), SPLIT_BITS)], w);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < SPLIT_BINS; i += 1024)
+        if (h[i]) atomicAdd(&code_hist[i], h[i]);
+}
+
+__global__ void __launch_bounds__(1024) split_pick_kernel(const uint32_t* __restrict__ code_hist, uint32_t tiles, uint32_t near_per_tile,
+                                                          uint32_t dense_avg, int force, SplitState* __restrict__ split) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ uint32_t pick;
+    constexpr int PER = SPLIT_BINS / 1024;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t v[PER];
+    unsigned long long local = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { v[k] = code_hist[tid * PER + k]; local += v[k]; }
+    unsigned long long incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long up = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    if (tid == 0) pick = SPLIT_OFF;
+    __syncthreads();
+    unsigned long long base = 0, total = 0;
+    for (uint32_t w = 0; w < 16; w++) {
+        if (w < wave) base += wsum[w];
+        total += wsum[w];
+    }
+    const unsigned long long want = (unsigned long long)near_per_tile * tiles;
+    const bool on = want < total && (force || total >= (unsigned long long)dense_avg * tiles);
+    if (on) {
+        unsigned long long run = base + incl - local;  // instances of all smaller codes
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            // the first code whose inclusive count reaches `want`: exactly one (tid, k) satisfies this
+            if (run < want && run + v[k] >= want) pick = tid * PER + k;
+            run += v[k];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // a threshold at the last code keeps everything near: nothing to gain
+        split->near_code = (pick != SPLIT_OFF && pick + 1 < SPLIT_BINS) ? pick : SPLIT_OFF;
+        split->need_far = 0u;
+    }
+}
+
+hipError_t launch_split_threshold(int P, const GeometryState& g, const ImageState& img, int tiles, bool force, uint32_t near_per_tile,
+                                  hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(img.code_hist, 0, SPLIT_BINS * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(img.far_cursor, 0, (size_t)tiles * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const int blocks = P >= (1 << 20) ? 128 : max(1, (P + 8191) / 8192);
+    hipLaunchKernelGGL(split_hist_kernel, dim3(blocks), dim3(1024), 0, stream, P, g.depths, g.tiles_touched, img.code_hist);
+    hipLaunchKernelGGL(split_pick_kernel, dim3(1), dim3(1024), 0, stream, img.code_hist, (uint32_t)tiles, near_per_tile, 1500u, force ? 1 : 0,
+                       img.split);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_scatter_far(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles, int code_bits,
+                                   hipStream_t stream) {
+    if (P <= 0) return hipSuccess;
+    if (g.band_list != nullptr)
+        hipLaunchKernelGGL(tile_scatter_far_kernel<true>, dim3(BIN_CHUNKS * 8), dim3(256), 0, stream, P, g.rects, g.depths, img.tile_offset,
+                           img.tile_near, img.tile_state, img.far_cursor, g.band_list, g.band_cnt, b.bucket_ids, gx, tiles, code_bits, img.split);
+    else
+        hipLaunchKernelGGL(tile_scatter_far_kernel<false>, dim3(BIN_CHUNKS * 8), dim3(256), 0, stream, P, g.rects, g.depths, img.tile_offset,
+                           img.tile_near, img.tile_state, img.far_cursor, (const uint16_t*)nullptr, (const uint32_t*)nullptr, b.bucket_ids, gx,
+                           tiles, code_bits, img.split);
+    return hipGetLastError();
 }
 
 // ---- per-tile sort ----------------------------------------------------------------------------------------------------
@@ -644,7 +824,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restri
 __global__ void __launch_bounds__(256) tile_front_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bucket_ids,
                                                               const float* __restrict__ depths, uint32_t* __restrict__ point_list,
                                                               uint32_t* __restrict__ seg_end, uint32_t min_len, uint32_t target, uint32_t cap,
-                                                              uint32_t id_mask) {
+                                                              uint32_t id_mask, const uint32_t* __restrict__ tile_near) {
     // the selection scratch (12 KB) and the sort's cross-wave exchange buffer (16 KB) are never live together: one 16 KB block,
     // which lets 8 workgroups share a CU instead of 5 (the kernel is a chain of dependent phases, latency-bound)
     __shared__ uint64_t smem[256 * 8];
@@ -653,7 +833,8 @@ __global__ void __launch_bounds__(256) tile_front_sort_kernel(const uint32_t* __
     uint64_t* skeys = smem;
     const int tile = blockIdx.x;
     const uint32_t begin = tile_offset[tile];
-    const uint32_t n = tile_offset[tile + 1] - begin;
+    // near / far split: only the near instances, the first tile_near[tile] entries of the bucket, exist at this point
+    const uint32_t n = tile_near ? tile_near[tile] : tile_offset[tile + 1] - begin;
     if (n == 0) {
         if (threadIdx.x == 0) seg_end[tile] = 0;
         return;
@@ -741,33 +922,38 @@ static hipError_t ensure_lds(const void* fn, size_t bytes) {
     return e;
 }
 
-hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, hipStream_t stream) {
+hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, bool split, hipStream_t stream) {
     const size_t lds = (size_t)tiles * sizeof(uint32_t);
     hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_count_kernel), lds);
     if (e != hipSuccess) return e;
+    const SplitState* sp = split ? img.split : nullptr;
     hipLaunchKernelGGL(tile_count_kernel, dim3(BIN_CHUNKS), dim3(BIN_THREADS), lds, stream, P, g.rects, img.chunk_hist, g.band_list, g.band_cnt,
-                       gx, tiles);
+                       gx, tiles, g.depths, sp);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(chunk_scan_kernel, dim3((tiles + 63) / 64), dim3(64 * SCAN_WAVES), 0, stream, img.chunk_hist, img.tile_count, tiles);
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3((tiles + 63) / 64), dim3(64 * SCAN_WAVES), 0, stream, img.chunk_hist, img.tile_count, tiles,
+                       split ? img.tile_near : (uint32_t*)nullptr, sp);
     return hipGetLastError();
 }
 
-hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, hipStream_t stream) {
+hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, bool split, hipStream_t stream) {
+    const SplitState* sp = split ? img.split : nullptr;
     // BIN_MAX_TILES / 1024 = 36 tiles per thread at most; 8 covers 1080p (8160 tiles)
     if (tiles <= 8 * 1024)
         hipLaunchKernelGGL(tile_scan_kernel<8>, dim3(1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges, img.stats, tiles,
-                           mailbox_dev, seq);
+                           mailbox_dev, seq, sp);
     else
         hipLaunchKernelGGL((tile_scan_kernel<BIN_MAX_TILES / 1024>), dim3(1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges,
-                           img.stats, tiles, mailbox_dev, seq);
+                           img.stats, tiles, mailbox_dev, seq, sp);
     return hipGetLastError();
 }
 
 
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
-                               uint32_t num_rendered, int code_bits, int g_staged_scatter, int g_staged_cap, hipStream_t stream) {
+                               uint32_t num_rendered, int code_bits, int g_staged_scatter, int g_staged_cap, bool split, hipStream_t stream) {
     if (P <= 0) return hipSuccess;
+    const SplitState* sp = split ? img.split : nullptr;
+    const uint32_t* last_prefix = split ? img.tile_near : img.tile_count;  // what follows the last chunk's prefix in a tile's column
     // staged scatter for long lists: G chunks per workgroup such that an average share fits the staging area with headroom
     const bool want = g_staged_scatter == 1 || (g_staged_scatter < 0 && tiles > 0 && num_rendered / (uint32_t)tiles >= 1500u);
     if (want) {
@@ -791,12 +977,12 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
             const bool use_lists = g.band_list != nullptr && (share1 * G > (double)cap || (double)num_rendered < 10.0 * (double)P);
             if (use_lists)
                 hipLaunchKernelGGL(tile_scatter_staged_kernel<true>, dim3(BIN_CHUNKS / G * 8), dim3(1024), lds, stream, P, g.rects, g.depths,
-                                   img.tile_offset, img.tile_count, img.chunk_hist, g.band_list, g.band_cnt, b.bucket_ids, gx, tiles, G, nbmax,
-                                   cap, code_bits);
+                                   img.tile_offset, last_prefix, img.chunk_hist, g.band_list, g.band_cnt, b.bucket_ids, gx, tiles, G, nbmax,
+                                   cap, code_bits, sp);
             else
                 hipLaunchKernelGGL(tile_scatter_staged_kernel<false>, dim3(BIN_CHUNKS / G * 8), dim3(1024), lds, stream, P, g.rects, g.depths,
-                                   img.tile_offset, img.tile_count, img.chunk_hist, (const uint16_t*)nullptr, (const uint32_t*)nullptr,
-                                   b.bucket_ids, gx, tiles, G, nbmax, cap, code_bits);
+                                   img.tile_offset, last_prefix, img.chunk_hist, (const uint16_t*)nullptr, (const uint32_t*)nullptr,
+                                   b.bucket_ids, gx, tiles, G, nbmax, cap, code_bits, sp);
             return hipGetLastError();
         }
     }
@@ -806,10 +992,10 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
     if (e != hipSuccess) return e;
     if (g.band_list != nullptr)
         hipLaunchKernelGGL(tile_scatter_kernel<true>, dim3(BIN_CHUNKS * 8), dim3(256), lds, stream, P, g.rects, g.depths, img.tile_offset,
-                           img.chunk_hist, g.band_list, g.band_cnt, b.bucket_ids, gx, tiles, code_bits);
+                           img.chunk_hist, g.band_list, g.band_cnt, b.bucket_ids, gx, tiles, code_bits, sp);
     else
         hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(BIN_CHUNKS * 8), dim3(256), lds, stream, P, g.rects, g.depths, img.tile_offset,
-                           img.chunk_hist, (const uint16_t*)nullptr, (const uint32_t*)nullptr, b.bucket_ids, gx, tiles, code_bits);
+                           img.chunk_hist, (const uint16_t*)nullptr, (const uint32_t*)nullptr, b.bucket_ids, gx, tiles, code_bits, sp);
     return hipGetLastError();
 }
 
@@ -825,10 +1011,11 @@ static hipError_t launch_tile_sort_e(const ImageState& img, const BinningState& 
 }
 
 hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, int code_bits,
-                                 const LazyConfig& g_lazy, hipStream_t stream) {
+                                 const LazyConfig& g_lazy, bool split, hipStream_t stream) {
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(tile_front_sort_kernel, dim3(tiles), dim3(256), 0, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list,
-                       img.seg_end, g_lazy.min_len, g_lazy.target, g_lazy.cap, code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu);
+                       img.seg_end, g_lazy.min_len, g_lazy.target, g_lazy.cap, code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu,
+                       split ? img.tile_near : (const uint32_t*)nullptr);
     return hipGetLastError();
 }
 

@@ -24,6 +24,10 @@ namespace wg {
 
 constexpr int BATCH = 64;
 
+#ifndef WG_BWD_MFMA_REDUCE
+#define WG_BWD_MFMA_REDUCE 0
+#endif
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
@@ -97,10 +101,24 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
+#if WG_BWD_MFMA_REDUCE
+    // Experiment (rejected, numbers in DESIGN.md): the wave reduction on the matrix pipe.  Ten chained
+    // v_mfma_f32_16x16x4_f32 with a row selector as A (A[i][k] = [i == v]) and the per-lane partial sums as B leave
+    // D[v][j] = sum over the four 16-lane rows of value v at column j, i.e. lane l holds values 4 (l / 16) .. + 3 in its four
+    // accumulator registers; four DPP steps per register finish the sum over the row's 16 lanes.
+    float sel[10];
+#pragma unroll
+    for (int v = 0; v < 10; v++) sel[v] = (lane & 15) == v ? 1.0f : 0.0f;
+    const int vidx = 4 * (lane >> 4) + (lane & 3);
+    const bool issue = (lane & 15) < 4 && vidx < 10;
+    const bool owner = issue;
+    (void)owner;
+#else
     // which of the ten reduced values this lane owns after butterfly10(), and where it accumulates it:
     //   0,1,2 -> dL_dcolor[3id + k]; 3,4,5 -> dL_dmean2D[3id + k-3]; 6,7,8 -> dL_dconic[4id + {0,1,3}]; 9 -> dL_dopacity[id]
     const int vidx = (lane & 2) ? 8 + ((lane >> 5) & 1) : 4 * (lane & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
     const bool owner = (lane & 12) == 0;  // lanes with bits 2,3 clear: one lane per value (two spare for value 8/9 copies)
+#endif
     float* abase;
     uint32_t astride;
     if (RECORD) { abase = grad_rec + vidx; astride = GRAD_REC_FLOATS; }
@@ -108,8 +126,10 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     else if (vidx < 6) { abase = dL_dmean2D + (vidx - 3); astride = 3; }
     else if (vidx < 9) { abase = dL_dconic + (vidx == 8 ? 3 : vidx - 6); astride = 4; }
     else { abase = dL_dopacity; astride = 1; }
+#if !WG_BWD_MFMA_REDUCE
     // values 8 and 9 (bit1 set) are replicated over bits 0 and 4: let only the bit0 == bit4 == 0 copy issue
     const bool issue = owner && !((lane & 2) && (lane & 17));
+#endif
     // constant factor of this lane's value (see the per-pair sums below); values 3..8 also carry the splat's opacity
     const bool oscale = vidx >= 3 && vidx <= 8;
     constexpr float INV_L = 1.0f / WG_LOG2E;  // u, v above carry a factor -log2(e)
@@ -228,7 +248,32 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
                 }
             }
             if (__ballot(any) == 0ull) continue;
+#if WG_BWD_MFMA_REDUCE
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f d = {0.f, 0.f, 0.f, 0.f};
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[0], acr, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[1], acg, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[2], acb, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[3], sx, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[4], sy, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[5], sab, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[6], sxx, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[7], sxy, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[8], syy, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[9], sq, d, 0, 0, 0);
+            float dr[4] = {d[0], d[1], d[2], d[3]};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                dr[r] += dpp_f<0xB1>(dr[r]);
+                dr[r] += dpp_f<0x4E>(dr[r]);
+                dr[r] += dpp_f<0x124>(dr[r]);
+                dr[r] += dpp_f<0x128>(dr[r]);
+            }
+            const int rsel = lane & 3;
+            const float total = rsel == 0 ? dr[0] : rsel == 1 ? dr[1] : rsel == 2 ? dr[2] : dr[3];
+#else
             const float total = butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
+#endif
             if (RECORD) {
                 if (issue) unsafeAtomicAdd(abase + (size_t)__float_as_uint(r1.z) * GRAD_REC_FLOATS, total);  // 64-bit: shift-adds, no quarter-rate 32-bit multiply
             } else {

@@ -276,7 +276,8 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, uint32_t* point_list, const uint32_t* __restrict__ bucket_ids,
     const float* __restrict__ depths, const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset,
     const float* __restrict__ bg, uint32_t* __restrict__ tile_state, float* final_T, uint32_t* n_contrib,
-    uint32_t* __restrict__ tile_last, float* out_color, uint32_t target, uint32_t cap, uint32_t id_mask) {
+    uint32_t* __restrict__ tile_last, float* out_color, uint32_t target, uint32_t cap, uint32_t id_mask,
+    const uint32_t* __restrict__ tile_near, SplitState* split, int phase) {
     __shared__ float4 lds[BATCH * 3];
     __shared__ uint64_t skeys[256 * 8];
     __shared__ SelectScratch sc;
@@ -288,14 +289,23 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     const bool walker = tid < 64;
     const uint2 range = ranges[tile];
     const uint32_t n = range.y - range.x;
-    const uint32_t* bag = bucket_ids + range.x;
+    // Near / far split (binning.hip): the bucket holds the near instances in [0, n_near) -- all there is in phase 0 -- and, once the
+    // far scatter has run for this tile, the far ones in [n_near, n).  Without a split n_near == n and phase 1 never runs.
+    const uint32_t n_near = tile_near ? tile_near[tile] : n;
+    const uint32_t bag_lo = phase == 0 ? 0u : n_near, bag_hi = phase == 0 ? n_near : n;
+    if (done >= bag_hi) {  // this bag is used up already (phase 0: the front was all of the near instances, or there are none)
+        if (phase == 0 && tid == 0) split->need_far = 1u;  // n_near < n here: a finished tile does not arrive
+        return;
+    }
+    const uint32_t* bag = bucket_ids + range.x + bag_lo;
     uint32_t* list = point_list + range.x;
     FwdTile st;
     if (walker) fwd_init(st, W, H, gx, tile, tid, subpixel_offset, true, final_T, n_contrib, out_color);
+    bool complete = false;
     for (;;) {
-        // everything at or below the last sorted key has been taken (done >= 1: only front-split tiles arrive here)
-        const uint64_t lo = depth_key(depths, list[done - 1]);
-        const uint32_t F = extract_front(bag, n, depths, lo, n - done, target, cap, id_mask, sc);
+        // everything at or below the last sorted key has been taken (nothing yet when the tile had no sorted front at all)
+        const uint64_t lo = done > 0 ? depth_key(depths, list[done - 1]) : 0ull;
+        const uint32_t F = extract_front(bag, bag_hi - bag_lo, depths, lo, bag_hi - done, target, cap, id_mask, sc);
         if (F <= 1024) tile_sort_body<4>(skeys, F, sc.ids, depths, list + done, 0xffffffffu);
         else tile_sort_body<8>(skeys, F, sc.ids, depths, list + done, 0xffffffffu);
         __threadfence_block();
@@ -306,22 +316,28 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
         }
         done += F;
         __syncthreads();
-        if (s_complete) break;
+        complete = s_complete != 0;
+        if (complete || done >= bag_hi) break;
         __syncthreads();  // s_complete is rewritten next round
     }
-    if (walker) fwd_store(st, true, W, H, tile, tid, bg, final_T, n_contrib, tile_last, out_color);
-    if (tid == 0) tile_state[tile] = 0xffffffffu;
+    // complete: final outputs.  Otherwise the near bag ran out with pixels still accumulating: park the state again and ask for
+    // the far instances (phase 1 continues from here).
+    if (walker) fwd_store(st, complete, W, H, tile, tid, bg, final_T, n_contrib, tile_last, out_color);
+    if (tid == 0) {
+        tile_state[tile] = complete ? 0xffffffffu : done;
+        if (!complete) split->need_far = 1u;
+    }
 }
 
 hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
                                const float* subpixel_offset, const float* background, float* out_color, const LazyConfig& g_lazy,
-                               hipStream_t stream) {
+                               bool split, int phase, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(render_fixup_kernel, dim3(tiles), dim3(256), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, b.bucket_ids,
                        g.depths, g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.tile_state, img.final_T,
                        img.n_contrib, img.tile_last, out_color, 1536u < g_lazy.cap ? 1536u : (g_lazy.cap * 3u) / 4u, g_lazy.cap < FRONT_CAP ? g_lazy.cap : FRONT_CAP,
-                       code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu);
+                       code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu, split ? img.tile_near : (const uint32_t*)nullptr, img.split, phase);
     return hipGetLastError();
 }
 

@@ -49,6 +49,19 @@ constexpr int GRAD_REC_FLOATS = 12;
 struct BinStats {  // read back by the host once per forward (the reference's num_rendered sync point)
     uint32_t num_rendered;
     uint32_t max_tile_count;
+    uint32_t split_active;  // 1: the near / far split is on for this frame (SplitState::near_code is a real threshold)
+    uint32_t pad;
+};
+
+// Near / far split of dense frames (binning.hip): a frame-wide depth-code threshold, chosen on the device from a histogram of the
+// visible Gaussians' 12-bit depth codes weighted by their tile counts, such that about `near_per_tile` instances per tile are
+// "near".  Only the near instances are scattered and front-sorted; a tile whose pixels are still accumulating when its near
+// instances are used up gets its far ones scattered afterwards (rare).  near_code == SPLIT_OFF: no split (every instance is near).
+constexpr uint32_t SPLIT_BITS = 12, SPLIT_BINS = 1u << SPLIT_BITS, SPLIT_OFF = 0xffffffffu;
+struct SplitState {
+    uint32_t near_code;  // instances of Gaussians with depth_code(depth, SPLIT_BITS) <= near_code are near
+    uint32_t need_far;   // set by the first fix-up phase when some tile ran out of near instances
+    uint32_t pad[2];
 };
 
 // Host-visible (pinned, mapped, coherent) mailbox the tile scan writes the same two numbers to, followed by a sequence
@@ -57,7 +70,7 @@ struct HostMailbox {
     uint32_t num_rendered;
     uint32_t max_tile_count;
     uint32_t seq;
-    uint32_t pad;
+    uint32_t split_active;
 };
 
 struct ImageState {
@@ -72,6 +85,10 @@ struct ImageState {
     uint32_t* seg_end;      // lazy sort: length of the tile's sorted front after the first round (== count when sorted in full)
     uint32_t* tile_state;   // lazy sort: 0xffffffff = tile finished, else the list length the forward pass has consumed
     BinStats* stats;
+    uint32_t* tile_near;    // near / far split: per-tile count of near instances (== tile_count without a split)
+    uint32_t* far_cursor;   //                   per-tile append cursor of the far scatter
+    uint32_t* code_hist;    //                   [SPLIT_BINS] tile-count-weighted histogram of the visible Gaussians' depth codes
+    SplitState* split;
     static ImageState fromChunk(char*& chunk, size_t N, size_t tiles);
 };
 
@@ -146,12 +163,17 @@ hipError_t launch_duplicate_keys(int P, const GeometryState& g, const BinningSta
 hipError_t run_sort(const BinningState& b, int R, int end_bit, hipStream_t stream);
 hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& img, int tiles, hipStream_t stream);
 hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_or_null, uint32_t* order, int tiles, hipStream_t stream);
-hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, hipStream_t stream);
-hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, hipStream_t stream);
+// split == nullptr: no near / far split attempted (small P): the kernels are exactly the ones without it
+hipError_t launch_split_threshold(int P, const GeometryState& g, const ImageState& img, int tiles, bool force, uint32_t near_per_tile,
+                                  hipStream_t stream);
+hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, bool split, hipStream_t stream);
+hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, bool split, hipStream_t stream);
+hipError_t launch_tile_scatter_far(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles, int code_bits,
+                                   hipStream_t stream);
 // code_bits > 0: bucket entries carry a coarse depth code of that width above the id (wg_sort.h: depth_code); only the lazy
 // sort reads it
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
-                               uint32_t num_rendered, int code_bits, int staged_scatter, int staged_cap, hipStream_t stream);
+                               uint32_t num_rendered, int code_bits, int staged_scatter, int staged_cap, bool split, hipStream_t stream);
 struct LazyConfig {
     bool enabled = true;
     uint32_t min_len = 1024;  // tiles listing more than this are front-split instead of sorted in full (the lazy path as a whole is
@@ -169,14 +191,18 @@ struct Options {
     int band_list_min_p = 2000000;    // from here on the scatter kernels read per-band candidate lists instead of whole chunks
     int depth_codes = 1;              // 0 / 1 / 8..12: off (as for P > 2^24) / automatic width / forced width (tests)
     int grad_record = 1;              // 0: the per-tile backward accumulates into the four arrays themselves (A/B)
+    int near_split = -1;              // near / far split of dense frames: -1 automatic (P >= band_list_min_p and >= 1500 instances per
+                                      // tile) / 0 off / 1 whenever possible (tests)
+    int near_per_tile = 0;            // aimed near instances per tile; 0 = 2.5 x lazy.target
     bool force_global_sort = false;   // exercise the fallback binning path
     bool use_mailbox = true;          // 0 restores the copy + synchronise read-back
 };
 hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, int code_bits,
-                                 const LazyConfig& lazy, hipStream_t stream);
+                                 const LazyConfig& lazy, bool split, hipStream_t stream);
+// phase 0: the near bag (all of the bucket without a split); phase 1: the far bag of the tiles that asked for it
 hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
                                const float* subpixel_offset, const float* background, float* out_color, const LazyConfig& lazy,
-                               hipStream_t stream);
+                               bool split, int phase, hipStream_t stream);
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
                             hipStream_t stream);
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,

@@ -75,7 +75,7 @@ class _BinningView(C.Structure):
 
 
 class _ImageView(C.Structure):
-    _fields_ = [(n, _vp) for n in ("final_T", "n_contrib", "ranges", "tile_last")]
+    _fields_ = [(n, _vp) for n in ("final_T", "n_contrib", "ranges", "tile_last", "tile_near", "split")]
 
 
 _lib.wg_view_geometry.restype = _i
@@ -312,7 +312,9 @@ def view_image(imageBuffer, H, W):
     return dict(final_T=_from_ptr(v.final_T, (H, W), torch.float32, imageBuffer),
                 n_contrib=_from_ptr(v.n_contrib, (H, W), torch.int32, imageBuffer),
                 ranges=_from_ptr(v.ranges, (tiles, 2), torch.int32, imageBuffer),
-                tile_last=_from_ptr(v.tile_last, (tiles,), torch.int32, imageBuffer))
+                tile_last=_from_ptr(v.tile_last, (tiles,), torch.int32, imageBuffer),
+                tile_near=_from_ptr(v.tile_near, (tiles,), torch.int32, imageBuffer),
+                split=_from_ptr(v.split, (2,), torch.int32, imageBuffer))
 
 
 _lib.wg_set_option.restype = _i

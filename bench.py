@@ -84,16 +84,23 @@ def kernel_source_sha() -> str:
 def load_pmc(workload_key: str):
     """PMC HBM traffic per stage (separate rocprofv3 --pmc passes, scripts/profile_gpu.sh), only when it was collected on this very
     workload AND on these very kernel sources; otherwise {} and the reason."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pt = json.load(f)
-    except (OSError, ValueError):
-        return {}, "profiles/pmc_traffic.json missing"
-    if pt.get("workload") != workload_key:
-        return {}, f"pmc_traffic.json is for another workload ({pt.get('workload')})"
-    if pt.get("kernel_source_sha") != kernel_source_sha():
-        return {}, f"pmc_traffic.json is stale: measured on kernel sources {pt.get('kernel_source_sha')}, these are {kernel_source_sha()}"
-    return pt.get("stages", {}), f"pmc passes of {pt.get('collected', '?')} on kernel sources {pt.get('kernel_source_sha')}"
+    import glob
+    why = "no profiles/pmc_traffic*.json"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic*.json"))):   # one file per profiled workload
+        try:
+            with open(path) as f:
+                pt = json.load(f)
+        except (OSError, ValueError):
+            continue
+        name = os.path.basename(path)
+        if pt.get("workload") != workload_key:
+            why = f"{name} is for another workload ({pt.get('workload')})" if why.startswith("no ") else why
+            continue
+        if pt.get("kernel_source_sha") != kernel_source_sha():
+            why = f"{name} is stale: measured on kernel sources {pt.get('kernel_source_sha')}, these are {kernel_source_sha()}"
+            continue
+        return pt.get("stages", {}), f"{name}: pmc passes of {pt.get('collected', '?')} on kernel sources {pt.get('kernel_source_sha')}"
+    return {}, why
 
 
 def self_launch(n: int):
@@ -277,7 +284,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{P} Gaussians{'' if args.scale_mult == 1.0 else f' (scales x{args.scale_mult:g})'}, {W}x{H}, "
                                f"{'SH deg 3' if args.colors == 'sh' else 'precomputed colours'}, "
-                               f"fwd+bwd, one view per GPU (view-parallel, loss all-reduce only)",
+                               f"{'forward only' if args.forward_only else 'fwd+bwd'}, one view per GPU (view-parallel, loss all-reduce only)",
                    "gaussians": P, "width": W, "height": H, "colors": args.colors, "views_per_step": world},
         "forward_fps": round(fwd_fps, 2),
         "forward_mpix_per_s": round(fwd_fps * N / 1e6, 1),
@@ -290,11 +297,13 @@ def main():
     }
 
     if stages:
-        per_stage = {k: (ms / n if n else 0.0) for k, (ms, n) in stages.items()}
+        # time of a stage per STEP: a stage may consist of several event-bracketed scopes per call (scan = threshold + count +
+        # tile scan; render_backward = record clear + kernel; duplicate_keys = near + far scatter), so total / steps, not / scopes
+        per_stage = {k: ms / args.steps for k, (ms, n) in stages.items()}
         out["stages_ms"] = {k: round(v, 4) for k, v in per_stage.items()}
         out["stages_note"] = ("HIP-event pairs around each stage over a second timed pass of the same K steps "
                               f"({round(1000.0 * t_train_profiled / args.steps, 4)} ms/step with the events in)")
-        dom = max(stages, key=lambda k: stages[k][0])
+        dom = max(per_stage, key=lambda k: per_stage[k])
         is_sh = args.colors == "sh"
         kw = dict(P=P, V=V, R=int(R), N=N, tiles=tiles, M=M, sh=is_sh)
         pmc, pmc_note = load_pmc(f"{P} Gaussians, {W}x{H}, {args.colors}" + ("" if args.scale_mult == 1.0 else f", scales x{args.scale_mult:g}"))

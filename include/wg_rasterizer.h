@@ -200,7 +200,7 @@ typedef struct wg_image_view {
     const uint32_t* ranges;     /* [tiles*2] (start,end) */
     const uint32_t* tile_last;  /* [tiles] max n_contrib over the tile's pixels */
     const uint32_t* tile_near;  /* [tiles] near / far split: near instances of the tile (meaningful only when the split was attempted) */
-    const uint32_t* split;      /* [2] {depth-code threshold of the split, 0xffffffff = off; 1 = some tile needed its far instances} */
+    const uint32_t* split;      /* [2] {depth-code threshold of the split, 0xffffffff = off; bit b = a tile of XCD band b needed its far instances} */
 } wg_image_view;
 
 int wg_view_geometry(char* geom_buffer, int P, wg_geometry_view* out);
@@ -242,7 +242,7 @@ const char* wg_stage_name(int stage);
  * exercises the uncoded path, 8..12 force a width (not wider than the ids allow). */
 /* "near_split" (-1 automatic / 0 off / 1 whenever possible, default -1): dense frames of large scenes (from "band_list_min_p"
  * Gaussians on, at 1500 or more instances per tile) first bin, scatter and front-sort only the NEAR instances -- those of the
- * Gaussians below a frame-wide depth-code threshold picked on the device so that about "near_per_tile" (0 = 2.5 x "lazy_target")
+ * Gaussians below a frame-wide depth-code threshold picked on the device so that about "near_per_tile" (0 = 1.5 x "lazy_target")
  * instances per tile qualify -- and scatter the far ones afterwards only into tiles whose pixels are still accumulating when their
  * near instances are used up.  num_rendered, radii, images, n_contrib and gradients are those of the full binning.
  */

@@ -17,7 +17,8 @@ sys.path.insert(0, ROOT)
 
 STAGE_OF = {"preprocess_kernel": "preprocess", "tile_count_kernel": "scan", "chunk_scan_kernel": "scan", "tile_scan_kernel": "scan",
             "tile_scatter_kernel": "duplicate_keys", "tile_scatter_staged_kernel": "duplicate_keys", "tile_sort_kernel": "sort",
-            "tile_front_sort_kernel": "sort", "render_fixup_kernel": "render_fixup", "tile_order_kernel": "tile_ranges", "render_forward_kernel": "render_forward",
+            "tile_front_sort_kernel": "sort", "render_fixup_kernel": "render_fixup", "tile_order_kernel": "tile_ranges",
+            "split_hist_kernel": "scan", "split_pick_kernel": "scan", "tile_scatter_far_kernel": "duplicate_keys", "render_forward_kernel": "render_forward",
             "render_backward_kernel": "render_backward", "preprocess_backward_kernel": "preprocess_backward"}
 vals = {}
 for line in open(sys.argv[1]):

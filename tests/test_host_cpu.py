@@ -253,4 +253,4 @@ def test_bench_byte_model():
     assert bench.design_bytes("render_backward", walked=2_700_000, **kw) == 4 * 2_700_000 + 88 * kw["V"] + 28 * kw["N"]
     assert len(bench.kernel_source_sha()) == 16
     stages, note = bench.load_pmc("no such workload")
-    assert stages == {} and "another workload" in note
+    assert stages == {} and ("another workload" in note or "no profiles" in note)

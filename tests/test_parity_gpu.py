@@ -508,7 +508,7 @@ def test_near_far_split_gives_the_fully_sorted_results(oracle, lazy_options, npt
     assert sp[0] != 0xffffffff and (near <= n).all() and near.sum() < 0.8 * n.sum()   # the split was on and did prune
     assert abs(near.sum() / max(1, (n > 0).sum()) - npt) <= 0.5 * npt + 20                # about npt near instances per tile
     if npt == 30:
-        assert sp[1] == 1   # far phase taken
+        assert sp[1] != 0   # far phase taken (bit b: by a tile of XCD band b)
     assert lz["num_rendered"] == full["num_rendered"]
     assert torch.equal(lz["color"], full["color"]) and torch.equal(lz["radii"], full["radii"])
     for k in ("final_T", "n_contrib", "tile_last", "ranges"):

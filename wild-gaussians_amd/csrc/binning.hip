@@ -651,7 +651,7 @@ __global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const 
 // ---- near / far split ---------------------------------------------------------------------------------------------------
 // Far scatter: after the first fix-up phase, the tiles whose pixels are still accumulating with every near instance consumed
 // (tile_state != 0xffffffff) get the instances of the far Gaussians, appended behind the near ones through a per-tile global
-// cursor (the slow kind of atomic, but this is the rare path).  Every workgroup leaves at once when no tile asked.
+// cursor (the slow kind of atomic, but this is the rare path).  A workgroup leaves at once when no tile of its band asked.
 template <bool LISTS>
 __global__ void __launch_bounds__(256) tile_scatter_far_kernel(int P, const ushort4* __restrict__ rects, const float* __restrict__ depths,
                                                                const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ tile_near,
@@ -659,9 +659,9 @@ __global__ void __launch_bounds__(256) tile_scatter_far_kernel(int P, const usho
                                                                const uint16_t* __restrict__ band_list, const uint32_t* __restrict__ band_cnt,
                                                                uint32_t* __restrict__ bucket_ids, int gx, int tiles, int code_bits,
                                                                const SplitState* __restrict__ split) {
-    if (split->need_far == 0u || split->near_code == SPLIT_OFF) return;
-    const uint32_t near_code = split->near_code;
     const int tid = threadIdx.x, band = blockIdx.x & 7, chunk = blockIdx.x >> 3;
+    if (((split->need_far >> band) & 1u) == 0u || split->near_code == SPLIT_OFF) return;  // no tile of this band asked
+    const uint32_t near_code = split->near_code;
     const int q = tiles >> 3, rem = tiles & 7;
     const int t0 = band * q + min(band, rem), t1 = t0 + q + (band < rem ? 1 : 0);
     if (t0 >= t1) return;

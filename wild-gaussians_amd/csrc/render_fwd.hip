@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     const uint32_t n_near = tile_near ? tile_near[tile] : n;
     const uint32_t bag_lo = phase == 0 ? 0u : n_near, bag_hi = phase == 0 ? n_near : n;
     if (done >= bag_hi) {  // this bag is used up already (phase 0: the front was all of the near instances, or there are none)
-        if (phase == 0 && tid == 0) split->need_far = 1u;  // n_near < n here: a finished tile does not arrive
+        if (phase == 0 && tid == 0) atomicOr(&split->need_far, 1u << (blockIdx.x & 7));  // n_near < n here: a finished tile does not arrive
         return;
     }
     const uint32_t* bag = bucket_ids + range.x + bag_lo;
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     if (walker) fwd_store(st, complete, W, H, tile, tid, bg, final_T, n_contrib, tile_last, out_color);
     if (tid == 0) {
         tile_state[tile] = complete ? 0xffffffffu : done;
-        if (!complete) split->need_far = 1u;
+        if (!complete) atomicOr(&split->need_far, 1u << (blockIdx.x & 7));  // xcd_tile: block b serves a tile of band b & 7
     }
 }
 

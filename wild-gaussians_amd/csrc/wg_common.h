@@ -60,7 +60,7 @@ struct BinStats {  // read back by the host once per forward (the reference's nu
 constexpr uint32_t SPLIT_BITS = 12, SPLIT_BINS = 1u << SPLIT_BITS, SPLIT_OFF = 0xffffffffu;
 struct SplitState {
     uint32_t near_code;  // instances of Gaussians with depth_code(depth, SPLIT_BITS) <= near_code are near
-    uint32_t need_far;   // set by the first fix-up phase when some tile ran out of near instances
+    uint32_t need_far;   // bit b: set by the first fix-up phase when a tile of XCD band b ran out of near instances
     uint32_t pad[2];
 };
 
@@ -193,7 +193,7 @@ struct Options {
     int grad_record = 1;              // 0: the per-tile backward accumulates into the four arrays themselves (A/B)
     int near_split = -1;              // near / far split of dense frames: -1 automatic (P >= band_list_min_p and >= 1500 instances per
                                       // tile) / 0 off / 1 whenever possible (tests)
-    int near_per_tile = 0;            // aimed near instances per tile; 0 = 2.5 x lazy.target
+    int near_per_tile = 0;            // aimed near instances per tile; 0 = 1.5 x lazy.target
     bool force_global_sort = false;   // exercise the fallback binning path
     bool use_mailbox = true;          // 0 restores the copy + synchronise read-back
 };

@@ -246,6 +246,9 @@ const char* wg_stage_name(int stage);
  * instances per tile qualify -- and scatter the far ones afterwards only into tiles whose pixels are still accumulating when their
  * near instances are used up.  num_rendered, radii, images, n_contrib and gradients are those of the full binning.
  */
+/* "box_count" (-1 automatic / 0 / 1, default -1: on for large scenes and after a dense frame, like the split): the per-tile instance
+ * counts are made from a difference grid (four LDS atomics per Gaussian: its rectangle's corners) and two prefix passes instead of
+ * one atomic per (Gaussian, tile) instance.  Identical counts. */
 /* "roctx" (0/1, default 0; WG_ROCTX=1 in the environment switches it on from the first call): a roctx range around every stage
  * ("wg:K1 preprocess" ... "wg:K10-K11 preprocess_backward"), for `rocprofv3 --marker-trace --kernel-trace`.  The marker library is
  * dlopen()ed on demand; WG_ERR_INVALID_ARGUMENT if none is found. */

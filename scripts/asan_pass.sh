@@ -6,12 +6,19 @@
 set -u
 cd "$(dirname "$0")/.."
 LOG=${1:-/dev/stdout}
-WG_BUILD_VARIANT=asan WG_EXTRA_FLAGS="-fsanitize=address -fno-gpu-sanitize -fno-omit-frame-pointer -g" python wild-gaussians_amd/build.py > /dev/null || exit 1
+WG_BUILD_VARIANT=asan WG_EXTRA_FLAGS="-fsanitize=address -fno-gpu-sanitize -fno-omit-frame-pointer -g" python wild-gaussians_amd/build.py --driver > /dev/null || exit 1
 export LD_PRELOAD=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 # protect_shadow_gap=0: the HIP runtime reserves address space inside ASan's shadow gap (as CUDA does)
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=0:protect_shadow_gap=0
 export WG_RASTERIZER_LIB=$PWD/wild-gaussians_amd/build/asan/libwg_rasterizer.so
 {
+  # 1. no interpreter in between: the torch-free driver (tests/native/c_abi_driver.cpp), itself built with ASan, runs a forward +
+  #    backward + markVisible through the instrumented library on the GPU (nothing to run without one)
+  if [ -e /dev/kfd ]; then
+    echo "== C-ABI driver under ASan (forward + backward + markVisible, 20000 Gaussians @ 320x200, then 200000 @ 1280x720)"
+    env -u LD_PRELOAD wild-gaussians_amd/build/asan/c_abi_driver 2>&1 | tail -20; echo "rc=${PIPESTATUS[0]}"
+    env -u LD_PRELOAD wild-gaussians_amd/build/asan/c_abi_driver 200000 1280 720 2>&1 | tail -20; echo "rc=${PIPESTATUS[0]}"
+  fi
   echo "== host tests under ASan ($WG_RASTERIZER_LIB)"
   python -m pytest tests/test_host_cpu.py -q -k "export or invalid or scratch or options" 2>&1 | tail -15
   echo "rc=${PIPESTATUS[0]}"

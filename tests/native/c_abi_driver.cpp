@@ -1,0 +1,139 @@
+// Torch-free driver of the C-ABI (include/wg_rasterizer.h): one forward + backward + markVisible on a small synthetic scene
+// with plain hipMalloc buffers and hipMalloc-backed allocator callbacks.  Two uses:
+//   * scripts/asan_pass.sh builds it and the library with -fsanitize=address (host side) and runs it on the GPU: the sanitizer
+//     pass SURVEY.md section 5 asks for, without a Python interpreter between ASan and the HIP runtime;
+//   * evidence that the boundary really is "plain pointers and sizes, no torch types" (tests/test_native_driver.py).
+// Prints one line "ok num_rendered=... checksum=..." and exits 0, or a diagnostic and a non-zero code.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "wg_rasterizer.h"
+
+#define CHECK_HIP(x)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } \
+    } while (0)
+
+struct Grow {  // one scratch buffer, grown on demand like the reference's resizeFunctional (rasterize_points.cu:27-33)
+    char* p = nullptr;
+    size_t cap = 0;
+    static char* alloc(size_t n, void* user) {
+        Grow* g = static_cast<Grow*>(user);
+        if (n > g->cap) {
+            if (g->p) (void)hipFree(g->p);
+            g->p = nullptr;
+            if (hipMalloc(reinterpret_cast<void**>(&g->p), n ? n : 1) != hipSuccess) return nullptr;
+            g->cap = n;
+        }
+        return g->p;
+    }
+};
+
+static uint32_t lcg(uint32_t& s) { s = s * 1664525u + 1013904223u; return s; }
+static float uni(uint32_t& s) { return (lcg(s) >> 8) * (1.0f / 16777216.0f); }
+
+template <typename T>
+static int upload(const std::vector<T>& h, T** d) {
+    CHECK_HIP(hipMalloc(reinterpret_cast<void**>(d), h.size() * sizeof(T)));
+    CHECK_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const int P = argc > 1 ? std::atoi(argv[1]) : 20000, W = argc > 2 ? std::atoi(argv[2]) : 320, H = argc > 3 ? std::atoi(argv[3]) : 200;
+    const int D = 1, M = 4;
+    uint32_t seed = 12345u;
+    const float tanx = std::tan(0.5f * 1.0471976f), tany = tanx * H / W;
+    std::vector<float> means(3 * P), scales(3 * P), rots(4 * P), opac(P), shs((size_t)P * M * 3);
+    for (int i = 0; i < P; i++) {
+        const float z = 1.0f + 9.0f * uni(seed);
+        means[3 * i] = z * tanx * (2.2f * uni(seed) - 1.1f);
+        means[3 * i + 1] = z * tany * (2.2f * uni(seed) - 1.1f);
+        means[3 * i + 2] = z;
+        for (int k = 0; k < 3; k++) scales[3 * i + k] = 0.02f * z * (0.5f + uni(seed));
+        float q[4], n = 0.f;
+        for (int k = 0; k < 4; k++) { q[k] = uni(seed) - 0.5f; n += q[k] * q[k]; }
+        n = 1.0f / std::sqrt(n + 1e-12f);
+        for (int k = 0; k < 4; k++) rots[4 * i + k] = q[k] * n;
+        opac[i] = 0.05f + 0.9f * uni(seed);
+        for (int k = 0; k < M * 3; k++) shs[(size_t)i * M * 3 + k] = (uni(seed) - 0.5f) * (k < 3 ? 1.0f : 0.2f);
+    }
+    // camera at the origin looking down +z: view = identity; proj = OpenCV projection (method.py:605-616), both transposed
+    const float fx = 0.5f * W / tanx, fy = fx, zn = 0.01f, zf = 100.0f;
+    std::vector<float> view = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::vector<float> Pm(16, 0.f);  // row-major P, then transposed into proj
+    Pm[0] = 2.f * fx / W; Pm[5] = 2.f * fy / H; Pm[10] = zf / (zf - zn); Pm[11] = -(zf * zn) / (zf - zn); Pm[14] = 1.f;
+    std::vector<float> proj(16);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) proj[4 * c + r] = Pm[4 * r + c];
+    std::vector<float> campos = {0, 0, 0}, bg = {0.1f, 0.2f, 0.3f};
+    std::vector<float> cot((size_t)3 * W * H);
+    for (auto& v : cot) v = (uni(seed) - 0.5f) / (3.0f * W * H);
+
+    float *d_means, *d_scales, *d_rots, *d_opac, *d_shs, *d_view, *d_proj, *d_campos, *d_bg, *d_cot;
+    if (upload(means, &d_means) || upload(scales, &d_scales) || upload(rots, &d_rots) || upload(opac, &d_opac) || upload(shs, &d_shs) ||
+        upload(view, &d_view) || upload(proj, &d_proj) || upload(campos, &d_campos) || upload(bg, &d_bg) || upload(cot, &d_cot))
+        return 2;
+    float* d_color;
+    int* d_radii;
+    CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d_color), (size_t)3 * W * H * sizeof(float)));
+    CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d_radii), (size_t)P * sizeof(int)));
+    hipStream_t stream;
+    CHECK_HIP(hipStreamCreate(&stream));
+    Grow geom, bin, img;
+
+    // argument validation comes before any device work
+    if (wg_rasterize_forward(nullptr, nullptr, Grow::alloc, &bin, Grow::alloc, &img, P, D, M, d_bg, W, H, d_means, d_shs, nullptr, d_opac, d_scales,
+                             1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, d_color, d_radii, 0, stream) !=
+        WG_ERR_INVALID_ARGUMENT) {
+        std::fprintf(stderr, "a NULL allocator was not refused\n");
+        return 3;
+    }
+    const int R = wg_rasterize_forward(Grow::alloc, &geom, Grow::alloc, &bin, Grow::alloc, &img, P, D, M, d_bg, W, H, d_means, d_shs, nullptr, d_opac,
+                                       d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, d_color, d_radii,
+                                       0, stream);
+    if (R <= 0) { std::fprintf(stderr, "forward: %s (%s)\n", wg_status_string(R), wg_last_hip_error()); return 4; }
+
+    float *g2d, *gcon, *gop, *gcol, *g3d, *gcov, *gsh, *gsc, *grot;
+    CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g2d), (size_t)P * 3 * 4));
+    CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&gcon), (size_t)P * 4 * 4));
+    CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&gop), (size_t)P * 4));
+    CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&gcol), (size_t)P * 3 * 4));
+    CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g3d), (size_t)P * 3 * 4));
+    CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&gcov), (size_t)P * 6 * 4));
+    CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&gsh), (size_t)P * M * 3 * 4));
+    CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&gsc), (size_t)P * 3 * 4));
+    CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&grot), (size_t)P * 4 * 4));
+    const int st = wg_rasterize_backward(P, D, M, R, d_bg, W, H, d_means, d_shs, nullptr, d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx,
+                                         tany, 0.1f, nullptr, d_radii, geom.p, bin.p, img.p, d_cot, g2d, gcon, gop, gcol, g3d, gcov, gsh, gsc, grot, 0,
+                                         stream);
+    if (st != WG_OK) { std::fprintf(stderr, "backward: %s (%s)\n", wg_status_string(st), wg_last_hip_error()); return 5; }
+    unsigned char* d_vis;
+    CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d_vis), (size_t)P));
+    if (wg_mark_visible(P, d_means, d_view, d_proj, d_vis, stream) != WG_OK) return 6;
+    CHECK_HIP(hipStreamSynchronize(stream));
+
+    std::vector<float> color((size_t)3 * W * H), gm(3 * (size_t)P);
+    std::vector<int> radii(P);
+    std::vector<unsigned char> vis(P);
+    CHECK_HIP(hipMemcpy(color.data(), d_color, color.size() * 4, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(gm.data(), g3d, gm.size() * 4, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(radii.data(), d_radii, radii.size() * 4, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(vis.data(), d_vis, vis.size(), hipMemcpyDeviceToHost));
+    double sum = 0, gsum = 0;
+    int nvis = 0, nrad = 0;
+    for (float v : color) { if (!std::isfinite(v)) { std::fprintf(stderr, "non-finite colour\n"); return 7; } sum += v; }
+    for (float v : gm) { if (!std::isfinite(v)) { std::fprintf(stderr, "non-finite gradient\n"); return 7; } gsum += std::fabs(v); }
+    for (int i = 0; i < P; i++) { nvis += vis[i]; nrad += radii[i] > 0; }
+    if (nrad == 0 || nvis < nrad || gsum <= 0) { std::fprintf(stderr, "implausible outputs: nrad %d nvis %d gsum %g\n", nrad, nvis, gsum); return 8; }
+    std::printf("ok num_rendered=%d visible=%d radii>0=%d checksum=%.6f grad_l1=%.6e\n", R, nvis, nrad, sum, gsum);
+    for (void* p : {(void*)d_means, (void*)d_scales, (void*)d_rots, (void*)d_opac, (void*)d_shs, (void*)d_view, (void*)d_proj, (void*)d_campos, (void*)d_bg,
+                    (void*)d_cot, (void*)d_color, (void*)d_radii, (void*)g2d, (void*)gcon, (void*)gop, (void*)gcol, (void*)g3d, (void*)gcov, (void*)gsh,
+                    (void*)gsc, (void*)grot, (void*)d_vis, (void*)geom.p, (void*)bin.p, (void*)img.p})
+        (void)hipFree(p);
+    (void)hipStreamDestroy(stream);
+    return 0;
+}

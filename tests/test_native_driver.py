@@ -1,0 +1,36 @@
+"""tests/native/c_abi_driver.cpp: the C-ABI driven without torch or Python -- plain hipMalloc buffers, hipMalloc-backed allocator
+callbacks, one forward + backward + markVisible.  Evidence for SURVEY 8(b): "plain pointers and sizes, no torch types"."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def driver():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wg_build", os.path.join(ROOT, "wild-gaussians_amd", "build.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.build_driver()
+
+
+def test_driver_builds_and_links_only_the_c_abi_library(driver):
+    assert os.path.exists(driver)
+    out = subprocess.run(["ldd", driver], capture_output=True, text=True).stdout
+    assert "libwg_rasterizer.so" in out and "libtorch" not in out and "libpython" not in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [[], ["200000", "1280", "720"]])
+def test_driver_runs_forward_backward_and_mark_visible(driver, args):
+    r = subprocess.run([driver] + args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"ok num_rendered=(\d+) visible=(\d+) radii>0=(\d+) checksum=([\d.eE+-]+) grad_l1=([\d.eE+-]+)", r.stdout)
+    assert m, r.stdout
+    R, vis, rad = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    assert R > rad > 0 and vis >= rad and float(m.group(5)) > 0

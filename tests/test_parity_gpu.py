@@ -46,17 +46,21 @@ def _scene(name):
     return cloud, cam, (deg if deg is not None else 0)
 
 
-@pytest.mark.parametrize("binning", ["tile_sort", "global_sort"])
+@pytest.mark.parametrize("binning", ["tile_sort", "global_sort", "box_count"])
 @pytest.mark.parametrize("name", list(CASES))
 def test_preprocess_and_binning_bit_exact(oracle, name, binning):
+    """binning: the LDS counting sort + per-tile sort (default), the reference's scheme on rocPRIM (fallback), and the default
+    with the per-tile counts made from a difference grid + prefix passes (wg_set_option "box_count": large / dense frames)."""
     from diff_gaussian_rasterization import _C
     cloud, cam, deg = _scene(name)
     o = oracle.run_scene(cloud, cam, sh_degree=deg)
     _C.set_option("force_global_sort", int(binning == "global_sort"))
+    _C.set_option("box_count", 1 if binning == "box_count" else -1)
     try:
         h = run_hip_native(cloud, cam, sh_degree=deg)
     finally:
         _C.set_option("force_global_sort", 0)
+        _C.set_option("box_count", -1)
     octx = o["ctx"]
     g, b, im = h["views"]["geometry"], h["views"]["binning"], h["views"]["image"]
     radii = h["radii"].cpu().numpy()
@@ -438,7 +442,7 @@ def lazy_options():
             _C.set_option(k, v)
     yield set_
     set_(lazy_sort=1, lazy_min_len=1024, lazy_target=820, lazy_cap=2048, depth_codes=1, near_split=-1, near_per_tile=0, band_list_min_p=2000000,
-         staged_scatter=-1, staged_scatter_cap=0)
+         staged_scatter=-1, staged_scatter_cap=0, box_count=-1)
 
 
 def _dense_scene():
@@ -488,7 +492,8 @@ def test_lazy_sort_gives_the_fully_sorted_results(oracle, lazy_options, opts):
         assert e <= 1e-3, (k, e)
 
 
-@pytest.mark.parametrize("extra", [dict(), dict(band_list_min_p=1), dict(staged_scatter=1, staged_scatter_cap=24), dict(depth_codes=0)])
+@pytest.mark.parametrize("extra", [dict(), dict(band_list_min_p=1), dict(staged_scatter=1, staged_scatter_cap=24), dict(depth_codes=0),
+                                   dict(box_count=1)])
 @pytest.mark.parametrize("npt", [30, 150, 500])
 def test_near_far_split_gives_the_fully_sorted_results(oracle, lazy_options, npt, extra):
     """Near / far split (wg_set_option "near_split"): only the instances of Gaussians below a frame-wide depth-code threshold are

@@ -15,9 +15,11 @@ from tests.test_parity_gpu import _sweep_case
 
 first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 100
 PATHS = {"default": {}, "lazy_tiny": dict(lazy_min_len=256, lazy_target=40, lazy_cap=64), "staged": dict(staged_scatter=1, staged_scatter_cap=7),
-         "global": dict(force_global_sort=1), "band_lists": dict(band_list_min_p=1, staged_scatter=0)}
+         "global": dict(force_global_sort=1), "band_lists": dict(band_list_min_p=1, staged_scatter=0),
+         "near_far_tiny": dict(near_split=1, near_per_tile=12, lazy_min_len=256, lazy_target=40, lazy_cap=64),   # nearly every tile takes the far phase
+         "arrays_not_record": dict(grad_record=0), "box_count": dict(box_count=1, near_split=1, near_per_tile=200)}
 RESET = dict(lazy_min_len=1024, lazy_target=820, lazy_cap=2048, staged_scatter=-1, staged_scatter_cap=0, force_global_sort=0,
-             band_list_min_p=2000000)
+             band_list_min_p=2000000, near_split=-1, near_per_tile=0, grad_record=1, box_count=-1)
 stats = dict(runs=0, radii_mismatch_runs=0, pixel_flip_runs=0, pixels_over=0, pixels=0, grad_over_runs=0, worst_grad=0.0, worst_fwd=0.0)
 for i in range(first, first + count):
     cloud, cam, deg, kw, W, H = _sweep_case(i)

@@ -79,5 +79,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+def build_driver(force: bool = False) -> str:
+    """tests/native/c_abi_driver.cpp: a torch-free program that drives the C-ABI (sanitizer pass, boundary evidence).  Built next to
+    the library it links (build/[<variant>/]c_abi_driver, rpath = the library's directory)."""
+    src = os.path.join(os.path.dirname(HERE), "tests", "native", "c_abi_driver.cpp")
+    out = os.path.join(OBJ, "c_abi_driver")
+    lib = build(force)
+    if force or _newer(out, [src, lib, os.path.join(INCLUDE, "wg_rasterizer.h")]):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-I" + INCLUDE] + EXTRA + [src, "-o", out, "-L" + os.path.dirname(lib),
+               "-lwg_rasterizer", "-Wl,-rpath," + os.path.dirname(lib)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return out
+
+
 if __name__ == "__main__":
+    if "--driver" in sys.argv:
+        print(build_driver(force="--force" in sys.argv))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

@@ -273,7 +273,8 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
         if (tiles <= wg::BIN_MAX_TILES) {
             if (try_split)
                 WG_STAGE(WG_STAGE_SCAN, wg::launch_split_threshold(P, geom, img, tiles, opt.near_split == 1, near_per_tile, stream), "split_threshold");
-            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_count(P, geom, img, gx, tiles, try_split, stream), "tile_count");
+            const bool box = opt.box_count == 1 || (opt.box_count < 0 && (P >= opt.band_list_min_p || t_last_instances_per_tile >= 1500u));
+            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_count(P, geom, img, gx, tiles, try_split, box, stream), "tile_count");
             mbox = (debug || !opt.use_mailbox) ? nullptr : get_mailbox();
             if (mbox) mbox->seq += 1;
             WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, mbox ? mbox->dev : nullptr, mbox ? mbox->seq : 0, try_split, stream), "tile_scan");
@@ -532,6 +533,7 @@ int wg_set_option(const char* name, int value) {
     if (std::strcmp(name, "band_list_min_p") == 0) { o.band_list_min_p = value > 0 ? value : 1; return WG_OK; }
     if (std::strcmp(name, "near_split") == 0) { o.near_split = value < 0 ? -1 : (value != 0); return WG_OK; }
     if (std::strcmp(name, "near_per_tile") == 0) { o.near_per_tile = value > 0 ? value : 0; return WG_OK; }
+    if (std::strcmp(name, "box_count") == 0) { o.box_count = value < 0 ? -1 : (value != 0); return WG_OK; }
     if (std::strcmp(name, "depth_codes") == 0) {
         if (value != 0 && value != 1 && (value < 8 || value > 12)) return WG_ERR_INVALID_ARGUMENT;
         o.depth_codes = value;
@@ -564,6 +566,7 @@ int wg_get_option(const char* name) {
     if (std::strcmp(name, "staged_scatter") == 0) return o.staged_scatter;
     if (std::strcmp(name, "near_split") == 0) return o.near_split;
     if (std::strcmp(name, "near_per_tile") == 0) return o.near_per_tile;
+    if (std::strcmp(name, "box_count") == 0) return o.box_count;
     if (std::strcmp(name, "lazy_min_len") == 0) return (int)o.lazy.min_len;
     if (std::strcmp(name, "lazy_target") == 0) return (int)o.lazy.target;
     if (std::strcmp(name, "lazy_cap") == 0) return (int)o.lazy.cap;

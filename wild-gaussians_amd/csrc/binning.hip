@@ -255,6 +255,13 @@ __device__ __forceinline__ int band_of_tile(int t, int tiles) {
 // With an active near / far split (split != nullptr and a real threshold in it) a histogram word counts two things at once: the
 // chunk's instances in the tile in its upper half, the near ones among them in its lower half (a chunk holds fewer than 65536
 // Gaussians whenever the split is attempted, so neither half can overflow).
+//
+// BOX (dense frames / large scenes, where a Gaussian covers tens of tiles): instead of one LDS atomic per (Gaussian, tile) instance
+// the rectangle is entered into the histogram as a DIFFERENCE grid -- +w at (x0, y0), -w at (x1, y0) and (x0, y1), +w at (x1, y1),
+// corners beyond the grid dropped -- and two prefix passes over the grid (along x, then along y) turn it into the per-tile counts:
+// four atomics per Gaussian whatever its size (10 M Gaussians at 4K: 211 M instances -> 40 M atomics).  Exact integer arithmetic
+// modulo 2^32, so the packed (total << 16 | near) words come out the same as well: identical histograms.
+template <bool BOX>
 __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const ushort4* __restrict__ rects, uint32_t* __restrict__ chunk_hist,
                                                          uint16_t* __restrict__ band_list, uint32_t* __restrict__ band_cnt, int gx,
                                                          int tiles, const float* __restrict__ depths, const SplitState* __restrict__ split) {
@@ -302,10 +309,68 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const us
                     if (in) lists[(size_t)b * per + wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)local;
                 }
             }
-            for_each_tile<16>(valid, r[k].x, r[k].y, r[k].z, r[k].w, (int)inc[k], [&](int x, int y, int add) { atomicAdd(&hist[y * gx + x], (uint32_t)add); });
+            if (BOX) {
+                if (valid) {
+                    const int gy = tiles / gx;
+                    const uint32_t w = inc[k];
+                    const int x0 = r[k].x, y0 = r[k].y, x1 = r[k].z, y1 = r[k].w;
+                    atomicAdd(&hist[y0 * gx + x0], w);
+                    if (x1 < gx) atomicAdd(&hist[y0 * gx + x1], 0u - w);
+                    if (y1 < gy) {
+                        atomicAdd(&hist[y1 * gx + x0], 0u - w);
+                        if (x1 < gx) atomicAdd(&hist[y1 * gx + x1], w);
+                    }
+                }
+            } else {
+                for_each_tile<16>(valid, r[k].x, r[k].y, r[k].z, r[k].w, (int)inc[k], [&](int x, int y, int add) { atomicAdd(&hist[y * gx + x], (uint32_t)add); });
+            }
         }
     }
     __syncthreads();
+    if (BOX) {
+        const int gy = tiles / gx, wave = tid >> 6;
+        // inclusive prefix along x: one wave per row, 64 columns per step, the carry handed on wave-uniformly
+        for (int row = wave; row < gy; row += BIN_THREADS / 64) {
+            uint32_t carry = 0;
+            for (int xb = 0; xb < gx; xb += 64) {
+                const int x = xb + lane;
+                uint32_t v = x < gx ? hist[row * gx + x] : 0u;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)v, d);
+                    if (lane >= d) v += up;
+                }
+                v += carry;
+                if (x < gx) hist[row * gx + x] = v;
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+            }
+        }
+        __syncthreads();
+        // inclusive prefix along y: a column is cut into SEG segments scanned by different threads, then offset by the totals of
+        // the segments above (columns are few -- 240 at 4K -- and a single thread per column would be a 135-step chain)
+        const int SEG = max(1, min(8, BIN_THREADS / gx)), rows_per = (gy + SEG - 1) / SEG;
+        const int col = tid % gx, seg = tid / gx;
+        const bool mine = tid < gx * SEG;
+        const int ya = seg * rows_per, yb = min(gy, ya + rows_per);
+        uint32_t run = 0;
+        if (mine)
+            for (int y = ya; y < yb; y++) {
+                run += hist[y * gx + col];
+                hist[y * gx + col] = run;
+            }
+        __syncthreads();
+        // totals of the segments above this one: their last rows (read before anybody adds offsets)
+        uint32_t off = 0;
+        if (mine)
+            for (int sgi = 0; sgi < seg; sgi++) {
+                const int last = min(gy, (sgi + 1) * rows_per) - 1;
+                if (last >= sgi * rows_per) off += hist[last * gx + col];
+            }
+        __syncthreads();
+        if (mine && off != 0u)
+            for (int y = ya; y < yb; y++) hist[y * gx + col] += off;
+        __syncthreads();
+    }
     uint32_t* out = chunk_hist + (size_t)chunk * tiles;
     for (int t = tid; t < tiles; t += BIN_THREADS) out[t] = hist[t];
     if (lists && tid < 8) band_cnt[chunk * 8 + tid] = bcnt[tid];
@@ -922,13 +987,18 @@ static hipError_t ensure_lds(const void* fn, size_t bytes) {
     return e;
 }
 
-hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, bool split, hipStream_t stream) {
+hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, bool split, bool box, hipStream_t stream) {
     const size_t lds = (size_t)tiles * sizeof(uint32_t);
-    hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_count_kernel), lds);
+    hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_count_kernel<false>), lds);
+    if (e == hipSuccess) e = ensure_lds(reinterpret_cast<const void*>(tile_count_kernel<true>), lds);
     if (e != hipSuccess) return e;
     const SplitState* sp = split ? img.split : nullptr;
-    hipLaunchKernelGGL(tile_count_kernel, dim3(BIN_CHUNKS), dim3(BIN_THREADS), lds, stream, P, g.rects, img.chunk_hist, g.band_list, g.band_cnt,
-                       gx, tiles, g.depths, sp);
+    if (box && gx <= BIN_THREADS)
+        hipLaunchKernelGGL(tile_count_kernel<true>, dim3(BIN_CHUNKS), dim3(BIN_THREADS), lds, stream, P, g.rects, img.chunk_hist, g.band_list,
+                           g.band_cnt, gx, tiles, g.depths, sp);
+    else
+        hipLaunchKernelGGL(tile_count_kernel<false>, dim3(BIN_CHUNKS), dim3(BIN_THREADS), lds, stream, P, g.rects, img.chunk_hist, g.band_list,
+                           g.band_cnt, gx, tiles, g.depths, sp);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(chunk_scan_kernel, dim3((tiles + 63) / 64), dim3(64 * SCAN_WAVES), 0, stream, img.chunk_hist, img.tile_count, tiles,

@@ -166,7 +166,8 @@ hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_o
 // split == nullptr: no near / far split attempted (small P): the kernels are exactly the ones without it
 hipError_t launch_split_threshold(int P, const GeometryState& g, const ImageState& img, int tiles, bool force, uint32_t near_per_tile,
                                   hipStream_t stream);
-hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, bool split, hipStream_t stream);
+// box: count through a difference grid + two prefix passes (four atomics per Gaussian) instead of one atomic per instance
+hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, bool split, bool box, hipStream_t stream);
 hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, bool split, hipStream_t stream);
 hipError_t launch_tile_scatter_far(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles, int code_bits,
                                    hipStream_t stream);
@@ -194,6 +195,7 @@ struct Options {
     int near_split = -1;              // near / far split of dense frames: -1 automatic (P >= band_list_min_p and >= 1500 instances per
                                       // tile) / 0 off / 1 whenever possible (tests)
     int near_per_tile = 0;            // aimed near instances per tile; 0 = 1.5 x lazy.target
+    int box_count = -1;               // tile counting through a difference grid: -1 automatic (with the split's "large or dense" rule) / 0 / 1
     bool force_global_sort = false;   // exercise the fallback binning path
     bool use_mailbox = true;          // 0 restores the copy + synchronise read-back
 };

@@ -829,6 +829,7 @@ def record_option():
     from diff_gaussian_rasterization import _C
     yield _C
     _C.set_option("grad_record", 1)
+    _C.set_option("deterministic_backward", 0)
 
 
 def test_gradient_record_and_in_place_accumulation_agree(oracle, record_option):
@@ -889,6 +890,28 @@ def test_c_abi_backward_overwrites_its_outputs_and_returns_the_intermediates_on_
                                                      rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset, H, W,
                                                      e, 0, e, False, False)
     assert R2 == n["num_rendered"] and torch.equal(col2, n["color"])
+
+
+def test_deterministic_backward_mode_is_bit_reproducible(oracle, record_option):
+    """wg_set_option("deterministic_backward", 1): per-instance slots + an ordered per-Gaussian sum instead of float atomics."""
+    _C = record_option
+    W, H, P = 640, 360, 60_000
+    cam, cot = S.make_camera(W, H), S.make_cotangent(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=2, seed=8, scale_mult=3.0)
+    default = run_hip(cloud, cam, sh_degree=2, cotangent=cot)
+    _C.set_option("deterministic_backward", 1)
+    try:
+        a = run_hip(cloud, cam, sh_degree=2, cotangent=cot)
+        b = run_hip(cloud, cam, sh_degree=2, cotangent=cot)
+        c = run_hip(cloud, cam, sh_degree=2, cotangent=cot)
+    finally:
+        _C.set_option("deterministic_backward", 0)
+    for k in a["grads"]:
+        assert np.array_equal(a["grads"][k], b["grads"][k]) and np.array_equal(a["grads"][k], c["grads"][k]), k
+        assert rel_err(a["grads"][k], default["grads"][k]) <= 2e-6, k
+    o = oracle.run_scene(cloud, cam, sh_degree=2, cotangent=cot)
+    for k, e in compare_grads(a["grads"], o["grads"]).items():
+        assert e <= 1e-3, (k, e)
 
 
 def test_backward_run_to_run_spread_is_at_rounding_level():

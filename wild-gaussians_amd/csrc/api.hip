@@ -430,7 +430,7 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     if (!dL_dmean2D || !dL_dopacity || !dL_dmean3D || !dL_dcov3D) return WG_ERR_INVALID_ARGUMENT;
     // dL_dconic (always an intermediate) and, with SH colours, dL_dcolor (the gradient of the evaluated RGB, an intermediate there)
     // may be NULL with the gradient record: nobody reads them.  Without the record they are accumulation targets.
-    if (!g_grad_record && (!dL_dconic || !dL_dcolor)) return WG_ERR_INVALID_ARGUMENT;
+    if (!g_grad_record && !opt.deterministic_backward && (!dL_dconic || !dL_dcolor)) return WG_ERR_INVALID_ARGUMENT;
     if (!dL_dcolor && shs == nullptr) return WG_ERR_INVALID_ARGUMENT;
     if (shs != nullptr && (!dL_dsh || !campos)) return WG_ERR_INVALID_ARGUMENT;
     if (scales != nullptr && (!rotations || !dL_dscale || !dL_drot)) return WG_ERR_INVALID_ARGUMENT;
@@ -445,7 +445,18 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     // grad_record (default): the per-tile pass accumulates into one 64-byte record per Gaussian inside the geometry buffer, cleared
     // here; the per-Gaussian kernel then WRITES the four arrays (they need no clearing by the caller).  Off: the arrays are the
     // accumulation targets and must arrive zeroed, as the reference demands of its caller (rasterize_points.cu:157-165).
-    const bool record = g_grad_record != 0;
+    // deterministic_backward: per-instance slots (stream-ordered scratch of 40 B per tile instance, cleared) + an ordered
+    // per-Gaussian sum instead of float atomics; needs the exclusive prefix of tiles_touched, which the LDS binning path never made
+    const bool det = opt.deterministic_backward != 0 && R > 0;
+    const bool record = g_grad_record != 0 || det;
+    float* det_slots = nullptr;
+    if (det) {
+        StageScope scope_(WG_STAGE_RENDER_BACKWARD, stream);
+        hipError_t e = wg::run_scan(geom, P, stream);
+        if (e == hipSuccess) e = hipMallocAsync(reinterpret_cast<void**>(&det_slots), (size_t)R * 10 * sizeof(float), stream);
+        if (e == hipSuccess) e = hipMemsetAsync(det_slots, 0, (size_t)R * 10 * sizeof(float), stream);
+        if (e != hipSuccess) return hip_fail(e, "deterministic backward scratch");
+    }
     if (record) {
         StageScope scope_(WG_STAGE_RENDER_BACKWARD, stream);
         hipError_t e = hipMemsetAsync(geom.grad_rec, 0, (size_t)P * wg::GRAD_REC_FLOATS * sizeof(float), stream);
@@ -454,7 +465,7 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     if (R > 0) {
         WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_order(img.tile_last, nullptr, img.order_bwd, gx * gy, stream), "tile_order");
         WG_STAGE(WG_STAGE_RENDER_BACKWARD, wg::launch_render_backward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, dL_dpix,
-                                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, stream),
+                                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, det_slots, P, stream),
                  "render_backward");
     }
 
@@ -470,6 +481,10 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     WG_STAGE(WG_STAGE_PREPROCESS_BACKWARD, wg::launch_preprocess_backward(bp, device_tone(tone), geom, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                             dL_dscale, dL_drot, record, stream),
              "preprocess_backward");
+    if (det_slots) {
+        hipError_t e = hipFreeAsync(det_slots, stream);
+        if (e != hipSuccess) return hip_fail(e, "deterministic backward scratch release");
+    }
     return WG_OK;
 }
 
@@ -530,6 +545,7 @@ int wg_set_option(const char* name, int value) {
     if (std::strcmp(name, "force_global_sort") == 0) { o.force_global_sort = value != 0; return WG_OK; }
     if (std::strcmp(name, "host_mailbox") == 0) { o.use_mailbox = value != 0; return WG_OK; }
     if (std::strcmp(name, "grad_record") == 0) { o.grad_record = value != 0; return WG_OK; }
+    if (std::strcmp(name, "deterministic_backward") == 0) { o.deterministic_backward = value != 0; return WG_OK; }
     if (std::strcmp(name, "band_list_min_p") == 0) { o.band_list_min_p = value > 0 ? value : 1; return WG_OK; }
     if (std::strcmp(name, "near_split") == 0) { o.near_split = value < 0 ? -1 : (value != 0); return WG_OK; }
     if (std::strcmp(name, "near_per_tile") == 0) { o.near_per_tile = value > 0 ? value : 0; return WG_OK; }
@@ -558,6 +574,7 @@ int wg_get_option(const char* name) {
     if (std::strcmp(name, "roctx") == 0) return g_roctx.enabled ? 1 : 0;
     const wg::Options o = options_snapshot();
     if (std::strcmp(name, "grad_record") == 0) return o.grad_record;
+    if (std::strcmp(name, "deterministic_backward") == 0) return o.deterministic_backward;
     if (std::strcmp(name, "force_global_sort") == 0) return o.force_global_sort ? 1 : 0;
     if (std::strcmp(name, "host_mailbox") == 0) return o.use_mailbox ? 1 : 0;
     if (std::strcmp(name, "lazy_sort") == 0) return o.lazy.enabled ? 1 : 0;

@@ -24,10 +24,6 @@ namespace wg {
 
 constexpr int BATCH = 64;
 
-#ifndef WG_BWD_MFMA_REDUCE
-#define WG_BWD_MFMA_REDUCE 0
-#endif
-
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
@@ -83,13 +79,20 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
 // -0.5, 1 / log2 e) are applied once per Gaussian by the preprocess backward kernel, which also writes the caller-visible
 // dL_dmean2D / dL_dconic / dL_dopacity / dL_dcolor.  !RECORD: the arrays themselves are the accumulation targets (as in the
 // reference, backward.cu:568-603), factors applied per instance.
-template <bool RECORD>
+// DET (wg_set_option("deterministic_backward"), implies RECORD): no atomics at all.  Every (tile, Gaussian) instance owns a
+// slot of ten floats -- slot = (exclusive prefix of tiles_touched)[id] + the tile's index inside the Gaussian's tile rectangle --
+// into which the ten lanes STORE the wave-reduced sums; det_reduce_kernel then adds a Gaussian's slots in slot order into its
+// gradient record.  Same sums as the atomic path up to the order of a Gaussian's per-tile terms, which is now fixed: two runs
+// give bit-identical gradients.
+template <bool RECORD, bool DET = false>
 __global__ void __launch_bounds__(64) render_backward_kernel(
     int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_last,
     const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
-    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ grad_rec) {
+    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ grad_rec,
+    const ushort4* __restrict__ rects, const uint32_t* __restrict__ offsets_incl, const uint32_t* __restrict__ tiles_touched,
+    float* __restrict__ det_slots) {
     __shared__ float4 lds[BATCH * 3];
 
     const int tile = (int)order[xcd_tile(blockIdx.x, tiles)];
@@ -101,24 +104,10 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
-#if WG_BWD_MFMA_REDUCE
-    // Experiment (rejected, numbers in DESIGN.md): the wave reduction on the matrix pipe.  Ten chained
-    // v_mfma_f32_16x16x4_f32 with a row selector as A (A[i][k] = [i == v]) and the per-lane partial sums as B leave
-    // D[v][j] = sum over the four 16-lane rows of value v at column j, i.e. lane l holds values 4 (l / 16) .. + 3 in its four
-    // accumulator registers; four DPP steps per register finish the sum over the row's 16 lanes.
-    float sel[10];
-#pragma unroll
-    for (int v = 0; v < 10; v++) sel[v] = (lane & 15) == v ? 1.0f : 0.0f;
-    const int vidx = 4 * (lane >> 4) + (lane & 3);
-    const bool issue = (lane & 15) < 4 && vidx < 10;
-    const bool owner = issue;
-    (void)owner;
-#else
     // which of the ten reduced values this lane owns after butterfly10(), and where it accumulates it:
     //   0,1,2 -> dL_dcolor[3id + k]; 3,4,5 -> dL_dmean2D[3id + k-3]; 6,7,8 -> dL_dconic[4id + {0,1,3}]; 9 -> dL_dopacity[id]
     const int vidx = (lane & 2) ? 8 + ((lane >> 5) & 1) : 4 * (lane & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
     const bool owner = (lane & 12) == 0;  // lanes with bits 2,3 clear: one lane per value (two spare for value 8/9 copies)
-#endif
     float* abase;
     uint32_t astride;
     if (RECORD) { abase = grad_rec + vidx; astride = GRAD_REC_FLOATS; }
@@ -126,10 +115,8 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     else if (vidx < 6) { abase = dL_dmean2D + (vidx - 3); astride = 3; }
     else if (vidx < 9) { abase = dL_dconic + (vidx == 8 ? 3 : vidx - 6); astride = 4; }
     else { abase = dL_dopacity; astride = 1; }
-#if !WG_BWD_MFMA_REDUCE
     // values 8 and 9 (bit1 set) are replicated over bits 0 and 4: let only the bit0 == bit4 == 0 copy issue
     const bool issue = owner && !((lane & 2) && (lane & 17));
-#endif
     // constant factor of this lane's value (see the per-pair sums below); values 3..8 also carry the splat's opacity
     const bool oscale = vidx >= 3 && vidx <= 8;
     constexpr float INV_L = 1.0f / WG_LOG2E;  // u, v above carry a factor -log2(e)
@@ -248,33 +235,15 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
                 }
             }
             if (__ballot(any) == 0ull) continue;
-#if WG_BWD_MFMA_REDUCE
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            v4f d = {0.f, 0.f, 0.f, 0.f};
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[0], acr, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[1], acg, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[2], acb, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[3], sx, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[4], sy, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[5], sab, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[6], sxx, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[7], sxy, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[8], syy, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[9], sq, d, 0, 0, 0);
-            float dr[4] = {d[0], d[1], d[2], d[3]};
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                dr[r] += dpp_f<0xB1>(dr[r]);
-                dr[r] += dpp_f<0x4E>(dr[r]);
-                dr[r] += dpp_f<0x124>(dr[r]);
-                dr[r] += dpp_f<0x128>(dr[r]);
-            }
-            const int rsel = lane & 3;
-            const float total = rsel == 0 ? dr[0] : rsel == 1 ? dr[1] : rsel == 2 ? dr[2] : dr[3];
-#else
             const float total = butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
-#endif
-            if (RECORD) {
+            if (DET) {
+                if (issue) {
+                    const uint32_t id = __float_as_uint(r1.z);
+                    const ushort4 rc = rects[id];
+                    const uint32_t slot = offsets_incl[id] - tiles_touched[id] + (uint32_t)((ty - rc.y) * (rc.z - rc.x) + (tx - rc.x));
+                    det_slots[(size_t)slot * 10 + vidx] = total;
+                }
+            } else if (RECORD) {
                 if (issue) unsafeAtomicAdd(abase + (size_t)__float_as_uint(r1.z) * GRAD_REC_FLOATS, total);  // 64-bit: shift-adds, no quarter-rate 32-bit multiply
             } else {
                 if (issue) unsafeAtomicAdd(abase + astride * __float_as_uint(r1.z), total * (oscale ? (vidx == 5 ? fabsf(o) : o) * vscale : vscale));  // 4*P < 2^32
@@ -284,18 +253,41 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     }
 }
 
+// One thread per Gaussian: its tiles_touched slots, in slot order, into its gradient record (the layout the atomic path leaves).
+__global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* __restrict__ offsets_incl, const uint32_t* __restrict__ tiles_touched,
+                                                         const float* __restrict__ det_slots, float* __restrict__ grad_rec) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    const uint32_t n = tiles_touched[g];
+    if (n == 0u) return;  // the record was cleared
+    const float* s = det_slots + (size_t)(offsets_incl[g] - n) * 10;
+    float acc[10];
+#pragma unroll
+    for (int v = 0; v < 10; v++) acc[v] = 0.f;
+    for (uint32_t k = 0; k < n; k++) {
+#pragma unroll
+        for (int v = 0; v < 10; v++) acc[v] += s[(size_t)k * 10 + v];
+    }
+#pragma unroll
+    for (int v = 0; v < 10; v++) grad_rec[(size_t)g * GRAD_REC_FLOATS + v] = acc[v];
+}
+
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                   const GeometryState& g, const float* subpixel_offset, const float* background,
                                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                  float* dL_dcolor, bool record, hipStream_t stream) {
+                                  float* dL_dcolor, bool record, float* det_slots, int P, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
-#define WG_LAUNCH(REC)                                                                                                                      \
-    hipLaunchKernelGGL(render_backward_kernel<REC>, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.order_bwd, img.ranges, b.point_list, \
-                       g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.final_T, img.n_contrib, img.tile_last,   \
-                       dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, g.grad_rec)
-    if (record) WG_LAUNCH(true);
-    else WG_LAUNCH(false);
+#define WG_LAUNCH(REC, DET)                                                                                                                 \
+    hipLaunchKernelGGL((render_backward_kernel<REC, DET>), dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.order_bwd, img.ranges,     \
+                       b.point_list, g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.final_T, img.n_contrib,    \
+                       img.tile_last, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, g.grad_rec, g.rects, g.point_offsets,         \
+                       g.tiles_touched, det_slots)
+    if (det_slots) {
+        WG_LAUNCH(true, true);
+        hipLaunchKernelGGL(det_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, g.point_offsets, g.tiles_touched, det_slots, g.grad_rec);
+    } else if (record) WG_LAUNCH(true, false);
+    else WG_LAUNCH(false, false);
 #undef WG_LAUNCH
     return hipGetLastError();
 }

@@ -30,14 +30,6 @@ namespace wg {
 
 constexpr int BATCH = 64;
 
-// code-shape switches of the compositing loop (A/B builds: wild-gaussians_amd/build.py WG_EXTRA_FLAGS; numbers in DESIGN.md)
-#ifndef WG_FWD_HOIST_GB
-#define WG_FWD_HOIST_GB 1
-#endif
-#ifndef WG_FWD_FLAT_STOP
-#define WG_FWD_FLAT_STOP 0
-#endif
-
 // ---- the per-tile walk, as device functions shared by render_forward_kernel and the lazy-sort fix-up kernel (binning.hip) ----
 // One wave owns a tile.  The walk is resumable: it composites list positions [pos_begin, pos_end) and can be continued
 // later from the state parked in the output buffers (fwd_store with complete == false / fwd_init with resume == true).
@@ -144,9 +136,9 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
             const float4 r0 = lds[3 * j];      // mx, my, ca, cb
             const float4 r1 = lds[3 * j + 1];  // cc, opacity, -, red
             const SplatCoef sc = coef_of(r0, r1);
-#if WG_FWD_HOIST_GB
-            const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);  // green, blue: requested with the rest of the record
-#endif
+            // green, blue: requested with the rest of the record (inside the blend branch it was an LDS round trip on every blending
+            // strip's dependency chain: 0.288 -> 0.2815 ms)
+            const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
             const uint32_t pos = (uint32_t)(pos_begin + base + j + 1);
             const uint32_t alive_before = alive;
 #pragma unroll
@@ -158,33 +150,15 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
                 if (((alive >> s) & 1u) && pass) {
                     const float w = alpha * T[s];
                     const float test_T = T[s] - w;  // T (1 - alpha), forward.cu:367, one rounding step apart
-#if WG_FWD_FLAT_STOP
-                    // the stop (forward.cu:368-372: the instance is not blended, the pixel is done) as selects, not a nested branch
-                    const bool keep = !(test_T < 0.0001f);
-                    const float wk = keep ? w : 0.0f;
-#if !WG_FWD_HOIST_GB
-                    const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
-#endif
-                    Cr[s] += r1.w * wk;
-                    Cg[s] += gb.x * wk;
-                    Cb[s] += gb.y * wk;
-                    T[s] = keep ? test_T : T[s];
-                    last[s] = keep ? pos : last[s];
-                    alive = keep ? alive : (alive & ~(1u << s));
-#else
                     if (test_T < 0.0001f) {
                         alive &= ~(1u << s);  // done (forward.cu:368-372): this instance is not blended
                     } else {
-#if !WG_FWD_HOIST_GB
-                        const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
-#endif
                         Cr[s] += r1.w * w;
                         Cg[s] += gb.x * w;
                         Cb[s] += gb.y * w;
                         T[s] = test_T;
                         last[s] = pos;
                     }
-#endif
                 }
             }
             if (__ballot(alive != alive_before) != 0ull) {  // some pixel saturated: refresh the strip liveness

@@ -192,6 +192,7 @@ struct Options {
     int band_list_min_p = 2000000;    // from here on the scatter kernels read per-band candidate lists instead of whole chunks
     int depth_codes = 1;              // 0 / 1 / 8..12: off (as for P > 2^24) / automatic width / forced width (tests)
     int grad_record = 1;              // 0: the per-tile backward accumulates into the four arrays themselves (A/B)
+    int deterministic_backward = 0;   // 1: per-instance slots + an ordered per-Gaussian sum instead of float atomics (bit-reproducible)
     int near_split = -1;              // near / far split of dense frames: -1 automatic (P >= band_list_min_p and >= 1500 instances per
                                       // tile) / 0 off / 1 whenever possible (tests)
     int near_per_tile = 0;            // aimed near instances per tile; 0 = 1.5 x lazy.target
@@ -213,7 +214,7 @@ hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState&
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                   const GeometryState& g, const float* subpixel_offset, const float* background,
                                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                  float* dL_dcolor, bool record, hipStream_t stream);
+                                  float* dL_dcolor, bool record, float* det_slots, int P, hipStream_t stream);  // det_slots != nullptr: deterministic mode
 
 struct BwdParams {
     int P, D, M, W, H;

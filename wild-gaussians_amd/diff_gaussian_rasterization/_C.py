@@ -212,7 +212,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     # everything else is fully written by the per-Gaussian kernel (zeros for culled Gaussians).
     # With the gradient record (the default, include/wg_rasterizer.h) the library clears its own accumulator and these four are
     # plain outputs too.
-    record = P != 0 and _lib.wg_get_option(b"grad_record") == 1
+    record = P != 0 and (_lib.wg_get_option(b"grad_record") == 1 or _lib.wg_get_option(b"deterministic_backward") == 1)
     if record:
         dL_dconic = None   # the reference's intermediate: not returned (rasterize_points.cu:201), so not requested
         dL_dmeans2D = torch.empty((P, 3), dtype=torch.float32, device=device)

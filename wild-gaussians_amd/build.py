@@ -22,6 +22,8 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 # library under build/<name>/; load it with WG_RASTERIZER_LIB=<path> (diff_gaussian_rasterization/_C.py).
 VARIANT = os.environ.get("WG_BUILD_VARIANT", "")
 EXTRA = os.environ.get("WG_EXTRA_FLAGS", "").split()
+# per-file extra flags of a variant build: WG_FILE_FLAGS="render_fwd.hip:-mllvm -amdgpu-skip-threshold=24;render_bwd.hip:..."
+FILE_EXTRA = {k: v.split() for k, v in (kv.split(":", 1) for kv in filter(None, os.environ.get("WG_FILE_FLAGS", "").split(";")))}
 if VARIANT:
     OBJ = os.path.join(OBJ, VARIANT)
     OUT = os.path.join(OBJ, "libwg_rasterizer.so")
@@ -61,7 +63,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            jobs.append([HIPCC] + COMMON + extra + EXTRA + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + COMMON + extra + EXTRA + FILE_EXTRA.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

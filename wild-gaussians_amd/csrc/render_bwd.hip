@@ -151,6 +151,15 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
         sb.y1[s] = wave_max_uniform(inside ? pfy[s] : -inf);
     }
 
+    // the last list position any pixel of a strip blended (wave-uniform: the largest n_contrib of the strip)
+    int strip_last[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        int m = last[s];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
+        strip_last[s] = __builtin_amdgcn_readfirstlane(m);
+    }
     const uint2 range = ranges[tile];
     // the ten partial sums live across instances and are cleared after each reduction only: an instance without any
     // contributing lane (19 % of them) leaves them at zero
@@ -177,10 +186,16 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             lds[3 * lane + 2] = q2;
         }
         __syncthreads();
-        // the batch's strip masks as wave-uniform 64-bit words (see render_fwd.hip)
+        // the batch's strip masks as wave-uniform 64-bit words (see render_fwd.hip).  A strip none of whose pixels was still
+        // accumulating at a list position cannot receive anything from it (backward.cu:536 skips per pixel): instance j of the
+        // batch sits at position hi - 1 - j, so only j >= hi - strip_last[s] are of interest to strip s.
         uint64_t reach[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) reach[s] = __ballot((mymask >> s) & 1u);
+        for (int s = 0; s < 4; s++) {
+            const int first = hi - strip_last[s];  // wave-uniform
+            const uint64_t live = first <= 0 ? ~0ull : (first >= 64 ? 0ull : (~0ull << first));
+            reach[s] = __ballot((mymask >> s) & 1u) & live;
+        }
         uint64_t todo = reach[0] | reach[1] | reach[2] | reach[3];
         while (todo != 0ull) {
             const int j = __builtin_ctzll(todo);

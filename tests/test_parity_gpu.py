@@ -532,6 +532,25 @@ def test_near_far_split_gives_the_fully_sorted_results(oracle, lazy_options, npt
         assert e <= 1e-3, (k, e)
 
 
+def test_near_far_split_far_phase_at_scale(lazy_options):
+    """2 M Gaussians at 1600x1200 (band lists, staged scatter, difference-grid counting: the automatic choices of a large dense
+    frame) with only 150 near instances per tile, so that most tiles take the far phase: image, radii, n_contrib, tile_last and the
+    instance count equal the run without the split, bit for bit."""
+    W, H, P = 1600, 1200, 2_000_000
+    cam, cloud = S.make_camera(W, H), S.make_cloud(P, W, H, sh_degree=None, seed=6, scale_mult=2.0)
+    lazy_options(near_split=0, box_count=0)
+    a = run_hip_native(cloud, cam, sh_degree=0)
+    lazy_options(near_split=-1, box_count=-1, near_per_tile=150)
+    b = run_hip_native(cloud, cam, sh_degree=0)
+    sp = b["views"]["image"]["split"].cpu().numpy().view(np.uint32)
+    assert sp[0] != 0xffffffff and sp[1] != 0        # split active, far phase taken
+    far_tiles = int((b["views"]["image"]["tile_last"] > b["views"]["image"]["tile_near"]).sum())
+    assert far_tiles > 1000
+    assert a["num_rendered"] == b["num_rendered"] and torch.equal(a["color"], b["color"]) and torch.equal(a["radii"], b["radii"])
+    for k in ("final_T", "n_contrib", "tile_last", "ranges"):
+        assert torch.equal(a["views"]["image"][k], b["views"]["image"][k]), k
+
+
 def test_near_far_split_stays_off_on_frames_that_are_not_dense(lazy_options):
     """Automatic mode: attempted from band_list_min_p Gaussians on, but switched off on the device below 1500 instances per tile."""
     W, H, P = 640, 360, 60000

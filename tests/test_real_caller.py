@@ -98,3 +98,30 @@ def test_real_render_internal_matches_the_reference_build(trained):
         assert int((err > 1e-4).sum()) <= 3 and float(err.max()) <= 5e-3, (int((err > 1e-4).sum()), float(err.max()))
         assert float((acc - ref["accumulation"]).abs().max()) <= 5e-3
     assert torch.equal(out["render"], tap.calls[1]["out"][0]) and torch.equal(out["raw_render"], tap.calls[0]["out"][0])
+
+
+@pytest.mark.gpu
+@needs_staged
+def test_real_training_loop_through_densification_pruning_and_opacity_reset():
+    """The part of the reference's loop that changes the NUMBER of Gaussians between rasterizer calls -- `densify_and_prune`
+    (clone / split / prune from the statistics the operator's means2D gradient feeds, method.py:1420-1468), `compute_3D_filter`,
+    `reset_opacity`, the SH-degree step -- with the schedule pulled forward so that 80 steps cross all of it."""
+    m, wg = harness.make_method(40_000, 480, 320, n_cams=3, overrides={
+        "densify_from_iter": 10, "densification_interval": 15, "opacity_reset_interval": 40, "densify_until_iter": 70,
+        "densify_grad_threshold": 0.00002})
+    counts, losses = [], []
+    for i in range(80):
+        if i == 30:
+            wg.model.oneupSHdegree()   # method.py:1896 does this every 1000 iterations
+        out = wg.train_iteration(i)
+        counts.append(out["num_gaussians"])
+        losses.append(out["loss"])
+    assert np.isfinite(losses).all()
+    assert len(set(counts)) > 2 and max(counts) > 40_000, sorted(set(counts))   # clones / splits happened (and pruning changed the count again)
+    assert int(wg.model.active_sh_degree) == 1
+    for p in (wg.model.xyz, wg.model.scales, wg.model.rotations, wg.model.opacities, wg.model.features_dc, wg.model.features_rest):
+        assert torch.isfinite(p).all() and p.shape[0] == counts[-1]
+    # and the model still renders (the public entry point of the reference, method.py:1832-1866)
+    from wildgaussians.types import RenderOutput  # noqa: F401
+    out = wg.render(wg.train_cameras[0])
+    assert out["color"].shape == (320, 480, 3) and np.isfinite(out["color"]).all()

@@ -125,3 +125,18 @@ def test_real_training_loop_through_densification_pruning_and_opacity_reset():
     from wildgaussians.types import RenderOutput  # noqa: F401
     out = wg.render(wg.train_cameras[0])
     assert out["color"].shape == (320, 480, 3) and np.isfinite(out["color"]).all()
+
+
+@pytest.mark.gpu
+@needs_staged
+def test_real_optimize_embedding_runs_the_rasterizer_with_gradients_to_the_colours_only(trained):
+    """`WildGaussians.optimize_embedding` (method.py:1755-1830): test-time optimisation of one image's appearance vector -- the
+    operator inside `_render_internal` under `enable_grad` with only the appearance MLP's input requiring a gradient."""
+    m, wg, _ = trained
+    ds, _cloud = harness.make_dataset(1000, 640, 480, n_cams=3)
+    one = dict(ds, cameras=ds["cameras"][[1]], images=[ds["images"][1]], image_paths=["1.png"])
+    wg.config.appearance_embedding_optim_iters = 12
+    out = wg.optimize_embedding(one)
+    loss = out["metrics"]["loss"]
+    assert len(loss) == 12 and np.isfinite(loss).all() and min(loss[6:]) < loss[0], loss
+    assert out["embedding"].shape == (wg.config.appearance_embedding_dim,) and np.abs(out["embedding"]).max() > 0

@@ -242,9 +242,11 @@ const char* wg_stage_name(int stage);
  * exercises the uncoded path, 8..12 force a width (not wider than the ids allow). */
 /* "near_split" (-1 automatic / 0 off / 1 whenever possible, default -1): dense frames of large scenes (from "band_list_min_p"
  * Gaussians on, at 1500 or more instances per tile) first bin, scatter and front-sort only the NEAR instances -- those of the
- * Gaussians below a frame-wide depth-code threshold picked on the device so that about "near_per_tile" (0 = 1.5 x "lazy_target")
+ * Gaussians below a frame-wide depth-code threshold picked on the device so that about "near_per_tile" (0 = 1.1 x "lazy_target")
  * instances per tile qualify -- and scatter the far ones afterwards only into tiles whose pixels are still accumulating when their
  * near instances are used up.  num_rendered, radii, images, n_contrib and gradients are those of the full binning.
+ * In automatic mode a frame that needed the far phase in two or more bands (pixels that do not saturate: low opacities) switches
+ * the attempt off for the calling thread's next 64 frames.
  */
 /* "deterministic_backward" (0/1, default 0): the per-tile backward pass adds a Gaussian's per-tile terms with float atomics, so
  * their order -- and the last bits of the gradients -- vary from run to run (as in the reference, whose atomics are per pixel).

@@ -551,6 +551,30 @@ def test_near_far_split_far_phase_at_scale(lazy_options):
         assert torch.equal(a["views"]["image"][k], b["views"]["image"][k]), k
 
 
+def test_near_far_split_backs_off_when_pixels_do_not_saturate(lazy_options):
+    """Opacities of 0.01 (what `reset_opacity` leaves, method.py:1249): no pixel saturates, every tile walks its whole list and asks
+    for its far instances.  The frame is still right, and in automatic mode the thread stops attempting the split for a while."""
+    from diff_gaussian_rasterization import _C
+    W, H, P = 320, 200, 30000
+    cam = S.make_camera(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=1, seed=5, scale_mult=11.0)   # ~2500 instances per tile: dense enough for the automatic split
+    cloud = dict(cloud, opacities=np.full_like(cloud["opacities"], 0.01))
+    lazy_options(near_split=0)
+    ref = run_hip_native(cloud, cam, sh_degree=1)
+    assert ref["num_rendered"] / 260 >= 1600 and int(ref["views"]["image"]["tile_last"].max()) > 1500       # dense, deep walks
+    lazy_options(near_split=-1, band_list_min_p=1)                    # automatic mode, attempted from the first frame (P >= band_list_min_p)
+    a = run_hip_native(cloud, cam, sh_degree=1)
+    sp = a["views"]["image"]["split"].cpu().numpy().view(np.uint32)
+    assert sp[0] != 0xffffffff and bin(int(sp[1])).count("1") >= 2    # split active, far phase in several bands
+    assert torch.equal(a["color"], ref["color"]) and torch.equal(a["views"]["image"]["n_contrib"], ref["views"]["image"]["n_contrib"])
+    torch.cuda.synchronize()
+    b = run_hip_native(cloud, cam, sh_degree=1)                        # reads the previous frame's request mask: backs off
+    assert _C.get_option("near_split_backoff") > 0
+    assert torch.equal(b["color"], ref["color"]) and b["num_rendered"] == ref["num_rendered"]
+    c = run_hip_native(cloud, cam, sh_degree=1)
+    assert torch.equal(c["color"], ref["color"])
+
+
 def test_near_far_split_stays_off_on_frames_that_are_not_dense(lazy_options):
     """Automatic mode: attempted from band_list_min_p Gaussians on, but switched off on the device below 1500 instances per tile."""
     W, H, P = 640, 360, 60000

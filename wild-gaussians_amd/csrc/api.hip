@@ -60,6 +60,7 @@ struct Mailbox {
 };
 thread_local Mailbox t_mailbox;
 thread_local uint32_t t_last_instances_per_tile = 0;  // density of this thread's previous frame: the near / far split's "try it" hint
+thread_local uint32_t t_split_backoff = 0;            // frames for which the split is not attempted after one that needed the far phase
 
 // the options (wg_common.h: Options): written by wg_set_option under the mutex, copied once per call
 std::mutex g_opt_mu;
@@ -261,12 +262,27 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
     // comes back with the instance count.
     // (measured at 10 M Gaussians / 4K, where pixels stop ~220 instances deep: 2050 near instances per tile 300 fps, 1400 324 fps,
     // 1000 359 fps, none of them sending a tile to the far phase; 1.5 x the front target keeps a margin for deeper walks)
-    const uint32_t near_per_tile = opt.near_per_tile > 0 ? (uint32_t)opt.near_per_tile : (opt.lazy.target * 3u) / 2u;
+    //  With the difference-grid counting: 1230 / 1000 / 900 per tile 365 / 404 / 427 fps there, 1021 / 1103 / 1145 train iter/s on
+    //  the dense x3 frame: a near bag that fits the 1024-key network is sorted without a selection pass.)
+    const uint32_t near_per_tile = opt.near_per_tile > 0 ? (uint32_t)opt.near_per_tile : (opt.lazy.target * 11u) / 10u;
+    // Frames whose pixels do not saturate (low opacities: after an opacity reset, early in training) walk their whole lists: every
+    // band then asks for its far instances and the split only adds a second, slower scatter.  The last split frame's request mask
+    // arrives through the mailbox; after a frame that needed the far phase in two or more bands the split is not attempted for
+    // the next 64 frames of this thread (automatic mode only).
+    if (opt.near_split < 0) {
+        Mailbox& mb = t_mailbox;
+        if (mb.host && mb.host->need_far != 0u) {
+            if (__builtin_popcount(mb.host->need_far) >= 2) t_split_backoff = 64;
+            mb.host->need_far = 0u;
+        }
+    }
+    const bool backoff = opt.near_split < 0 && t_split_backoff > 0;
+    if (backoff) t_split_backoff--;
     // Automatic mode attempts it for large scenes and whenever this host thread's previous frame was dense (a performance hint only:
     // the threshold pass costs ~15 us, the results are the same either way).
     const bool try_split = P > 0 && tiles <= wg::BIN_MAX_TILES && opt.lazy.enabled && !opt.force_global_sort && opt.near_split != 0 &&
                            wg::GeometryState::band_lists_possible((size_t)P) &&
-                           (opt.near_split == 1 || P >= opt.band_list_min_p || t_last_instances_per_tile >= 1500u);
+                           (opt.near_split == 1 || P >= opt.band_list_min_p || t_last_instances_per_tile >= 1500u) && !backoff;
     bool split_active = false;
     if (P > 0) {
         WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, device_tone(tone), geom, radii, stream), "preprocess");
@@ -382,12 +398,12 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
              "render_forward");
     if (lazy_render) {
         WG_STAGE(WG_STAGE_RENDER_FIXUP,
-                 wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, try_split, 0, stream),
+                 wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, try_split, 0, (wg::HostMailbox*)nullptr, stream),
                  "render_fixup");
         if (split_active) {  // both return at once unless some tile ran out of near instances with pixels still accumulating
             WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter_far(P, geom, img, bin, gx, tiles, code_bits, stream), "tile_scatter_far");
             WG_STAGE(WG_STAGE_RENDER_FIXUP,
-                     wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, true, 1, stream),
+                     wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, true, 1, mbox ? mbox->dev : (wg::HostMailbox*)nullptr, stream),
                      "render_fixup_far");
         }
     }
@@ -547,7 +563,13 @@ int wg_set_option(const char* name, int value) {
     if (std::strcmp(name, "grad_record") == 0) { o.grad_record = value != 0; return WG_OK; }
     if (std::strcmp(name, "deterministic_backward") == 0) { o.deterministic_backward = value != 0; return WG_OK; }
     if (std::strcmp(name, "band_list_min_p") == 0) { o.band_list_min_p = value > 0 ? value : 1; return WG_OK; }
-    if (std::strcmp(name, "near_split") == 0) { o.near_split = value < 0 ? -1 : (value != 0); return WG_OK; }
+    if (std::strcmp(name, "near_split") == 0) {  // (also clears the calling thread's back-off and density hint: a fresh start)
+        o.near_split = value < 0 ? -1 : (value != 0);
+        t_split_backoff = 0;
+        t_last_instances_per_tile = 0;
+        if (t_mailbox.host) t_mailbox.host->need_far = 0u;
+        return WG_OK;
+    }
     if (std::strcmp(name, "near_per_tile") == 0) { o.near_per_tile = value > 0 ? value : 0; return WG_OK; }
     if (std::strcmp(name, "box_count") == 0) { o.box_count = value < 0 ? -1 : (value != 0); return WG_OK; }
     if (std::strcmp(name, "depth_codes") == 0) {
@@ -572,6 +594,7 @@ int wg_set_option(const char* name, int value) {
 int wg_get_option(const char* name) {
     if (!name) return -1;
     if (std::strcmp(name, "roctx") == 0) return g_roctx.enabled ? 1 : 0;
+    if (std::strcmp(name, "near_split_backoff") == 0) return (int)t_split_backoff;  // read-only, of the calling thread
     const wg::Options o = options_snapshot();
     if (std::strcmp(name, "grad_record") == 0) return o.grad_record;
     if (std::strcmp(name, "deterministic_backward") == 0) return o.deterministic_backward;

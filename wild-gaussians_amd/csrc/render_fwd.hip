@@ -251,11 +251,15 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     const float* __restrict__ depths, const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset,
     const float* __restrict__ bg, uint32_t* __restrict__ tile_state, float* final_T, uint32_t* n_contrib,
     uint32_t* __restrict__ tile_last, float* out_color, uint32_t target, uint32_t cap, uint32_t id_mask,
-    const uint32_t* __restrict__ tile_near, SplitState* split, int phase) {
+    const uint32_t* __restrict__ tile_near, SplitState* split, int phase, HostMailbox* mailbox) {
     __shared__ float4 lds[BATCH * 3];
     __shared__ uint64_t skeys[256 * 8];
     __shared__ SelectScratch sc;
     __shared__ int s_complete;
+    // phase 1 runs after every tile's phase 0 (stream order): which bands asked for far instances is final, and goes to the host's
+    // mailbox as the hint for later frames (api.hip: a thread whose frames keep needing the far phase stops attempting the split)
+    if (phase == 1 && mailbox && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(&mailbox->need_far, split->need_far, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int tile = xcd_tile(blockIdx.x, tiles);
     uint32_t done = tile_state[tile];
     if (done == 0xffffffffu) return;  // workgroup-uniform
@@ -305,13 +309,13 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
 
 hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
                                const float* subpixel_offset, const float* background, float* out_color, const LazyConfig& g_lazy,
-                               bool split, int phase, hipStream_t stream) {
+                               bool split, int phase, HostMailbox* mailbox_dev, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(render_fixup_kernel, dim3(tiles), dim3(256), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, b.bucket_ids,
                        g.depths, g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.tile_state, img.final_T,
                        img.n_contrib, img.tile_last, out_color, 1536u < g_lazy.cap ? 1536u : (g_lazy.cap * 3u) / 4u, g_lazy.cap < FRONT_CAP ? g_lazy.cap : FRONT_CAP,
-                       code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu, split ? img.tile_near : (const uint32_t*)nullptr, img.split, phase);
+                       code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu, split ? img.tile_near : (const uint32_t*)nullptr, img.split, phase, mailbox_dev);
     return hipGetLastError();
 }
 

@@ -71,6 +71,9 @@ struct HostMailbox {
     uint32_t max_tile_count;
     uint32_t seq;
     uint32_t split_active;
+    uint32_t need_far;   // written at the END of a split frame (fix-up phase 1): the bands whose tiles needed far instances.  Read by
+                         // the host at the start of a LATER frame as a hint only (no waiting: it may be a frame old)
+    uint32_t pad[3];
 };
 
 struct ImageState {
@@ -195,7 +198,7 @@ struct Options {
     int deterministic_backward = 0;   // 1: per-instance slots + an ordered per-Gaussian sum instead of float atomics (bit-reproducible)
     int near_split = -1;              // near / far split of dense frames: -1 automatic (P >= band_list_min_p and >= 1500 instances per
                                       // tile) / 0 off / 1 whenever possible (tests)
-    int near_per_tile = 0;            // aimed near instances per tile; 0 = 1.5 x lazy.target
+    int near_per_tile = 0;            // aimed near instances per tile; 0 = 1.1 x lazy.target
     int box_count = -1;               // tile counting through a difference grid: -1 automatic (with the split's "large or dense" rule) / 0 / 1
     bool force_global_sort = false;   // exercise the fallback binning path
     bool use_mailbox = true;          // 0 restores the copy + synchronise read-back
@@ -205,7 +208,7 @@ hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, c
 // phase 0: the near bag (all of the bucket without a split); phase 1: the far bag of the tiles that asked for it
 hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
                                const float* subpixel_offset, const float* background, float* out_color, const LazyConfig& lazy,
-                               bool split, int phase, hipStream_t stream);
+                               bool split, int phase, HostMailbox* mailbox_dev, hipStream_t stream);
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
                             hipStream_t stream);
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,

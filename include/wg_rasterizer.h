@@ -245,8 +245,8 @@ const char* wg_stage_name(int stage);
  * Gaussians below a frame-wide depth-code threshold picked on the device so that about "near_per_tile" (0 = 1.1 x "lazy_target")
  * instances per tile qualify -- and scatter the far ones afterwards only into tiles whose pixels are still accumulating when their
  * near instances are used up.  num_rendered, radii, images, n_contrib and gradients are those of the full binning.
- * In automatic mode a frame that needed the far phase in two or more bands (pixels that do not saturate: low opacities) switches
- * the attempt off for the calling thread's next 64 frames.
+ * In automatic mode a frame in which more than 2 % of the tiles needed the far phase (pixels that do not saturate: low opacities)
+ * switches the attempt off for the calling thread's next 64 frames.
  */
 /* "deterministic_backward" (0/1, default 0): the per-tile backward pass adds a Gaussian's per-tile terms with float atomics, so
  * their order -- and the last bits of the gradients -- vary from run to run (as in the reference, whose atomics are per pixel).

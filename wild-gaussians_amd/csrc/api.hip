@@ -267,12 +267,14 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
     const uint32_t near_per_tile = opt.near_per_tile > 0 ? (uint32_t)opt.near_per_tile : (opt.lazy.target * 11u) / 10u;
     // Frames whose pixels do not saturate (low opacities: after an opacity reset, early in training) walk their whole lists: every
     // band then asks for its far instances and the split only adds a second, slower scatter.  The last split frame's request mask
-    // arrives through the mailbox; after a frame that needed the far phase in two or more bands the split is not attempted for
-    // the next 64 frames of this thread (automatic mode only).
+    // arrives through the mailbox: the number of tiles that asked.  A few deep tiles are what the far phase is for (its cost is a
+    // walk of the flagged bands' far Gaussians); after a frame in which more than 2 % of the tiles asked, the split is not
+    // attempted for the next 64 frames of this thread (automatic mode only).
     if (opt.near_split < 0) {
         Mailbox& mb = t_mailbox;
         if (mb.host && mb.host->need_far != 0u) {
-            if (__builtin_popcount(mb.host->need_far) >= 2) t_split_backoff = 64;
+            const uint32_t far_tiles = mb.host->need_far - 1u;
+            if ((uint64_t)far_tiles * 50u > (uint64_t)tiles) t_split_backoff = 64;
             mb.host->need_far = 0u;
         }
     }

@@ -816,6 +816,7 @@ __global__ void __launch_bounds__(1024) split_pick_kernel(const uint32_t* __rest
         // a threshold at the last code keeps everything near: nothing to gain
         split->near_code = (pick != SPLIT_OFF && pick + 1 < SPLIT_BINS) ? pick : SPLIT_OFF;
         split->need_far = 0u;
+        split->far_tiles = 0u;
     }
 }
 

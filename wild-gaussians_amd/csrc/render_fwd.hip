@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     // phase 1 runs after every tile's phase 0 (stream order): which bands asked for far instances is final, and goes to the host's
     // mailbox as the hint for later frames (api.hip: a thread whose frames keep needing the far phase stops attempting the split)
     if (phase == 1 && mailbox && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(&mailbox->need_far, split->need_far, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mailbox->need_far, 1u + split->far_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int tile = xcd_tile(blockIdx.x, tiles);
     uint32_t done = tile_state[tile];
     if (done == 0xffffffffu) return;  // workgroup-uniform
@@ -272,7 +272,10 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     const uint32_t n_near = tile_near ? tile_near[tile] : n;
     const uint32_t bag_lo = phase == 0 ? 0u : n_near, bag_hi = phase == 0 ? n_near : n;
     if (done >= bag_hi) {  // this bag is used up already (phase 0: the front was all of the near instances, or there are none)
-        if (phase == 0 && tid == 0) atomicOr(&split->need_far, 1u << (blockIdx.x & 7));  // n_near < n here: a finished tile does not arrive
+        if (phase == 0 && tid == 0) {  // n_near < n here: a finished tile does not arrive
+            atomicOr(&split->need_far, 1u << (blockIdx.x & 7));
+            atomicAdd(&split->far_tiles, 1u);
+        }
         return;
     }
     const uint32_t* bag = bucket_ids + range.x + bag_lo;
@@ -303,7 +306,10 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     if (walker) fwd_store(st, complete, W, H, tile, tid, bg, final_T, n_contrib, tile_last, out_color);
     if (tid == 0) {
         tile_state[tile] = complete ? 0xffffffffu : done;
-        if (!complete) atomicOr(&split->need_far, 1u << (blockIdx.x & 7));  // xcd_tile: block b serves a tile of band b & 7
+        if (!complete) {
+            atomicOr(&split->need_far, 1u << (blockIdx.x & 7));  // xcd_tile: block b serves a tile of band b & 7
+            atomicAdd(&split->far_tiles, 1u);
+        }
     }
 }
 

@@ -61,7 +61,8 @@ constexpr uint32_t SPLIT_BITS = 12, SPLIT_BINS = 1u << SPLIT_BITS, SPLIT_OFF = 0
 struct SplitState {
     uint32_t near_code;  // instances of Gaussians with depth_code(depth, SPLIT_BITS) <= near_code are near
     uint32_t need_far;   // bit b: set by the first fix-up phase when a tile of XCD band b ran out of near instances
-    uint32_t pad[2];
+    uint32_t far_tiles;  // how many tiles did
+    uint32_t pad;
 };
 
 // Host-visible (pinned, mapped, coherent) mailbox the tile scan writes the same two numbers to, followed by a sequence
@@ -71,8 +72,9 @@ struct HostMailbox {
     uint32_t max_tile_count;
     uint32_t seq;
     uint32_t split_active;
-    uint32_t need_far;   // written at the END of a split frame (fix-up phase 1): the bands whose tiles needed far instances.  Read by
-                         // the host at the start of a LATER frame as a hint only (no waiting: it may be a frame old)
+    uint32_t need_far;   // written at the END of a split frame (fix-up phase 1): 1 + the number of tiles that needed far instances
+                         // (0 = nothing new).  Read by the host at the start of a LATER frame as a hint only (no waiting: it may be
+                         // a frame old)
     uint32_t pad[3];
 };
 

@@ -241,7 +241,7 @@ const char* wg_stage_name(int stage);
  * bits, what the ids leave free) above the id, so that the front extraction fetches exact depths only near its bounds; 0
  * exercises the uncoded path, 8..12 force a width (not wider than the ids allow). */
 /* "near_split" (-1 automatic / 0 off / 1 whenever possible, default -1): dense frames of large scenes (from "band_list_min_p"
- * Gaussians on, at 1500 or more instances per tile) first bin, scatter and front-sort only the NEAR instances -- those of the
+ * Gaussians on or after a dense frame, at 1100 or more instances per tile) first bin, scatter and front-sort only the NEAR instances -- those of the
  * Gaussians below a frame-wide depth-code threshold picked on the device so that about "near_per_tile" (0 = 1.1 x "lazy_target")
  * instances per tile qualify -- and scatter the far ones afterwards only into tiles whose pixels are still accumulating when their
  * near instances are used up.  num_rendered, radii, images, n_contrib and gradients are those of the full binning.

@@ -284,7 +284,7 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
     // the threshold pass costs ~15 us, the results are the same either way).
     const bool try_split = P > 0 && tiles <= wg::BIN_MAX_TILES && opt.lazy.enabled && !opt.force_global_sort && opt.near_split != 0 &&
                            wg::GeometryState::band_lists_possible((size_t)P) &&
-                           (opt.near_split == 1 || P >= opt.band_list_min_p || t_last_instances_per_tile >= 1500u) && !backoff;
+                           (opt.near_split == 1 || P >= opt.band_list_min_p || t_last_instances_per_tile >= wg::SPLIT_DENSE_AVG) && !backoff;
     bool split_active = false;
     if (P > 0) {
         WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, device_tone(tone), geom, radii, stream), "preprocess");

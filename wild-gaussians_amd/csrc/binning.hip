@@ -828,7 +828,7 @@ hipError_t launch_split_threshold(int P, const GeometryState& g, const ImageStat
     if (e != hipSuccess) return e;
     const int blocks = P >= (1 << 20) ? 128 : max(1, (P + 8191) / 8192);
     hipLaunchKernelGGL(split_hist_kernel, dim3(blocks), dim3(1024), 0, stream, P, g.depths, g.tiles_touched, img.code_hist);
-    hipLaunchKernelGGL(split_pick_kernel, dim3(1), dim3(1024), 0, stream, img.code_hist, (uint32_t)tiles, near_per_tile, 1500u, force ? 1 : 0,
+    hipLaunchKernelGGL(split_pick_kernel, dim3(1), dim3(1024), 0, stream, img.code_hist, (uint32_t)tiles, near_per_tile, SPLIT_DENSE_AVG, force ? 1 : 0,
                        img.split);
     return hipGetLastError();
 }

@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             float4 q0 = splats[3 * (size_t)id];
             float4 q1 = splats[3 * (size_t)id + 1];
             float4 q2 = splats[3 * (size_t)id + 2];
-            mymask = strip_mask(q0, q2, sb);
+            mymask = strip_mask(q0, q1, q2, sb);
             scale_conic(q0, q1);
             q2.z = 2.0f * q0.z;  // 2 ca, 2 cc: the gradient of the exponent, up to the factor 1 / log2(e) applied after the reduction
             q2.w = 2.0f * q1.x;

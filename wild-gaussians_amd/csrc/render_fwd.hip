@@ -93,35 +93,42 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
     uint32_t alive = st.alive, strips_alive = st.strips_alive;
     const StripBounds sb = st.sb;
 
+    // Records travel list -> registers -> LDS one batch ahead of the walk, their ids two batches ahead, so that neither of the two
+    // dependent global loads is waited for while it is in flight.  Indices are clamped to the list instead of predicated (lanes past
+    // the end re-read its last entry: one more cache hit): with a conditional load the loop-carried registers are a merge of "loaded"
+    // and "kept", and hipcc resolved that merge with copies placed right behind the loads -- i.e. an s_waitcnt that stalled the wave
+    // on the "prefetch" it had just issued.
+    if (n <= 0 || strips_alive == 0) return;  // nothing to do: st is unchanged
+    const int nl = n - 1;
     float4 a0, a1, a2;
-    a0 = a1 = a2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < n && strips_alive != 0) {
-        const uint32_t id = list[lane];
-        a0 = splats[3 * (size_t)id];
-        a1 = splats[3 * (size_t)id + 1];
-        a2 = splats[3 * (size_t)id + 2];
+    {
+        const size_t r = 3 * (size_t)list[min(lane, nl)];
+        a0 = splats[r];
+        a1 = splats[r + 1];
+        a2 = splats[r + 2];
     }
+    uint32_t id_next = list[min(BATCH + lane, nl)];
 
     for (int base = 0; base < n && strips_alive != 0; base += BATCH) {
         const int cnt = min(BATCH, n - base);
-        const uint32_t mymask = lane < cnt ? strip_mask(a0, a2, sb) : 0u;
+        float4 s0 = a0, s1 = a1;
+        const float4 s2 = a2;
+        const uint32_t mymask = lane < cnt ? strip_mask(s0, s1, s2, sb) : 0u;
         // The wave is the staging area's only user and its LDS operations execute in issue order, so no barrier is needed for
         // correctness.  WGB (legal only when the workgroup IS the wave) keeps the s_barrier-free __syncthreads() of the one-wave
         // kernel anyway: hipcc schedules and allocates the compositing loop measurably better around it (0.325 vs 0.340 ms).
         if (WGB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-        {
-            float4 s0 = a0, s1 = a1;
-            scale_conic(s0, s1);
-            lds[3 * lane] = s0;
-            lds[3 * lane + 1] = s1;
-            lds[3 * lane + 2] = a2;
-        }
+        scale_conic(s0, s1);
+        lds[3 * lane] = s0;
+        lds[3 * lane + 1] = s1;
+        lds[3 * lane + 2] = s2;
         if (WGB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-        if (base + BATCH + lane < n) {  // prefetch the next batch under this batch's math
-            const uint32_t id = list[base + BATCH + lane];
-            a0 = splats[3 * (size_t)id];
-            a1 = splats[3 * (size_t)id + 1];
-            a2 = splats[3 * (size_t)id + 2];
+        {
+            const size_t r = 3 * (size_t)id_next;
+            a0 = splats[r];
+            a1 = splats[r + 1];
+            a2 = splats[r + 2];
+            id_next = list[min(base + 2 * BATCH + lane, nl)];
         }
         // The batch's strip masks as four wave-uniform 64-bit words (bit j of word s: instance j can reach strip s):
         // the walk below never touches an instance no live strip can see, and knows which strips to evaluate before
@@ -210,7 +217,18 @@ __device__ void fwd_store(const FwdTile& st, bool complete, int W, int H, int ti
 // seg_end == nullptr: the whole list is sorted (default).  Otherwise (lazy sort, binning.hip) only the first seg_end[tile]
 // entries are; a tile that is still accumulating when they run out parks its state and reports the length it consumed in
 // tile_state[tile] (0xffffffff = finished) for the fix-up kernel.
-__global__ void __launch_bounds__(64) render_forward_kernel(
+// The exact strip test's staging temporaries would take the kernel from 62 to 67 VGPRs, i.e. from 8 to 7 waves per SIMD; the walk wants
+// all 8 (it is bounded by dependency chains that only other waves can fill), so the allocation is pinned to 64 and two
+// values that are only needed after the walk (the tile's store addresses) live in scratch across it.
+#ifndef WG_FWD_WAVES
+#define WG_FWD_WAVES 8
+#endif
+#if WG_FWD_WAVES
+#define WG_FWD_OCC __attribute__((amdgpu_waves_per_eu(WG_FWD_WAVES, WG_FWD_WAVES)))
+#else
+#define WG_FWD_OCC
+#endif
+__global__ void __launch_bounds__(64) WG_FWD_OCC render_forward_kernel(
     int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     const uint32_t* __restrict__ seg_end, uint32_t* __restrict__ tile_state,

@@ -115,13 +115,57 @@ __device__ __forceinline__ float2 splat_extent(float A, float B, float C, float 
     const float idet = 1.0f / det;
     return make_float2(__builtin_sqrtf(fmaxf(tau2 * C * idet, 0.0f)) + 0.01f, __builtin_sqrtf(fmaxf(tau2 * A * idet, 0.0f)) + 0.01f);
 }
-__device__ __forceinline__ uint32_t strip_mask(const float4 r0, const float4 r2, const StripBounds& sb) {
+__device__ __forceinline__ uint32_t strip_mask_box(const float4 r0, const float4 r2, const StripBounds& sb) {
     const float mx = r0.x, my = r0.y, ex = r2.z, ey = r2.w;
     uint32_t m = 0;
 #pragma unroll
     for (int s = 0; s < 4; s++)
         if (mx + ex >= sb.x0[s] && mx - ex <= sb.x1[s] && my + ey >= sb.y0[s] && my - ey <= sb.y1[s]) m |= 1u << s;
     return m;
+}
+
+// The same question answered exactly: does the ellipse itself (not its box) meet the strip's sample box?  f(d) = A dx^2 + 2 B dx dy +
+// C dy^2 is convex with its minimum at the mean, so its minimum over a box is attained on the box sides that face the mean; with
+// xf = clamp(0, X0, X1) (the box's x nearest the mean; 0 when the box straddles it) and yf likewise, the two lines x = xf and
+// y = yf inside the box contain those sides, and a 1-D clamped minimisation along each gives the minimum (0 when the mean is inside).
+// One lane does this once per staged instance (~1.5 wave-instructions per instance), and the walk evaluates 16 % fewer strips and
+// enters 11 % fewer instances than with the box test at the bench scene (tests/tools/strip_reach_estimate.py: 2.13 -> 1.78 strips per
+// visited instance; 1.78 is also the count of strips with a passing pixel, i.e. nothing is left to cull at this granularity).
+// Conservative by construction: tau^2 carries the same inflation as splat_extent(), plus a rounding allowance of 2e-6 of the largest
+// magnitude the three products can take anywhere in the tile (both this evaluation and the per-pixel one round each product to
+// ~1e-7 of it); a conic that is not safely positive definite reaches every strip.
+#ifndef WG_STRIP_EXACT
+#define WG_STRIP_EXACT 1
+#endif
+__device__ __forceinline__ uint32_t strip_mask_exact(const float4 r0, const float4 r1, const StripBounds& sb) {
+    const float mx = r0.x, my = r0.y, A = r0.z, B = r0.w, C = r1.x, o = r1.y;
+    const bool vis = o * 1.001f >= (1.0f / 255.0f);  // false for NaN
+    const float AC = A * C;
+    const bool definite = A > 0.0f && C > 0.0f && (AC - B * B) > 4e-6f * AC;
+    const float tau2 = 2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(255.0f * o) * 1.002f + 0.002f;
+    const float nBC = -B * __builtin_amdgcn_rcpf(C), nBA = -B * __builtin_amdgcn_rcpf(A), B2 = 2.0f * B;
+    // the tile's sample box (wave-uniform; +-inf bounds of strips outside the image drop out of the min / max)
+    const float bx0 = fminf(fminf(sb.x0[0], sb.x0[1]), fminf(sb.x0[2], sb.x0[3])), bx1 = fmaxf(fmaxf(sb.x1[0], sb.x1[1]), fmaxf(sb.x1[2], sb.x1[3]));
+    const float by0 = fminf(fminf(sb.y0[0], sb.y0[1]), fminf(sb.y0[2], sb.y0[3])), by1 = fmaxf(fmaxf(sb.y1[0], sb.y1[1]), fmaxf(sb.y1[2], sb.y1[3]));
+    const float Mx = fmaxf(fabsf(bx0 - mx), fabsf(bx1 - mx)), My = fmaxf(fabsf(by0 - my), fabsf(by1 - my));
+    const float thr = tau2 + 2e-6f * (A * Mx * Mx + fabsf(B2) * Mx * My + C * My * My);
+    uint32_t m = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        if (!(sb.x0[s] <= sb.x1[s])) continue;  // wave-uniform: no pixel of the strip is inside the image
+        const float X0 = sb.x0[s] - mx, X1 = sb.x1[s] - mx, Y0 = sb.y0[s] - my, Y1 = sb.y1[s] - my;
+        const float xf = __builtin_amdgcn_fmed3f(X0, 0.0f, X1), yf = __builtin_amdgcn_fmed3f(Y0, 0.0f, Y1);
+        const float t = __builtin_amdgcn_fmed3f(nBC * xf, Y0, Y1);  // argmin of f(xf, .) over the box
+        const float fv = xf * (A * xf + B2 * t) + C * t * t;
+        const float u = __builtin_amdgcn_fmed3f(nBA * yf, X0, X1);  // argmin of f(., yf)
+        const float fh = yf * (C * yf + B2 * u) + A * u * u;
+        if (fminf(fv, fh) <= thr) m |= 1u << s;
+    }
+    return vis ? (definite ? m : 15u) : 0u;
+}
+// r0, r1, r2: the record as preprocess wrote it (conic unscaled)
+__device__ __forceinline__ uint32_t strip_mask(const float4 r0, const float4 r1, const float4 r2, const StripBounds& sb) {
+    return WG_STRIP_EXACT ? strip_mask_exact(r0, r1, sb) : strip_mask_box(r0, r2, sb);
 }
 
 }  // namespace wg

@@ -94,11 +94,23 @@ def main():
         assert not (m_hit & ~m_exact).any(), "the exact test excluded a passing pixel"
         assert not (m_exact & ~m_aabb).any()
         tot["inst"] += n
+        for k, m in (("exact", m_exact),):
+            cnt = m.sum(axis=1)
+            for c in range(5):
+                tot[f"n{c}"] = tot.get(f"n{c}", 0) + int((cnt == c).sum())
+            tot["pairs_rows"] = tot.get("pairs_rows", 0) + int((m[:, 0] | m[:, 1]).sum() + (m[:, 2] | m[:, 3]).sum())   # top / bottom halves
+            tot["pairs_cols"] = tot.get("pairs_cols", 0) + int((m[:, 0] | m[:, 2]).sum() + (m[:, 1] | m[:, 3]).sum())   # left / right halves
+            tot["both_rows"] = tot.get("both_rows", 0) + int((m[:, 0] & m[:, 1]).sum() + (m[:, 2] & m[:, 3]).sum())
         for k, m in (("aabb", m_aabb), ("exact", m_exact), ("hit", m_hit)):
             tot[k] += int(m.sum())
             tot["none_" + k] += int((~m.any(axis=1)).sum())
     n = tot["inst"]
     print(f"tiles sampled {len(sample)}, listed instances {tot['listed']}, visited {n} ({n / max(tot['listed'], 1):.3f})")
+    ent = n - tot["n0"]
+    print("exact: reached-strip count distribution over entering instances:", {c: round(tot[f"n{c}"] / ent, 3) for c in range(1, 5)})
+    print(f"exact: strips / entering instance {tot['exact'] / ent:.3f}; strip PAIRS / entering instance: top|bottom halves "
+          f"{tot['pairs_rows'] / ent:.3f} (both strips of the pair reached in {tot['both_rows'] / max(tot['pairs_rows'], 1):.3f} of them), "
+          f"left|right halves {tot['pairs_cols'] / ent:.3f}")
     for k in ("aabb", "exact", "hit"):
         print(f"{k:6s} strips / visited instance {tot[k] / n:.3f}   instances with no strip {tot['none_' + k] / n:.3f}")
 

@@ -193,6 +193,11 @@ def _vp_worker(rank, world, port, q):
     slowest = VP.max_over_ranks(float(r + 1), torch.device("cpu"))
     seen = VP.gather_over_ranks([float(r), 10.0 * r], torch.device("cpu"))
     assert seen == [[0.0, 0.0], [1.0, 10.0]] and VP.backend_name() == "gloo"
+    # bench.py's per-step loss path (LossStream): without a HIP device it is the synchronous dot + all-reduce
+    ls = VP.LossStream()
+    img, c = torch.full((3, 4, 5), float(r + 1)), torch.full((60,), 0.5)
+    got = ls.submit(img, c)
+    assert abs(ls.last() - 90.0) < 1e-5 and abs(float(got.item()) - 90.0) < 1e-5   # 60 * 0.5 * (1 + 2)
     q.put((r, float(loss.item()), local, slowest))
     torch.distributed.destroy_process_group()
 

@@ -155,6 +155,7 @@ def main():
                     help="SURVEY 8f N3 (caller side): hand the SH features to the operator (shs=) instead of evaluating them in torch")
     ap.add_argument("--fused-activations", action="store_true", help="SURVEY 8f N3: wg_fused_gaussians.activate instead of the torch ops")
     ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the foreach implementation")
+    ap.add_argument("--wg-adam", action="store_true", help="SURVEY 8f N4: wg_fused_gaussians.FusedAdam (one launch over all parameters)")
     ap.add_argument("--densification-stats", choices=["off", "torch", "fused"], default="off",
                     help="the loop's per-Gaussian bookkeeping after backward (method.py:1995-1998, 1470-1477): torch statements, or "
                          "SURVEY 8f N4 wg_fused_gaussians.add_densification_stats")
@@ -197,8 +198,12 @@ def main():
     prm = {k: nn.Parameter(v) for k, v in prm.items()}
     filter_3d = torch.full((P, 1), 1e-3, device=dev)
     mlp = nn.Sequential(nn.Linear(3 + 24 + 32, 128), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 6)).to(dev)
-    opt = torch.optim.Adam([{"params": [p], "lr": 1e-4} for p in prm.values()] + [{"params": mlp.parameters(), "lr": 5e-4}], eps=1e-15,
-                           **({"fused": True} if args.fused_adam else {}))
+    if args.wg_adam:
+        from wg_fused_gaussians import FusedAdam as Adam
+    else:
+        Adam = torch.optim.Adam
+    opt = Adam([{"params": [p], "lr": 1e-4} for p in prm.values()] + [{"params": mlp.parameters(), "lr": 5e-4}], eps=1e-15,
+               **({"fused": True} if args.fused_adam and not args.wg_adam else {}))
     if args.tall_linear:
         layers = [m for m in mlp if isinstance(m, nn.Linear)]
 
@@ -309,7 +314,7 @@ def main():
     torch.cuda.synchronize()
     dop = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"workload": f"WildGaussians-style train step: {P} Gaussians + appearance MLP, {W}x{H}, 2 fwd + 2 bwd raster calls, "
-                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)" + (", SH evaluated in the operator" if args.in_kernel_sh or args.in_kernel_tone else "") + (", appearance toning in the operator" if args.in_kernel_tone else "") + (", fused L1+DSSIM loss" if args.fused_loss else ", fused SSIM" if args.fused_ssim else "") + (", fused activations" if args.fused_activations else "") + ("" if args.densification_stats == "off" else f", densification statistics ({args.densification_stats})"),
+                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)" + (", SH evaluated in the operator" if args.in_kernel_sh or args.in_kernel_tone else "") + (", appearance toning in the operator" if args.in_kernel_tone else "") + (", fused L1+DSSIM loss" if args.fused_loss else ", fused SSIM" if args.fused_ssim else "") + (", fused activations" if args.fused_activations else "") + (", wg FusedAdam" if args.wg_adam else ", torch fused Adam" if args.fused_adam else "") + ("" if args.densification_stats == "off" else f", densification statistics ({args.densification_stats})"),
                       "train_step_ms": round(dt * 1e3, 3), "train_steps_per_s": round(1.0 / dt, 2),
                       "rasterizer_only_ms (2 fwd + 2 bwd)": round(dop * 1e3, 3), "rasterizer_share": round(dop / dt, 3),
                       "visible": int((vis[0] > 0).sum().item()), "loss": float(step().item())}))

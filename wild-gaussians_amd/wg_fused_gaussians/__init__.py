@@ -110,3 +110,87 @@ def add_densification_stats(radii, viewspace_grad, xyz_grad, denom, max_radii2D=
     with torch.cuda.device(radii.device):
         _native._check(_lib.wg_densification_stats(P, radii.data_ptr(), g.data_ptr(), bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], stream),
                        "wg_densification_stats")
+
+
+# ---- fused Adam (include/wg_adam.h, csrc/adam.hip) -------------------------------------------------------------
+class _AdamTensor(C.Structure):
+    _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("numel", C.c_size_t),
+                ("beta2", C.c_float), ("one_minus_beta1", C.c_float), ("one_minus_beta2", C.c_float), ("step_size", C.c_float),
+                ("bias_correction2_sqrt", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
+
+
+_lib.wg_fused_adam.restype = _i
+_lib.wg_fused_adam.argtypes = [_i, C.POINTER(_AdamTensor), _vp]
+
+
+class FusedAdam(torch.optim.Adam):
+    """``torch.optim.Adam`` as the reference builds it (wildgaussians/method.py:1030-1049: one parameter group per Gaussian attribute,
+    per-group ``lr`` / ``weight_decay``, ``eps=1e-15``) with ``step()`` (method.py:2019) as ONE kernel launch over all parameters
+    instead of torch's ~ten elementwise passes per tensor:
+
+        torch.optim.Adam = wg_fused_gaussians.FusedAdam      # before the model builds its optimizer, or edit that one line
+
+    It IS a ``torch.optim.Adam``: ``param_groups``, ``state`` (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter, the layout the
+    reference's densification code edits in place: method.py:1094-1102, 1268-1278, 1284-1297, 1312-1328), ``state_dict`` /
+    ``load_state_dict``, ``zero_grad`` and the learning-rate schedule (``param_group['lr'] = ...``, method.py:1206-1210) are
+    inherited; a state dict moves freely between the two classes.  Parameters must be float32 on a HIP device (others, and any
+    group with ``amsgrad`` / ``maximize``, raise: there is no silent fallback); parameters without a gradient are skipped, as torch
+    does.  The update is torch's, operation for operation in float32 (include/wg_adam.h)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **kw):
+        for k in ("amsgrad", "maximize", "capturable", "differentiable"):
+            if kw.get(k):
+                raise NotImplementedError(f"wg_fused_gaussians.FusedAdam: {k}=True is not implemented")
+        kw.pop("foreach", None)
+        kw.pop("fused", None)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False,
+                         **{k: v for k, v in kw.items() if k in ("amsgrad", "maximize", "capturable", "differentiable")})
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        by_device = {}
+        for group in self.param_groups:
+            if group.get("amsgrad") or group.get("maximize"):
+                raise NotImplementedError("wg_fused_gaussians.FusedAdam: amsgrad / maximize are not implemented")
+            beta1, beta2 = group["betas"]
+            if not (0.5 < beta1 < 1.0 and 0.0 <= beta2 < 1.0):
+                raise NotImplementedError("wg_fused_gaussians.FusedAdam: betas outside (0.5, 1) x [0, 1) are not implemented")
+            lr = float(group["lr"])
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad
+                if g.is_sparse:
+                    raise RuntimeError("wg_fused_gaussians.FusedAdam does not support sparse gradients")
+                if not (p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and p.is_contiguous()):
+                    raise RuntimeError("wg_fused_gaussians.FusedAdam: parameters must be contiguous float32 tensors on a HIP device "
+                                       "(there is no CPU path)")
+                st = self.state[p]
+                if len(st) == 0:   # torch's lazy state initialisation (torch/optim/adam.py: _init_group)
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if torch.is_tensor(st["step"]):
+                    st["step"] += 1   # in place: a host scalar (a state dict loaded from torch.optim.Adam keeps it that way)
+                    step = float(st["step"])
+                else:
+                    st["step"] = step = st["step"] + 1
+                m, v = st["exp_avg"], st["exp_avg_sq"]
+                if not (m.is_contiguous() and v.is_contiguous() and m.shape == p.shape and v.shape == p.shape
+                        and m.dtype == torch.float32 and v.dtype == torch.float32 and m.device == p.device and v.device == p.device):
+                    raise RuntimeError("wg_fused_gaussians.FusedAdam: exp_avg / exp_avg_sq must be contiguous float32 tensors shaped "
+                                       "and placed like their parameter")
+                g = g if g.is_contiguous() else g.contiguous()
+                # the step's scalars in double precision, rounded once when they enter the struct -- as torch's Python computes them
+                d = _AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), beta2, 1.0 - beta1, 1.0 - beta2,
+                                lr / (1.0 - beta1 ** step), (1.0 - beta2 ** step) ** 0.5, float(group["eps"]), float(group["weight_decay"]))
+                by_device.setdefault(p.device, []).append((d, g))   # g: keeps a contiguous copy alive until the launch is queued
+        for dev, items in by_device.items():
+            arr = (_AdamTensor * len(items))(*[d for d, _ in items])
+            with torch.cuda.device(dev):
+                _native._check(_lib.wg_fused_adam(len(items), arr, torch.cuda.current_stream(dev).cuda_stream), "wg_fused_adam")
+        return loss

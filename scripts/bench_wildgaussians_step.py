@@ -104,6 +104,9 @@ def real_caller(args):
     P, W, H = args.gaussians, args.width, args.height
     m, wg = harness.make_method(P, W, H, n_cams=args.cameras, cloud_shapes="bench", gt="random")
     wg.model.active_sh_degree.fill_(3)   # the state a trained model is in (oneupSHdegree every 1000 iterations, method.py:1896)
+    if args.optins:   # the run-time opt-ins that need no source edit (wg_integration.apply_optins): fused SSIM, FusedAdam, fused densification
+        import wg_integration   # statistics, fused activations
+        wg_integration.apply_optins(m, model=wg.model)
     losses = []
     for i in range(args.warmup):
         losses.append(wg.train_iteration(i)["loss"])
@@ -135,7 +138,9 @@ def real_caller(args):
         op_only()
     torch.cuda.synchronize()
     dop = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"workload": f"REAL caller: wildgaussians/method.py WildGaussians.train_iteration unchanged (staged copy, sha256-verified), "
+    print(json.dumps({"workload": f"REAL caller: wildgaussians/method.py WildGaussians.train_iteration unchanged (staged copy, sha256-verified)"
+                                  + (" + wg_integration.apply_optins (run-time swaps: fused SSIM, FusedAdam, fused densification statistics, fused activations), "
+                                     if args.optins else ", ") +
                                   f"{P} Gaussians + appearance MLP, {W}x{H}, {args.cameras} cameras, default.yml with uncertainty_mode=disabled, "
                                   "num_sky_gaussians=0, active SH degree 3",
                       "train_step_ms": round(dt * 1e3, 3), "train_steps_per_s": round(1.0 / dt, 2),
@@ -169,6 +174,7 @@ def main():
     ap.add_argument("--fused-loss", action="store_true",
                     help="SURVEY 8f N4: wg_fused_ssim.l1_ssim_loss -- the whole (1 - l) L1 + l DSSIM image loss (method.py:1948-1965) in two "
                          "launches each way instead of the L1 / mean / SSIM statement chain")
+    ap.add_argument("--optins", action="store_true", help="with --real-caller: apply wg_integration.apply_optins (run-time swaps, no source edits)")
     ap.add_argument("--real-caller", action="store_true",
                     help="run the reference's OWN `WildGaussians.train_iteration` (method.py:1880-2024, staged unchanged by "
                          "tests/real_caller/stage_reference_caller.py) instead of the restated step; none of the opt-ins apply")

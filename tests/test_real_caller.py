@@ -140,3 +140,41 @@ def test_real_optimize_embedding_runs_the_rasterizer_with_gradients_to_the_colou
     loss = out["metrics"]["loss"]
     assert len(loss) == 12 and np.isfinite(loss).all() and min(loss[6:]) < loss[0], loss
     assert out["embedding"].shape == (wg.config.appearance_embedding_dim,) and np.abs(out["embedding"]).max() > 0
+
+
+@pytest.mark.gpu
+@needs_staged
+def test_runtime_optins_leave_the_real_step_where_it_was():
+    """wg_integration.apply_optins swaps four names of the reference's module at run time (fused SSIM, FusedAdam, fused densification
+    statistics, fused activations) and touches no source.  The same seeded model takes the same first steps either way: the
+    losses agree to the fused pieces' own tolerances, the per-Gaussian statistics the densification reads agree, and the loop
+    then runs on through densification, pruning and the opacity reset."""
+    import random
+    import wg_integration
+    ov = {"densify_from_iter": 10, "densification_interval": 15, "opacity_reset_interval": 40, "densify_until_iter": 55,
+          "densify_grad_threshold": 0.00002}
+
+    def run(optins, steps):
+        random.seed(7), np.random.seed(7), torch.manual_seed(7)
+        m, wg = harness.make_method(30_000, 480, 320, n_cams=3, overrides=ov)
+        undo = wg_integration.apply_optins(m, model=wg.model) if optins else (lambda: None)
+        try:
+            random.seed(11)
+            out = [wg.train_iteration(i) for i in range(steps)]
+            kinds = (type(wg.model.optimizer), m.ssim.__module__)
+        finally:
+            undo()
+        return m, wg, out, kinds
+    m, wg_a, a, kinds_a = run(False, 6)
+    m, wg_b, b, kinds_b = run(True, 70)
+    from wg_fused_gaussians import FusedAdam
+    assert kinds_b == (FusedAdam, "wg_fused_ssim") and kinds_a[0] is torch.optim.Adam and "wg_fused" not in kinds_a[1]
+    assert type(wg_b.model.optimizer) is torch.optim.Adam   # undo() hands the adopted optimizer back too
+    assert "wg_fused" not in m.ssim.__module__ and "apply_optins" not in m.GaussianModel.get_gaussians.__qualname__   # undone
+    for i in range(6):   # the first steps, before the atomics' rounding noise has been through many Adam steps
+        assert abs(a[i]["loss"] - b[i]["loss"]) <= 2e-3 * abs(a[i]["loss"]), (i, a[i]["loss"], b[i]["loss"])
+        assert abs(a[i]["ssim"] - b[i]["ssim"]) <= 2e-3
+    counts = [o["num_gaussians"] for o in b]
+    assert np.isfinite([o["loss"] for o in b]).all() and len(set(counts)) > 2
+    for p in (wg_b.model.xyz, wg_b.model.scales, wg_b.model.rotations, wg_b.model.opacities, wg_b.model.features_dc):
+        assert torch.isfinite(p).all() and p.shape[0] == counts[-1]

@@ -146,6 +146,16 @@ class FusedAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False,
                          **{k: v for k, v in kw.items() if k in ("amsgrad", "maximize", "capturable", "differentiable")})
 
+    @classmethod
+    def adopt(cls, optimizer: torch.optim.Adam) -> "FusedAdam":
+        """A FusedAdam over the SAME parameters, group options (``lr``, ``name``, ``weight_decay`` ...) and state tensors as an existing
+        ``torch.optim.Adam`` -- for callers whose code constructs the optimizer itself (wg_integration.apply_optins)."""
+        groups = [{k: v for k, v in g.items() if k not in ("foreach", "fused")} for g in optimizer.param_groups]
+        new = cls(groups, **{k: optimizer.defaults[k] for k in ("lr", "betas", "eps", "weight_decay")})
+        for p, st in optimizer.state.items():
+            new.state[p] = st
+        return new
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -154,8 +164,8 @@ class FusedAdam(torch.optim.Adam):
                 loss = closure()
         by_device = {}
         for group in self.param_groups:
-            if group.get("amsgrad") or group.get("maximize"):
-                raise NotImplementedError("wg_fused_gaussians.FusedAdam: amsgrad / maximize are not implemented")
+            if group.get("amsgrad") or group.get("maximize") or group.get("decoupled_weight_decay"):
+                raise NotImplementedError("wg_fused_gaussians.FusedAdam: amsgrad / maximize / decoupled_weight_decay are not implemented")
             beta1, beta2 = group["betas"]
             if not (0.5 < beta1 < 1.0 and 0.0 <= beta2 < 1.0):
                 raise NotImplementedError("wg_fused_gaussians.FusedAdam: betas outside (0.5, 1) x [0, 1) are not implemented")

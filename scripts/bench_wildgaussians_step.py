@@ -105,7 +105,7 @@ def real_caller(args):
     m, wg = harness.make_method(P, W, H, n_cams=args.cameras, cloud_shapes="bench", gt="random")
     wg.model.active_sh_degree.fill_(3)   # the state a trained model is in (oneupSHdegree every 1000 iterations, method.py:1896)
     if args.optins:   # the run-time opt-ins that need no source edit (wg_integration.apply_optins): fused SSIM, FusedAdam, fused densification
-        import wg_integration   # statistics, fused activations
+        import wg_integration   # statistics, fused activations, fused eval_sh
         wg_integration.apply_optins(m, model=wg.model)
     losses = []
     for i in range(args.warmup):
@@ -139,7 +139,7 @@ def real_caller(args):
     torch.cuda.synchronize()
     dop = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"workload": f"REAL caller: wildgaussians/method.py WildGaussians.train_iteration unchanged (staged copy, sha256-verified)"
-                                  + (" + wg_integration.apply_optins (run-time swaps: fused SSIM, FusedAdam, fused densification statistics, fused activations), "
+                                  + (" + wg_integration.apply_optins (run-time swaps: fused SSIM, FusedAdam, fused densification statistics, fused activations, fused eval_sh), "
                                      if args.optins else ", ") +
                                   f"{P} Gaussians + appearance MLP, {W}x{H}, {args.cameras} cameras, default.yml with uncertainty_mode=disabled, "
                                   "num_sky_gaussians=0, active SH degree 3",

@@ -95,7 +95,8 @@ def test_real_render_internal_matches_the_reference_build(trained):
         color, radii, acc = call["out"]
         assert torch.equal(radii, ref["radii"])
         err = (color - ref["color"]).abs()
-        assert int((err > 1e-4).sum()) <= 3 and float(err.max()) <= 5e-3, (int((err > 1e-4).sum()), float(err.max()))
+        flipped = int((err > 1e-4).any(dim=0).sum())   # PIXELS on the other side of a threshold (a flip moves up to three channels)
+        assert flipped <= 3 and float(err.max()) <= 5e-3, (flipped, float(err.max()))
         assert float((acc - ref["accumulation"]).abs().max()) <= 5e-3
     assert torch.equal(out["render"], tap.calls[1]["out"][0]) and torch.equal(out["raw_render"], tap.calls[0]["out"][0])
 

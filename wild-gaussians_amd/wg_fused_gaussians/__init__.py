@@ -204,3 +204,56 @@ class FusedAdam(torch.optim.Adam):
             with torch.cuda.device(dev):
                 _native._check(_lib.wg_fused_adam(len(items), arr, torch.cuda.current_stream(dev).cuda_stream), "wg_fused_adam")
         return loss
+
+
+# ---- fused eval_sh (include/wg_sh_eval.h, csrc/sh_eval.hip) ------------------------------------------------------
+_lib.wg_eval_sh_forward.restype = _i
+_lib.wg_eval_sh_forward.argtypes = [_i, _i, _i, _vp, _vp, _vp, _vp]
+_lib.wg_eval_sh_backward.restype = _i
+_lib.wg_eval_sh_backward.argtypes = [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]
+
+
+class _EvalSH(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, deg, sh, dirs):
+        P, K = sh.shape[0], sh.shape[2]
+        out = torch.empty((P, 3), device=sh.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(sh.device).cuda_stream
+        with torch.cuda.device(sh.device):
+            _native._check(_lib.wg_eval_sh_forward(P, deg, K, sh.data_ptr(), dirs.data_ptr(), out.data_ptr(), stream), "wg_eval_sh_forward")
+        ctx.deg = deg
+        ctx.save_for_backward(sh, dirs)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        sh, dirs = ctx.saved_tensors
+        P, K = sh.shape[0], sh.shape[2]
+        g = grad_out.contiguous()
+        need_sh, need_dirs = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if not (need_sh or need_dirs):
+            return None, None, None
+        grad_sh = torch.empty_like(sh)   # written whole by the kernel (it is the cheaper of the two outputs to always produce)
+        grad_dirs = torch.empty_like(dirs) if need_dirs else None
+        stream = torch.cuda.current_stream(sh.device).cuda_stream
+        with torch.cuda.device(sh.device):
+            _native._check(_lib.wg_eval_sh_backward(P, ctx.deg, K, sh.data_ptr(), dirs.data_ptr(), g.data_ptr(), grad_sh.data_ptr(),
+                                                    None if grad_dirs is None else grad_dirs.data_ptr(), stream), "wg_eval_sh_backward")
+        return None, grad_sh if need_sh else None, grad_dirs
+
+
+def eval_sh(deg, sh: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
+    """The reference's ``eval_sh(deg, sh, dirs)`` (wildgaussians/method.py:493-548) for ``sh`` [..., 3, K] and ``dirs`` [..., 3], degrees
+    0..3, as one kernel forward and one backward (gradients to ``sh`` and ``dirs``) instead of ~60 elementwise kernels over strided
+    slices and, backward, a zero-fill + slice-add of a [..., 3, K] tensor per coefficient.  float32 on a HIP device; no CPU path."""
+    deg = int(deg)
+    if not 0 <= deg <= 3:
+        raise NotImplementedError("wg_fused_gaussians.eval_sh: degrees 0..3 are implemented")
+    if sh.shape[-2] != 3 or dirs.shape[-1] != 3 or sh.shape[:-2] != dirs.shape[:-1] or sh.shape[-1] < (deg + 1) ** 2:
+        raise RuntimeError("wg_fused_gaussians.eval_sh: expected sh [..., 3, K >= (deg + 1)^2] and dirs [..., 3] with equal leading dimensions")
+    for name, t in (("sh", sh), ("dirs", dirs)):
+        if not (t.is_cuda and t.dtype == torch.float32):
+            raise RuntimeError(f"wg_fused_gaussians.eval_sh: {name} must be a float32 tensor on a HIP device (there is no CPU path)")
+    lead = sh.shape[:-2]
+    out = _EvalSH.apply(deg, sh.reshape(-1, 3, sh.shape[-1]).contiguous(), dirs.reshape(-1, 3).contiguous())
+    return out.reshape(*lead, 3)

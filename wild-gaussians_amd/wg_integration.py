@@ -15,13 +15,16 @@ needs the few-line edits INTEGRATION.md lists.  What IS swapped, each with the r
                         an optimizer that already exists on `model` is adopted at once (pass `model=`)
   densification_stats   `GaussianModel.add_densification_stats` (method.py:1470-1477) -> wg_fused_gaussians.add_densification_stats
   activations           `GaussianModel.get_gaussians` (method.py:1060-1086)          -> wg_fused_gaussians.activate (same dict)
+  eval_sh               `method.eval_sh` (method.py:493-548, called at :1564, :1597) -> wg_fused_gaussians.eval_sh; calls it does not cover
+                        (degree 4, a channel count other than 3, CPU tensors) go to the original function
 """
 from __future__ import annotations
 
 import torch
 
 
-def apply_optins(method_module, model=None, ssim: bool = True, adam: bool = True, densification_stats: bool = True, activations: bool = True):
+def apply_optins(method_module, model=None, ssim: bool = True, adam: bool = True, densification_stats: bool = True, activations: bool = True,
+                 eval_sh: bool = True):
     """-> a function that restores everything that was replaced.  `model`: an already constructed GaussianModel (e.g.
     `WildGaussians(...).model`) whose existing optimizer should be adopted too."""
     import wg_fused_gaussians as FG
@@ -61,6 +64,17 @@ def apply_optins(method_module, model=None, ssim: bool = True, adam: bool = True
             opacities, scales, rotations = FG.activate(self.opacities, self.scales, self.rotations, self.filter_3D)
             return {"xyz": self.xyz, "opacities": opacities, "scales": scales, "rotations": rotations, "features": features}
         swap(GM, "get_gaussians", get_gaussians)
+
+    if eval_sh:
+        orig_eval_sh = method_module.eval_sh
+
+        def fused_eval_sh(deg, sh, dirs):
+            d = int(deg)
+            if (d > 3 or not torch.is_tensor(sh) or not torch.is_tensor(dirs) or sh.dim() < 2 or sh.shape[-2] != 3 or not sh.is_cuda
+                    or sh.dtype != torch.float32 or dirs.dtype != torch.float32):
+                return orig_eval_sh(deg, sh, dirs)   # the caller's own code, not a fallback of this library
+            return FG.eval_sh(d, sh, dirs)
+        swap(method_module, "eval_sh", fused_eval_sh)
 
     def undo():
         while saved:

@@ -107,6 +107,10 @@ def real_caller(args):
     if args.optins:   # the run-time opt-ins that need no source edit (wg_integration.apply_optins): fused SSIM, FusedAdam, fused densification
         import wg_integration   # statistics, fused activations, fused eval_sh
         wg_integration.apply_optins(m, model=wg.model)
+    if args.tall_linear and wg.model.appearance_mlp is not None:   # measurement scaffolding for the caller's MLP (see _TallLinear)
+        for lin in wg.model.appearance_mlp.mlp:
+            if isinstance(lin, torch.nn.Linear):
+                lin.forward = (lambda x, l=lin: tall_linear(x, l.weight, l.bias))
     losses = []
     for i in range(args.warmup):
         losses.append(wg.train_iteration(i)["loss"])
@@ -140,7 +144,7 @@ def real_caller(args):
     dop = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"workload": f"REAL caller: wildgaussians/method.py WildGaussians.train_iteration unchanged (staged copy, sha256-verified)"
                                   + (" + wg_integration.apply_optins (run-time swaps: fused SSIM, FusedAdam, fused densification statistics, fused activations, fused eval_sh), "
-                                     if args.optins else ", ") +
+                                     if args.optins else ", ") + ("tall_linear for the appearance MLP's layers (this script), " if args.tall_linear else "") +
                                   f"{P} Gaussians + appearance MLP, {W}x{H}, {args.cameras} cameras, default.yml with uncertainty_mode=disabled, "
                                   "num_sky_gaussians=0, active SH degree 3",
                       "train_step_ms": round(dt * 1e3, 3), "train_steps_per_s": round(1.0 / dt, 2),

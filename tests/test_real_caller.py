@@ -96,7 +96,8 @@ def test_real_render_internal_matches_the_reference_build(trained):
         assert torch.equal(radii, ref["radii"])
         err = (color - ref["color"]).abs()
         flipped = int((err > 1e-4).any(dim=0).sum())   # PIXELS on the other side of a threshold (a flip moves up to three channels)
-        assert flipped <= 3 and float(err.max()) <= 5e-3, (flipped, float(err.max()))
+        # observed 1..2 of 307 200; the trained state itself differs from run to run (atomics in the 45 training steps), hence the margin
+        assert flipped <= 6 and float(err.max()) <= 5e-3, (flipped, float(err.max()))
         assert float((acc - ref["accumulation"]).abs().max()) <= 5e-3
     assert torch.equal(out["render"], tap.calls[1]["out"][0]) and torch.equal(out["raw_render"], tap.calls[0]["out"][0])
 

@@ -259,3 +259,54 @@ def test_bench_byte_model():
     assert len(bench.kernel_source_sha()) == 16
     stages, note = bench.load_pmc("no such workload")
     assert stages == {} and ("another workload" in note or "no profiles" in note)
+
+
+def test_runtime_optins_swap_and_restore_module_attributes():
+    """wg_integration.apply_optins on a stand-in for the reference's module (pure host logic: what is swapped, what `undo` restores,
+    which eval_sh calls are handed back to the caller's own function).  The fused pieces themselves are GPU tests."""
+    import types
+    import wg_integration
+
+    class GaussianModel:
+        def _setup_optimizers(self):
+            self.optimizer = "built"
+
+        def add_densification_stats(self, v, f):
+            return "orig stats"
+
+        def get_gaussians(self):
+            return "orig gaussians"
+    calls = []
+    mod = types.SimpleNamespace(GaussianModel=GaussianModel, ssim=lambda *a, **k: "orig ssim",
+                                eval_sh=lambda deg, sh, dirs: calls.append(("orig", int(deg))) or "orig sh")
+    before = (mod.ssim, mod.eval_sh, GaussianModel._setup_optimizers, GaussianModel.add_densification_stats, GaussianModel.get_gaussians)
+    undo = wg_integration.apply_optins(mod, adam=False)
+    assert mod.ssim.__module__ == "wg_fused_ssim" and mod.eval_sh is not before[1]
+    assert GaussianModel._setup_optimizers is before[2]                      # adam=False: left alone
+    assert GaussianModel.add_densification_stats is not before[3] and GaussianModel.get_gaussians is not before[4]
+    # calls the fused eval_sh does not cover go to the caller's own function: degree 4, CPU tensors, a channel count other than 3
+    assert mod.eval_sh(4, torch.zeros(2, 3, 25), torch.zeros(2, 3)) == "orig sh"
+    assert mod.eval_sh(torch.tensor(2), torch.zeros(2, 3, 16), torch.zeros(2, 3)) == "orig sh"
+    assert mod.eval_sh(1, torch.zeros(2, 5, 4), torch.zeros(2, 3)) == "orig sh" and [c[1] for c in calls] == [4, 2, 1]
+    undo()
+    assert (mod.ssim, mod.eval_sh, GaussianModel._setup_optimizers, GaussianModel.add_densification_stats, GaussianModel.get_gaussians) == before
+    undo()   # idempotent
+
+
+def test_fused_optimizer_is_a_torch_adam_and_refuses_what_it_does_not_implement():
+    from wg_fused_gaussians import FusedAdam
+    p = torch.nn.Parameter(torch.zeros(5))
+    ref = torch.optim.Adam([{"params": [p], "lr": 0.25, "name": "xyz", "weight_decay": 0.5}], lr=1.0, eps=1e-15)
+    ref.state[p] = {"step": torch.tensor(3.0), "exp_avg": torch.ones(5), "exp_avg_sq": torch.ones(5)}
+    o = FusedAdam.adopt(ref)
+    g = o.param_groups[0]
+    assert isinstance(o, torch.optim.Adam) and (g["lr"], g["name"], g["weight_decay"], g["eps"]) == (0.25, "xyz", 0.5, 1e-15)
+    assert o.state[p]["exp_avg"] is ref.state[p]["exp_avg"] and g["params"][0] is p          # the same tensors, not copies
+    assert set(o.state_dict()["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    p.grad = torch.ones(5)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        o.step()
+    with pytest.raises(NotImplementedError):
+        FusedAdam([p], amsgrad=True)
+    with pytest.raises(NotImplementedError):
+        FusedAdam([p], betas=(0.3, 0.999)).step()

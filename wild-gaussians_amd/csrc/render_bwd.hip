@@ -163,7 +163,20 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     const uint2 range = ranges[tile];
     // the ten partial sums live across instances and are cleared after each reduction only: an instance without any
     // contributing lane (19 % of them) leaves them at zero
-    float acr = 0.f, acg = 0.f, acb = 0.f, sx = 0.f, sy = 0.f, sab = 0.f, sxx = 0.f, sxy = 0.f, syy = 0.f, sq = 0.f;
+    // the ten sums live in five register PAIRS, so that clearing them after a reduction is five v_mov_b64 instead of ten v_mov_b32
+    // (backward 0.4272 -> 0.4234 ms; the names below are the pairs' halves)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, p3 = {0.f, 0.f}, p4 = {0.f, 0.f};
+#define acr p0.x
+#define acg p0.y
+#define acb p1.x
+#define sx p1.y
+#define sy p2.x
+#define sab p2.y
+#define sxx p3.x
+#define sxy p3.y
+#define syy p4.x
+#define sq p4.y
 
     for (int hi = hi0; hi > 0; hi -= BATCH) {
         // lane l stages the instance at list position hi-1-l (back to front, backward.cu:517)
@@ -263,10 +276,23 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             } else {
                 if (issue) unsafeAtomicAdd(abase + astride * __float_as_uint(r1.z), total * (oscale ? (vidx == 5 ? fabsf(o) : o) * vscale : vscale));  // 4*P < 2^32
             }
-            acr = acg = acb = sx = sy = sab = sxx = sxy = syy = sq = 0.f;
+            // (hipcc scalarises "p = {0, 0}" into two v_mov_b32: spelled out)
+            asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\tv_mov_b64 %4, 0"
+                         : "=v"(p0), "=v"(p1), "=v"(p2), "=v"(p3), "=v"(p4));
         }
     }
 }
+
+#undef acr
+#undef acg
+#undef acb
+#undef sx
+#undef sy
+#undef sab
+#undef sxx
+#undef sxy
+#undef syy
+#undef sq
 
 // One thread per Gaussian: its tiles_touched slots, in slot order, into its gradient record (the layout the atomic path leaves).
 __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* __restrict__ offsets_incl, const uint32_t* __restrict__ tiles_touched,

@@ -69,12 +69,18 @@ def design_bytes(stage: str, P: int, V: int, R: int, N: int, tiles: int, M: int,
     return float(table[stage])
 
 
+OPERATOR_SOURCES = ("api.hip", "binning.hip", "preprocess.hip", "preprocess_bwd.hip", "render_fwd.hip", "render_bwd.hip",
+                    "wg_common.h", "wg_alpha.h", "wg_sort.h")
+
+
 def kernel_source_sha() -> str:
-    """Hash of every kernel source + the build flags: stamps profiles/pmc_traffic.json to the code it was measured on."""
+    """Hash of the operator's kernel sources (everything a bench.py stage runs) + the build script with its flags: stamps
+    profiles/pmc_traffic.json to the code it was measured on.  The opt-in kernels either side of the path (knn, ssim, activations,
+    densify, adam, sh_eval) are not part of any stage and not part of the stamp."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "wild-gaussians_amd", "csrc")
-    for f in sorted(os.listdir(d)) + ["../build.py"]:
+    for f in sorted(OPERATOR_SOURCES) + ["../build.py"]:
         if f.endswith((".hip", ".h", ".py")):
             with open(os.path.join(d, f), "rb") as fh:
                 h.update(f.encode() + b"\0" + fh.read())

@@ -94,7 +94,7 @@ extern "C" {
 
 int wg_activations_forward(int P, const float* raw_rotations, const float* raw_scales, const float* raw_opacities,
                            const float* filter_3D, float* rotations, float* scales, float* opacities, void* stream) {
-    if (P < 0) return WG_ERR_INVALID_ARGUMENT;
+    if (P < 0 || P > 0x7fffffff / 4) return WG_ERR_INVALID_ARGUMENT;  // per-Gaussian element indices (3 i, 4 i) are 32-bit
     if (P == 0) return WG_OK;
     if (!raw_rotations || !raw_scales || !raw_opacities || !filter_3D || !rotations || !scales || !opacities) return WG_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(wg::activations_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), P,
@@ -106,7 +106,7 @@ int wg_activations_forward(int P, const float* raw_rotations, const float* raw_s
 int wg_activations_backward(int P, const float* raw_rotations, const float* raw_scales, const float* raw_opacities,
                             const float* filter_3D, const float* dL_drotations, const float* dL_dscales, const float* dL_dopacities,
                             float* dL_draw_rotations, float* dL_draw_scales, float* dL_draw_opacities, void* stream) {
-    if (P < 0) return WG_ERR_INVALID_ARGUMENT;
+    if (P < 0 || P > 0x7fffffff / 4) return WG_ERR_INVALID_ARGUMENT;  // per-Gaussian element indices (3 i, 4 i) are 32-bit
     if (P == 0) return WG_OK;
     if (!raw_rotations || !raw_scales || !raw_opacities || !filter_3D || !dL_draw_rotations || !dL_draw_scales || !dL_draw_opacities)
         return WG_ERR_INVALID_ARGUMENT;

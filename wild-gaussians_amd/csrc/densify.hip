@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) densification_stats_kernel(int P, const i
 
 extern "C" int wg_densification_stats(int P, const int* radii, const float* viewspace_grad, float* xyz_grad, float* xyz_gradient_accum_abs,
                                       float* xyz_gradient_accum_abs_max, float* denom, float* max_radii2D, void* stream) {
-    if (P < 0) return WG_ERR_INVALID_ARGUMENT;
+    if (P < 0 || P > 0x7fffffff / 4) return WG_ERR_INVALID_ARGUMENT;  // per-Gaussian element indices (3 i, 4 i) are 32-bit
     if (P == 0) return WG_OK;
     if (!radii || !viewspace_grad || !xyz_grad || !denom) return WG_ERR_INVALID_ARGUMENT;
     if ((xyz_gradient_accum_abs == nullptr) != (xyz_gradient_accum_abs_max == nullptr)) return WG_ERR_INVALID_ARGUMENT;

@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(256) eval_sh_forward_kernel(int P, int K, cons
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     float b[N];
-    sh_basis<DEG>(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], b);
+    const size_t i3 = 3 * (size_t)i;
+    sh_basis<DEG>(dirs[i3], dirs[i3 + 1], dirs[i3 + 2], b);
     const bool vec = (K & 3) == 0 && (reinterpret_cast<uintptr_t>(sh) & 15u) == 0;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -72,7 +73,7 @@ __global__ void __launch_bounds__(256) eval_sh_forward_kernel(int P, int K, cons
         float r = b[0] * v[0];
 #pragma unroll
         for (int k = 1; k < N; k++) r += b[k] * v[k];
-        out[3 * i + c] = r;
+        out[i3 + c] = r;
     }
 }
 
@@ -83,10 +84,11 @@ __global__ void __launch_bounds__(256) eval_sh_backward_kernel(int P, int K, con
     constexpr int N = (DEG + 1) * (DEG + 1);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    const float x = dirs[3 * i], y = dirs[3 * i + 1], z = dirs[3 * i + 2];
+    const size_t i3 = 3 * (size_t)i;
+    const float x = dirs[i3], y = dirs[i3 + 1], z = dirs[i3 + 2];
     float b[N];
     sh_basis<DEG>(x, y, z, b);
-    const float g[3] = {grad_out[3 * i], grad_out[3 * i + 1], grad_out[3 * i + 2]};
+    const float g[3] = {grad_out[i3], grad_out[i3 + 1], grad_out[i3 + 2]};
     const bool vec = (K & 3) == 0 && ((reinterpret_cast<uintptr_t>(sh) | reinterpret_cast<uintptr_t>(grad_sh)) & 15u) == 0;
     float s[N];  // s_k = sum_c grad_out[c] * sh[c][k]: what the direction's gradient needs of the coefficients
 #pragma unroll
@@ -148,9 +150,9 @@ __global__ void __launch_bounds__(256) eval_sh_backward_kernel(int P, int K, con
                   s14 * 2.0f * yz - s15 * 6.0f * xy;
             gz += s10 * xy + s11 * 8.0f * yz + s12 * (6.0f * zz - 3.0f * xx - 3.0f * yy) + s13 * 8.0f * xz + s14 * (xx - yy);
         }
-        grad_dirs[3 * i] = gx;
-        grad_dirs[3 * i + 1] = gy;
-        grad_dirs[3 * i + 2] = gz;
+        grad_dirs[i3] = gx;
+        grad_dirs[i3 + 1] = gy;
+        grad_dirs[i3 + 2] = gz;
     }
 }
 

@@ -73,6 +73,9 @@ OPERATOR_SOURCES = ("api.hip", "binning.hip", "preprocess.hip", "preprocess_bwd.
                     "wg_common.h", "wg_alpha.h", "wg_sort.h")
 
 
+OPT_IN_SOURCES = ("knn.hip", "ssim.hip", "activations.hip", "densify.hip", "adam.hip", "sh_eval.hip")   # SURVEY 8f kernels: in no bench.py stage
+
+
 def kernel_source_sha() -> str:
     """Hash of the operator's kernel sources (everything a bench.py stage runs) + the build script with its flags: stamps
     profiles/pmc_traffic.json to the code it was measured on.  The opt-in kernels either side of the path (knn, ssim, activations,

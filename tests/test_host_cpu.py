@@ -257,6 +257,10 @@ def test_bench_byte_model():
         assert bench.design_bytes(k, walked=2_700_000, **kw) < bench.algorithmic_bytes(k, **kw)
     assert bench.design_bytes("render_backward", walked=2_700_000, **kw) == 4 * 2_700_000 + 88 * kw["V"] + 28 * kw["N"]
     assert len(bench.kernel_source_sha()) == 16
+    # every kernel source is either part of the PMC stamp (the operator) or declared an opt-in kernel outside bench.py's stages
+    csrc = os.path.join(ROOT, "wild-gaussians_amd", "csrc")
+    files = {f for f in os.listdir(csrc) if f.endswith((".hip", ".h"))}
+    assert files == set(bench.OPERATOR_SOURCES) | set(bench.OPT_IN_SOURCES), files ^ (set(bench.OPERATOR_SOURCES) | set(bench.OPT_IN_SOURCES))
     stages, note = bench.load_pmc("no such workload")
     assert stages == {} and ("another workload" in note or "no profiles" in note)
 

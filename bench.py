@@ -122,9 +122,13 @@ def self_launch(n: int):
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")
-    if torch.cuda.is_available() and torch.cuda.device_count() < n and "WG_DIST_BACKEND" not in env:
-        env["WG_DIST_BACKEND"] = "gloo"
+    # every rank gets its own slice of the host cores (wg_viewparallel.pin_rank) and a thread pool no larger than that slice
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, cores // max(n, 1)))))
+    if torch.cuda.is_available() and torch.cuda.device_count() < n and env.get("WG_DIST_BACKEND") != "gloo":
+        raise SystemExit(f"--gpus {n} but only {torch.cuda.device_count()} HIP device(s) visible: one process per GPU needs {n}.  "
+                         "(WG_DIST_BACKEND=gloo lets ranks share devices over the host-side transport: a test of the launch flow, "
+                         "not a scaling measurement.)")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
@@ -144,6 +148,8 @@ def main():
     ap.add_argument("--forward-only", action="store_true", help="stress mode: time only the forward pass (e.g. 10M Gaussians @ 4K)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (parity + CPU timing)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events in the timed region")
+    ap.add_argument("--baseline-iters-per-s", type=float, default=None,
+                    help="the 1-GPU value of this metric: the line then carries scaling_efficiency = value / (N * baseline)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="wg_set_option(NAME, VALUE) before the run (A/B of library options, e.g. grad_record=0); recorded in the JSON line")
     args = ap.parse_args()
@@ -204,17 +210,8 @@ def main():
 
     t_train_local = [0.0]
 
-    def timed(fn, steps, keep=None):
-        VP.barrier()
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize(device)
-        if keep is not None:
-            keep[0] = time.perf_counter() - t0   # this rank's own time, before waiting for the others
-        VP.barrier()
-        return VP.max_over_ranks(time.perf_counter() - t0, device)
+    def timed(fn, steps, keep=None):   # barrier + synchronize on both sides of exactly `steps` calls, max over ranks
+        return VP.timed_region(fn, steps, device, keep)
 
     if args.forward_only:
         train_step = fwd_step
@@ -270,7 +267,8 @@ def main():
     my_ms = 1000.0 * t_train_local[0] / args.steps
     ranks_seen = VP.gather_over_ranks([float(rank), float(local_rank), my_ms], device)
 
-    iters_per_s = world * args.steps / t_train
+    job = VP.job_fields(world, args.steps, t_train, ranks_seen, args.baseline_iters_per_s)
+    iters_per_s = job["value"]
     pl = f"{P // 1_000_000}M" if P % 1_000_000 == 0 and P >= 1_000_000 else (f"{P // 1000}k" if P % 1000 == 0 else str(P))
     size_label = f"{pl} Gaussians @{'1080p' if (W, H) == (1920, 1080) else '4K' if (W, H) == (3840, 2160) else f'{W}x{H}'}" + \
                  ("" if args.scale_mult == 1.0 else f", scales x{args.scale_mult:g}")
@@ -290,10 +288,11 @@ def main():
         "loss_allreduced_last_step": None if args.forward_only else round(loss_stream.last(), 9),
         "loss_note": "loss = <image, cotangent> on the rasterizer's stream; its 4-byte all-reduce is queued asynchronously (wg_viewparallel.LossStream) "
                      "and covered by the device-wide synchronize that ends the timed region",
-        "rccl_ranks_seen": sorted(int(r[0]) for r in ranks_seen),
-        "per_rank_ms_per_step": {str(int(r[0])): round(r[2], 4) for r in ranks_seen},
-        "per_rank_device": {str(int(r[0])): int(r[1]) for r in ranks_seen},
+        "rccl_ranks_seen": job["rccl_ranks_seen"],
+        "per_rank_ms_per_step": job["per_rank_ms_per_step"],
+        "per_rank_device": job["per_rank_device"],
         "vs_baseline": None,
+        **({"scaling_efficiency": job["scaling_efficiency"]} if "scaling_efficiency" in job else {}),
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{P} Gaussians{'' if args.scale_mult == 1.0 else f' (scales x{args.scale_mult:g})'}, {W}x{H}, "
@@ -378,6 +377,53 @@ def main():
                 if all(k in pmc for k in names if per_stage[k] > 0 and k != "tile_ranges"):
                     pipe[nm + "_hbm_traffic_GBps"] = round(sum(pmc[k]["hbm_bytes"] for k in names if k in pmc) / (tt * 1e-3) / 1e9, 1)
         out["pipeline_roofline"] = pipe
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.forward_only:
+        # Forward-only workloads (BASELINE config 5: 10 M Gaussians @ 4K): the same two checkers, forward legs only.
+        # (1) the CPU oracle, on a BOUNDED sample -- the first min(P, 2 M) Gaussians of the same cloud, same camera and frame (its
+        #     single-threaded key sort of the full 211 M instances would take minutes) -- timed as cpu_baseline and used to check
+        #     the product on that very sample;
+        from oracle import oracle
+        oracle.build()
+        cores = os.cpu_count() or 1
+        Ps = min(P, 2_000_000)
+        sub = {k: np.ascontiguousarray(v[:Ps]) for k, v in cloud.items()}
+        t0 = time.perf_counter()
+        o = oracle.run_scene(sub, cam, sh_degree=deg)
+        t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(1.0 / t_cpu, 4), "unit": "iter/s", "cores": cores, "kind": "port",
+                               "sample": (f"1 forward pass over the first {Ps} of the {P} Gaussians, same camera and {W}x{H} frame "
+                                          "(OpenMP over Gaussians/tiles; the (tile|depth) key sort is single-threaded)"),
+                               "seconds": round(t_cpu, 2)}
+        from tests.wg_testlib import run_hip_native
+        hs = run_hip_native(sub, cam, sh_degree=deg, device=device)
+        cf = compare_forward(hs["color"].cpu().numpy(), o)
+        out["parity"] = {"checker": f"CPU oracle on the cpu_baseline sample ({Ps} Gaussians, {W}x{H}, forward)",
+                         "fwd_max_abs_err_solid_pixels": float(f"{cf['max_err_solid']:.3e}"),
+                         "fwd_fragile_pixels": cf["n_fragile"], "fwd_fragile_over_1e-4": cf["n_over_in_fragile"],
+                         "radii_equal": bool((hs["radii"].cpu().numpy() == o["radii"]).all()),
+                         "num_rendered_equal": bool(int(hs["num_rendered"]) == o["num_rendered"])}
+        del hs, o, sub
+        torch.cuda.empty_cache()
+        # (2) the reference's own kernels (oracle/_ref, its CUDA sources built for gfx950 without fp contraction: the arithmetic the
+        #     sources spell) on the FULL workload, beside the product: timing + full-size comparison of radii and image.
+        ref_lib = os.path.join(ROOT, "oracle", "_ref", "libref_hip_rasterizer_nofma.so")
+        if os.path.exists(ref_lib):
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_hip_bench.py"), "--gaussians", str(P), "--width", str(W),
+                                    "--height", str(H), "--colors", args.colors, "--scale-mult", str(args.scale_mult), "--forward-only",
+                                    "--variant", "nofma", "--steps", "5", "--warmup", "2"], capture_output=True, text=True, timeout=420)
+                ref = json.loads(r.stdout.strip().splitlines()[-1])
+                out["reference_on_this_gpu"] = ref
+                out["speedup_vs_reference_on_this_gpu"] = {"forward": round(fwd_fps / ref["forward_fps"], 2)}
+                pv = ref.get("product_vs_reference", {})
+                out["parity"]["full_size_vs_reference_build"] = {
+                    "radii_mismatch": pv.get("radii_mismatch"), "num_rendered_equal": bool(int(R) == int(ref["num_rendered"])),
+                    "pixels_over_1e-4": pv.get("pixels_over_1e-4"), "pixels": pv.get("pixels"), "color_max_abs": pv.get("color_max_abs"),
+                    "color_p9999_abs": pv.get("color_p9999_abs")}
+            except Exception as ex:  # noqa: BLE001 -- a reported extra, never a reason to lose the bench line
+                out["reference_on_this_gpu"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.forward_only:
         # CPU leg: the oracle (a CPU port of the reference's algorithm) on the same workload, timed on the host

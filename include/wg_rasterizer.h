@@ -95,7 +95,7 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user,
  * Rasterizer::backward (rasterizer.h:61-88, rasterizer_impl.cu:344-443).
  * The reference requires all nine gradient outputs zero-filled by the caller (rasterize_points.cu:157-165).  Here, by default
  * (option "grad_record" = 1), ALL nine are fully overwritten (zeros for culled Gaussians): the per-tile pass accumulates into a
- * 64-byte record per Gaussian inside geom_buffer, which this call clears itself, and the per-Gaussian kernel writes dL_dmean2D,
+ * 48-byte record per Gaussian inside geom_buffer, which this call clears itself, and the per-Gaussian kernel writes dL_dmean2D,
  * dL_dconic, dL_dopacity and dL_dcolor from it -- a caller following the reference's protocol (zeroed buffers) gets the same
  * values.  dL_dconic (an intermediate of the reference) and, with SH colours, dL_dcolor (the gradient of the evaluated RGB, an
  * intermediate there) may then be NULL: they are not written.  With "grad_record" = 0 those four ARE the accumulation targets,

@@ -4,11 +4,16 @@
 //     pass SURVEY.md section 5 asks for, without a Python interpreter between ASan and the HIP runtime;
 //   * evidence that the boundary really is "plain pointers and sizes, no torch types" (tests/test_native_driver.py).
 // Prints one line "ok num_rendered=... checksum=..." and exits 0, or a diagnostic and a non-zero code.
+// With a fourth argument (a path) it also DUMPS its inputs and every output of the three calls there, raw little-endian:
+//   int32 {P, W, H, D, M, R}, float32 {tanx, tany}, then float32 arrays means[3P] scales[3P] rots[4P] opac[P] shs[3MP] view[16] proj[16]
+//   campos[3] bg[3] cot[3WH] | color[3WH] g2d[3P] gcon[4P] gop[P] gcol[3P] g3d[3P] gcov[6P] gsh[3MP] gsc[3P] grot[4P], int32 radii[P],
+//   uint8 vis[P] -- tests/test_native_driver.py feeds the same inputs to the CPU oracle and compares everything.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 #include "wg_rasterizer.h"
 
@@ -129,6 +134,26 @@ int main(int argc, char** argv) {
     for (float v : gm) { if (!std::isfinite(v)) { std::fprintf(stderr, "non-finite gradient\n"); return 7; } gsum += std::fabs(v); }
     for (int i = 0; i < P; i++) { nvis += vis[i]; nrad += radii[i] > 0; }
     if (nrad == 0 || nvis < nrad || gsum <= 0) { std::fprintf(stderr, "implausible outputs: nrad %d nvis %d gsum %g\n", nrad, nvis, gsum); return 8; }
+    if (argc > 4) {
+        std::FILE* f = std::fopen(argv[4], "wb");
+        if (!f) { std::fprintf(stderr, "cannot open %s\n", argv[4]); return 9; }
+        const int32_t hdr[6] = {P, W, H, D, M, R};
+        const float fov[2] = {tanx, tany};
+        std::fwrite(hdr, sizeof(hdr), 1, f);
+        std::fwrite(fov, sizeof(fov), 1, f);
+        for (const std::vector<float>* v : {&means, &scales, &rots, &opac, &shs, &view, &proj, &campos, &bg, &cot}) std::fwrite(v->data(), 4, v->size(), f);
+        std::fwrite(color.data(), 4, color.size(), f);
+        const std::pair<float*, size_t> outs[] = {{g2d, 3u * (size_t)P}, {gcon, 4u * (size_t)P}, {gop, (size_t)P}, {gcol, 3u * (size_t)P}, {g3d, 3u * (size_t)P},
+                                                  {gcov, 6u * (size_t)P}, {gsh, (size_t)P * M * 3}, {gsc, 3u * (size_t)P}, {grot, 4u * (size_t)P}};
+        for (const auto& o : outs) {
+            std::vector<float> h(o.second);
+            CHECK_HIP(hipMemcpy(h.data(), o.first, o.second * 4, hipMemcpyDeviceToHost));
+            std::fwrite(h.data(), 4, h.size(), f);
+        }
+        std::fwrite(radii.data(), 4, radii.size(), f);
+        std::fwrite(vis.data(), 1, vis.size(), f);
+        std::fclose(f);
+    }
     std::printf("ok num_rendered=%d visible=%d radii>0=%d checksum=%.6f grad_l1=%.6e\n", R, nvis, nrad, sum, gsum);
     for (void* p : {(void*)d_means, (void*)d_scales, (void*)d_rots, (void*)d_opac, (void*)d_shs, (void*)d_view, (void*)d_proj, (void*)d_campos, (void*)d_bg,
                     (void*)d_cot, (void*)d_color, (void*)d_radii, (void*)g2d, (void*)gcon, (void*)gop, (void*)gcol, (void*)g3d, (void*)gcov, (void*)gsh,

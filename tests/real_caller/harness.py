@@ -104,18 +104,22 @@ class RasterizerTap:
     """Records every `GaussianRasterizer.forward` call (inputs, settings, outputs) through torch's global module hooks --
     the caller and the operator stay untouched."""
 
-    def __init__(self, method_module):
+    def __init__(self, method_module, grads: bool = False):
         self.cls = method_module.GaussianRasterizer
         self.calls = []
         self._h = None
+        self.grads = grads   # also record dL/d(image) of every call as it arrives in the backward pass (call["grad_out"])
 
     def __enter__(self):
         import torch
 
         def hook(mod, args, kwargs, out):
             if isinstance(mod, self.cls):
-                self.calls.append(dict(kwargs={k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in kwargs.items()},
-                                       settings=mod.raster_settings, out=tuple(o.detach().clone() if torch.is_tensor(o) else o for o in out)))
+                call = dict(kwargs={k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in kwargs.items()},
+                            settings=mod.raster_settings, out=tuple(o.detach().clone() if torch.is_tensor(o) else o for o in out))
+                self.calls.append(call)
+                if self.grads and torch.is_tensor(out[0]) and out[0].requires_grad:
+                    out[0].register_hook(lambda g, call=call: call.__setitem__("grad_out", g.detach().clone()))
         self._h = torch.nn.modules.module.register_module_forward_hook(hook, with_kwargs=True)
         return self
 

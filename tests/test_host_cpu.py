@@ -225,6 +225,72 @@ def test_view_parallel_loss_allreduce_world2_gloo(oracle):
     assert abs(sum(l for _, _, l, _ in res) - serial) <= 1e-5 * abs(serial) + 1e-9
 
 
+def _job8_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), WG_DIST_BACKEND="gloo")
+    for p in (ROOT, os.path.join(ROOT, "wild-gaussians_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import time
+    import wg_viewparallel as VP
+    before = sorted(os.sched_getaffinity(0))
+    r, lr, w = VP.init()
+    after = sorted(os.sched_getaffinity(0))
+    cam = VP.view_cameras(w, 64, 48)[r]          # bench.py: one camera per rank, rank 0 = the base camera
+    own = [0.0]
+    t = VP.timed_region(lambda: time.sleep(0.002 * (1 + (r == 5))), 5, None, own)   # rank 5 is the slow one
+    seen = VP.gather_over_ranks([float(r), float(lr), 1000.0 * own[0] / 5], None)
+    job = VP.job_fields(w, 5, t, seen, baseline_iters_per_s=400.0)
+    ls = VP.LossStream()
+    ls.submit(torch.full((3, 2, 2), float(r)), torch.ones(12))
+    q.put((r, job, float(cam["viewmatrix"][0, 2]), ls.last(), before, after))
+    torch.distributed.destroy_process_group()
+
+
+def test_bench_job_flow_with_eight_ranks_gloo():
+    """The 8-rank flow the driver's SCALE run executes, on CPU over gloo: rendezvous, one camera per rank, per-rank
+    core slices, barrier-bracketed timing with the MAX over ranks, the all-gather of who took part, the whole-job value and the
+    efficiency figure, the loss all-reduce.  Only the rasterizer call and the collective's transport differ on the GPU node."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 8
+    procs = [ctx.Process(target=_job8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    yaws = [x[2] for x in res]
+    assert len({round(y, 6) for y in yaws}) == 8 and abs(yaws[0]) < 1e-9      # eight different cameras, rank 0 unrotated
+    for r, job, _yaw, loss, before, after in res:
+        assert job["n_gpus"] == 8 and job["rccl_ranks_seen"] == list(range(8)) and set(job["per_rank_ms_per_step"]) == {str(k) for k in range(8)}
+        assert job["ms_per_step"] >= 4.0                                       # the slowest rank (4 ms steps) sets the job's time ...
+        assert max(job["per_rank_ms_per_step"].values()) <= job["ms_per_step"] * 1.001 and job["per_rank_ms_per_step"]["0"] < 3.9
+        assert abs(job["value"] - 8 * 1000.0 / job["ms_per_step"]) <= 1e-2 * job["value"]   # ... and all eight ranks' steps count
+        eff = job["scaling_efficiency"]
+        assert abs(eff["efficiency"] - job["value"] / (8 * 400.0)) < 1e-3
+        assert abs(loss - 12.0 * sum(range(8))) < 1e-4                         # SUM all-reduce of <image, cotangent> over the 8 ranks
+        if len(before) >= 8:                                                    # every rank on its own slice of the allowed cores
+            per = len(before) // 8
+            assert after == before[r * per:(r + 1) * per], (r, before, after)
+
+
+def test_rank_without_a_device_of_its_own_is_refused():
+    import wg_viewparallel as VP
+    assert VP.device_for_rank(3, 8, "nccl") == 3 and VP.device_for_rank(0, 1, None) == 0
+    with pytest.raises(RuntimeError, match="no GPU of its own"):
+        VP.device_for_rank(1, 1, "nccl")
+    with pytest.raises(RuntimeError, match="no GPU of its own"):
+        VP.device_for_rank(9, 8, None)
+    assert VP.device_for_rank(9, 8, "gloo") == 1                                # explicit host-side transport: ranks may share
+    assert VP.cores_for_rank(2, 8, list(range(256))) == list(range(64, 96)) and VP.cores_for_rank(0, 8, [3, 1]) == [1, 3]
+    with pytest.raises(RuntimeError, match="expected ranks"):
+        VP.job_fields(2, 10, 1.0, [[0.0, 0.0, 1.0], [0.0, 0.0, 1.0]])
+
+
 def test_bench_self_launch_builds_the_launcher_command(monkeypatch):
     """`python bench.py --gpus N` without WORLD_SIZE re-executes itself under torch.distributed.run with N ranks on 127.0.0.1."""
     sys.path.insert(0, ROOT)
@@ -243,6 +309,17 @@ def test_bench_self_launch_builds_the_launcher_command(monkeypatch):
     assert a[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in a and a[a.index("--nproc-per-node") + 1] == "4"
     assert a[a.index("--master-addr") + 1] == "127.0.0.1" and a[-4:] == ["--gpus", "4", "--steps", "7"]
     assert a[-5] == os.path.join(ROOT, "bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert 1 <= int(seen["env"]["OMP_NUM_THREADS"]) <= 8
+    # more ranks than visible devices: refused unless the host-side transport is asked for by name
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.delenv("WG_DIST_BACKEND", raising=False)
+    with pytest.raises(SystemExit, match="one process per GPU"):
+        bench.self_launch(4)
+    monkeypatch.setenv("WG_DIST_BACKEND", "gloo")
+    with pytest.raises(SystemExit) as ex:
+        bench.self_launch(4)
+    assert ex.value.code == 0 and seen["env"]["WG_DIST_BACKEND"] == "gloo"
 
 
 def test_bench_byte_model():

@@ -853,8 +853,14 @@ def test_bench_flow_with_two_ranks(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    # the driver's own form: no launcher, bench.py starts its ranks itself (and, finding one device for two ranks, picks gloo)
+    # the driver's own form: no launcher, bench.py starts its ranks itself.  Two ranks on ONE device must be asked for explicitly
+    # (WG_DIST_BACKEND=gloo); without it bench.py refuses, which is checked first
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "WG_DIST_BACKEND")}
+    if torch.cuda.device_count() < 2:
+        refused = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                                 capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert refused.returncode != 0 and "one process per GPU" in (refused.stderr + refused.stdout)
+        env["WG_DIST_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
                         "--gaussians", "200000", "--width", "640", "--height", "360"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
@@ -994,6 +1000,25 @@ def test_deterministic_backward_mode_is_bit_reproducible(oracle, record_option):
     o = oracle.run_scene(cloud, cam, sh_degree=2, cotangent=cot)
     for k, e in compare_grads(a["grads"], o["grads"]).items():
         assert e <= 1e-3, (k, e)
+
+
+def test_deterministic_backward_without_any_instance_gives_zeros(record_option):
+    """deterministic_backward = 1 with grad_record = 0 and NO instance rendered (every Gaussian behind the camera).  The
+    binding passes no dL_dconic and uninitialised accumulation targets on the strength of the options alone, so the library must take
+    the record path on the options alone too: all gradients exactly zero, no fault."""
+    _C = record_option
+    W, H, P = 320, 200, 5000
+    cam, cot = S.make_camera(W, H), S.make_cotangent(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=1, seed=4)
+    cloud["means3D"] = cloud["means3D"].copy()
+    cloud["means3D"][:, 2] = -np.abs(cloud["means3D"][:, 2]) - 1.0   # behind the near plane: culled (auxiliary.h:154)
+    for rec, det in ((0, 1), (1, 1), (0, 0), (1, 0)):
+        _C.set_option("grad_record", rec)
+        _C.set_option("deterministic_backward", det)
+        h = run_hip(cloud, cam, sh_degree=1, cotangent=cot)
+        assert not h["radii"].any() and not h["color"].any()
+        for k, g in h["grads"].items():
+            assert np.isfinite(g).all() and not g.any(), (rec, det, k)
 
 
 def test_backward_run_to_run_spread_is_at_rounding_level():

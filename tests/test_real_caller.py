@@ -180,3 +180,97 @@ def test_runtime_optins_leave_the_real_step_where_it_was():
     assert np.isfinite([o["loss"] for o in b]).all() and len(set(counts)) > 2
     for p in (wg_b.model.xyz, wg_b.model.scales, wg_b.model.rotations, wg_b.model.opacities, wg_b.model.features_dc):
         assert torch.isfinite(p).all() and p.shape[0] == counts[-1]
+
+
+@pytest.mark.gpu
+@needs_staged
+def test_real_step_backward_replayed_through_the_reference_build(trained):
+    """VERDICT r2 missing item 3, first half: one REAL `train_iteration` (method.py:1880-2024) with every rasterizer call recorded --
+    inputs, settings and the dL/d(image) autograd hands it -- and each call's backward pass replayed, on those very tensors, through
+    this repo's operator and through oracle/_ref (the reference's own kernels, no-contraction build): every gradient <= 1e-3."""
+    from oracle.ref_hip import ref_hip
+    if not ref_hip.available("nofma"):
+        pytest.skip("oracle/_ref not built")
+    import ref_backed
+    from diff_gaussian_rasterization import GaussianRasterizer
+    m, wg, _ = trained
+    with harness.RasterizerTap(m, grads=True) as tap:
+        wg.train_iteration(wg.step)
+    assert len(tap.calls) == 2 and all("grad_out" in c for c in tap.calls)   # raw + toned colours over the same geometry
+    for call in tap.calls:
+        kw, rs, g_out = call["kwargs"], call["settings"], call["grad_out"]
+        assert float(g_out.abs().max()) > 0
+        ins = {k: (v.clone().requires_grad_(True) if torch.is_tensor(v) else v) for k, v in kw.items()}
+        color, radii, _acc = GaussianRasterizer(rs)(**ins)
+        color.backward(g_out)
+        ref_color, ref_radii, ref_g = ref_backed.replay(kw, rs, g_out)
+        assert torch.equal(radii, ref_radii)
+        assert int(((color - ref_color).abs() > 1e-4).any(dim=0).sum()) <= 6
+        names = dict(means3D="means3D", means2D="means2D", opacities="opacities", colors_precomp="colors_precomp", scales="scales", rotations="rotations")
+        for k_in, k_ref in names.items():
+            g, r = ins[k_in].grad, ref_g[k_ref]
+            rel = float((g - r.view_as(g)).abs().max() / (r.abs().max() + 1e-12))
+            assert rel <= 1e-3, (k_in, rel)
+
+
+def _trajectory(backend, steps, ov, seed=7):
+    """Train the reference's real loop for `steps` iterations from one seed on `backend` ("product" | "reference"), then render the
+    three training views WITH THE PRODUCT (so that the numbers compare the trained models, not the renderers)."""
+    import random
+    random.seed(seed), np.random.seed(seed), torch.manual_seed(seed)
+    m, wg = harness.make_method(100_000, 640, 480, n_cams=3, overrides=ov)
+    ours = m.GaussianRasterizer
+    if backend == "reference":
+        import ref_backed
+        m.GaussianRasterizer = ref_backed.make("nofma")
+    try:
+        random.seed(11)
+        outs = [wg.train_iteration(i) for i in range(steps)]
+    finally:
+        m.GaussianRasterizer = ours
+    ds, _ = harness.make_dataset(100_000, 640, 480, n_cams=3)
+    psnr = []
+    for k, cam in enumerate(wg.train_cameras):
+        img = wg.render(cam)["color"].astype(np.float64)
+        gt = ds["images"][k].astype(np.float64) / 255.0
+        psnr.append(float(-10.0 * np.log10(np.mean((img - gt) ** 2))))
+    return dict(loss=float(np.mean([o["loss"] for o in outs[-15:]])), psnr=psnr, num_gaussians=int(outs[-1]["num_gaussians"]),
+                counts=sorted({int(o["num_gaussians"]) for o in outs}), first_loss=float(np.mean([o["loss"] for o in outs[:15]])))
+
+
+@pytest.mark.gpu
+@needs_staged
+def test_training_trajectory_on_the_product_and_on_the_reference_kernels():
+    """VERDICT r2 missing item 3, second half.  The hand-written backward pass is inexact by design (backward.cu:536-603) and the
+    densification thresholds (method.py:1420-1468) turn gradient differences into different models, so operator-level 1e-3 does not
+    by itself bound what hundreds of Adam steps do.  Here the same seeded 100 k-Gaussian model takes 300 real `train_iteration`s --
+    through clone / split / prune and an opacity reset -- twice on this repo's operator and once on the reference's own kernels
+    (tests/real_caller/ref_backed.py over oracle/_ref).  Final loss, PSNR of the three training views and the number of Gaussians
+    on the reference kernels must lie within the spread of the two product runs (x 2, with small floors: float atomics make any
+    two runs of either implementation differ)."""
+    import json
+    from oracle.ref_hip import ref_hip
+    if not ref_hip.available("nofma"):
+        pytest.skip("oracle/_ref not built")
+    ov = {"densify_from_iter": 30, "densification_interval": 40, "opacity_reset_interval": 120, "densify_until_iter": 260,
+          "densify_grad_threshold": 0.00002}
+    a1 = _trajectory("product", 300, ov)
+    a2 = _trajectory("product", 300, ov)
+    b = _trajectory("reference", 300, ov)
+    report = dict(product_1=a1, product_2=a2, reference_kernels=b)
+    print(json.dumps(report))
+    out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "trajectory_parity.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    for r in (a1, a2, b):
+        assert np.isfinite(r["loss"]) and r["loss"] < 0.9 * r["first_loss"] and len(r["counts"]) > 2, r
+    mid = lambda k: 0.5 * (a1[k] + a2[k])  # noqa: E731
+    tol_loss = max(2 * abs(a1["loss"] - a2["loss"]), 0.03 * mid("loss"))
+    assert abs(b["loss"] - mid("loss")) <= tol_loss, (b["loss"], a1["loss"], a2["loss"])
+    tol_n = max(2 * abs(a1["num_gaussians"] - a2["num_gaussians"]), 0.02 * mid("num_gaussians"))
+    assert abs(b["num_gaussians"] - mid("num_gaussians")) <= tol_n, (b["num_gaussians"], a1["num_gaussians"], a2["num_gaussians"])
+    for k in range(3):
+        pa = 0.5 * (a1["psnr"][k] + a2["psnr"][k])
+        tol = max(2 * abs(a1["psnr"][k] - a2["psnr"][k]), 0.3)
+        assert abs(b["psnr"][k] - pa) <= tol, (k, b["psnr"][k], a1["psnr"][k], a2["psnr"][k])

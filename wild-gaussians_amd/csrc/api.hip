@@ -460,14 +460,24 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     wg::ImageState img = wg::ImageState::fromChunk(image_buffer, (size_t)width * height, (size_t)gx * gy);
     if (radii == nullptr) radii = geom.radii;  // rasterizer_impl.cu:381-384
 
-    // grad_record (default): the per-tile pass accumulates into one 64-byte record per Gaussian inside the geometry buffer, cleared
+    // grad_record (default): the per-tile pass accumulates into one 48-byte record per Gaussian (wg_common.h: GRAD_REC_FLOATS) inside the geometry buffer, cleared
     // here; the per-Gaussian kernel then WRITES the four arrays (they need no clearing by the caller).  Off: the arrays are the
     // accumulation targets and must arrive zeroed, as the reference demands of its caller (rasterize_points.cu:157-165).
     // deterministic_backward: per-instance slots (stream-ordered scratch of 40 B per tile instance, cleared) + an ordered
     // per-Gaussian sum instead of float atomics; needs the exclusive prefix of tiles_touched, which the LDS binning path never made
+    // The record decision follows the OPTIONS alone (it is what the NULL checks above and the binding's allocation key on); only the
+    // slot scratch, its scan and the ordered sum need instances to exist.  With nothing rendered the cleared record gives zeros.
     const bool det = opt.deterministic_backward != 0 && R > 0;
-    const bool record = g_grad_record != 0 || det;
-    float* det_slots = nullptr;
+    const bool record = g_grad_record != 0 || opt.deterministic_backward != 0;
+    // stream-ordered scratch of the deterministic mode, released on every way out of this function
+    struct DetSlots {
+        float* p = nullptr;
+        hipStream_t s;
+        explicit DetSlots(hipStream_t st) : s(st) {}
+        ~DetSlots() { if (p) (void)hipFreeAsync(p, s); }
+        hipError_t release() { float* q = p; p = nullptr; return q ? hipFreeAsync(q, s) : hipSuccess; }
+    } det_guard(stream);
+    float*& det_slots = det_guard.p;
     if (det) {
         StageScope scope_(WG_STAGE_RENDER_BACKWARD, stream);
         hipError_t e = wg::run_scan(geom, P, stream);
@@ -499,8 +509,8 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     WG_STAGE(WG_STAGE_PREPROCESS_BACKWARD, wg::launch_preprocess_backward(bp, device_tone(tone), geom, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                             dL_dscale, dL_drot, record, stream),
              "preprocess_backward");
-    if (det_slots) {
-        hipError_t e = hipFreeAsync(det_slots, stream);
+    {
+        hipError_t e = det_guard.release();
         if (e != hipSuccess) return hip_fail(e, "deterministic backward scratch release");
     }
     return WG_OK;

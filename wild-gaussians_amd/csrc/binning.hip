@@ -36,8 +36,9 @@ size_t query_sort_temp_bytes(size_t R) {
     return bytes;
 }
 
-// chunk-local indices are 16-bit: lists can exist up to P = 65536 * BIN_CHUNKS (and are wanted from Options::band_list_min_p on)
-bool GeometryState::band_lists_possible(size_t P) { return (P + BIN_CHUNKS - 1) / BIN_CHUNKS <= 65536; }
+// chunk-local indices are 16-bit, and the near / far split packs (total << 16 | near) per (chunk, tile) histogram word: a chunk must
+// hold FEWER than 65536 Gaussians (65536 of them on one tile would carry the near half into the total half), i.e. P <= 65535 * BIN_CHUNKS
+bool GeometryState::band_lists_possible(size_t P) { return (P + BIN_CHUNKS - 1) / BIN_CHUNKS <= 65535; }
 
 GeometryState GeometryState::fromChunk(char*& chunk, size_t P, bool lists) {
     GeometryState g;

@@ -31,7 +31,7 @@ struct GeometryState {
     uint32_t* point_offsets;
     uint16_t* band_list;  // large P only (g_band_list_min_p): [BIN_CHUNKS][8][chunk size] chunk-local indices of the Gaussians touching
     uint32_t* band_cnt;   // each XCD band of tiles, and their counts [BIN_CHUNKS][8]; the candidates of both scatter kernels
-    float* grad_rec;      // backward only: one 64-byte gradient record per Gaussian (GRAD_REC_*), cleared at the start of every backward
+    float* grad_rec;      // backward only: one 48-byte gradient record per Gaussian (GRAD_REC_*), cleared at the start of every backward
     char* scan_temp;
     size_t scan_temp_bytes;
     // band_lists: whether the two band-list arrays exist.  They are carved LAST, so that everything the backward pass and the
@@ -201,8 +201,8 @@ struct Options {
     int depth_codes = 1;              // 0 / 1 / 8..12: off (as for P > 2^24) / automatic width / forced width (tests)
     int grad_record = 1;              // 0: the per-tile backward accumulates into the four arrays themselves (A/B)
     int deterministic_backward = 0;   // 1: per-instance slots + an ordered per-Gaussian sum instead of float atomics (bit-reproducible)
-    int near_split = -1;              // near / far split of dense frames: -1 automatic (P >= band_list_min_p and >= 1500 instances per
-                                      // tile) / 0 off / 1 whenever possible (tests)
+    int near_split = -1;              // near / far split of dense frames: -1 automatic (P >= band_list_min_p or a dense previous frame, and >= SPLIT_DENSE_AVG =
+                                      // 1100 instances per tile) / 0 off / 1 whenever possible (tests)
     int near_per_tile = 0;            // aimed near instances per tile; 0 = 1.1 x lazy.target
     int box_count = -1;               // tile counting through a difference grid: -1 automatic (with the split's "large or dense" rule) / 0 / 1
     bool force_global_sort = false;   // exercise the fallback binning path

@@ -19,20 +19,60 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def device_for_rank(local_rank: int, device_count: int, backend: str | None) -> int:
+    """One process per GPU means one GPU per process: a local rank without a device of its own is an ERROR (RCCL refuses two ranks on
+    one device, and silently wrapping around would report a 'scaling' number measured on shared hardware) -- unless the job was
+    EXPLICITLY put on the host-side transport (WG_DIST_BACKEND=gloo / backend="gloo": the 1-GPU test box exercising the N > 1 flow),
+    where ranks share devices round-robin."""
+    if device_count <= 0:
+        raise RuntimeError("no HIP device visible")
+    if local_rank < device_count:
+        return local_rank
+    if backend == "gloo":
+        return local_rank % device_count
+    raise RuntimeError(f"local rank {local_rank} has no GPU of its own: {device_count} device(s) visible.  Launch at most one rank per "
+                       f"visible GPU, or set WG_DIST_BACKEND=gloo to let ranks share devices over the host-side transport (tests only)")
+
+
+def cores_for_rank(local_rank: int, local_world: int, cores: List[int]) -> List[int]:
+    """The host cores local rank r of `local_world` may run on: an equal, contiguous slice of the allowed set (every rank has a thread
+    that polls the rasterizer's mailbox once per forward pass; eight of them must not share cores).  Fewer cores than ranks: all."""
+    cores = sorted(cores)
+    per = len(cores) // max(local_world, 1)
+    if per < 1:
+        return cores
+    return cores[local_rank * per:(local_rank + 1) * per]
+
+
+def pin_rank(local_rank: int, local_world: int) -> List[int]:
+    """Apply cores_for_rank to this process (WG_NO_AFFINITY=1 leaves the affinity alone) and size the OpenMP / torch intra-op pools
+    to it.  Returns the core list in force."""
+    if not hasattr(os, "sched_getaffinity"):
+        return []
+    allowed = sorted(os.sched_getaffinity(0))
+    if local_world <= 1 or os.environ.get("WG_NO_AFFINITY") == "1":
+        return allowed
+    mine = cores_for_rank(local_rank, local_world, allowed)
+    try:
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), int(os.environ.get("OMP_NUM_THREADS", len(mine))))))
+    except OSError:
+        return allowed
+    return mine
+
+
 def init(backend: str | None = None) -> tuple[int, int, int]:
     rank, local_rank, world = env_world()
+    if backend is None:  # WG_DIST_BACKEND=gloo: exercise the N > 1 flow of bench.py where RCCL cannot run (ranks sharing one GPU)
+        backend = os.environ.get("WG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        local_rank = device_for_rank(local_rank, torch.cuda.device_count(), backend if world > 1 else "gloo")
+        torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:  # WG_DIST_BACKEND=gloo: exercise the N > 1 flow of bench.py where RCCL cannot run (ranks sharing one GPU)
-            backend = os.environ.get("WG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if torch.cuda.is_available():
-            local_rank %= torch.cuda.device_count()
-            torch.cuda.set_device(local_rank)
+        pin_rank(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    elif torch.cuda.is_available():
-        local_rank %= torch.cuda.device_count()
-        torch.cuda.set_device(local_rank)
     return rank, local_rank, world
 
 
@@ -131,3 +171,37 @@ def gather_over_ranks(values, device):
 def backend_name() -> str:
     """"nccl" is RCCL on ROCm; "none" for a single process."""
     return dist.get_backend() if dist.is_available() and dist.is_initialized() else "none"
+
+
+def timed_region(fn, steps: int, device, keep=None) -> float:
+    """bench.py's timing contract: barrier + device synchronize on both sides of exactly `steps` calls of fn, MAX over ranks.
+    keep (a one-element list) receives this rank's own time, taken before it waits for the others."""
+    import time
+    sync = (lambda: torch.cuda.synchronize(device)) if torch.cuda.is_available() and device is not None and torch.device(device).type == "cuda" else (lambda: None)
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    if keep is not None:
+        keep[0] = time.perf_counter() - t0
+    barrier()
+    return max_over_ranks(time.perf_counter() - t0, device)
+
+
+def job_fields(world: int, steps: int, t_region: float, ranks_seen, baseline_iters_per_s: float | None = None) -> dict:
+    """The whole-job part of bench.py's JSON line from the timed region and the all-gathered (rank, device, own ms/step) rows.
+    `value` = iterations of ALL ranks per second of the slowest rank's region (weak scaling: one view per GPU).  With the 1-GPU
+    rate supplied the line also states efficiency = T(N) / (N T(1)) -- the driver computes its own from the per-N lines."""
+    rows = sorted(ranks_seen, key=lambda r: r[0])
+    out = {"value": round(world * steps / t_region, 3), "n_gpus": world, "ms_per_step": round(1000.0 * t_region / steps, 4),
+           "rccl_ranks_seen": [int(r[0]) for r in rows], "per_rank_ms_per_step": {str(int(r[0])): round(r[2], 4) for r in rows},
+           "per_rank_device": {str(int(r[0])): int(r[1]) for r in rows}}
+    if len(rows) != world or out["rccl_ranks_seen"] != list(range(world)):
+        raise RuntimeError(f"expected ranks 0..{world - 1}, saw {out['rccl_ranks_seen']}")
+    if baseline_iters_per_s:
+        out["scaling_efficiency"] = {"baseline_iters_per_s_1gpu": baseline_iters_per_s,
+                                     "efficiency": round(out["value"] / (world * baseline_iters_per_s), 4),
+                                     "definition": "T(N) / (N * T(1)), T = whole-job iterations per second"}
+    return out

@@ -26,7 +26,14 @@ def _f(t):
     return t if t is None or t.numel() == 0 else t.detach().float().contiguous()
 
 
+def _cam(rs):
+    """The settings' tensors as contiguous float32 -- kept alive by the caller for the duration of the native call (a `.T` view, as
+    the caller's viewmatrix is, becomes a temporary whose block the next temporary would reuse)."""
+    return dict(bg=_f(rs.bg), view=_f(rs.viewmatrix), proj=_f(rs.projmatrix), campos=_f(rs.campos), so=_f(rs.subpixel_offset))
+
+
 def _forward(lib, a, rs, want_state=True):
+    c = _cam(rs)
     P = a["means3D"].shape[0]
     H, W = int(rs.image_height), int(rs.image_width)
     dev = a["means3D"].device
@@ -35,16 +42,18 @@ def _forward(lib, a, rs, want_state=True):
     radii = torch.zeros((P,), dtype=torch.int32, device=dev)
     final_T = torch.zeros((H * W,), device=dev) if want_state else None
     n_contrib = torch.zeros((H * W,), dtype=torch.int32, device=dev) if want_state else None
-    R = lib.refhip_forward(P, int(rs.sh_degree), M, _dp(_f(rs.bg)), W, H, _dp(a["means3D"]), _dp(a["sh"]), _dp(a["colors_precomp"]),
+    R = lib.refhip_forward(P, int(rs.sh_degree), M, _dp(c["bg"]), W, H, _dp(a["means3D"]), _dp(a["sh"]), _dp(a["colors_precomp"]),
                            _dp(a["opacities"]), _dp(a["scales"]), float(rs.scale_modifier), _dp(a["rotations"]), _dp(a["cov3Ds_precomp"]),
-                           _dp(_f(rs.viewmatrix)), _dp(_f(rs.projmatrix)), _dp(_f(rs.campos)), float(rs.tanfovx), float(rs.tanfovy),
-                           float(rs.kernel_size), _dp(_f(rs.subpixel_offset)), 0, _dp(color), _dp(radii), _dp(final_T), _dp(n_contrib), 0)
+                           _dp(c["view"]), _dp(c["proj"]), _dp(c["campos"]), float(rs.tanfovx), float(rs.tanfovy),
+                           float(rs.kernel_size), _dp(c["so"]), 0, _dp(color), _dp(radii), _dp(final_T), _dp(n_contrib), 0)
     if R < 0:
         raise MemoryError("reference build: scratch allocation failed")
     return R, color, radii, final_T
 
 
 def _backward(lib, a, rs, radii, grad_out):
+    c = _cam(rs)
+    grad_out = _f(grad_out)
     P = a["means3D"].shape[0]
     H, W = int(rs.image_height), int(rs.image_width)
     dev = a["means3D"].device
@@ -52,10 +61,10 @@ def _backward(lib, a, rs, radii, grad_out):
     z = lambda *s: torch.zeros(s, device=dev)  # noqa: E731
     g = dict(means2D=z(P, 3), conic=z(P, 2, 2), opacities=z(P, 1), colors_precomp=z(P, 3), means3D=z(P, 3), cov3Ds_precomp=z(P, 6),
              sh=z(P, max(M, 1), 3), scales=z(P, 3), rotations=z(P, 4))
-    lib.refhip_backward(P, int(rs.sh_degree), M, _dp(_f(rs.bg)), W, H, _dp(a["means3D"]), _dp(a["sh"]), _dp(a["colors_precomp"]), _dp(a["scales"]),
-                        float(rs.scale_modifier), _dp(a["rotations"]), _dp(a["cov3Ds_precomp"]), _dp(_f(rs.viewmatrix)), _dp(_f(rs.projmatrix)),
-                        _dp(_f(rs.campos)), float(rs.tanfovx), float(rs.tanfovy), float(rs.kernel_size), _dp(_f(rs.subpixel_offset)), _dp(radii),
-                        _dp(_f(grad_out)), _dp(g["means2D"]), _dp(g["conic"]), _dp(g["opacities"]), _dp(g["colors_precomp"]), _dp(g["means3D"]),
+    lib.refhip_backward(P, int(rs.sh_degree), M, _dp(c["bg"]), W, H, _dp(a["means3D"]), _dp(a["sh"]), _dp(a["colors_precomp"]), _dp(a["scales"]),
+                        float(rs.scale_modifier), _dp(a["rotations"]), _dp(a["cov3Ds_precomp"]), _dp(c["view"]), _dp(c["proj"]),
+                        _dp(c["campos"]), float(rs.tanfovx), float(rs.tanfovy), float(rs.kernel_size), _dp(c["so"]), _dp(radii),
+                        _dp(grad_out), _dp(g["means2D"]), _dp(g["conic"]), _dp(g["opacities"]), _dp(g["colors_precomp"]), _dp(g["means3D"]),
                         _dp(g["cov3Ds_precomp"]), _dp(g["sh"]), _dp(g["scales"]), _dp(g["rotations"]), 0)
     if M == 0:
         g["sh"] = torch.zeros((P, 0, 3), device=dev)

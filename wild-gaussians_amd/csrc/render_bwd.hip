@@ -24,6 +24,26 @@ namespace wg {
 
 constexpr int BATCH = 64;
 
+// A/B knobs of this kernel (wild-gaussians_amd/build.py: WG_BUILD_VARIANT / WG_EXTRA_FLAGS; results in EXPERIMENTS.md):
+//   WG_BWD_PK      the per-pair arithmetic on float PAIRS of one pixel -- (dx,dy), (xx,xy), (u,v) and the accumulator pairs
+//                  (acr,acg) (sx,sy) (sxx,sxy) (syy,sq) -- as v_pk_add/mul/fma_f32 with the shared multiplier broadcast by op_sel.
+//                  Packing WITHIN a pixel keeps the per-strip skip granularity (packing strip pairs lost it).  Same products, same
+//                  fused multiply-adds: every output is bit-identical to the scalar build.
+//   WG_BWD_ANYMASK "did any lane contribute to this instance" as an OR of the strips' lane masks in SGPRs instead of a per-lane flag
+//                  that hipcc turns back into a mask with v_cndmask + v_cmp (2 VALU per visited instance).
+//   WG_BWD_BANKMASK the two select levels of the butterfly as bank-masked DPP adds (2 instead of 3 VALU each).
+#ifndef WG_BWD_PK
+#define WG_BWD_PK 0
+#endif
+#ifndef WG_BWD_ANYMASK
+#define WG_BWD_ANYMASK 0
+#endif
+#ifndef WG_BWD_BANKMASK
+#define WG_BWD_BANKMASK 0
+#endif
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
@@ -58,6 +78,17 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
     const float w0 = pair_x32(v0, v1), w1 = pair_x32(v2, v3), w2 = pair_x32(v4, v5), w3 = pair_x32(v6, v7), w4 = pair_x32(v8, v9);
     // xor 16: five -> three;  u_m = w_{2m + bit4}, u2 = w4
     const float u0 = pair_x16(w0, w1), u1 = pair_x16(w2, w3), u2 = pair_x16(w4, w4);
+#if WG_BWD_BANKMASK
+    // xor 1: every lane takes u0's pair sum, then the odd lanes (banks 1, 3) are overwritten with u1's: a DPP operation only writes the
+    // lanes its bank mask enables.  (Spelled in asm: the intrinsic is a move; the s_nop covers the VALU-write -> DPP-read wait states.)
+    float x0 = u0 + dpp_f<0xB1>(u0);
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xa" : "+v"(x0) : "v"(u1));
+    const float x1 = u2 + dpp_f<0xB1>(u2);
+    // xor 2: likewise, lanes with bit 1 set (banks 2, 3) take x1's pair sum
+    float y = x0 + dpp_f<0x4E>(x0);
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xc" : "+v"(y) : "v"(x1));
+    (void)lane;
+#else
     // xor 1 (quad_perm [1,0,3,2]): x0 = u_{bit0}, x1 = u2
     const bool b0 = lane & 1;
     const float keep0 = b0 ? u1 : u0, send0 = b0 ? u0 : u1;
@@ -67,6 +98,7 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
     const bool b1 = lane & 2;
     const float keep1 = b1 ? x1 : x0, send1 = b1 ? x0 : x1;
     float y = keep1 + dpp_f<0x4E>(send1);
+#endif
     // lanes l, l+4, l+8, l+12 of each row: row_ror 4, row_ror 8
     y += dpp_f<0x124>(y);
     y += dpp_f<0x128>(y);
@@ -84,8 +116,16 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
 // into which the ten lanes STORE the wave-reduced sums; det_reduce_kernel then adds a Gaussian's slots in slot order into its
 // gradient record.  Same sums as the atomic path up to the order of a Gaussian's per-tile terms, which is now fixed: two runs
 // give bit-identical gradients.
+#ifndef WG_BWD_WAVES
+#define WG_BWD_WAVES 0
+#endif
+#if WG_BWD_WAVES
+#define WG_BWD_OCC __attribute__((amdgpu_waves_per_eu(WG_BWD_WAVES, WG_BWD_WAVES)))
+#else
+#define WG_BWD_OCC
+#endif
 template <bool RECORD, bool DET = false>
-__global__ void __launch_bounds__(64) render_backward_kernel(
+__global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
     int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_last,
@@ -123,6 +163,9 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     const float vscale = vidx == 3 ? ddelx_dx * INV_L : vidx == 4 ? ddely_dy * INV_L : vidx == 5 ? INV_L : (vidx >= 6 && vidx <= 8) ? -0.5f : 1.0f;
 
     float pfx[4], pfy[4], T[4], tfb[4], dLr[4], dLg[4], dLb[4], recd[4];
+#if WG_BWD_PK
+    f2 pf[4], dLrg[4];  // (pfx, pfy) and (dL_dred, dL_dgreen) of the lane's four pixels as register pairs
+#endif
     int last[4];
     StripBounds sb;
 #pragma unroll
@@ -144,6 +187,10 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
         pfy[s] = (float)py + off.y;
         tfb[s] = -T[s] * (bg0 * dLr[s] + bg1 * dLg[s] + bg2 * dLb[s]);  // -T_final * <bg, dL_dpixel>
         recd[s] = 0.f;
+#if WG_BWD_PK
+        pf[s] = f2{pfx[s], pfy[s]};
+        dLrg[s] = f2{dLr[s], dLg[s]};
+#endif
         const float inf = __builtin_huge_valf();
         sb.x0[s] = wave_min_uniform(inside ? pfx[s] : inf);
         sb.x1[s] = wave_max_uniform(inside ? pfx[s] : -inf);
@@ -165,8 +212,20 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
     // contributing lane (19 % of them) leaves them at zero
     // the ten sums live in five register PAIRS, so that clearing them after a reduction is five v_mov_b64 instead of ten v_mov_b32
     // (backward 0.4272 -> 0.4234 ms; the names below are the pairs' halves)
-    typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, p3 = {0.f, 0.f}, p4 = {0.f, 0.f};
+#if WG_BWD_PK
+    // pairs that share a multiplier: (acr, acg) += w (dLr, dLg);  (sx, sy) += q (u, v);  (sxx, sxy) += q (xx, xy);  (syy, sq) += q (yy, 1)
+#define acr p0.x
+#define acg p0.y
+#define acb p1.x
+#define sab p1.y
+#define sx p2.x
+#define sy p2.y
+#define sxx p3.x
+#define sxy p3.y
+#define syy p4.x
+#define sq p4.y
+#else
 #define acr p0.x
 #define acg p0.y
 #define acb p1.x
@@ -177,6 +236,7 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
 #define sxy p3.y
 #define syy p4.x
 #define sq p4.y
+#endif
 
     for (int hi = hi0; hi > 0; hi -= BATCH) {
         // lane l stages the instance at list position hi-1-l (back to front, backward.cu:517)
@@ -227,14 +287,66 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             //   dL_dmean2D.y = -o * 0.5H * sum(q v)           dL_dconic.xy = -0.5 o * sum(q dx dy)
             //   dL_dmean2D.z =  o * sum(|q| (0.5W |u| + 0.5H |v|))   dL_dconic.yy = -0.5 o * sum(q dy dy)
             //   dL_dopacity  = sum(q)
+#if WG_BWD_ANYMASK
+            uint64_t anym = 0ull;
+#else
             bool any = false;
+#endif
+#if WG_BWD_PK
+            const f2 mxy = {r0.x, r0.y}, gzw = {gb.z, gb.w};
+#endif
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 if (((reach[s] >> j) & 1ull) == 0ull) continue;  // wave-uniform
+#if WG_BWD_PK
+                // eval_alpha() on pairs: the same differences, products and fused multiply-adds, two per instruction
+                const f2 d = mxy - pf[s];                       // (dx, dy)
+                const f2 xq = f2{d.x, d.x} * d;                 // (dx dx, dx dy)
+                const float yy = d.y * d.y;
+                const float pw2 = sc.ca * xq.x + sc.cb * xq.y + sc.cc * yy;
+                const float G = __builtin_amdgcn_exp2f(pw2);
+                const float alpha = fminf(0.99f, sc.o * G);
+                const bool pass = pw2 <= 0.0f && alpha >= (1.0f / 255.0f);
+                const bool contrib = pos < last[s] && pass;
+#if WG_BWD_ANYMASK
+                anym |= __builtin_amdgcn_ballot_w64(contrib);   // (HIP's __ballot goes through a zero-extended compare: v_cndmask + v_cmp)
+#endif
+                if (contrib) {
+#if !WG_BWD_ANYMASK
+                    any = true;
+#endif
+                    const float a = alpha;
+                    const float inv = __builtin_amdgcn_rcpf(1.0f - a);
+                    const float Tn = T[s] * inv;
+                    T[s] = Tn;
+                    const float w = a * Tn;
+                    p0 += f2{w, w} * dLrg[s];
+                    acb += w * dLb[s];
+                    const float cd = colr * dLrg[s].x + colg * dLrg[s].y + colb * dLb[s];
+                    const float diff = cd - recd[s];
+                    recd[s] += a * diff;
+                    const float dLda = diff * Tn + tfb[s] * inv;
+                    const float q = G * dLda;
+                    const f2 cross = f2{r0.w, r0.w} * f2{d.y, d.x};   // cb (dy, dx)
+                    const f2 uv = gzw * d + cross;                    // (2ca dx + cb dy, 2cc dy + cb dx), the scalar build's roundings
+                    const f2 qq = {q, q};
+                    p2 += qq * uv;
+                    sab += fabsf(q) * (ddelx_dx * fabsf(uv.x) + ddely_dy * fabsf(uv.y));
+                    p3 += qq * xq;
+                    p4 += qq * f2{yy, 1.0f};
+                }
+            }
+#else
                 PairEval e;
                 const bool pass = eval_alpha(sc, pfx[s], pfy[s], e);
+#if WG_BWD_ANYMASK
+                const bool contrib = pos < last[s] && pass;
+                anym |= __builtin_amdgcn_ballot_w64(contrib);   // (HIP's __ballot goes through a zero-extended compare: v_cndmask + v_cmp)
+                if (contrib) {
+#else
                 if (pos < last[s] && pass) {
                     any = true;
+#endif
                     const float a = e.alpha;
                     const float inv = __builtin_amdgcn_rcpf(1.0f - a);
                     const float Tn = T[s] * inv;  // T / (1 - alpha), backward.cu:548
@@ -262,7 +374,12 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
                     syy += q * e.yy;
                 }
             }
+#endif
+#if WG_BWD_ANYMASK
+            if (anym == 0ull) continue;
+#else
             if (__ballot(any) == 0ull) continue;
+#endif
             const float total = butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
             if (DET) {
                 if (issue) {

@@ -112,6 +112,41 @@ def load_pmc(workload_key: str):
     return {}, why
 
 
+def governing_roofline(dom: str, d: dict, pmc_row, launch_ms: float, survey_bytes: float, design_b: float) -> dict:
+    """The bench line's `roofline` object for the dominant kernel `dom`: d = its stage_rooflines row, pmc_row = its PMC record
+    (hbm_bytes, SQ_INSTS_VALU) or None when no PMC pass is stamped to the running sources."""
+    by_traffic = "hbm_traffic_GBps" in d
+    s8d = d["reference_scheme_equiv_GBps"]
+    # HBM view of the kernel, three byte counts over the same HIP-event time.  SURVEY 8(d)'s algorithmic bytes are the contract's
+    # definition of `achieved`; they are quoted as a fraction only where they are one (the reference-scheme count exceeds what
+    # this design moves for the binning stages).
+    hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "by_survey_8d_bytes": {"bytes_per_launch": survey_bytes, "achieved": s8d,
+                                  "frac": round(s8d / HBM_PEAK_GBS, 4) if s8d <= HBM_PEAK_GBS else None},
+           "by_design_bytes": {"bytes_per_launch": design_b, "achieved": d["design_GBps"], "frac": d["frac_of_peak_by_design_bytes"]},
+           "by_pmc_traffic": ({"bytes_per_launch": pmc_row["hbm_bytes"], "achieved": d["hbm_traffic_GBps"],
+                               "frac": d["frac_of_peak_by_traffic"]} if by_traffic else None)}
+    hbm_frac = max(v["frac"] or 0.0 for v in hbm.values() if isinstance(v, dict))
+    valu_frac = d.get("frac_of_valu_issue_peak")
+    # The two render kernels never touch most of their bytes in HBM (a tile band's records stay in its XCD's L2) and issue ~140
+    # vector instructions per visited (tile, Gaussian) instance: what bounds them is VALU issue (SURVEY 8d's secondary ceiling:
+    # 256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave64 instruction).  A kernel is labelled by the ceiling it is closest to; the
+    # VALU count needs a PMC pass stamped to these sources, without one the label falls back to HBM by SURVEY 8(d) bytes.
+    if valu_frac is not None and valu_frac >= hbm_frac:
+        r = {"bound": "valu_issue", "kernel": dom, "achieved": round(valu_frac * VALU_ISSUE_PEAK_G, 1), "peak": round(VALU_ISSUE_PEAK_G, 1),
+             "unit": "G wave-instr/s", "frac": valu_frac, "wave_instructions_per_launch": pmc_row["SQ_INSTS_VALU"],
+             "note": "SQ_INSTS_VALU (PMC pass, stamped to these kernel sources) / this run's HIP-event time; a few instruction kinds "
+                     "(readlane, DPP moves) take fewer than 4 cycles, so a kernel at the ceiling can read above 1"}
+    else:
+        basis = "by_survey_8d_bytes" if hbm["by_survey_8d_bytes"]["frac"] is not None else ("by_pmc_traffic" if by_traffic else "by_design_bytes")
+        r = {"bound": "hbm", "kernel": dom, "achieved": hbm[basis]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": hbm[basis]["frac"], "frac_basis": basis}
+    r.update({"traffic": pmc_row["hbm_bytes"] if by_traffic else None, "hbm": hbm, "avg_launch_ms": round(launch_ms, 4),
+              "hbm_target_note": "north_star's >= 0.60 of 8 TB/s is met by the two streaming per-Gaussian kernels (stage_rooflines) "
+                                 "and NOT by the render kernels, which VALU issue governs"})
+    return r
+
+
 def self_launch(n: int):
     """`python bench.py --gpus N` without a launcher: replace this process by `torch.distributed.run` with N ranks of the same
     command line (one process per GPU, rendezvous on 127.0.0.1, a free port).  With fewer than N devices visible (the 1-GPU test
@@ -342,28 +377,8 @@ def main():
         out["stage_rooflines"] = rows
         out["stage_rooflines_note"] = pmc_note
 
-        d = rows[dom]
-        by_traffic = "hbm_traffic_GBps" in d
-        ach = d["hbm_traffic_GBps"] if by_traffic else d["design_GBps"]
-        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4),
-                           "frac_basis": "pmc hbm traffic / event time" if by_traffic else "design bytes / event time (no valid PMC pass for these sources)",
-                           "traffic": pmc[dom]["hbm_bytes"] if by_traffic else None,
-                           "design_bytes_per_launch": design_bytes(dom, walked=walked, **kw),
-                           "frac_by_design_bytes": d["frac_of_peak_by_design_bytes"],
-                           "survey_8d_bytes_per_launch": algorithmic_bytes(dom, **kw),
-                           "survey_8d_equiv_GBps": d["reference_scheme_equiv_GBps"],
-                           # SURVEY 8(d)'s own definition of the achieved rate; quoted as a fraction only where it is one (the
-                           # reference-scheme byte count exceeds what this design moves for the binning stages)
-                           "frac_by_survey_8d_bytes": (round(d["reference_scheme_equiv_GBps"] / HBM_PEAK_GBS, 4)
-                                                       if d["reference_scheme_equiv_GBps"] <= HBM_PEAK_GBS else None),
-                           "avg_launch_ms": round(per_stage[dom], 4)}
-        if "frac_of_valu_issue_peak" in d:
-            # what actually bounds this kernel: VALU issue.  SQ_INSTS_VALU per launch (PMC pass) / this run's time.
-            out["roofline"]["valu_issue"] = {"wave_instructions_per_launch": pmc[dom]["SQ_INSTS_VALU"], "peak": round(VALU_ISSUE_PEAK_G, 1),
-                                             "unit": "G wave-instr/s", "frac": d["frac_of_valu_issue_peak"],
-                                             "note": "SQ_INSTS_VALU counts every VALU issue; a few kinds (readlane, DPP moves) take fewer than 4 "
-                                                     "cycles, so a kernel at the ceiling can read above 1"}
+        out["roofline"] = governing_roofline(dom, rows[dom], pmc.get(dom), per_stage[dom], algorithmic_bytes(dom, **kw),
+                                             design_bytes(dom, walked=walked, **kw))
         # whole forward / backward pipelines against the same roofline, for context
         fwd_names = ["preprocess", "scan", "duplicate_keys", "sort", "tile_ranges", "render_forward"]
         bwd_names = ["render_backward", "preprocess_backward"]

@@ -338,6 +338,18 @@ def test_bench_byte_model():
     csrc = os.path.join(ROOT, "wild-gaussians_amd", "csrc")
     files = {f for f in os.listdir(csrc) if f.endswith((".hip", ".h"))}
     assert files == set(bench.OPERATOR_SOURCES) | set(bench.OPT_IN_SOURCES), files ^ (set(bench.OPERATOR_SOURCES) | set(bench.OPT_IN_SOURCES))
+    # the roofline label follows the ceiling the kernel is closest to: VALU issue for the render kernels when a PMC pass says so,
+    # HBM by SURVEY 8(d) bytes otherwise (never "hbm, 0.0955" for a kernel at 1.00 of the VALU ceiling)
+    row = {"ms": 0.42, "design_GBps": 346.0, "reference_scheme_equiv_GBps": 1614.0, "frac_of_peak_by_design_bytes": 0.0433,
+           "hbm_traffic_GBps": 758.0, "frac_of_peak_by_traffic": 0.0948, "frac_of_valu_issue_peak": 1.002}
+    r = bench.governing_roofline("render_backward", row, {"hbm_bytes": 318361600, "SQ_INSTS_VALU": 258500000}, 0.42, 677980720.0, 145484664.0)
+    assert r["bound"] == "valu_issue" and r["frac"] == 1.002 and r["unit"] == "G wave-instr/s" and abs(r["peak"] - 614.4) < 1e-9
+    assert r["hbm"]["by_survey_8d_bytes"]["frac"] == round(1614.0 / 8000.0, 4) and r["hbm"]["by_pmc_traffic"]["frac"] == 0.0948 and r["traffic"] == 318361600
+    row2 = {k: v for k, v in row.items() if "traffic" not in k and "valu" not in k}
+    r2 = bench.governing_roofline("render_backward", row2, None, 0.42, 677980720.0, 145484664.0)
+    assert r2["bound"] == "hbm" and r2["frac_basis"] == "by_survey_8d_bytes" and r2["frac"] == round(1614.0 / 8000.0, 4) and r2["traffic"] is None
+    row3 = dict(row2, reference_scheme_equiv_GBps=14000.0)   # a binning stage: the reference-scheme bytes exceed the peak -> not a fraction
+    assert bench.governing_roofline("sort", row3, None, 0.07, 1.0, 1.0)["frac_basis"] == "by_design_bytes"
     stages, note = bench.load_pmc("no such workload")
     assert stages == {} and ("another workload" in note or "no profiles" in note)
 

@@ -24,22 +24,24 @@ namespace wg {
 
 constexpr int BATCH = 64;
 
-// A/B knobs of this kernel (wild-gaussians_amd/build.py: WG_BUILD_VARIANT / WG_EXTRA_FLAGS; results in EXPERIMENTS.md):
+// A/B knobs of this kernel (scripts/ab_variants.sh + scripts/ab_run.sh; numbers in EXPERIMENTS.md, round 3).  Both are OFF: measured, lost.
 //   WG_BWD_PK      the per-pair arithmetic on float PAIRS of one pixel -- (dx,dy), (xx,xy), (u,v) and the accumulator pairs
-//                  (acr,acg) (sx,sy) (sxx,sxy) (syy,sq) -- as v_pk_add/mul/fma_f32 with the shared multiplier broadcast by op_sel.
-//                  Packing WITHIN a pixel keeps the per-strip skip granularity (packing strip pairs lost it).  Same products, same
-//                  fused multiply-adds: every output is bit-identical to the scalar build.
+//                  (acr,acg) (sx,sy) (sxx,sxy) (syy,sq) -- as v_pk_add/mul/fma_f32 with the shared multiplier broadcast by op_sel
+//                  (packing WITHIN a pixel keeps the per-strip skip granularity that packing strip pairs lost).
+//                  Same products, same fused multiply-adds.  12 instead of 14 VALU per strip evaluation, 23 instead of 29 per
+//                  contributing strip (9 of them packed) -- and 0.4218 -> 0.4367 ms, at 5 or at 6 waves per SIMD alike: in this
+//                  dependent mix a v_pk_*_f32 occupies its SIMD for about two plain VALU slots (MI355X_MICROARCH.md calls packed
+//                  f32 "an anti-lever" beside other work too), so an instruction count that falls by a fifth buys nothing.
 //   WG_BWD_ANYMASK "did any lane contribute to this instance" as an OR of the strips' lane masks in SGPRs instead of a per-lane flag
-//                  that hipcc turns back into a mask with v_cndmask + v_cmp (2 VALU per visited instance).
-//   WG_BWD_BANKMASK the two select levels of the butterfly as bank-masked DPP adds (2 instead of 3 VALU each).
+//                  that hipcc turns back into a mask with v_cndmask + v_cmp (2 VALU per visited instance): bit-identical, 0.4218 ->
+//                  0.4276 ms -- the four s_or_b64 sit on the scalar chain between the strips' branches.
+//   (A third idea, the butterfly's two select levels as bank-masked DPP adds, does not exist on this ISA: a DPP bank is four
+//    CONSECUTIVE lanes of a row, not lane % 4, so a bank mask cannot address the odd lanes.)
 #ifndef WG_BWD_PK
 #define WG_BWD_PK 0
 #endif
 #ifndef WG_BWD_ANYMASK
 #define WG_BWD_ANYMASK 0
-#endif
-#ifndef WG_BWD_BANKMASK
-#define WG_BWD_BANKMASK 0
 #endif
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -78,17 +80,6 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
     const float w0 = pair_x32(v0, v1), w1 = pair_x32(v2, v3), w2 = pair_x32(v4, v5), w3 = pair_x32(v6, v7), w4 = pair_x32(v8, v9);
     // xor 16: five -> three;  u_m = w_{2m + bit4}, u2 = w4
     const float u0 = pair_x16(w0, w1), u1 = pair_x16(w2, w3), u2 = pair_x16(w4, w4);
-#if WG_BWD_BANKMASK
-    // xor 1: every lane takes u0's pair sum, then the odd lanes (banks 1, 3) are overwritten with u1's: a DPP operation only writes the
-    // lanes its bank mask enables.  (Spelled in asm: the intrinsic is a move; the s_nop covers the VALU-write -> DPP-read wait states.)
-    float x0 = u0 + dpp_f<0xB1>(u0);
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xa" : "+v"(x0) : "v"(u1));
-    const float x1 = u2 + dpp_f<0xB1>(u2);
-    // xor 2: likewise, lanes with bit 1 set (banks 2, 3) take x1's pair sum
-    float y = x0 + dpp_f<0x4E>(x0);
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xc" : "+v"(y) : "v"(x1));
-    (void)lane;
-#else
     // xor 1 (quad_perm [1,0,3,2]): x0 = u_{bit0}, x1 = u2
     const bool b0 = lane & 1;
     const float keep0 = b0 ? u1 : u0, send0 = b0 ? u0 : u1;
@@ -98,7 +89,6 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
     const bool b1 = lane & 2;
     const float keep1 = b1 ? x1 : x0, send1 = b1 ? x0 : x1;
     float y = keep1 + dpp_f<0x4E>(send1);
-#endif
     // lanes l, l+4, l+8, l+12 of each row: row_ror 4, row_ror 8
     y += dpp_f<0x124>(y);
     y += dpp_f<0x128>(y);

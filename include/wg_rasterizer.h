@@ -24,7 +24,9 @@
  * documented property: the image-state buffer starts, at its first 256-byte-aligned address, with
  * final_T as float[H*W] (the transmittance left at each pixel), so that
  * accumulation = 1 - final_T can be read back by the caller like the reference's Python wrapper does
- * (diff_gaussian_rasterization/__init__.py:101-113).
+ * (diff_gaussian_rasterization/__init__.py:101-113) -- and, at the next 256-byte-aligned address behind
+ * final_T (wg_image_accumulation_offset()), holds that very array, accumulation as float[H*W], written by
+ * the forward pass itself: a caller can hand out a view instead of running an elementwise kernel.
  */
 #ifndef WG_RASTERIZER_H_INCLUDED
 #define WG_RASTERIZER_H_INCLUDED
@@ -56,6 +58,8 @@ typedef char* (*wg_alloc_fn)(size_t bytes, void* user);
 size_t wg_geometry_buffer_size(int P);
 size_t wg_image_buffer_size(int width, int height);
 size_t wg_binning_buffer_size(int num_rendered);
+/* Byte offset of accumulation[H*W] from final_T (= from the buffer's first 256-byte-aligned address). */
+size_t wg_image_accumulation_offset(int width, int height);
 
 /*
  * Rasterizer::forward (rasterizer.h:33-59, rasterizer_impl.cu:198-340).
@@ -175,6 +179,21 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
                                 float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                                 float* dL_drot, int debug, void* stream, const wg_sh_tone* tone);
 
+/*
+ * Beyond the reference: a further rasterization of the SAME Gaussians through the SAME camera with other precomputed colours
+ * (WildGaussians renders raw and toned colours over identical geometry in every step, wildgaussians/method.py:1573-1611; the
+ * reference projects, bins and sorts twice).  parent_*: the three scratch buffers a wg_rasterize_forward call over that geometry
+ * returned (R = its return value) -- they must stay alive and unmodified by the caller; they are read, and the image state is
+ * rewritten with the identical per-pixel values.  The call allocates ONE new geometry buffer (its backward pass accumulates into
+ * records of its own), copies the projected state into it with the new colours and composites along the parent's sorted lists.
+ * out_color, radii (optional) as in wg_rasterize_forward; the image equals what wg_rasterize_forward would give for these colours,
+ * bit for bit.  Backward: wg_rasterize_backward with the NEW geometry buffer and the parent's binning and image buffers.
+ * Returns R or a negative wg_status.
+ */
+int wg_rasterize_forward_recolor(wg_alloc_fn geometry_alloc, void* geometry_user, char* parent_geom_buffer, char* parent_binning_buffer,
+                                 char* parent_image_buffer, int P, int R, const float* background, int width, int height,
+                                 const float* colors_precomp, const float* subpixel_offset, float* out_color, int* radii, void* stream);
+
 /* Rasterizer::markVisible (rasterizer.h:26-31, rasterizer_impl.cu:141-153). present: unsigned char[P]. */
 int wg_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     unsigned char* present, void* stream);
@@ -196,6 +215,7 @@ typedef struct wg_binning_view {
 
 typedef struct wg_image_view {
     const float* final_T;       /* [H*W] */
+    const float* accumulation;  /* [H*W] 1 - final_T */
     const uint32_t* n_contrib;  /* [H*W] */
     const uint32_t* ranges;     /* [tiles*2] (start,end) */
     const uint32_t* tile_last;  /* [tiles] max n_contrib over the tile's pixels */

@@ -129,10 +129,12 @@ def real_caller(args):
     cot = torch.randn(3, H, W, device="cuda") / (3 * H * W)
 
     def op_only():
+        # as in _render_internal: ONE set of geometry tensors per step, handed to every rasterizer call; only the colours differ
+        shared = {k: (v.clone().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() else v)
+                  for k, v in calls[0]["kwargs"].items() if k != "colors_precomp"}
         outs = []
         for c in calls:
-            kw = {k: (v.clone().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in c["kwargs"].items()}
-            outs.append(rast(**kw)[0])
+            outs.append(rast(colors_precomp=c["kwargs"]["colors_precomp"].clone().requires_grad_(True), **shared)[0])
         sum(outs).backward(cot)
     for _ in range(3):
         op_only()
@@ -142,7 +144,12 @@ def real_caller(args):
         op_only()
     torch.cuda.synchronize()
     dop = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"workload": f"REAL caller: wildgaussians/method.py WildGaussians.train_iteration unchanged (staged copy, sha256-verified)"
+    from diff_gaussian_rasterization import _C
+    lib_state = {"options": args.option, "geometry_reuse": _C.get_option("geometry_reuse"), "speculative_forward": _C.get_option("speculative_forward"),
+                 "geometry_reuse_hits": _C.geometry_reuse_hits(), "spec_frames": _C.get_option("spec_frames"), "spec_misses": _C.get_option("spec_misses"),
+                 "forward_polls": _C.get_option("forward_polls"), "forward_polls_that_waited": _C.get_option("forward_polls_waited"),
+                 "forward_wait_us_total": _C.get_option("forward_wait_us_total")}
+    print(json.dumps({"library": lib_state, "workload": f"REAL caller: wildgaussians/method.py WildGaussians.train_iteration unchanged (staged copy, sha256-verified)"
                                   + (" + wg_integration.apply_optins (run-time swaps: fused SSIM, FusedAdam, fused densification statistics, fused activations, fused eval_sh), "
                                      if args.optins else ", ") + ("tall_linear for the appearance MLP's layers (this script), " if args.tall_linear else "") +
                                   f"{P} Gaussians + appearance MLP, {W}x{H}, {args.cameras} cameras, default.yml with uncertainty_mode=disabled, "
@@ -183,7 +190,13 @@ def main():
                     help="run the reference's OWN `WildGaussians.train_iteration` (method.py:1880-2024, staged unchanged by "
                          "tests/real_caller/stage_reference_caller.py) instead of the restated step; none of the opt-ins apply")
     ap.add_argument("--cameras", type=int, default=4)
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="wg_set_option(NAME, VALUE) before the run")
     args = ap.parse_args()
+    if args.option:
+        from diff_gaussian_rasterization import _C
+        for kv in args.option:
+            k, v = kv.split("=", 1)
+            _C.set_option(k, int(v))
     if args.real_caller:
         return real_caller(args)
     import wg_scenes as S

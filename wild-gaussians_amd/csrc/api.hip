@@ -62,6 +62,44 @@ thread_local Mailbox t_mailbox;
 thread_local uint32_t t_last_instances_per_tile = 0;  // density of this thread's previous frame: the near / far split's "try it" hint
 thread_local uint32_t t_split_backoff = 0;            // frames for which the split is not attempted after one that needed the far phase
 
+// Speculative forward: what this host thread's recent frames looked like.  A prediction is made only from frames of the same image
+// size and a similar number of Gaussians (training: the model grows slowly, the cameras alternate -- hence the maximum over the last
+// eight frames, not the last one).
+struct SpecHistory {
+    static constexpr int N = 8;
+    int W = 0, H = 0, P = 0, n = 0, head = 0;
+    uint32_t rendered[N] = {}, longest[N] = {};
+    bool usable(int P_, int W_, int H_) const {
+        return n > 0 && W_ == W && H_ == H && (int64_t)P_ * 2 >= (int64_t)P && (int64_t)P_ <= (int64_t)P * 2;
+    }
+    void push(int P_, int W_, int H_, uint32_t R, uint32_t L) {
+        if (W_ != W || H_ != H) { n = 0; head = 0; W = W_; H = H_; }
+        P = P_;
+        rendered[head] = R; longest[head] = L;
+        head = (head + 1) % N;
+        if (n < N) n++;
+    }
+    uint32_t max_rendered() const { uint32_t m = 0; for (int i = 0; i < n; i++) m = std::max(m, rendered[i]); return m; }
+    uint32_t max_longest() const { uint32_t m = 0; for (int i = 0; i < n; i++) m = std::max(m, longest[i]); return m; }
+    uint32_t last_rendered() const { return n ? rendered[(head + N - 1) % N] : 0u; }
+    void clear() { n = 0; head = 0; }
+};
+thread_local SpecHistory t_spec;
+// How long the forward calls of this thread waited for the count (wg_get_option "forward_wait_*": evidence for "no host wait in
+// steady state"), and how the speculation fared.
+struct WaitStats {
+    uint64_t polls = 0, waited = 0, spec_frames = 0, spec_misses = 0;
+    double wait_us = 0.0, last_wait_us = 0.0;
+    template <typename D>
+    void record(bool spun, D d, bool) {
+        polls += 1;
+        last_wait_us = std::chrono::duration<double, std::micro>(d).count();
+        if (spun) { waited += 1; wait_us += last_wait_us; }
+    }
+    void clear() { *this = WaitStats(); }
+};
+thread_local WaitStats t_wait;
+
 // the options (wg_common.h: Options): written by wg_set_option under the mutex, copied once per call
 std::mutex g_opt_mu;
 wg::Options g_opt;
@@ -184,6 +222,10 @@ size_t wg_image_buffer_size(int width, int height) {
     const size_t tiles = (size_t)((width + wg::TILE_X - 1) / wg::TILE_X) * (size_t)((height + wg::TILE_Y - 1) / wg::TILE_Y);
     return required_bytes([&](char*& c) { wg::ImageState::fromChunk(c, N, tiles); });
 }
+size_t wg_image_accumulation_offset(int width, int height) {
+    const size_t N = (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0);
+    return (((N ? N : 1) * sizeof(float)) + wg::ALIGN - 1) & ~(wg::ALIGN - 1);  // carve(): the next ALIGN-aligned address
+}
 size_t wg_binning_buffer_size(int R) {  // upper bound over both binning paths
     return required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)(R > 0 ? R : 0), true); });
 }
@@ -286,8 +328,61 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
                            wg::GeometryState::band_lists_possible((size_t)P) &&
                            (opt.near_split == 1 || P >= opt.band_list_min_p || t_last_instances_per_tile >= wg::SPLIT_DENSE_AVG) && !backoff;
     bool split_active = false;
+
+    // ---- what depends on the instance count, as functions of it (used by the speculative and by the classic flow alike) ----
+    // Longest per-tile list decides the binning path: full register sort of every tile, lazy front sort when lists are long,
+    // global radix sort (the reference's scheme) when forced, when the frame is too large for the LDS histogram, or when a
+    // list exceeds the register sort and the lazy sort is switched off.
+    // (an active split implies the lazy path: its buckets only hold the near instances at first)
+    auto lazy_for = [&](bool split_on, uint32_t longest) {
+        return split_on || (opt.lazy.enabled && !opt.force_global_sort && !huge_frame && longest > opt.lazy.min_len + opt.lazy.min_len / 4);
+    };
+    // lazy sort: bucket entries carry a coarse depth code above the id for the front extraction, as wide as the ids allow
+    // (2^20 Gaussians or fewer: 12 bits; up to 2^24: 8 bits; more: none)
+    auto code_bits_for = [&](bool lazy) {
+        int code_bits = 0;
+        if (lazy && opt.depth_codes && P <= (1 << 24)) {
+            int id_bits = 20;
+            while ((1 << id_bits) < P) id_bits++;
+            code_bits = 32 - id_bits;
+            if (opt.depth_codes >= 8 && opt.depth_codes <= code_bits) code_bits = opt.depth_codes;  // a narrower code than the ids allow
+        }
+        return code_bits;
+    };
+    // Everything behind the count on the LDS binning path: scatter -> per-tile sort (full, or lazy front) -> render -> [fix-up ->
+    // far scatter -> fix-up].  R sizes the scatter's staging passes only; `longest` picks the sort network; `far` = the split may be
+    // active (its two extra launches return at once when it is not, or when no tile asked); guard = the frame's BinStats when the
+    // kernels are enqueued BEFORE the count is known (speculation), nullptr otherwise.
+    auto enqueue_tail = [&](const wg::BinningState& bin, uint32_t R, uint32_t longest, bool lazy, bool far, const wg::BinStats* guard) -> int {
+        const int code_bits = code_bits_for(lazy);
+        uint32_t emit = R;  // what the scatter will emit, for the sizing of its staging passes: everything, or about near_per_tile per tile
+        if (far) emit = (uint32_t)std::min<uint64_t>(emit, (uint64_t)near_per_tile * (uint64_t)tiles * 5u / 4u);
+        WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, emit, code_bits, opt.staged_scatter, opt.staged_cap, try_split, guard, stream), "tile_scatter");
+        if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, code_bits, opt.lazy, try_split, guard, stream), "tile_sort_lazy");
+        else WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, geom, tiles, longest, guard, stream), "tile_sort");
+        WG_STAGE(WG_STAGE_RENDER_FORWARD,
+                 wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, lazy, guard, stream),
+                 "render_forward");
+        if (lazy) {
+            WG_STAGE(WG_STAGE_RENDER_FIXUP,
+                     wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, try_split, 0, (wg::HostMailbox*)nullptr, guard, stream),
+                     "render_fixup");
+            if (far) {  // both return at once unless some tile ran out of near instances with pixels still accumulating
+                WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter_far(P, geom, img, bin, gx, tiles, code_bits, guard, stream), "tile_scatter_far");
+                WG_STAGE(WG_STAGE_RENDER_FIXUP,
+                         wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, true, 1, mbox ? mbox->dev : (wg::HostMailbox*)nullptr, guard, stream),
+                         "render_fixup_far");
+            }
+        }
+        return WG_OK;
+    };
+
+    bool rendered = false;  // the render kernels of this frame are already in the stream (a speculation that held)
     if (P > 0) {
         WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, device_tone(tone), geom, radii, stream), "preprocess");
+        wg::SpecLimits spec;   // all zero: the classic flow
+        char* spec_chunk = nullptr;
+        bool spec_lazy = false;
         if (tiles <= wg::BIN_MAX_TILES) {
             if (try_split)
                 WG_STAGE(WG_STAGE_SCAN, wg::launch_split_threshold(P, geom, img, tiles, opt.near_split == 1, near_per_tile, stream), "split_threshold");
@@ -295,13 +390,40 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
             WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_count(P, geom, img, gx, tiles, try_split, box, stream), "tile_count");
             mbox = (debug || !opt.use_mailbox) ? nullptr : get_mailbox();
             if (mbox) mbox->seq += 1;
-            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, mbox ? mbox->dev : nullptr, mbox ? mbox->seq : 0, try_split, stream), "tile_scan");
+            // ---- speculative forward (option "speculative_forward", default on) ----
+            // The reference's forward pass stops in its middle for the instance count (rasterizer_impl.cu:284: it sizes the binning
+            // buffer), the GPU idles while the host then launches the rest.  Frames of one training run resemble one another, so the
+            // count of THIS frame is predicted from this thread's recent frames of the same shape: the binning buffer is allocated
+            // with a margin, everything behind the count is enqueued at once -- each kernel guarded by the verdict tile_scan leaves
+            // in BinStats::spec_fail -- and the host looks at the mailbox only after its last launch, by which time the count has
+            // usually long arrived.  A frame that does not fit (more instances than the buffer holds, a list longer than the launched
+            // sort network covers) runs none of the guarded kernels; the host then re-issues the tail with the real numbers, i.e.
+            // falls back to the classic flow for that frame.  Results are the classic flow's, bit for bit.
+            if (mbox && opt.speculative > 0 && !opt.force_global_sort && t_spec.usable(P, width, height)) {
+                const uint64_t cap64 = (uint64_t)t_spec.max_rendered() * (100u + (uint32_t)opt.spec_margin_pct) / 100u + 4096u;
+                const uint32_t longest = t_spec.max_longest() + t_spec.max_longest() / 8u + 16u;
+                // the split's decision is taken on the device: when it is attempted the (superset) lazy flow is enqueued
+                spec_lazy = lazy_for(try_split, longest);
+                const uint32_t cover = spec_lazy ? 0xffffffffu : (longest <= 1024u ? 1024u : longest <= 2048u ? 2048u : longest <= 4096u ? 4096u : wg::TILE_SORT_MAX);
+                if (cap64 < 0x7fffffffull && (spec_lazy || longest <= wg::TILE_SORT_MAX)) {
+                    spec.capacity = (uint32_t)cap64;
+                    spec.max_list = cover;
+                    spec_chunk = binning_alloc(required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)spec.capacity, false); }), binning_user);
+                    if (!spec_chunk) return WG_ERR_ALLOC;
+                }
+            }
+            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, mbox ? mbox->dev : nullptr, mbox ? mbox->seq : 0, try_split, spec, stream), "tile_scan");
+            if (spec.capacity != 0u) {
+                wg::BinningState sbin = wg::BinningState::fromChunk(spec_chunk, (size_t)spec.capacity, false);
+                const int st_ = enqueue_tail(sbin, t_spec.last_rendered(), spec.max_list == 0xffffffffu ? 0u : spec.max_list, spec_lazy, try_split, img.stats);
+                if (st_ != WG_OK) return st_;
+            }
         } else {
             huge_frame = true;  // tile histogram does not fit LDS: count through the per-Gaussian prefix sum instead
             WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
             WG_STAGE(WG_STAGE_SCAN, wg::launch_scan_overflow_check(geom, P, &img.stats->max_tile_count, stream), "scan_overflow_check");
         }
-        // the one host sync of the forward pass (rasterizer_impl.cu:284): sizes the binning buffer
+        // the one host rendezvous of the forward pass (rasterizer_impl.cu:284) -- behind the frame's last launch when speculating
         wg::BinStats st{};
         hipError_t e;
         bool have_stats = false;
@@ -319,8 +441,10 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
                 st.num_rendered = mbox->host->num_rendered;
                 st.max_tile_count = mbox->host->max_tile_count;
                 st.split_active = mbox->host->split_active;
+                st.spec_fail = mbox->host->spec_fail;
                 have_stats = true;
             }
+            t_wait.record(spins != 0u, std::chrono::steady_clock::now() - t0, spec.capacity != 0u);
         }
         if (have_stats) {
             e = hipSuccess;
@@ -344,31 +468,22 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
         max_tile_count = st.max_tile_count;
         split_active = try_split && !huge_frame && st.split_active != 0u;
         t_last_instances_per_tile = tiles > 0 ? st.num_rendered / (uint32_t)tiles : 0u;
+        if (!huge_frame) t_spec.push(P, width, height, st.num_rendered, st.max_tile_count);
+        if (spec.capacity != 0u) {
+            if (st.spec_fail == 0u) rendered = true;
+            t_wait.spec_frames += 1;
+            t_wait.spec_misses += st.spec_fail != 0u ? 1 : 0;
+        }
     } else {
         hipError_t e = hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream);
         if (e != hipSuccess) return hip_fail(e, "ranges memset");
     }
+    if (rendered) return num_rendered;
 
-    // Longest per-tile list decides the binning path: LDS tile sort (default) or global radix sort (fallback).
-    // Longest per-tile list decides the binning path: full register sort of every tile, lazy front sort when lists are long,
-    // global radix sort (the reference's scheme) when forced, when the frame is too large for the LDS histogram, or when a
-    // list exceeds the register sort and the lazy sort is switched off.
-    // (an active split implies the lazy path: its buckets only hold the near instances at first)
-    const bool lazy = split_active ||
-                      (opt.lazy.enabled && !opt.force_global_sort && !huge_frame && max_tile_count > opt.lazy.min_len + opt.lazy.min_len / 4);
+    const bool lazy = lazy_for(split_active, max_tile_count);
     const bool global_sort = opt.force_global_sort || huge_frame || (!lazy && max_tile_count > wg::TILE_SORT_MAX);
-    // lazy sort: bucket entries carry a coarse depth code above the id for the front extraction, as wide as the ids allow
-    // (2^20 Gaussians or fewer: 12 bits; up to 2^24: 8 bits; more: none)
-    int code_bits = 0;
-    const int g_depth_codes = opt.depth_codes;
-    if (lazy && g_depth_codes && P <= (1 << 24)) {
-        int id_bits = 20;
-        while ((1 << id_bits) < P) id_bits++;
-        code_bits = 32 - id_bits;
-        if (g_depth_codes >= 8 && g_depth_codes <= code_bits) code_bits = g_depth_codes;  // a narrower code than the ids allow
-    }
     size_t bin_bytes = required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)num_rendered, global_sort); });
-    char* bin_chunk = binning_alloc(bin_bytes, binning_user);
+    char* bin_chunk = binning_alloc(bin_bytes, binning_user);   // (a second call of this frame after a speculation that did not hold)
     if (!bin_chunk) return WG_ERR_ALLOC;
     wg::BinningState bin = wg::BinningState::fromChunk(bin_chunk, (size_t)num_rendered, global_sort);
 
@@ -376,40 +491,44 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
         hipError_t e = hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream);
         if (e != hipSuccess) return hip_fail(e, "ranges memset");
     }
+    if (num_rendered > 0 && !global_sort) {
+        const int st_ = enqueue_tail(bin, (uint32_t)num_rendered, max_tile_count, lazy, split_active, nullptr);
+        return st_ != WG_OK ? st_ : num_rendered;
+    }
     if (num_rendered > 0) {
-        if (!global_sort) {
-            // what the scatter will emit, for the sizing of its staging passes: everything, or about near_per_tile per tile
-            uint32_t emit = (uint32_t)num_rendered;
-            if (split_active) emit = (uint32_t)std::min<uint64_t>(emit, (uint64_t)near_per_tile * (uint64_t)tiles * 5u / 4u);
-            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter(P, geom, img, bin, gx, tiles, emit, code_bits, opt.staged_scatter, opt.staged_cap, try_split, stream), "tile_scatter");
-            if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, code_bits, opt.lazy, try_split, stream), "tile_sort_lazy");
-            else WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, geom, tiles, max_tile_count, stream), "tile_sort");
-        } else {
-            if (!huge_frame) WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
-            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_duplicate_keys(P, geom, bin, gx, stream), "duplicate_keys");
-            const int bit = (int)wg::higher_msb((uint32_t)tiles);  // rasterizer_impl.cu:303
-            WG_STAGE(WG_STAGE_SORT, wg::run_sort(bin, num_rendered, 32 + bit, stream), "radix_sort_pairs");
-            // tile_scan already produced ranges identical to identifyTileRanges on the sorted keys; only frames
-            // too large for the LDS histogram need the key-boundary pass
-            if (huge_frame) WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_ranges(num_rendered, bin, img, tiles, stream), "tile_ranges");
-        }
+        if (!huge_frame) WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
+        WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_duplicate_keys(P, geom, bin, gx, stream), "duplicate_keys");
+        const int bit = (int)wg::higher_msb((uint32_t)tiles);  // rasterizer_impl.cu:303
+        WG_STAGE(WG_STAGE_SORT, wg::run_sort(bin, num_rendered, 32 + bit, stream), "radix_sort_pairs");
+        // tile_scan already produced ranges identical to identifyTileRanges on the sorted keys; only frames
+        // too large for the LDS histogram need the key-boundary pass
+        if (huge_frame) WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_ranges(num_rendered, bin, img, tiles, stream), "tile_ranges");
     }
-    const bool lazy_render = lazy && num_rendered > 0 && !global_sort;
     WG_STAGE(WG_STAGE_RENDER_FORWARD,
-             wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, lazy_render, stream),
+             wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, false, nullptr, stream),
              "render_forward");
-    if (lazy_render) {
-        WG_STAGE(WG_STAGE_RENDER_FIXUP,
-                 wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, try_split, 0, (wg::HostMailbox*)nullptr, stream),
-                 "render_fixup");
-        if (split_active) {  // both return at once unless some tile ran out of near instances with pixels still accumulating
-            WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter_far(P, geom, img, bin, gx, tiles, code_bits, stream), "tile_scatter_far");
-            WG_STAGE(WG_STAGE_RENDER_FIXUP,
-                     wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, true, 1, mbox ? mbox->dev : (wg::HostMailbox*)nullptr, stream),
-                     "render_fixup_far");
-        }
-    }
     return num_rendered;
+}
+
+int wg_rasterize_forward_recolor(wg_alloc_fn geometry_alloc, void* geometry_user, char* parent_geom_buffer, char* parent_binning_buffer,
+                                 char* parent_image_buffer, int P, int R, const float* background, int width, int height,
+                                 const float* colors_precomp, const float* subpixel_offset, float* out_color, int* radii, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const bool debug = false;
+    if (!geometry_alloc || !parent_geom_buffer || !parent_binning_buffer || !parent_image_buffer) return WG_ERR_INVALID_ARGUMENT;
+    if (P <= 0 || R < 0 || width <= 0 || height <= 0 || !background || !colors_precomp || !out_color) return WG_ERR_INVALID_ARGUMENT;
+    const int gx = (width + wg::TILE_X - 1) / wg::TILE_X, gy = (height + wg::TILE_Y - 1) / wg::TILE_Y;
+    wg::GeometryState parent = wg::GeometryState::fromChunk(parent_geom_buffer, (size_t)P, false);
+    wg::BinningState bin = wg::BinningState::fromChunk(parent_binning_buffer, (size_t)R, false);  // point_list only
+    wg::ImageState img = wg::ImageState::fromChunk(parent_image_buffer, (size_t)width * height, (size_t)gx * gy);
+    char* chunk = geometry_alloc(required_bytes([&](char*& c) { wg::GeometryState::fromChunk(c, (size_t)P, false); }), geometry_user);
+    if (!chunk) return WG_ERR_ALLOC;
+    wg::GeometryState geom = wg::GeometryState::fromChunk(chunk, (size_t)P, false);
+    WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_recolor(P, parent, geom, colors_precomp, radii, stream), "recolor");
+    WG_STAGE(WG_STAGE_RENDER_FORWARD,
+             wg::launch_render_forward_replay(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, stream),
+             "render_forward_replay");
+    return R;
 }
 
 int wg_rasterize_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
@@ -478,14 +597,19 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
         hipError_t release() { float* q = p; p = nullptr; return q ? hipFreeAsync(q, s) : hipSuccess; }
     } det_guard(stream);
     float*& det_slots = det_guard.p;
-    if (det) {
+    unsigned char* det_flags = nullptr;
+    if (det) {  // slots: 40 B per tile instance, never cleared; flags: 1 B per instance behind them, cleared
         StageScope scope_(WG_STAGE_RENDER_BACKWARD, stream);
+        const size_t slot_bytes = (((size_t)R * 10 * sizeof(float)) + 255) & ~(size_t)255;
         hipError_t e = wg::run_scan(geom, P, stream);
-        if (e == hipSuccess) e = hipMallocAsync(reinterpret_cast<void**>(&det_slots), (size_t)R * 10 * sizeof(float), stream);
-        if (e == hipSuccess) e = hipMemsetAsync(det_slots, 0, (size_t)R * 10 * sizeof(float), stream);
+        if (e == hipSuccess) e = hipMallocAsync(reinterpret_cast<void**>(&det_slots), slot_bytes + (size_t)R, stream);
+        if (e == hipSuccess) {
+            det_flags = reinterpret_cast<unsigned char*>(det_slots) + slot_bytes;
+            e = hipMemsetAsync(det_flags, 0, (size_t)R, stream);
+        }
         if (e != hipSuccess) return hip_fail(e, "deterministic backward scratch");
     }
-    if (record) {
+    if (record && !det) {  // (the deterministic mode's ordered sum writes every record in full)
         StageScope scope_(WG_STAGE_RENDER_BACKWARD, stream);
         hipError_t e = hipMemsetAsync(geom.grad_rec, 0, (size_t)P * wg::GRAD_REC_FLOATS * sizeof(float), stream);
         if (e != hipSuccess) return hip_fail(e, "gradient record memset");
@@ -493,7 +617,7 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     if (R > 0) {
         WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_order(img.tile_last, nullptr, img.order_bwd, gx * gy, stream), "tile_order");
         WG_STAGE(WG_STAGE_RENDER_BACKWARD, wg::launch_render_backward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, dL_dpix,
-                                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, det_slots, P, stream),
+                                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, det_slots, det_flags, P, stream),
                  "render_backward");
     }
 
@@ -553,6 +677,7 @@ int wg_view_image(char* image_buffer, int width, int height, wg_image_view* out)
     const int gx = (width + wg::TILE_X - 1) / wg::TILE_X, gy = (height + wg::TILE_Y - 1) / wg::TILE_Y;
     wg::ImageState img = wg::ImageState::fromChunk(image_buffer, (size_t)width * height, (size_t)gx * gy);
     out->final_T = img.final_T;
+    out->accumulation = img.accum;
     out->n_contrib = img.n_contrib;
     out->ranges = reinterpret_cast<const uint32_t*>(img.ranges);
     out->tile_last = img.tile_last;
@@ -573,6 +698,9 @@ int wg_set_option(const char* name, int value) {
     if (std::strcmp(name, "force_global_sort") == 0) { o.force_global_sort = value != 0; return WG_OK; }
     if (std::strcmp(name, "host_mailbox") == 0) { o.use_mailbox = value != 0; return WG_OK; }
     if (std::strcmp(name, "grad_record") == 0) { o.grad_record = value != 0; return WG_OK; }
+    if (std::strcmp(name, "geometry_reuse") == 0) { o.geometry_reuse = value != 0; return WG_OK; }
+    if (std::strcmp(name, "speculative_forward") == 0) { o.speculative = value != 0; t_spec.clear(); t_wait.clear(); return WG_OK; }
+    if (std::strcmp(name, "spec_margin_pct") == 0) { if (value < 0 || value > 1000) return WG_ERR_INVALID_ARGUMENT; o.spec_margin_pct = value; return WG_OK; }
     if (std::strcmp(name, "deterministic_backward") == 0) { o.deterministic_backward = value != 0; return WG_OK; }
     if (std::strcmp(name, "band_list_min_p") == 0) { o.band_list_min_p = value > 0 ? value : 1; return WG_OK; }
     if (std::strcmp(name, "near_split") == 0) {  // (also clears the calling thread's back-off and density hint: a fresh start)
@@ -607,8 +735,18 @@ int wg_get_option(const char* name) {
     if (!name) return -1;
     if (std::strcmp(name, "roctx") == 0) return g_roctx.enabled ? 1 : 0;
     if (std::strcmp(name, "near_split_backoff") == 0) return (int)t_split_backoff;  // read-only, of the calling thread
+    // read-only counters of the calling thread since the last wg_set_option("speculative_forward", ...)
+    if (std::strcmp(name, "spec_frames") == 0) return (int)std::min<uint64_t>(t_wait.spec_frames, 0x7fffffffu);
+    if (std::strcmp(name, "spec_misses") == 0) return (int)std::min<uint64_t>(t_wait.spec_misses, 0x7fffffffu);
+    if (std::strcmp(name, "forward_polls") == 0) return (int)std::min<uint64_t>(t_wait.polls, 0x7fffffffu);
+    if (std::strcmp(name, "forward_polls_waited") == 0) return (int)std::min<uint64_t>(t_wait.waited, 0x7fffffffu);
+    if (std::strcmp(name, "forward_wait_us_total") == 0) return (int)std::min(t_wait.wait_us, 2147483647.0);
+    if (std::strcmp(name, "forward_wait_us_last") == 0) return (int)std::min(t_wait.last_wait_us, 2147483647.0);
     const wg::Options o = options_snapshot();
     if (std::strcmp(name, "grad_record") == 0) return o.grad_record;
+    if (std::strcmp(name, "geometry_reuse") == 0) return o.geometry_reuse;
+    if (std::strcmp(name, "speculative_forward") == 0) return o.speculative;
+    if (std::strcmp(name, "spec_margin_pct") == 0) return o.spec_margin_pct;
     if (std::strcmp(name, "deterministic_backward") == 0) return o.deterministic_backward;
     if (std::strcmp(name, "force_global_sort") == 0) return o.force_global_sort ? 1 : 0;
     if (std::strcmp(name, "host_mailbox") == 0) return o.use_mailbox ? 1 : 0;

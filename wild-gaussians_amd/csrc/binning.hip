@@ -64,6 +64,7 @@ GeometryState GeometryState::fromChunk(char*& chunk, size_t P, bool lists) {
 ImageState ImageState::fromChunk(char*& chunk, size_t N, size_t tiles) {
     ImageState img;
     carve(chunk, img.final_T, N ? N : 1);
+    carve(chunk, img.accum, N ? N : 1);
     carve(chunk, img.n_contrib, N ? N : 1);
     carve(chunk, img.ranges, tiles ? tiles : 1);
     carve(chunk, img.tile_last, tiles ? tiles : 1);
@@ -432,7 +433,7 @@ __global__ void __launch_bounds__(64 * SCAN_WAVES) chunk_scan_kernel(uint32_t* _
 template <int PER>
 __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
                                                          uint2* __restrict__ ranges, BinStats* __restrict__ stats, int tiles,
-                                                         HostMailbox* mailbox, uint32_t seq, const SplitState* __restrict__ split) {
+                                                         HostMailbox* mailbox, uint32_t seq, const SplitState* __restrict__ split, SpecLimits spec) {
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t wave_max[16];
     __shared__ uint32_t wave_ovf[16];
@@ -485,10 +486,14 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
         stats->num_rendered = total;
         stats->max_tile_count = gmax;
         stats->split_active = active;
+        // speculative forward: does the frame fit what the host has already enqueued behind this kernel?
+        const uint32_t fail = (spec.capacity != 0u && (total > spec.capacity || gmax > spec.max_list)) ? 1u : 0u;
+        stats->spec_fail = fail;
         if (mailbox) {
             mailbox->num_rendered = total;
             mailbox->max_tile_count = gmax;
             mailbox->split_active = active;
+            mailbox->spec_fail = fail;
             __hip_atomic_store(&mailbox->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -521,8 +526,9 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4*
                                                            const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ chunk_hist,
                                                            const uint16_t* __restrict__ band_list, const uint32_t* __restrict__ band_cnt,
                                                            uint32_t* __restrict__ bucket_ids, int gx, int tiles, int code_bits,
-                                                           const SplitState* __restrict__ split) {
+                                                           const SplitState* __restrict__ split, const BinStats* __restrict__ guard) {
     extern __shared__ uint32_t cursor[];
+    if (guard && guard->spec_fail) return;  // workgroup-uniform
     const int tid = threadIdx.x, band = blockIdx.x & 7, chunk = blockIdx.x >> 3;
     const uint32_t near_code = split ? split->near_code : SPLIT_OFF;
     const bool near_only = near_code != SPLIT_OFF;  // active split: only the near Gaussians are scattered (chunk_hist holds their prefix)
@@ -587,8 +593,9 @@ __global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const 
                                                                   const uint32_t* __restrict__ chunk_hist, const uint16_t* __restrict__ band_list,
                                                                   const uint32_t* __restrict__ band_cnt, uint32_t* __restrict__ bucket_ids,
                                                                   int gx, int tiles, int G, int nbmax, uint32_t cap, int code_bits,
-                                                                  const SplitState* __restrict__ split) {
+                                                                  const SplitState* __restrict__ split, const BinStats* __restrict__ guard) {
     extern __shared__ uint32_t smem[];
+    if (guard && guard->spec_fail) return;  // workgroup-uniform
     // active split: only near Gaussians are emitted; chunk_hist holds the prefix of the near counts and `tile_count` is tile_near
     const uint32_t near_code = split ? split->near_code : SPLIT_OFF;
     const bool near_only = near_code != SPLIT_OFF;
@@ -724,8 +731,9 @@ __global__ void __launch_bounds__(256) tile_scatter_far_kernel(int P, const usho
                                                                const uint32_t* __restrict__ tile_state, uint32_t* __restrict__ far_cursor,
                                                                const uint16_t* __restrict__ band_list, const uint32_t* __restrict__ band_cnt,
                                                                uint32_t* __restrict__ bucket_ids, int gx, int tiles, int code_bits,
-                                                               const SplitState* __restrict__ split) {
+                                                               const SplitState* __restrict__ split, const BinStats* __restrict__ guard) {
     const int tid = threadIdx.x, band = blockIdx.x & 7, chunk = blockIdx.x >> 3;
+    if (guard && guard->spec_fail) return;
     if (((split->need_far >> band) & 1u) == 0u || split->near_code == SPLIT_OFF) return;  // no tile of this band asked
     const uint32_t near_code = split->near_code;
     const int q = tiles >> 3, rem = tiles & 7;
@@ -835,15 +843,15 @@ hipError_t launch_split_threshold(int P, const GeometryState& g, const ImageStat
 }
 
 hipError_t launch_tile_scatter_far(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles, int code_bits,
-                                   hipStream_t stream) {
+                                   const BinStats* guard, hipStream_t stream) {
     if (P <= 0) return hipSuccess;
     if (g.band_list != nullptr)
         hipLaunchKernelGGL(tile_scatter_far_kernel<true>, dim3(BIN_CHUNKS * 8), dim3(256), 0, stream, P, g.rects, g.depths, img.tile_offset,
-                           img.tile_near, img.tile_state, img.far_cursor, g.band_list, g.band_cnt, b.bucket_ids, gx, tiles, code_bits, img.split);
+                           img.tile_near, img.tile_state, img.far_cursor, g.band_list, g.band_cnt, b.bucket_ids, gx, tiles, code_bits, img.split, guard);
     else
         hipLaunchKernelGGL(tile_scatter_far_kernel<false>, dim3(BIN_CHUNKS * 8), dim3(256), 0, stream, P, g.rects, g.depths, img.tile_offset,
                            img.tile_near, img.tile_state, img.far_cursor, (const uint16_t*)nullptr, (const uint32_t*)nullptr, b.bucket_ids, gx,
-                           tiles, code_bits, img.split);
+                           tiles, code_bits, img.split, guard);
     return hipGetLastError();
 }
 
@@ -867,8 +875,9 @@ hipError_t launch_tile_scatter_far(int P, const GeometryState& g, const ImageSta
 template <int EMAX>
 __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bucket_ids,
                                                         const float* __restrict__ depths, uint32_t* __restrict__ point_list, uint32_t n_min,
-                                                        uint32_t n_max, uint32_t id_mask) {
+                                                        uint32_t n_max, uint32_t id_mask, const BinStats* __restrict__ guard) {
     extern __shared__ uint64_t skeys[];
+    if (guard && guard->spec_fail) return;
     const int tile = blockIdx.x;
     const uint32_t begin = tile_offset[tile];
     const uint32_t n = tile_offset[tile + 1] - begin;
@@ -891,13 +900,14 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restri
 __global__ void __launch_bounds__(256) tile_front_sort_kernel(const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bucket_ids,
                                                               const float* __restrict__ depths, uint32_t* __restrict__ point_list,
                                                               uint32_t* __restrict__ seg_end, uint32_t min_len, uint32_t target, uint32_t cap,
-                                                              uint32_t id_mask, const uint32_t* __restrict__ tile_near) {
+                                                              uint32_t id_mask, const uint32_t* __restrict__ tile_near, const BinStats* __restrict__ guard) {
     // the selection scratch (12 KB) and the sort's cross-wave exchange buffer (16 KB) are never live together: one 16 KB block,
     // which lets 8 workgroups share a CU instead of 5 (the kernel is a chain of dependent phases, latency-bound)
     __shared__ uint64_t smem[256 * 8];
     static_assert(sizeof(SelectScratch) <= sizeof(uint64_t) * 256 * 8, "selection scratch must fit the exchange buffer");
     SelectScratch& sc = *reinterpret_cast<SelectScratch*>(smem);
     uint64_t* skeys = smem;
+    if (guard && guard->spec_fail) return;
     const int tile = blockIdx.x;
     const uint32_t begin = tile_offset[tile];
     // near / far split: only the near instances, the first tile_near[tile] entries of the bucket, exist at this point
@@ -1008,21 +1018,23 @@ hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& im
     return hipGetLastError();
 }
 
-hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, bool split, hipStream_t stream) {
+hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, bool split, const SpecLimits& spec,
+                            hipStream_t stream) {
     const SplitState* sp = split ? img.split : nullptr;
     // BIN_MAX_TILES / 1024 = 36 tiles per thread at most; 8 covers 1080p (8160 tiles)
     if (tiles <= 8 * 1024)
         hipLaunchKernelGGL(tile_scan_kernel<8>, dim3(1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges, img.stats, tiles,
-                           mailbox_dev, seq, sp);
+                           mailbox_dev, seq, sp, spec);
     else
         hipLaunchKernelGGL((tile_scan_kernel<BIN_MAX_TILES / 1024>), dim3(1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges,
-                           img.stats, tiles, mailbox_dev, seq, sp);
+                           img.stats, tiles, mailbox_dev, seq, sp, spec);
     return hipGetLastError();
 }
 
 
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
-                               uint32_t num_rendered, int code_bits, int g_staged_scatter, int g_staged_cap, bool split, hipStream_t stream) {
+                               uint32_t num_rendered, int code_bits, int g_staged_scatter, int g_staged_cap, bool split, const BinStats* guard,
+                               hipStream_t stream) {
     if (P <= 0) return hipSuccess;
     const SplitState* sp = split ? img.split : nullptr;
     const uint32_t* last_prefix = split ? img.tile_near : img.tile_count;  // what follows the last chunk's prefix in a tile's column
@@ -1050,11 +1062,11 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
             if (use_lists)
                 hipLaunchKernelGGL(tile_scatter_staged_kernel<true>, dim3(BIN_CHUNKS / G * 8), dim3(1024), lds, stream, P, g.rects, g.depths,
                                    img.tile_offset, last_prefix, img.chunk_hist, g.band_list, g.band_cnt, b.bucket_ids, gx, tiles, G, nbmax,
-                                   cap, code_bits, sp);
+                                   cap, code_bits, sp, guard);
             else
                 hipLaunchKernelGGL(tile_scatter_staged_kernel<false>, dim3(BIN_CHUNKS / G * 8), dim3(1024), lds, stream, P, g.rects, g.depths,
                                    img.tile_offset, last_prefix, img.chunk_hist, (const uint16_t*)nullptr, (const uint32_t*)nullptr,
-                                   b.bucket_ids, gx, tiles, G, nbmax, cap, code_bits, sp);
+                                   b.bucket_ids, gx, tiles, G, nbmax, cap, code_bits, sp, guard);
             return hipGetLastError();
         }
     }
@@ -1064,41 +1076,41 @@ hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& 
     if (e != hipSuccess) return e;
     if (g.band_list != nullptr)
         hipLaunchKernelGGL(tile_scatter_kernel<true>, dim3(BIN_CHUNKS * 8), dim3(256), lds, stream, P, g.rects, g.depths, img.tile_offset,
-                           img.chunk_hist, g.band_list, g.band_cnt, b.bucket_ids, gx, tiles, code_bits, sp);
+                           img.chunk_hist, g.band_list, g.band_cnt, b.bucket_ids, gx, tiles, code_bits, sp, guard);
     else
         hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(BIN_CHUNKS * 8), dim3(256), lds, stream, P, g.rects, g.depths, img.tile_offset,
-                           img.chunk_hist, (const uint16_t*)nullptr, (const uint32_t*)nullptr, b.bucket_ids, gx, tiles, code_bits, sp);
+                           img.chunk_hist, (const uint16_t*)nullptr, (const uint32_t*)nullptr, b.bucket_ids, gx, tiles, code_bits, sp, guard);
     return hipGetLastError();
 }
 
 template <int E>
 static hipError_t launch_tile_sort_e(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t n_min,
-                                     uint32_t n_max, hipStream_t stream) {
+                                     uint32_t n_max, const BinStats* guard, hipStream_t stream) {
     const size_t lds = (size_t)256 * E * sizeof(uint64_t);  // exchange buffer of the cross-wave stages
     hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_sort_kernel<E>), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tile_sort_kernel<E>, dim3(tiles), dim3(256), lds, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list, n_min,
-                       n_max, 0xffffffffu);
+                       n_max, 0xffffffffu, guard);
     return hipGetLastError();
 }
 
 hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, int code_bits,
-                                 const LazyConfig& g_lazy, bool split, hipStream_t stream) {
+                                 const LazyConfig& g_lazy, bool split, const BinStats* guard, hipStream_t stream) {
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(tile_front_sort_kernel, dim3(tiles), dim3(256), 0, stream, img.tile_offset, b.bucket_ids, g.depths, b.point_list,
                        img.seg_end, g_lazy.min_len, g_lazy.target, g_lazy.cap, code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu,
-                       split ? img.tile_near : (const uint32_t*)nullptr);
+                       split ? img.tile_near : (const uint32_t*)nullptr, guard);
     return hipGetLastError();
 }
 
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
-                            hipStream_t stream) {
+                            const BinStats* guard, hipStream_t stream) {
     if (tiles <= 0 || max_count == 0) return hipSuccess;
-    if (max_count <= 1024) return launch_tile_sort_e<4>(img, b, g, tiles, 1u, 1024u, stream);
-    if (max_count <= 2048) return launch_tile_sort_e<8>(img, b, g, tiles, 1u, 2048u, stream);
-    hipError_t e = launch_tile_sort_e<16>(img, b, g, tiles, 1u, 4096u, stream);
+    if (max_count <= 1024) return launch_tile_sort_e<4>(img, b, g, tiles, 1u, 1024u, guard, stream);
+    if (max_count <= 2048) return launch_tile_sort_e<8>(img, b, g, tiles, 1u, 2048u, guard, stream);
+    hipError_t e = launch_tile_sort_e<16>(img, b, g, tiles, 1u, 4096u, guard, stream);
     if (e != hipSuccess || max_count <= 4096) return e;
-    return launch_tile_sort_e<32>(img, b, g, tiles, 4097u, TILE_SORT_MAX, stream);
+    return launch_tile_sort_e<32>(img, b, g, tiles, 4097u, TILE_SORT_MAX, guard, stream);
 }
 
 }  // namespace wg

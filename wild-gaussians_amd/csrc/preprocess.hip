@@ -308,6 +308,41 @@ hipError_t launch_preprocess(const FwdParams& p, const ShTone& tone_in, const Ge
     return hipGetLastError();
 }
 
+// Geometry reuse (api.hip: wg_rasterize_forward_recolor): a second rasterization of the SAME Gaussians through the same camera with
+// other precomputed colours -- WildGaussians renders raw and toned colours over identical geometry, method.py:1573-1611 -- needs none
+// of K1's projection and none of the binning again.  This kernel gives the call a geometry state of its own (its backward pass
+// accumulates into its own gradient records): everything the backward kernels read is copied from the parent state, the splat
+// records with the new colours in place of the old.  One Gaussian per thread, ~200 B per Gaussian of traffic (K1 + binning: the
+// whole forward pass in front of the compositing).
+__global__ void __launch_bounds__(256) recolor_kernel(int P, GeometryState src, GeometryState dst, const float* __restrict__ colors, int* __restrict__ radii_out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const int r = src.radii[idx];
+    dst.radii[idx] = r;
+    if (radii_out) radii_out[idx] = r;
+    dst.depths[idx] = src.depths[idx];
+    dst.clamped[idx] = 0;  // precomputed colours are never clamped (forward.cu:253-258)
+    dst.rects[idx] = src.rects[idx];
+    dst.tiles_touched[idx] = src.tiles_touched[idx];
+    if (r > 0) {
+        const float4* a = src.splats + 3 * (size_t)idx;
+        float4* b = dst.splats + 3 * (size_t)idx;
+        float4 r0 = a[0], r1 = a[1], r2 = a[2];
+        r1.w = colors[3 * idx];
+        r2.x = colors[3 * idx + 1];
+        r2.y = colors[3 * idx + 2];
+        b[0] = r0; b[1] = r1; b[2] = r2;
+#pragma unroll
+        for (int k = 0; k < 6; k++) dst.cov3D[6 * (size_t)idx + k] = src.cov3D[6 * (size_t)idx + k];
+    }
+}
+
+hipError_t launch_recolor(int P, const GeometryState& src, const GeometryState& dst, const float* colors, int* radii_out, hipStream_t stream) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(recolor_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, src, dst, colors, radii_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t stream) {
     if (P <= 0) return hipSuccess;
     hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means3D, viewmatrix, present);

@@ -192,7 +192,7 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
 // parked in the same buffers for a later fwd_init(resume): colour without background, -T for stopped pixels.
 __device__ void fwd_store(const FwdTile& st, bool complete, int W, int H, int tile, int lane, const float* __restrict__ bg,
                           float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last,
-                          float* __restrict__ out_color) {
+                          float* __restrict__ out_color, float* __restrict__ accum) {
     uint32_t lmax = 0;
     const size_t plane = (size_t)W * H;
     const float bg0 = complete ? bg[0] : 0.f, bg1 = complete ? bg[1] : 0.f, bg2 = complete ? bg[2] : 0.f;
@@ -202,6 +202,7 @@ __device__ void fwd_store(const FwdTile& st, bool complete, int W, int H, int ti
         if (px < W && py < H) {
             const size_t pix = (size_t)W * py + px;
             final_T[pix] = (complete || ((st.alive >> s) & 1u)) ? st.T[s] : -st.T[s];
+            if (complete) accum[pix] = 1.0f - st.T[s];  // accumulation (__init__.py:101-113 of the reference computes it from final_T)
             n_contrib[pix] = st.last[s];
             out_color[pix] = st.Cr[s] + st.T[s] * bg0;
             out_color[plane + pix] = st.Cg[s] + st.T[s] * bg1;
@@ -233,8 +234,9 @@ __global__ void __launch_bounds__(64) WG_FWD_OCC render_forward_kernel(
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     const uint32_t* __restrict__ seg_end, uint32_t* __restrict__ tile_state,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last,
-    float* __restrict__ out_color) {
+    float* __restrict__ out_color, const BinStats* __restrict__ guard, int replay, float* __restrict__ accum) {
     __shared__ float4 lds[BATCH * 3];
+    if (guard && guard->spec_fail) return;  // speculative forward (api.hip): the frame did not fit what was enqueued; the host re-issues
     const int tile = xcd_tile(blockIdx.x, tiles);
     const int lane = threadIdx.x;
     FwdTile st;
@@ -243,19 +245,32 @@ __global__ void __launch_bounds__(64) WG_FWD_OCC render_forward_kernel(
     const int n = (int)(range.y - range.x);
     const int end = seg_end ? min(n, (int)seg_end[tile]) : n;
     fwd_walk<true>(st, lds, lane, point_list + range.x, splats, 0, end);
-    const bool complete = st.strips_alive == 0 || end == n;
-    fwd_store(st, complete, W, H, tile, lane, bg, final_T, n_contrib, tile_last, out_color);
+    // replay (geometry reuse): seg_end is the tile's walked length of an earlier pass over the same geometry -- nothing behind it
+    // contributes, so the tile is complete whatever is left of the list
+    const bool complete = st.strips_alive == 0 || end == n || replay != 0;
+    fwd_store(st, complete, W, H, tile, lane, bg, final_T, n_contrib, tile_last, out_color, accum);
     if (tile_state && lane == 0) tile_state[tile] = complete ? 0xffffffffu : (uint32_t)end;
 }
 
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                  const GeometryState& g, const float* subpixel_offset, const float* background,
-                                 float* out_color, bool lazy, hipStream_t stream) {
+                                 float* out_color, bool lazy, const BinStats* guard, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(render_forward_kernel, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats,
                        reinterpret_cast<const float2*>(subpixel_offset), background, lazy ? img.seg_end : (const uint32_t*)nullptr,
-                       lazy ? img.tile_state : (uint32_t*)nullptr, img.final_T, img.n_contrib, img.tile_last, out_color);
+                       lazy ? img.tile_state : (uint32_t*)nullptr, img.final_T, img.n_contrib, img.tile_last, out_color, guard, 0, img.accum);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_forward_replay(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
+                                        const GeometryState& g, const float* subpixel_offset, const float* background,
+                                        float* out_color, hipStream_t stream) {
+    const int tiles = gx * gy;
+    if (tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(render_forward_kernel, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats,
+                       reinterpret_cast<const float2*>(subpixel_offset), background, (const uint32_t*)img.tile_last, (uint32_t*)nullptr,
+                       img.final_T, img.n_contrib, img.tile_last, out_color, (const BinStats*)nullptr, 1, img.accum);
     return hipGetLastError();
 }
 
@@ -269,11 +284,13 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     const float* __restrict__ depths, const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset,
     const float* __restrict__ bg, uint32_t* __restrict__ tile_state, float* final_T, uint32_t* n_contrib,
     uint32_t* __restrict__ tile_last, float* out_color, uint32_t target, uint32_t cap, uint32_t id_mask,
-    const uint32_t* __restrict__ tile_near, SplitState* split, int phase, HostMailbox* mailbox) {
+    const uint32_t* __restrict__ tile_near, SplitState* split, int phase, HostMailbox* mailbox, const BinStats* __restrict__ guard,
+    float* __restrict__ accum) {
     __shared__ float4 lds[BATCH * 3];
     __shared__ uint64_t skeys[256 * 8];
     __shared__ SelectScratch sc;
     __shared__ int s_complete;
+    if (guard && guard->spec_fail) return;
     // phase 1 runs after every tile's phase 0 (stream order): which bands asked for far instances is final, and goes to the host's
     // mailbox as the hint for later frames (api.hip: a thread whose frames keep needing the far phase stops attempting the split)
     if (phase == 1 && mailbox && blockIdx.x == 0 && threadIdx.x == 0)
@@ -321,7 +338,7 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     }
     // complete: final outputs.  Otherwise the near bag ran out with pixels still accumulating: park the state again and ask for
     // the far instances (phase 1 continues from here).
-    if (walker) fwd_store(st, complete, W, H, tile, tid, bg, final_T, n_contrib, tile_last, out_color);
+    if (walker) fwd_store(st, complete, W, H, tile, tid, bg, final_T, n_contrib, tile_last, out_color, accum);
     if (tid == 0) {
         tile_state[tile] = complete ? 0xffffffffu : done;
         if (!complete) {
@@ -333,13 +350,13 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
 
 hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
                                const float* subpixel_offset, const float* background, float* out_color, const LazyConfig& g_lazy,
-                               bool split, int phase, HostMailbox* mailbox_dev, hipStream_t stream) {
+                               bool split, int phase, HostMailbox* mailbox_dev, const BinStats* guard, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(render_fixup_kernel, dim3(tiles), dim3(256), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, b.bucket_ids,
                        g.depths, g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.tile_state, img.final_T,
                        img.n_contrib, img.tile_last, out_color, 1536u < g_lazy.cap ? 1536u : (g_lazy.cap * 3u) / 4u, g_lazy.cap < FRONT_CAP ? g_lazy.cap : FRONT_CAP,
-                       code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu, split ? img.tile_near : (const uint32_t*)nullptr, img.split, phase, mailbox_dev);
+                       code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu, split ? img.tile_near : (const uint32_t*)nullptr, img.split, phase, mailbox_dev, guard, img.accum);
     return hipGetLastError();
 }
 

@@ -50,7 +50,14 @@ struct BinStats {  // read back by the host once per forward (the reference's nu
     uint32_t num_rendered;
     uint32_t max_tile_count;
     uint32_t split_active;  // 1: the near / far split is on for this frame (SplitState::near_code is a real threshold)
-    uint32_t pad;
+    uint32_t spec_fail;     // speculative forward (api.hip): 1 = this frame does not fit what the host enqueued ahead of the count (more
+                            // instances than the binning buffer holds, or a list longer than the launched sort network covers):
+                            // every guarded kernel behind the scan returns at once and the host re-issues the tail with the real sizes
+};
+// What a speculative forward pass promises the kernels it enqueues before the instance count is known (all zero: no speculation).
+struct SpecLimits {
+    uint32_t capacity = 0;   // instances the binning buffer holds
+    uint32_t max_list = 0;   // longest per-tile list the launched sort path covers (0xffffffff: any, i.e. the lazy front sort)
 };
 
 // Near / far split of dense frames (binning.hip): a frame-wide depth-code threshold, chosen on the device from a histogram of the
@@ -78,11 +85,14 @@ struct HostMailbox {
     uint32_t need_far;   // written at the END of a split frame (fix-up phase 1): 1 + the number of tiles that needed far instances
                          // (0 = nothing new).  Read by the host at the start of a LATER frame as a hint only (no waiting: it may be
                          // a frame old)
-    uint32_t pad[3];
+    uint32_t spec_fail;  // BinStats::spec_fail of the same frame
+    uint32_t pad[2];
 };
 
 struct ImageState {
     float* final_T;  // MUST stay first: documented in wg_rasterizer.h
+    float* accum;    // MUST stay second: 1 - final_T, written by the forward kernels when a tile completes (the binding returns a
+                     // view of it as `accumulation` instead of launching an elementwise kernel per call)
     uint32_t* n_contrib;
     uint2* ranges;
     uint32_t* tile_last;
@@ -165,6 +175,7 @@ struct FwdParams {
 // kernels / stages (each launches on `stream`, returns hipGetLastError())
 hipError_t launch_preprocess(const FwdParams& p, const ShTone& tone, const GeometryState& g, int* radii_out, hipStream_t stream);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t stream);
+hipError_t launch_recolor(int P, const GeometryState& src, const GeometryState& dst, const float* colors, int* radii_out, hipStream_t stream);
 hipError_t run_scan(const GeometryState& g, int P, hipStream_t stream);
 hipError_t launch_scan_overflow_check(const GeometryState& g, int P, uint32_t* flag, hipStream_t stream);  // *flag = 1: the 32-bit scan wrapped
 hipError_t launch_duplicate_keys(int P, const GeometryState& g, const BinningState& b, int gx, hipStream_t stream);
@@ -176,13 +187,16 @@ hipError_t launch_split_threshold(int P, const GeometryState& g, const ImageStat
                                   hipStream_t stream);
 // box: count through a difference grid + two prefix passes (four atomics per Gaussian) instead of one atomic per instance
 hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, bool split, bool box, hipStream_t stream);
-hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, bool split, hipStream_t stream);
+hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, bool split, const SpecLimits& spec,
+                            hipStream_t stream);
+// guard (everywhere below): nullptr, or the frame's BinStats -- the kernel returns at once when spec_fail is set there
 hipError_t launch_tile_scatter_far(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles, int code_bits,
-                                   hipStream_t stream);
+                                   const BinStats* guard, hipStream_t stream);
 // code_bits > 0: bucket entries carry a coarse depth code of that width above the id (wg_sort.h: depth_code); only the lazy
 // sort reads it
 hipError_t launch_tile_scatter(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles,
-                               uint32_t num_rendered, int code_bits, int staged_scatter, int staged_cap, bool split, hipStream_t stream);
+                               uint32_t num_rendered, int code_bits, int staged_scatter, int staged_cap, bool split, const BinStats* guard,
+                               hipStream_t stream);
 struct LazyConfig {
     bool enabled = true;
     uint32_t min_len = 1024;  // tiles listing more than this are front-split instead of sorted in full (the lazy path as a whole is
@@ -199,6 +213,10 @@ struct Options {
     int staged_cap = 0;               // staging-area entries, 0 = what the LDS budget allows (tests: multi-pass)
     int band_list_min_p = 2000000;    // from here on the scatter kernels read per-band candidate lists instead of whole chunks
     int depth_codes = 1;              // 0 / 1 / 8..12: off (as for P > 2^24) / automatic width / forced width (tests)
+    int speculative = 1;              // speculative forward (api.hip): enqueue everything behind the instance count before it is known
+    int spec_margin_pct = 25;         //   binning buffer = the recent frames' largest count + this margin
+    int geometry_reuse = 1;           // read by the torch binding (_C.py): consecutive calls over identical geometry and camera share
+                                      // the projection and the binning of the first (wg_rasterize_forward_recolor)
     int grad_record = 1;              // 0: the per-tile backward accumulates into the four arrays themselves (A/B)
     int deterministic_backward = 0;   // 1: per-instance slots + an ordered per-Gaussian sum instead of float atomics (bit-reproducible)
     int near_split = -1;              // near / far split of dense frames: -1 automatic (P >= band_list_min_p or a dense previous frame, and >= SPLIT_DENSE_AVG =
@@ -209,20 +227,26 @@ struct Options {
     bool use_mailbox = true;          // 0 restores the copy + synchronise read-back
 };
 hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, int code_bits,
-                                 const LazyConfig& lazy, bool split, hipStream_t stream);
+                                 const LazyConfig& lazy, bool split, const BinStats* guard, hipStream_t stream);
 // phase 0: the near bag (all of the bucket without a split); phase 1: the far bag of the tiles that asked for it
 hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
                                const float* subpixel_offset, const float* background, float* out_color, const LazyConfig& lazy,
-                               bool split, int phase, HostMailbox* mailbox_dev, hipStream_t stream);
+                               bool split, int phase, HostMailbox* mailbox_dev, const BinStats* guard, hipStream_t stream);
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
-                            hipStream_t stream);
+                            const BinStats* guard, hipStream_t stream);
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                  const GeometryState& g, const float* subpixel_offset, const float* background,
-                                 float* out_color, bool lazy, hipStream_t stream);
+                                 float* out_color, bool lazy, const BinStats* guard, hipStream_t stream);
+// the compositing of a frame whose binning and per-pixel stops are known (img.tile_last, img.n_contrib of an earlier pass over the
+// same geometry): each tile walks exactly its list's first tile_last entries and stores final outputs
+hipError_t launch_render_forward_replay(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
+                                        const GeometryState& g, const float* subpixel_offset, const float* background,
+                                        float* out_color, hipStream_t stream);
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                   const GeometryState& g, const float* subpixel_offset, const float* background,
                                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                  float* dL_dcolor, bool record, float* det_slots, int P, hipStream_t stream);  // det_slots != nullptr: deterministic mode
+                                  float* dL_dcolor, bool record, float* det_slots, unsigned char* det_flags, int P,
+                                  hipStream_t stream);  // det_slots != nullptr: deterministic mode (det_flags: one byte per slot, cleared)
 
 struct BwdParams {
     int P, D, M, W, H;

@@ -68,14 +68,21 @@ __device__ __forceinline__ void sort_stage(SortCtx<E>& c) {
                 keep(c.key[r], ((uint64_t)hi << 32) | lo, keep_min);
             }
         } else {  // the partner keys sit in another wave: one round trip through LDS
-            uint64_t* mine = c.xchg + E * c.t;
+            // key r of thread t at xchg[256 r + t]: consecutive lanes on consecutive 8-byte words, for the writes and -- the partner
+            // thread t ^ (J/E) differs from t in a wave-index bit only -- for the reads alike.  (Round 2 kept a thread's E keys
+            // together, xchg[E t + r]: a 32-byte lane stride, 9.7 M LDS bank-conflict cycles per launch at the headline scene.)
+#ifndef WG_SORT_XCHG_TRANSPOSED
+#define WG_SORT_XCHG_TRANSPOSED 1
+#endif
+            constexpr uint32_t RS = WG_SORT_XCHG_TRANSPOSED ? 256u : 1u, TS = WG_SORT_XCHG_TRANSPOSED ? 1u : (uint32_t)E;
+            uint64_t* mine = c.xchg + TS * c.t;
 #pragma unroll
-            for (int r = 0; r < E; r++) mine[r] = c.key[r];
+            for (int r = 0; r < E; r++) mine[RS * r] = c.key[r];
             __syncthreads();
-            const uint64_t* theirs = c.xchg + E * (c.t ^ (J / E));
+            const uint64_t* theirs = c.xchg + TS * (c.t ^ (J / E));
             uint64_t other[E];
 #pragma unroll
-            for (int r = 0; r < E; r++) other[r] = theirs[r];
+            for (int r = 0; r < E; r++) other[r] = theirs[RS * r];
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < E; r++) keep(c.key[r], other[r], keep_min);

@@ -17,6 +17,8 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
+import weakref
 
 import torch
 
@@ -49,6 +51,8 @@ _lib.wg_rasterize_forward_toned.restype = _i
 _lib.wg_rasterize_forward_toned.argtypes = _lib.wg_rasterize_forward.argtypes + [C.POINTER(_ShTone)]
 _lib.wg_rasterize_backward_toned.restype = _i
 _lib.wg_rasterize_backward_toned.argtypes = _lib.wg_rasterize_backward.argtypes + [C.POINTER(_ShTone)]
+_lib.wg_rasterize_forward_recolor.restype = _i
+_lib.wg_rasterize_forward_recolor.argtypes = [_ALLOC_FN, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.wg_mark_visible.restype = _i
 _lib.wg_mark_visible.argtypes = [_i, _vp, _vp, _vp, _vp, _vp]
 for _name in ("wg_geometry_buffer_size", "wg_binning_buffer_size"):
@@ -56,6 +60,8 @@ for _name in ("wg_geometry_buffer_size", "wg_binning_buffer_size"):
     getattr(_lib, _name).argtypes = [_i]
 _lib.wg_image_buffer_size.restype = C.c_size_t
 _lib.wg_image_buffer_size.argtypes = [_i, _i]
+_lib.wg_image_accumulation_offset.restype = C.c_size_t
+_lib.wg_image_accumulation_offset.argtypes = [_i, _i]
 for _name in ("wg_status_string",):
     getattr(_lib, _name).restype = C.c_char_p
     getattr(_lib, _name).argtypes = [_i]
@@ -75,7 +81,7 @@ class _BinningView(C.Structure):
 
 
 class _ImageView(C.Structure):
-    _fields_ = [(n, _vp) for n in ("final_T", "n_contrib", "ranges", "tile_last", "tile_near", "split")]
+    _fields_ = [(n, _vp) for n in ("final_T", "accumulation", "n_contrib", "ranges", "tile_last", "tile_near", "split")]
 
 
 _lib.wg_view_geometry.restype = _i
@@ -86,6 +92,16 @@ _lib.wg_view_image.restype = _i
 _lib.wg_view_image.argtypes = [_vp, _i, _i, C.POINTER(_ImageView)]
 
 IMAGE_STATE_ALIGNMENT = 256  # final_T sits at the first 256-byte aligned address of imgBuffer (wg_rasterizer.h)
+_acc_offsets = {}
+
+
+def accumulation_offset(height: int, width: int) -> int:
+    """Bytes from final_T to the accumulation array inside imgBuffer (wg_image_accumulation_offset; cached per frame size)."""
+    k = (height, width)
+    if k not in _acc_offsets:
+        _acc_offsets[k] = int(_lib.wg_image_accumulation_offset(int(width), int(height)))
+    return _acc_offsets[k]
+
 
 
 def _check(status: int, what: str) -> int:
@@ -154,6 +170,55 @@ def _tone_block(sh_tone, device, P, grads=None):
     return t, keep
 
 
+# ----------------------------------------------------------------------------------------------------------
+# Geometry reuse across consecutive calls (option "geometry_reuse", default on).  WildGaussians rasterizes the same Gaussians
+# through the same camera twice per step -- raw colours, then toned colours (method.py:1573-1611), a third time for depth -- and the
+# reference projects, bins and sorts each time.  The binding remembers the LAST full forward call of the calling thread: when the
+# next call hands over the very same geometry tensors (same Python objects, same autograd versions: nothing wrote to them), the
+# same camera tensors and scalars and only other precomputed colours, it takes wg_rasterize_forward_recolor -- a copy of the
+# projected state with the new colours and the compositing along the parent's sorted lists; binning and image-state buffers are
+# shared with the parent call's (the per-pixel values are identical).  Identity is by object (weak references), never by address:
+# a freed tensor's address can be handed to a new one.
+_reuse = threading.local()
+
+
+def _tensor_token(t):
+    """What must be unchanged for a tensor argument to count as 'the same': the object and its version counter (zero-sized
+    'absent' sentinels are fresh objects on every call: they match each other)."""
+    if t is None or t.numel() == 0:
+        return None
+    return (weakref.ref(t), t._version, tuple(t.shape), t.dtype)
+
+
+def _same_token(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    return a[0]() is not None and a[0]() is b[0]() and a[1:] == b[1:]
+
+
+def _reuse_key(background, means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+               kernel_size, subpixel_offset, H, W, prefiltered, device):
+    tensors = tuple(_tensor_token(t) for t in (means3D, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, background,
+                                               subpixel_offset))
+    scalars = (float(scale_modifier), float(tan_fovx), float(tan_fovy), float(kernel_size), H, W, bool(prefiltered), str(device),
+               _stream(device))
+    return tensors, scalars
+
+
+def _reuse_lookup(key):
+    last = getattr(_reuse, "last", None)
+    if last is None or last["scalars"] != key[1] or len(last["tensors"]) != len(key[0]):
+        return None
+    if not all(_same_token(a, b) for a, b in zip(last["tensors"], key[0])):
+        return None
+    return last
+
+
+def forget_geometry():
+    """Drop the calling thread's remembered forward call (and the scratch buffers it keeps alive)."""
+    _reuse.last = None
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width, sh, degree,
                         campos, prefiltered, debug, sh_tone=None):
@@ -163,6 +228,32 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         raise RuntimeError("means3D must live on a HIP device: this rasterizer has no CPU path")
     device = means3D.device
     P, H, W = means3D.size(0), int(image_height), int(image_width)
+
+    # precomputed colours over remembered geometry: no projection, no binning
+    reusable = (P != 0 and sh_tone is None and not debug and colors.numel() == 3 * P and sh.numel() == 0
+                and _lib.wg_get_option(b"geometry_reuse") == 1)
+    key = None
+    if reusable:
+        key = _reuse_key(background, means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
+                         tan_fovy, kernel_size, subpixel_offset, H, W, prefiltered, device)
+        last = _reuse_lookup(key)
+        if last is not None:
+            geom = _Scratch(device)
+            out_color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+            colors_f, bg_f = _f32(colors, device), _f32(background, device)
+            so = torch.Tensor([]) if subpixel_offset is None else _f32(subpixel_offset, device)
+            try:
+                with torch.cuda.device(device):
+                    rendered = _lib.wg_rasterize_forward_recolor(
+                        geom.callback, None, last["geom"].data_ptr(), last["binning"].data_ptr(), last["img"].data_ptr(), P, int(last["R"]),
+                        _ptr(bg_f), W, H, _ptr(colors_f), _ptr(so), out_color.data_ptr(), None, _stream(device))
+            finally:
+                child = geom.take()
+            _check(rendered, "wg_rasterize_forward_recolor")
+            _reuse.hits = getattr(_reuse, "hits", 0) + 1
+            return (rendered, out_color, last["radii"], child, last["binning"], last["img"])
+    else:
+        _reuse.last = None   # any other kind of call ends the remembered one's reach
 
     geom, binning, img = _Scratch(device), _Scratch(device), _Scratch(device)
     if P == 0:  # rasterize_points.cu:83: nothing is launched, the image stays zero
@@ -193,6 +284,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     finally:
         buffers = (geom.take(), binning.take(), img.take())
     _check(rendered, "wg_rasterize_forward")
+    if key is not None and rendered >= 0:
+        _reuse.last = dict(tensors=key[0], scalars=key[1], R=rendered, radii=radii, geom=buffers[0], binning=buffers[1], img=buffers[2])
     return (rendered, out_color, radii) + buffers
 
 
@@ -310,6 +403,7 @@ def view_image(imageBuffer, H, W):
     _check(_lib.wg_view_image(imageBuffer.data_ptr(), int(W), int(H), C.byref(v)), "wg_view_image")
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     return dict(final_T=_from_ptr(v.final_T, (H, W), torch.float32, imageBuffer),
+                accumulation=_from_ptr(v.accumulation, (H, W), torch.float32, imageBuffer),
                 n_contrib=_from_ptr(v.n_contrib, (H, W), torch.int32, imageBuffer),
                 ranges=_from_ptr(v.ranges, (tiles, 2), torch.int32, imageBuffer),
                 tile_last=_from_ptr(v.tile_last, (tiles,), torch.int32, imageBuffer),
@@ -324,6 +418,12 @@ _lib.wg_set_option.argtypes = [C.c_char_p, _i]
 def set_option(name: str, value: int) -> None:
     """wg_set_option: e.g. set_option("force_global_sort", 1) selects the rocPRIM global-sort binning path."""
     _check(_lib.wg_set_option(name.encode(), int(value)), f"wg_set_option({name})")
+    forget_geometry()   # a remembered forward call was made under the old options
+
+
+def geometry_reuse_hits() -> int:
+    """How many calls of this thread took the geometry-reuse path so far."""
+    return getattr(_reuse, "hits", 0)
 
 
 def get_option(name: str) -> int:

@@ -63,11 +63,12 @@ def _call_native(fn, args, debug: bool, dump_path: str, what: str):
 
 
 def _accumulation_from_image_state(img_buffer: torch.Tensor, height: int, width: int) -> torch.Tensor:
-    """accumulation = 1 - final_T; final_T is the first array of the image-state buffer (wg_rasterizer.h)."""
+    """accumulation = 1 - final_T (reference __init__.py:101-113).  The forward kernels write it themselves, as the second array of
+    the image-state buffer (wg_rasterizer.h): a view, no elementwise kernel per call.  The memory belongs to this call's scratch
+    (kept alive by the view); calls that share an image state through the binding's geometry reuse share the values too."""
     align = _C.IMAGE_STATE_ALIGNMENT
-    start = (-img_buffer.data_ptr()) % align
-    final_T = img_buffer[start:start + 4 * height * width].view(torch.float32)
-    return (1.0 - final_T).view(height, width)
+    start = (-img_buffer.data_ptr()) % align + _C.accumulation_offset(height, width)
+    return img_buffer[start:start + 4 * height * width].view(torch.float32).view(height, width)
 
 
 class _RasterizeGaussians(torch.autograd.Function):

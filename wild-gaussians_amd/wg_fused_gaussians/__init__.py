@@ -199,6 +199,11 @@ class FusedAdam(torch.optim.Adam):
                 d = _AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), beta2, 1.0 - beta1, 1.0 - beta2,
                                 lr / (1.0 - beta1 ** step), (1.0 - beta2 ** step) ** 0.5, float(group["eps"]), float(group["weight_decay"]))
                 by_device.setdefault(p.device, []).append((d, g))   # g: keeps a contiguous copy alive until the launch is queued
+                # the kernel writes p, m and v behind torch's back: say so, as an in-place torch op would (autograd's saved-tensor
+                # checks and the rasterizer binding's geometry reuse both read the version counter)
+                torch.autograd.graph.increment_version(p)
+                torch.autograd.graph.increment_version(m)
+                torch.autograd.graph.increment_version(v)
         for dev, items in by_device.items():
             arr = (_AdamTensor * len(items))(*[d for d, _ in items])
             with torch.cuda.device(dev):

@@ -46,21 +46,28 @@ def _scene(name):
     return cloud, cam, (deg if deg is not None else 0)
 
 
-@pytest.mark.parametrize("binning", ["tile_sort", "global_sort", "box_count"])
+@pytest.mark.parametrize("binning", ["tile_sort", "global_sort", "box_count", "fused_scan"])
 @pytest.mark.parametrize("name", list(CASES))
 def test_preprocess_and_binning_bit_exact(oracle, name, binning):
-    """binning: the LDS counting sort + per-tile sort (default), the reference's scheme on rocPRIM (fallback), and the default
-    with the per-tile counts made from a difference grid + prefix passes (wg_set_option "box_count": large / dense frames)."""
+    """binning: the LDS counting sort + per-tile sort (default), the reference's scheme on rocPRIM (fallback), the default
+    with the per-tile counts made from a difference grid + prefix passes (wg_set_option "box_count": large / dense frames), and the
+    default with the column scan and the tile scan in one launch ("fused_scan": last-workgroup hand-over)."""
     from diff_gaussian_rasterization import _C
     cloud, cam, deg = _scene(name)
     o = oracle.run_scene(cloud, cam, sh_degree=deg)
     _C.set_option("force_global_sort", int(binning == "global_sort"))
     _C.set_option("box_count", 1 if binning == "box_count" else -1)
+    _C.set_option("fused_scan", int(binning == "fused_scan"))
     try:
         h = run_hip_native(cloud, cam, sh_degree=deg)
+        if binning == "fused_scan":   # twice more over the same (recycled) buffers: the ticket counter must start from zero every frame
+            for _ in range(2):
+                h2 = run_hip_native(cloud, cam, sh_degree=deg)
+                assert h2["num_rendered"] == h["num_rendered"] and torch.equal(h2["color"], h["color"])
     finally:
         _C.set_option("force_global_sort", 0)
         _C.set_option("box_count", -1)
+        _C.set_option("fused_scan", 0)
     octx = o["ctx"]
     g, b, im = h["views"]["geometry"], h["views"]["binning"], h["views"]["image"]
     radii = h["radii"].cpu().numpy()

@@ -387,7 +387,7 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
             if (try_split)
                 WG_STAGE(WG_STAGE_SCAN, wg::launch_split_threshold(P, geom, img, tiles, opt.near_split == 1, near_per_tile, stream), "split_threshold");
             const bool box = opt.box_count == 1 || (opt.box_count < 0 && (P >= opt.band_list_min_p || t_last_instances_per_tile >= 1500u));
-            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_count(P, geom, img, gx, tiles, try_split, box, stream), "tile_count");
+            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_count(P, geom, img, gx, tiles, try_split, box, opt.fused_scan != 0, stream), "tile_count");
             mbox = (debug || !opt.use_mailbox) ? nullptr : get_mailbox();
             if (mbox) mbox->seq += 1;
             // ---- speculative forward (option "speculative_forward", default on) ----
@@ -412,7 +412,7 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
                     if (!spec_chunk) return WG_ERR_ALLOC;
                 }
             }
-            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, mbox ? mbox->dev : nullptr, mbox ? mbox->seq : 0, try_split, spec, stream), "tile_scan");
+            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, mbox ? mbox->dev : nullptr, mbox ? mbox->seq : 0, try_split, spec, opt.fused_scan != 0, stream), "tile_scan");
             if (spec.capacity != 0u) {
                 wg::BinningState sbin = wg::BinningState::fromChunk(spec_chunk, (size_t)spec.capacity, false);
                 const int st_ = enqueue_tail(sbin, t_spec.last_rendered(), spec.max_list == 0xffffffffu ? 0u : spec.max_list, spec_lazy, try_split, img.stats);
@@ -429,19 +429,22 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
         bool have_stats = false;
         if (mbox) {
             // poll the mailbox (bounded: ~2 s, then fall back to a real synchronise so that a failed launch is reported)
-            volatile uint32_t* seqp = &mbox->host->seq;
+            volatile unsigned long long* w0 = &mbox->host->word0;
+            volatile unsigned long long* w1 = &mbox->host->word1;
+            const unsigned long long want = mbox->seq;
             const auto t0 = std::chrono::steady_clock::now();
             unsigned spins = 0;
-            while (*seqp != mbox->seq) {
+            unsigned long long a = *w0, b = *w1;
+            while ((a >> 32) != want || (b >> 32) != want) {
                 if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
                 __builtin_ia32_pause();
+                a = *w0; b = *w1;
             }
-            if (*seqp == mbox->seq) {
-                std::atomic_thread_fence(std::memory_order_acquire);
-                st.num_rendered = mbox->host->num_rendered;
-                st.max_tile_count = mbox->host->max_tile_count;
-                st.split_active = mbox->host->split_active;
-                st.spec_fail = mbox->host->spec_fail;
+            if ((a >> 32) == want && (b >> 32) == want) {
+                st.num_rendered = (uint32_t)a;
+                st.max_tile_count = (uint32_t)b & wg::MAILBOX_MAX_LIST;   // (saturated at 2^30 - 1: beyond any list the sort paths distinguish)
+                st.split_active = (uint32_t)(b >> 30) & 1u;
+                st.spec_fail = (uint32_t)(b >> 31) & 1u;
                 have_stats = true;
             }
             t_wait.record(spins != 0u, std::chrono::steady_clock::now() - t0, spec.capacity != 0u);
@@ -609,13 +612,17 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
         }
         if (e != hipSuccess) return hip_fail(e, "deterministic backward scratch");
     }
-    if (record && !det) {  // (the deterministic mode's ordered sum writes every record in full)
+    // the gradient records are cleared by the launch that orders the tiles (one launch instead of a fill kernel + the ordering);
+    // the deterministic mode's ordered sum writes every record in full and needs no clearing
+    const bool clear_records = record && !det;
+    if (clear_records && R <= 0) {
         StageScope scope_(WG_STAGE_RENDER_BACKWARD, stream);
         hipError_t e = hipMemsetAsync(geom.grad_rec, 0, (size_t)P * wg::GRAD_REC_FLOATS * sizeof(float), stream);
         if (e != hipSuccess) return hip_fail(e, "gradient record memset");
     }
     if (R > 0) {
-        WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_order(img.tile_last, nullptr, img.order_bwd, gx * gy, stream), "tile_order");
+        WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_order(img.tile_last, nullptr, img.order_bwd, gx * gy, clear_records ? geom.grad_rec : nullptr,
+                                                             (size_t)P * wg::GRAD_REC_FLOATS, stream), "tile_order");
         WG_STAGE(WG_STAGE_RENDER_BACKWARD, wg::launch_render_backward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, dL_dpix,
                                             dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, det_slots, det_flags, P, stream),
                  "render_backward");
@@ -699,6 +706,7 @@ int wg_set_option(const char* name, int value) {
     if (std::strcmp(name, "host_mailbox") == 0) { o.use_mailbox = value != 0; return WG_OK; }
     if (std::strcmp(name, "grad_record") == 0) { o.grad_record = value != 0; return WG_OK; }
     if (std::strcmp(name, "geometry_reuse") == 0) { o.geometry_reuse = value != 0; return WG_OK; }
+    if (std::strcmp(name, "fused_scan") == 0) { o.fused_scan = value != 0; return WG_OK; }
     if (std::strcmp(name, "speculative_forward") == 0) { o.speculative = value != 0; t_spec.clear(); t_wait.clear(); return WG_OK; }
     if (std::strcmp(name, "spec_margin_pct") == 0) { if (value < 0 || value > 1000) return WG_ERR_INVALID_ARGUMENT; o.spec_margin_pct = value; return WG_OK; }
     if (std::strcmp(name, "deterministic_backward") == 0) { o.deterministic_backward = value != 0; return WG_OK; }
@@ -745,6 +753,7 @@ int wg_get_option(const char* name) {
     const wg::Options o = options_snapshot();
     if (std::strcmp(name, "grad_record") == 0) return o.grad_record;
     if (std::strcmp(name, "geometry_reuse") == 0) return o.geometry_reuse;
+    if (std::strcmp(name, "fused_scan") == 0) return o.fused_scan;
     if (std::strcmp(name, "speculative_forward") == 0) return o.speculative;
     if (std::strcmp(name, "spec_margin_pct") == 0) return o.spec_margin_pct;
     if (std::strcmp(name, "deterministic_backward") == 0) return o.deterministic_backward;

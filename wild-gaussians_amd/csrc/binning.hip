@@ -6,6 +6,7 @@
 // reference's own scheme -- per-Gaussian prefix sum, (tile|depth) key emission, rocPRIM 64-bit radix sort, range extraction --
 // is kept as the fallback for frames whose tile histogram does not fit LDS (> 36 864 tiles) and for tests.
 // Integer work: point_list / ranges / num_rendered are bit-exact on every path.
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 #include <map>
@@ -79,6 +80,7 @@ ImageState ImageState::fromChunk(char*& chunk, size_t N, size_t tiles) {
     carve(chunk, img.far_cursor, tiles ? tiles : 1);
     carve(chunk, img.code_hist, SPLIT_BINS);
     carve(chunk, img.split, 1);
+    carve(chunk, img.scan_ticket, 1);
     return img;
 }
 
@@ -266,10 +268,12 @@ __device__ __forceinline__ int band_of_tile(int t, int tiles) {
 template <bool BOX>
 __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const ushort4* __restrict__ rects, uint32_t* __restrict__ chunk_hist,
                                                          uint16_t* __restrict__ band_list, uint32_t* __restrict__ band_cnt, int gx,
-                                                         int tiles, const float* __restrict__ depths, const SplitState* __restrict__ split) {
+                                                         int tiles, const float* __restrict__ depths, const SplitState* __restrict__ split,
+                                                         uint32_t* __restrict__ scan_ticket) {
     extern __shared__ uint32_t hist[];
     __shared__ uint32_t bcnt[8];
     const int tid = threadIdx.x, chunk = blockIdx.x, lane = tid & 63;
+    if (chunk == 0 && tid == 0) *scan_ticket = 0u;  // the fused column + tile scan's ticket counter (a fresh buffer holds anything)
     const uint32_t near_code = split ? split->near_code : SPLIT_OFF;
     const bool packed = near_code != SPLIT_OFF;  // workgroup-uniform
     for (int t = tid; t < tiles; t += BIN_THREADS) hist[t] = 0;
@@ -384,10 +388,9 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const us
 constexpr int SCAN_WAVES = 16;
 // With an active split the words are (total << 16 | near) per chunk: the prefix written back is that of the NEAR counts (the bucket
 // positions of the near scatter), tile_count gets the totals, tile_near the near totals.
-__global__ void __launch_bounds__(64 * SCAN_WAVES) chunk_scan_kernel(uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ tile_count, int tiles,
-                                                                     uint32_t* __restrict__ tile_near, const SplitState* __restrict__ split) {
-    __shared__ uint32_t part[SCAN_WAVES][64];
-    __shared__ uint32_t part_tot[SCAN_WAVES][64];
+__device__ __forceinline__ void chunk_scan_body(uint32_t* __restrict__ chunk_hist, uint32_t* tile_count, int tiles,
+                                                uint32_t* __restrict__ tile_near, const SplitState* __restrict__ split,
+                                                uint32_t (*part)[64], uint32_t (*part_tot)[64]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + lane;
     constexpr int Q = BIN_CHUNKS / SCAN_WAVES;
@@ -428,15 +431,20 @@ __global__ void __launch_bounds__(64 * SCAN_WAVES) chunk_scan_kernel(uint32_t* _
     }
 }
 
+__global__ void __launch_bounds__(64 * SCAN_WAVES) chunk_scan_kernel(uint32_t* __restrict__ chunk_hist, uint32_t* __restrict__ tile_count, int tiles,
+                                                                     uint32_t* __restrict__ tile_near, const SplitState* __restrict__ split) {
+    __shared__ uint32_t part[SCAN_WAVES][64];
+    __shared__ uint32_t part_tot[SCAN_WAVES][64];
+    chunk_scan_body(chunk_hist, tile_count, tiles, tile_near, split, part, part_tot);
+}
+
 // PER = tiles per thread, a compile-time bound so that a thread's counts are loaded together (the kernel is one workgroup on a
 // critical path: its duration is its chain of memory round trips) and kept in registers for the second pass.
 template <int PER>
-__global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
-                                                         uint2* __restrict__ ranges, BinStats* __restrict__ stats, int tiles,
-                                                         HostMailbox* mailbox, uint32_t seq, const SplitState* __restrict__ split, SpecLimits spec) {
-    __shared__ uint32_t wave_sum[16];
-    __shared__ uint32_t wave_max[16];
-    __shared__ uint32_t wave_ovf[16];
+__device__ __forceinline__ void tile_scan_body(const uint32_t* tile_count, uint32_t* __restrict__ tile_offset,
+                                               uint2* __restrict__ ranges, BinStats* __restrict__ stats, int tiles,
+                                               HostMailbox* mailbox, uint32_t seq, const SplitState* __restrict__ split, SpecLimits spec,
+                                               uint32_t* wave_sum, uint32_t* wave_max, uint32_t* wave_ovf) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // The instance total is a 32-bit sum (the reference's is a 32-bit int, rasterizer_impl.cu:280-284, and overflows silently).
     // Every addition below is checked for wrap-around: if none wraps, every partial sum is exact, so a total of 2^32 or more
@@ -490,11 +498,10 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
         const uint32_t fail = (spec.capacity != 0u && (total > spec.capacity || gmax > spec.max_list)) ? 1u : 0u;
         stats->spec_fail = fail;
         if (mailbox) {
-            mailbox->num_rendered = total;
-            mailbox->max_tile_count = gmax;
-            mailbox->split_active = active;
-            mailbox->spec_fail = fail;
-            __hip_atomic_store(&mailbox->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long hi = (unsigned long long)seq << 32;
+            __hip_atomic_store(&mailbox->word0, hi | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mailbox->word1, hi | ((unsigned long long)fail << 31) | ((unsigned long long)active << 30) | min(gmax, MAILBOX_MAX_LIST),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     uint32_t run = wave_base + incl - local;  // exclusive prefix of this thread's first tile
@@ -507,6 +514,44 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restr
             run += c;
         }
     }
+}
+
+template <int PER>
+__global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
+                                                         uint2* __restrict__ ranges, BinStats* __restrict__ stats, int tiles,
+                                                         HostMailbox* mailbox, uint32_t seq, const SplitState* __restrict__ split, SpecLimits spec) {
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t wave_max[16];
+    __shared__ uint32_t wave_ovf[16];
+    tile_scan_body<PER>(tile_count, tile_offset, ranges, stats, tiles, mailbox, seq, split, spec, wave_sum, wave_max, wave_ovf);
+}
+
+// chunk_scan + tile_scan in ONE launch (option "fused_scan"): every column-scan workgroup publishes its 64 tile totals with a
+// device-scope release and takes a ticket; the workgroup that draws the last ticket acquires and runs the tile scan.  Saves a launch
+// on the forward pass's critical chain; costs the device-scope fences (an L2 write-back per workgroup on this multi-XCD part).
+template <int PER>
+__global__ void __launch_bounds__(64 * SCAN_WAVES) chunk_tile_scan_kernel(uint32_t* __restrict__ chunk_hist, uint32_t* tile_count, int tiles,
+                                                                          uint32_t* __restrict__ tile_near, const SplitState* __restrict__ split,
+                                                                          uint32_t* __restrict__ ticket, uint32_t* __restrict__ tile_offset,
+                                                                          uint2* __restrict__ ranges, BinStats* __restrict__ stats,
+                                                                          HostMailbox* mailbox, uint32_t seq, SpecLimits spec) {
+    __shared__ uint32_t part[SCAN_WAVES][64];
+    __shared__ uint32_t part_tot[SCAN_WAVES][64];
+    __shared__ uint32_t s_last;
+    chunk_scan_body(chunk_hist, tile_count, tiles, tile_near, split, part, part_tot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();  // release: this workgroup's tile_count entries before its ticket
+        s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last == 0u) return;
+    __threadfence();  // acquire: every other workgroup's entries
+    if (threadIdx.x == 0) *ticket = 0u;  // ready for the next frame that carves the same buffer
+    uint32_t* wave_sum = &part[0][0];
+    uint32_t* wave_max = &part[1][0];
+    uint32_t* wave_ovf = &part[2][0];
+    tile_scan_body<PER>(tile_count, tile_offset, ranges, stats, tiles, mailbox, seq, split, spec, wave_sum, wave_max, wave_ovf);
 }
 
 // Scatter of the Gaussian ids into the tile buckets.  Each workgroup owns one (Gaussian chunk, XCD band of tiles) pair
@@ -937,10 +982,17 @@ __global__ void __launch_bounds__(256) tile_front_sort_kernel(const uint32_t* __
 // The order only has to be roughly descending, so it is a 256-bin counting sort (bin = cost scaled by the band's maximum; 5
 // barriers) rather than a comparison sort of the band's ~1000 keys (55 barriers: 14 us of pure latency in front of the backward
 // kernel).
+// Blocks 8 and up (when asked for) clear the backward pass's gradient records: the clear and the ordering are both needed in front of
+// the per-tile kernel and depend on nothing of each other, so they share a launch instead of queueing as a fill kernel + this one.
 __global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __restrict__ cost, const uint2* __restrict__ ranges,
-                                                          uint32_t* __restrict__ order, int tiles) {
+                                                          uint32_t* __restrict__ order, int tiles, float4* __restrict__ clear, size_t clear_vec4) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wmax[16];
+    if (blockIdx.x >= 8) {
+        const size_t stride = (size_t)(gridDim.x - 8) * 1024;
+        for (size_t i = (size_t)(blockIdx.x - 8) * 1024 + threadIdx.x; i < clear_vec4; i += stride) clear[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     const int q = tiles >> 3, rem = tiles & 7, x = blockIdx.x;
     const uint32_t start = x * q + min(x, rem), cnt = q + (x < rem ? 1 : 0);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -976,9 +1028,14 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __rest
     for (uint32_t i = tid; i < cnt; i += 1024) order[start + atomicAdd(&hist[bin_of(cost_of(i))], 1u)] = start + i;
 }
 
-hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_or_null, uint32_t* order, int tiles, hipStream_t stream) {
+hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_or_null, uint32_t* order, int tiles, float* clear, size_t clear_floats,
+                             hipStream_t stream) {
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(8), dim3(1024), 0, stream, cost_or_null, ranges_or_null, order, tiles);
+    // clear: 16-byte aligned, a multiple of 4 floats (the gradient records: 12 floats per Gaussian in a 256-byte aligned array)
+    const size_t vec4 = clear ? clear_floats / 4 : 0;
+    const unsigned clear_blocks = vec4 ? (unsigned)std::min<size_t>(2048, (vec4 + 4095) / 4096) : 0u;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(8 + clear_blocks), dim3(1024), 0, stream, cost_or_null, ranges_or_null, order, tiles,
+                       reinterpret_cast<float4*>(clear), vec4);
     return hipGetLastError();
 }
 
@@ -999,7 +1056,8 @@ static hipError_t ensure_lds(const void* fn, size_t bytes) {
     return e;
 }
 
-hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, bool split, bool box, hipStream_t stream) {
+hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, bool split, bool box, bool fused_scan,
+                             hipStream_t stream) {
     const size_t lds = (size_t)tiles * sizeof(uint32_t);
     hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_count_kernel<false>), lds);
     if (e == hipSuccess) e = ensure_lds(reinterpret_cast<const void*>(tile_count_kernel<true>), lds);
@@ -1007,20 +1065,30 @@ hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& im
     const SplitState* sp = split ? img.split : nullptr;
     if (box && gx <= BIN_THREADS)
         hipLaunchKernelGGL(tile_count_kernel<true>, dim3(BIN_CHUNKS), dim3(BIN_THREADS), lds, stream, P, g.rects, img.chunk_hist, g.band_list,
-                           g.band_cnt, gx, tiles, g.depths, sp);
+                           g.band_cnt, gx, tiles, g.depths, sp, img.scan_ticket);
     else
         hipLaunchKernelGGL(tile_count_kernel<false>, dim3(BIN_CHUNKS), dim3(BIN_THREADS), lds, stream, P, g.rects, img.chunk_hist, g.band_list,
-                           g.band_cnt, gx, tiles, g.depths, sp);
+                           g.band_cnt, gx, tiles, g.depths, sp, img.scan_ticket);
     e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || fused_scan) return e;  // fused: launch_tile_scan runs the column scan too
     hipLaunchKernelGGL(chunk_scan_kernel, dim3((tiles + 63) / 64), dim3(64 * SCAN_WAVES), 0, stream, img.chunk_hist, img.tile_count, tiles,
                        split ? img.tile_near : (uint32_t*)nullptr, sp);
     return hipGetLastError();
 }
 
 hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, bool split, const SpecLimits& spec,
-                            hipStream_t stream) {
+                            bool fused_scan, hipStream_t stream) {
     const SplitState* sp = split ? img.split : nullptr;
+    if (fused_scan) {
+        uint32_t* near = split ? img.tile_near : (uint32_t*)nullptr;
+        if (tiles <= 8 * 1024)
+            hipLaunchKernelGGL(chunk_tile_scan_kernel<8>, dim3((tiles + 63) / 64), dim3(64 * SCAN_WAVES), 0, stream, img.chunk_hist, img.tile_count, tiles,
+                               near, sp, img.scan_ticket, img.tile_offset, img.ranges, img.stats, mailbox_dev, seq, spec);
+        else
+            hipLaunchKernelGGL((chunk_tile_scan_kernel<BIN_MAX_TILES / 1024>), dim3((tiles + 63) / 64), dim3(64 * SCAN_WAVES), 0, stream, img.chunk_hist,
+                               img.tile_count, tiles, near, sp, img.scan_ticket, img.tile_offset, img.ranges, img.stats, mailbox_dev, seq, spec);
+        return hipGetLastError();
+    }
     // BIN_MAX_TILES / 1024 = 36 tiles per thread at most; 8 covers 1080p (8160 tiles)
     if (tiles <= 8 * 1024)
         hipLaunchKernelGGL(tile_scan_kernel<8>, dim3(1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges, img.stats, tiles,

@@ -405,38 +405,50 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
 #undef syy
 #undef sq
 
-// Ordered per-Gaussian sum of the deterministic mode.  Sixteen threads per Gaussian, one per value (ten sums + the record's two
-// pads, four idle): thread (g, v) adds value v of g's tiles_touched slots in slot order -- only the slots the per-tile pass flagged as
-// written; the slot array (40 B per tile instance) is never cleared, only the flags (1 B per instance) are -- and WRITES the whole
-// record, zeros for a Gaussian nothing was added to, so the record needs no clearing either.  A slot's ten floats are read by ten
-// consecutive lanes: one 40-byte segment per step.  The slots are taken eight at a time -- eight flag loads, then eight predicated
-// value loads, all independent -- and added in slot order: one memory round trip per eight slots instead of two per slot.
-// (Round 2: one thread per Gaussian over ten strided values, every slot cleared and read: 300 MB cleared + 300 MB read at the
-// headline scene, against 7 MB + 93 MB now.)
+// Ordered per-Gaussian sum of the deterministic mode.  One thread per Gaussian adds its tiles_touched slots in slot order -- only the
+// slots the per-tile pass flagged as written: the slot array (40 B per tile instance) is never cleared, only the flags (1 B per
+// instance) are -- and WRITES the whole 48-byte record, zeros for a Gaussian nothing was added to, so the record needs no clearing
+// either.  The kernel is a latency problem, not a bandwidth one (7 MB of flags, ~70 MB of flagged slots, 48 MB of records at the
+// headline scene): the slots are taken eight at a time -- eight flag loads, then the flagged slots' ten floats as five 8-byte
+// loads each, all independent -- and added in slot order, i.e. two memory round trips per eight slots (8.5 slots per Gaussian on
+// average, two of them flagged).
+// (Round 2: every slot cleared and read, ten dependent strided loads per slot: 300 MB cleared + 300 MB read.  A first round-3
+// version with sixteen threads per Gaussian, one per value: 237 us -- sixteen times the threads, each still a chain of round trips.)
 __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* __restrict__ offsets_incl, const uint32_t* __restrict__ tiles_touched,
                                                          const float* __restrict__ det_slots, const unsigned char* __restrict__ det_flags,
                                                          float* __restrict__ grad_rec) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int g = t >> 4, v = t & 15;
-    if (g >= P || v >= GRAD_REC_FLOATS) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
     const uint32_t n = tiles_touched[g];
-    float acc = 0.f;
-    if (n != 0u && v < 10) {
+    float acc[10];
+#pragma unroll
+    for (int v = 0; v < 10; v++) acc[v] = 0.f;
+    if (n != 0u) {
         const size_t base = (size_t)(offsets_incl[g] - n);
         constexpr uint32_t U = 8;
         for (uint32_t k0 = 0; k0 < n; k0 += U) {
             unsigned char f[U];
-            float x[U];
+            float2 x[U][5];
 #pragma unroll
             for (uint32_t u = 0; u < U; u++) f[u] = (k0 + u < n) ? det_flags[base + k0 + u] : (unsigned char)0;
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) x[u] = f[u] ? det_slots[(base + k0 + u) * 10 + v] : 0.f;
+            for (uint32_t u = 0; u < U; u++) {
+                const float2* sl = reinterpret_cast<const float2*>(det_slots + (base + k0 + u) * 10);  // 40-byte slots: 8-byte aligned
+#pragma unroll
+                for (int h = 0; h < 5; h++) x[u][h] = f[u] ? sl[h] : make_float2(0.f, 0.f);
+            }
 #pragma unroll
             for (uint32_t u = 0; u < U; u++)
-                if (f[u]) acc += x[u];
+                if (f[u]) {
+#pragma unroll
+                    for (int h = 0; h < 5; h++) { acc[2 * h] += x[u][h].x; acc[2 * h + 1] += x[u][h].y; }
+                }
         }
     }
-    grad_rec[(size_t)g * GRAD_REC_FLOATS + v] = acc;
+    float4* out = reinterpret_cast<float4*>(grad_rec + (size_t)g * GRAD_REC_FLOATS);
+    out[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    out[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    out[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
 }
 
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
@@ -452,8 +464,8 @@ hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState
                        g.tiles_touched, det_slots, det_flags)
     if (det_slots) {
         WG_LAUNCH(true, true);
-        hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)(((size_t)P * 16 + 255) / 256)), dim3(256), 0, stream, P, g.point_offsets, g.tiles_touched,
-                           det_slots, det_flags, g.grad_rec);
+        hipLaunchKernelGGL(det_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, g.point_offsets, g.tiles_touched, det_slots, det_flags,
+                           g.grad_rec);
     } else if (record) WG_LAUNCH(true, false);
     else WG_LAUNCH(false, false);
 #undef WG_LAUNCH

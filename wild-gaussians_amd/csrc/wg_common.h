@@ -78,16 +78,19 @@ struct SplitState {
 // Host-visible (pinned, mapped, coherent) mailbox the tile scan writes the same two numbers to, followed by a sequence
 // number with system-scope release: the host polls it instead of paying a D2H copy + stream synchronise.
 struct HostMailbox {
-    uint32_t num_rendered;
-    uint32_t max_tile_count;
-    uint32_t seq;
-    uint32_t split_active;
+    // Two self-describing 64-bit words, each stored with ONE relaxed system-scope store (an aligned 8-byte store reaches pinned
+    // host memory whole): the frame's sequence number in the upper half of both, so the host takes a pair only when both carry the
+    // number it waits for -- no release fence on the device, which at system scope writes the whole L2 back first (16 MB of
+    // chunk histograms at the headline scene).
+    //   word0 = seq << 32 | num_rendered
+    //   word1 = seq << 32 | spec_fail << 31 | split_active << 30 | min(max_tile_count, 2^30 - 1)
+    unsigned long long word0, word1;
     uint32_t need_far;   // written at the END of a split frame (fix-up phase 1): 1 + the number of tiles that needed far instances
                          // (0 = nothing new).  Read by the host at the start of a LATER frame as a hint only (no waiting: it may be
                          // a frame old)
-    uint32_t spec_fail;  // BinStats::spec_fail of the same frame
-    uint32_t pad[2];
+    uint32_t pad[3];
 };
+constexpr uint32_t MAILBOX_MAX_LIST = (1u << 30) - 1u;
 
 struct ImageState {
     float* final_T;  // MUST stay first: documented in wg_rasterizer.h
@@ -107,6 +110,7 @@ struct ImageState {
     uint32_t* far_cursor;   //                   per-tile append cursor of the far scatter
     uint32_t* code_hist;    //                   [SPLIT_BINS] tile-count-weighted histogram of the visible Gaussians' depth codes
     SplitState* split;
+    uint32_t* scan_ticket;  // fused column + tile scan: workgroups done so far
     static ImageState fromChunk(char*& chunk, size_t N, size_t tiles);
 };
 
@@ -181,14 +185,17 @@ hipError_t launch_scan_overflow_check(const GeometryState& g, int P, uint32_t* f
 hipError_t launch_duplicate_keys(int P, const GeometryState& g, const BinningState& b, int gx, hipStream_t stream);
 hipError_t run_sort(const BinningState& b, int R, int end_bit, hipStream_t stream);
 hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& img, int tiles, hipStream_t stream);
-hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_or_null, uint32_t* order, int tiles, hipStream_t stream);
+// clear != nullptr: the same launch zeroes clear_floats floats (the backward pass's gradient records)
+hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_or_null, uint32_t* order, int tiles, float* clear, size_t clear_floats,
+                             hipStream_t stream);
 // split == nullptr: no near / far split attempted (small P): the kernels are exactly the ones without it
 hipError_t launch_split_threshold(int P, const GeometryState& g, const ImageState& img, int tiles, bool force, uint32_t near_per_tile,
                                   hipStream_t stream);
 // box: count through a difference grid + two prefix passes (four atomics per Gaussian) instead of one atomic per instance
-hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, bool split, bool box, hipStream_t stream);
+hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, bool split, bool box, bool fused_scan,
+                             hipStream_t stream);
 hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, bool split, const SpecLimits& spec,
-                            hipStream_t stream);
+                            bool fused_scan, hipStream_t stream);
 // guard (everywhere below): nullptr, or the frame's BinStats -- the kernel returns at once when spec_fail is set there
 hipError_t launch_tile_scatter_far(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles, int code_bits,
                                    const BinStats* guard, hipStream_t stream);
@@ -215,6 +222,7 @@ struct Options {
     int depth_codes = 1;              // 0 / 1 / 8..12: off (as for P > 2^24) / automatic width / forced width (tests)
     int speculative = 1;              // speculative forward (api.hip): enqueue everything behind the instance count before it is known
     int spec_margin_pct = 25;         //   binning buffer = the recent frames' largest count + this margin
+    int fused_scan = 0;               // column scan + tile scan in one launch (last-workgroup hand-over); see EXPERIMENTS.md for the A/B
     int geometry_reuse = 1;           // read by the torch binding (_C.py): consecutive calls over identical geometry and camera share
                                       // the projection and the binning of the first (wg_rasterize_forward_recolor)
     int grad_record = 1;              // 0: the per-tile backward accumulates into the four arrays themselves (A/B)

@@ -341,7 +341,10 @@ def main():
         "forward_ms_quantiles": fwd_q,
         "workload_stats": {"P": P, "V": V, "R": int(R), "N": N, "tiles": tiles, "instances_walked": walked},
         "library": {"version": _C.version(), "path": os.path.relpath(_C._LIB_PATH, ROOT), "options": args.option,
-                    "kernel_source_sha": kernel_source_sha()},
+                    "kernel_source_sha": kernel_source_sha(),
+                    # speculative forward (rasterizer_impl.cu:284's rendezvous moved behind the call's last launch): how it fared in this process
+                    "speculative_forward": {k: _C.get_option(k) for k in ("speculative_forward", "spec_frames", "spec_misses", "forward_polls",
+                                                                          "forward_polls_waited", "forward_wait_us_total")}},
     }
 
     if stages:

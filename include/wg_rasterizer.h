@@ -66,8 +66,12 @@ size_t wg_image_accumulation_offset(int width, int height);
  * Returns num_rendered (>= 0) = number of (tile, Gaussian) instances, or a negative wg_status.
  * out_color: float[3*H*W] planar CHW.  radii: int[P] or NULL.  subpixel_offset: float[H*W*2] or NULL (beyond the reference:
  * NULL = all zero, nothing is read; the same in wg_rasterize_backward).  One host<->device rendezvous (the read-back
- * of num_rendered that sizes the binning buffer, as rasterizer_impl.cu:284): the host waits until the first
- * three kernels have run, but work queued on the stream before the call is only waited for, never flushed twice.
+ * of num_rendered that sizes the binning buffer, as rasterizer_impl.cu:284) -- but, by default ("speculative_forward"),
+ * behind the call's LAST launch, not in its middle: the count is predicted from the calling thread's recent frames of the same
+ * shape, the binning buffer is requested with a margin and every kernel behind the count is enqueued at once, guarded on the
+ * device by the verdict the tile scan leaves; a frame that does not fit runs none of them and the call re-issues the tail with
+ * the real sizes.  binning_alloc may therefore be called TWICE in one forward call; only the buffer returned last is used (and
+ * must be the one handed to wg_rasterize_backward).  Results are identical either way.
  */
 int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user,
                          wg_alloc_fn binning_alloc, void* binning_user,
@@ -271,11 +275,19 @@ const char* wg_stage_name(int stage);
 /* "deterministic_backward" (0/1, default 0): the per-tile backward pass adds a Gaussian's per-tile terms with float atomics, so
  * their order -- and the last bits of the gradients -- vary from run to run (as in the reference, whose atomics are per pixel).
  * With 1 every (tile, Gaussian) instance stores its ten wave-reduced sums into a slot of its own and a per-Gaussian kernel adds
- * the slots in a fixed order: bit-identical gradients run to run, at 40 B of stream-ordered scratch per tile instance and about a
- * quarter of the train step (912 -> 669 iter/s at the headline scene).  Values agree with the default mode to rounding (2e-6 of an array's largest magnitude). */
+ * the slots in a fixed order: bit-identical gradients run to run, at 41 B of stream-ordered scratch per tile instance and about
+ * 15 % of the train step (977 -> 833 iter/s at the headline scene; 27 % in round 2).  Values agree with the default mode to rounding
+ * (2e-6 of an array's largest magnitude). */
 /* "box_count" (-1 automatic / 0 / 1, default -1: on for large scenes and after a dense frame, like the split): the per-tile instance
  * counts are made from a difference grid (four LDS atomics per Gaussian: its rectangle's corners) and two prefix passes instead of
  * one atomic per (Gaussian, tile) instance.  Identical counts. */
+/* "speculative_forward" (1/0, default 1): see wg_rasterize_forward; "spec_margin_pct" (default 25): the binning buffer of a
+ * speculative frame holds the recent frames' largest instance count plus this margin.  Setting "speculative_forward" also clears the
+ * calling thread's frame history and the read-only counters wg_get_option reports for it: "spec_frames", "spec_misses",
+ * "forward_polls", "forward_polls_waited", "forward_wait_us_total", "forward_wait_us_last".
+ * "geometry_reuse" (1/0, default 1): read by the torch binding only (wg_rasterize_forward_recolor is always available).
+ * "fused_scan" (0/1, default 0): the column scan and the tile scan of the binning in one launch (measured slower on MI355X: the
+ * device-scope hand-over costs more than the launch it saves). */
 /* "roctx" (0/1, default 0; WG_ROCTX=1 in the environment switches it on from the first call): a roctx range around every stage
  * ("wg:K1 preprocess" ... "wg:K10-K11 preprocess_backward"), for `rocprofv3 --marker-trace --kernel-trace`.  The marker library is
  * dlopen()ed on demand; WG_ERR_INVALID_ARGUMENT if none is found. */

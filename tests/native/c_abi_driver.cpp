@@ -116,6 +116,32 @@ int main(int argc, char** argv) {
                                          tany, 0.1f, nullptr, d_radii, geom.p, bin.p, img.p, d_cot, g2d, gcon, gop, gcol, g3d, gcov, gsh, gsc, grot, 0,
                                          stream);
     if (st != WG_OK) { std::fprintf(stderr, "backward: %s (%s)\n", wg_status_string(st), wg_last_hip_error()); return 5; }
+    // geometry reuse: the same Gaussians and camera with other (precomputed) colours ride on the first call's projection and binning
+    {
+        std::vector<float> cols(3 * (size_t)P);
+        for (auto& v : cols) v = uni(seed);
+        float *d_cols, *d_color2;
+        if (upload(cols, &d_cols)) return 2;
+        CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d_color2), (size_t)3 * W * H * sizeof(float)));
+        Grow geom2;
+        const int R2 = wg_rasterize_forward_recolor(Grow::alloc, &geom2, geom.p, bin.p, img.p, P, R, d_bg, W, H, d_cols, nullptr, d_color2, nullptr, stream);
+        if (R2 != R) { std::fprintf(stderr, "recolor: %s (%s)\n", wg_status_string(R2), wg_last_hip_error()); return 10; }
+        const int st2 = wg_rasterize_backward(P, 0, 0, R, d_bg, W, H, d_means, nullptr, d_cols, d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx,
+                                              tany, 0.1f, nullptr, d_radii, geom2.p, bin.p, img.p, d_cot, g2d, gcon, gop, gcol, g3d, gcov, nullptr, gsc, grot,
+                                              0, stream);
+        if (st2 != WG_OK) { std::fprintf(stderr, "backward after recolor: %s (%s)\n", wg_status_string(st2), wg_last_hip_error()); return 11; }
+        CHECK_HIP(hipStreamSynchronize(stream));
+        std::vector<float> c2((size_t)3 * W * H);
+        CHECK_HIP(hipMemcpy(c2.data(), d_color2, c2.size() * 4, hipMemcpyDeviceToHost));
+        double s2 = 0;
+        for (float v : c2) { if (!std::isfinite(v)) { std::fprintf(stderr, "non-finite recoloured image\n"); return 12; } s2 += v; }
+        if (!(s2 > 0)) { std::fprintf(stderr, "empty recoloured image\n"); return 12; }
+        (void)hipFree(d_cols); (void)hipFree(d_color2); (void)hipFree(geom2.p);
+    }
+    // (the backward pass after the recolouring overwrote the gradient buffers: run the SH call's backward again for the dump below)
+    if (wg_rasterize_backward(P, D, M, R, d_bg, W, H, d_means, d_shs, nullptr, d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f,
+                              nullptr, d_radii, geom.p, bin.p, img.p, d_cot, g2d, gcon, gop, gcol, g3d, gcov, gsh, gsc, grot, 0, stream) != WG_OK)
+        return 5;
     unsigned char* d_vis;
     CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d_vis), (size_t)P));
     if (wg_mark_visible(P, d_means, d_view, d_proj, d_vis, stream) != WG_OK) return 6;

@@ -823,6 +823,6 @@ const char* wg_status_string(int status) {
 
 const char* wg_last_hip_error(void) { return g_last_hip_error.c_str(); }
 
-const char* wg_version(void) { return "wg_rasterizer 0.2 (gfx950)"; }
+const char* wg_version(void) { return "wg_rasterizer 0.3 (gfx950)"; }
 
 }  // extern "C"

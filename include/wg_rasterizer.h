@@ -198,6 +198,27 @@ int wg_rasterize_forward_recolor(wg_alloc_fn geometry_alloc, void* geometry_user
                                  char* parent_image_buffer, int P, int R, const float* background, int width, int height,
                                  const float* colors_precomp, const float* subpixel_offset, float* out_color, int* radii, void* stream);
 
+/*
+ * Beyond the reference: a forward pass WITHOUT any host<->device rendezvous, for callers that capture the step in a hipGraph (or
+ * simply must not block).  The caller supplies the binning capacity (instances); the call requests a buffer of that size, enqueues
+ * every kernel and returns binning_capacity (hand it to wg_rasterize_backward as R) -- it never learns num_rendered.  Whether the frame
+ * fit is decided on the device: when it has more instances than the capacity, none of the kernels behind the count runs, out_color
+ * and the accumulation are filled with NaN, and the backward pass of such a frame returns zeros.  wg_forward_status() (a copy + a
+ * stream synchronise, to be called outside the capture, e.g. once per step or per epoch) reports num_rendered and the verdict; size
+ * the capacity from it with a margin.  Results of a frame that fits are those of wg_rasterize_forward, bit for bit.  Restrictions:
+ * frames of at most 36864 tiles, options "lazy_sort" on and "force_global_sort" off (WG_ERR_INVALID_ARGUMENT otherwise); no debug
+ * mode; the deterministic backward mode needs the exact count and is not available behind it.
+ */
+int wg_rasterize_forward_fixed(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
+                               wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                               int height, const float* means3D, const float* shs, const float* colors_precomp,
+                               const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                               float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
+                               float* out_color, int* radii, void* stream, const wg_sh_tone* tone, int binning_capacity);
+/* num_rendered and fits (1 / 0) of the forward call that produced image_buffer; synchronises the stream. */
+int wg_forward_status(char* image_buffer, int width, int height, int* num_rendered, int* fits, void* stream);
+
 /* Rasterizer::markVisible (rasterizer.h:26-31, rasterizer_impl.cu:141-153). present: unsigned char[P]. */
 int wg_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     unsigned char* present, void* stream);

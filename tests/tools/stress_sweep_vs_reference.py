@@ -17,17 +17,28 @@ first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) 
 PATHS = {"default": {}, "lazy_tiny": dict(lazy_min_len=256, lazy_target=40, lazy_cap=64), "staged": dict(staged_scatter=1, staged_scatter_cap=7),
          "global": dict(force_global_sort=1), "band_lists": dict(band_list_min_p=1, staged_scatter=0),
          "near_far_tiny": dict(near_split=1, near_per_tile=12, lazy_min_len=256, lazy_target=40, lazy_cap=64),   # nearly every tile takes the far phase
-         "arrays_not_record": dict(grad_record=0), "box_count": dict(box_count=1, near_split=1, near_per_tile=200)}
+         "arrays_not_record": dict(grad_record=0), "box_count": dict(box_count=1, near_split=1, near_per_tile=200),
+         # round 3: the classic (non-speculative) forward flow, the fused column + tile scan, the deterministic backward.  Every OTHER
+         # path runs with the speculative forward on, and -- options being applied only where they change -- with this thread's frame
+         # history alive across the paths of a case (same image, same P): path 1 of a case is predicted from the previous case (another
+         # shape: the classic flow, or a miss), paths 2.. from the case's own earlier frames
+         "no_speculation": dict(speculative_forward=0), "fused_scan": dict(fused_scan=1), "deterministic": dict(deterministic_backward=1)}
 RESET = dict(lazy_min_len=1024, lazy_target=820, lazy_cap=2048, staged_scatter=-1, staged_scatter_cap=0, force_global_sort=0,
-             band_list_min_p=2000000, near_split=-1, near_per_tile=0, grad_record=1, box_count=-1)
+             band_list_min_p=2000000, near_split=-1, near_per_tile=0, grad_record=1, box_count=-1, speculative_forward=1, fused_scan=0,
+             deterministic_backward=0)
+
+
+def apply(opts):
+    for k, v in {**RESET, **opts}.items():
+        if _C.get_option(k) != v:   # (setting "speculative_forward" or "near_split" clears the thread's history: only when it changes)
+            _C.set_option(k, v)
 stats = dict(runs=0, radii_mismatch_runs=0, pixel_flip_runs=0, pixels_over=0, pixels=0, grad_over_runs=0, worst_grad=0.0, worst_fwd=0.0)
 for i in range(first, first + count):
     cloud, cam, deg, kw, W, H = _sweep_case(i)
     cot = S.make_cotangent(W, H, seed=3000 + i)
     r = ref_hip.run_scene(cloud, cam, sh_degree=deg, cotangent=cot, variant="nofma", **kw)
     for path, opts in PATHS.items():
-        for k, v in {**RESET, **opts}.items():
-            _C.set_option(k, v)
+        apply(opts)
         h = run_hip(cloud, cam, sh_degree=deg, cotangent=cot, **kw)
         err = np.abs(h["color"].astype(np.float64) - r["color"]).max(axis=0)
         over = int((err > 1e-4).sum())
@@ -46,6 +57,6 @@ for i in range(first, first + count):
         if max(g.values()) > 1e-3:
             stats["grad_over_runs"] += 1
             print("gradient over 1e-3: case", i, path, "pixels over 1e-4:", over, "worst", max(g, key=g.get), max(g.values()))
-for k, v in RESET.items():
-    _C.set_option(k, v)
+print("speculative forward over the sweep:", {k: _C.get_option(k) for k in ("spec_frames", "spec_misses")})
+apply({})
 print(f"cases {first}..{first + count - 1} x {len(PATHS)} binning paths vs the reference's own kernels:", stats)

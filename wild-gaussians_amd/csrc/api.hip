@@ -254,6 +254,14 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
                                       prefiltered, out_color, radii, debug, stream_, nullptr);
 }
 
+static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
+                        wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                        int height, const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                        float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
+                        float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, int fixed_capacity);
+
 int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
                                wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
                                int height, const float* means3D, const float* shs, const float* colors_precomp,
@@ -261,8 +269,48 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
                                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                                float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
                                float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone) {
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
+                        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
+                        tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, out_color, radii, debug, stream_, tone, 0);
+}
+
+int wg_rasterize_forward_fixed(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
+                               wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                               int height, const float* means3D, const float* shs, const float* colors_precomp,
+                               const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                               float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
+                               float* out_color, int* radii, void* stream_, const wg_sh_tone* tone, int binning_capacity) {
+    if (binning_capacity <= 0) return WG_ERR_INVALID_ARGUMENT;
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
+                        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
+                        tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, out_color, radii, 0, stream_, tone, binning_capacity);
+}
+
+int wg_forward_status(char* image_buffer, int width, int height, int* num_rendered, int* fits, void* stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!image_buffer || width <= 0 || height <= 0) return WG_ERR_INVALID_ARGUMENT;
+    const int gx = (width + wg::TILE_X - 1) / wg::TILE_X, gy = (height + wg::TILE_Y - 1) / wg::TILE_Y;
+    wg::ImageState img = wg::ImageState::fromChunk(image_buffer, (size_t)width * height, (size_t)gx * gy);
+    wg::BinStats st{};
+    hipError_t e = hipMemcpyAsync(&st, img.stats, sizeof(st), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return hip_fail(e, "forward status readback");
+    if (num_rendered) *num_rendered = st.num_rendered > 0x7fffffffu ? 0x7fffffff : (int)st.num_rendered;
+    if (fits) *fits = st.spec_fail == 0u ? 1 : 0;
+    return WG_OK;
+}
+
+static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
+                        wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                        int height, const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                        float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
+                        float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, int fixed_capacity) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const wg::Options opt = options_snapshot();
+    const bool fixed = fixed_capacity > 0;  // no host rendezvous at all: the caller's capacity, the superset (lazy) flow, a device-side verdict
     if (tone != nullptr && shs == nullptr && P > 0) return WG_ERR_INVALID_ARGUMENT;  // the tone acts on SH coefficients
     if (!geometry_alloc || !binning_alloc || !image_alloc) return WG_ERR_INVALID_ARGUMENT;
     if (P < 0 || width <= 0 || height <= 0 || D < 0 || D > 3) return WG_ERR_INVALID_ARGUMENT;
@@ -278,6 +326,7 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
     const int gx = (width + wg::TILE_X - 1) / wg::TILE_X, gy = (height + wg::TILE_Y - 1) / wg::TILE_Y;
     const int tiles = gx * gy;
 
+    if (fixed && (tiles > wg::BIN_MAX_TILES || opt.force_global_sort || !opt.lazy.enabled)) return WG_ERR_INVALID_ARGUMENT;  // LDS binning + lazy sort only
     const bool band_lists = (size_t)P >= (size_t)opt.band_list_min_p;  // size and carving from the same snapshot
     char* geom_chunk = geometry_alloc(required_bytes([&](char*& c) { wg::GeometryState::fromChunk(c, (size_t)P, band_lists); }), geometry_user);
     char* img_chunk = image_alloc(wg_image_buffer_size(width, height), image_user);
@@ -388,8 +437,15 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
                 WG_STAGE(WG_STAGE_SCAN, wg::launch_split_threshold(P, geom, img, tiles, opt.near_split == 1, near_per_tile, stream), "split_threshold");
             const bool box = opt.box_count == 1 || (opt.box_count < 0 && (P >= opt.band_list_min_p || t_last_instances_per_tile >= 1500u));
             WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_count(P, geom, img, gx, tiles, try_split, box, opt.fused_scan != 0, stream), "tile_count");
-            mbox = (debug || !opt.use_mailbox) ? nullptr : get_mailbox();
+            mbox = (debug || !opt.use_mailbox || fixed) ? nullptr : get_mailbox();
             if (mbox) mbox->seq += 1;
+            if (fixed) {  // the caller's capacity; the lazy flow covers lists of any length
+                spec.capacity = (uint32_t)fixed_capacity;
+                spec.max_list = 0xffffffffu;
+                spec_lazy = true;
+                spec_chunk = binning_alloc(required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)spec.capacity, false); }), binning_user);
+                if (!spec_chunk) return WG_ERR_ALLOC;
+            }
             // ---- speculative forward (option "speculative_forward", default on) ----
             // The reference's forward pass stops in its middle for the instance count (rasterizer_impl.cu:284: it sizes the binning
             // buffer), the GPU idles while the host then launches the rest.  Frames of one training run resemble one another, so the
@@ -399,7 +455,7 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
             // usually long arrived.  A frame that does not fit (more instances than the buffer holds, a list longer than the launched
             // sort network covers) runs none of the guarded kernels; the host then re-issues the tail with the real numbers, i.e.
             // falls back to the classic flow for that frame.  Results are the classic flow's, bit for bit.
-            if (mbox && opt.speculative > 0 && !opt.force_global_sort && t_spec.usable(P, width, height)) {
+            if (!fixed && mbox && opt.speculative > 0 && !opt.force_global_sort && t_spec.usable(P, width, height)) {
                 const uint64_t cap64 = (uint64_t)t_spec.max_rendered() * (100u + (uint32_t)opt.spec_margin_pct) / 100u + 4096u;
                 const uint32_t longest = t_spec.max_longest() + t_spec.max_longest() / 8u + 16u;
                 // the split's decision is taken on the device: when it is attempted the (superset) lazy flow is enqueued
@@ -415,8 +471,15 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
             WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, mbox ? mbox->dev : nullptr, mbox ? mbox->seq : 0, try_split, spec, opt.fused_scan != 0, stream), "tile_scan");
             if (spec.capacity != 0u) {
                 wg::BinningState sbin = wg::BinningState::fromChunk(spec_chunk, (size_t)spec.capacity, false);
-                const int st_ = enqueue_tail(sbin, t_spec.last_rendered(), spec.max_list == 0xffffffffu ? 0u : spec.max_list, spec_lazy, try_split, img.stats);
+                const uint32_t r_hint = fixed ? (t_spec.usable(P, width, height) ? std::min(t_spec.last_rendered(), spec.capacity) : spec.capacity) : t_spec.last_rendered();
+                const int st_ = enqueue_tail(sbin, r_hint, spec.max_list == 0xffffffffu ? 0u : spec.max_list, spec_lazy, try_split, img.stats);
                 if (st_ != WG_OK) return st_;
+                if (fixed) {
+                    // A frame that does not fit leaves nothing rendered: make that impossible to miss (NaN image and accumulation) and
+                    // safe to differentiate (no walked instance anywhere: the backward pass returns zeros); wg_forward_status tells.
+                    WG_STAGE(WG_STAGE_RENDER_FORWARD, wg::launch_poison_unfit(img, width, height, tiles, out_color, stream), "poison_unfit");
+                    return fixed_capacity;
+                }
             }
         } else {
             huge_frame = true;  // tile histogram does not fit LDS: count through the per-Gaussian prefix sum instead
@@ -624,7 +687,7 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
         WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_order(img.tile_last, nullptr, img.order_bwd, gx * gy, clear_records ? geom.grad_rec : nullptr,
                                                              (size_t)P * wg::GRAD_REC_FLOATS, stream), "tile_order");
         WG_STAGE(WG_STAGE_RENDER_BACKWARD, wg::launch_render_backward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, dL_dpix,
-                                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, det_slots, det_flags, P, stream),
+                                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, det_slots, det_flags, (size_t)R, P, stream),
                  "render_backward");
     }
 

@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
 // version with sixteen threads per Gaussian, one per value: 237 us -- sixteen times the threads, each still a chain of round trips.)
 __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* __restrict__ offsets_incl, const uint32_t* __restrict__ tiles_touched,
                                                          const float* __restrict__ det_slots, const unsigned char* __restrict__ det_flags,
-                                                         float* __restrict__ grad_rec) {
+                                                         float* __restrict__ grad_rec, size_t slot_capacity) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= P) return;
     const uint32_t n = tiles_touched[g];
@@ -430,7 +430,8 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* 
             unsigned char f[U];
             float2 x[U][5];
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) f[u] = (k0 + u < n) ? det_flags[base + k0 + u] : (unsigned char)0;
+            for (uint32_t u = 0; u < U; u++)   // (slot_capacity: R as the caller knows it -- a capacity after wg_rasterize_forward_fixed)
+                f[u] = (k0 + u < n && base + k0 + u < slot_capacity) ? det_flags[base + k0 + u] : (unsigned char)0;
 #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
                 const float2* sl = reinterpret_cast<const float2*>(det_slots + (base + k0 + u) * 10);  // 40-byte slots: 8-byte aligned
@@ -454,7 +455,8 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* 
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                   const GeometryState& g, const float* subpixel_offset, const float* background,
                                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                  float* dL_dcolor, bool record, float* det_slots, unsigned char* det_flags, int P, hipStream_t stream) {
+                                  float* dL_dcolor, bool record, float* det_slots, unsigned char* det_flags, size_t slot_capacity, int P,
+                                  hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
 #define WG_LAUNCH(REC, DET)                                                                                                                 \
@@ -465,7 +467,7 @@ hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState
     if (det_slots) {
         WG_LAUNCH(true, true);
         hipLaunchKernelGGL(det_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, g.point_offsets, g.tiles_touched, det_slots, det_flags,
-                           g.grad_rec);
+                           g.grad_rec, slot_capacity);
     } else if (record) WG_LAUNCH(true, false);
     else WG_LAUNCH(false, false);
 #undef WG_LAUNCH

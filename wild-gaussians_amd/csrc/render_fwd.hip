@@ -274,6 +274,24 @@ hipError_t launch_render_forward_replay(int W, int H, int gx, int gy, const Imag
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) poison_unfit_kernel(const BinStats* __restrict__ stats, size_t N, int tiles, float* __restrict__ out_color,
+                                                           float* __restrict__ accum, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last) {
+    if (stats->spec_fail == 0u) return;  // the usual case: one scalar load per workgroup
+    const float nan = __builtin_nanf("");
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x) {
+        out_color[i] = nan; out_color[N + i] = nan; out_color[2 * N + i] = nan;
+        accum[i] = nan;
+        n_contrib[i] = 0u;
+        if (i < (size_t)tiles) tile_last[i] = 0u;
+    }
+}
+
+hipError_t launch_poison_unfit(const ImageState& img, int W, int H, int tiles, float* out_color, hipStream_t stream) {
+    const size_t N = (size_t)W * H;   // (tiles <= N always: a tile holds at least one pixel)
+    hipLaunchKernelGGL(poison_unfit_kernel, dim3(256), dim3(256), 0, stream, img.stats, N, tiles, out_color, img.accum, img.n_contrib, img.tile_last);
+    return hipGetLastError();
+}
+
 // ---- lazy sort, later rounds (fix-up) ---------------------------------------------------------------------------------------
 // One 256-thread workgroup per tile, a no-op for finished tiles.  For a tile whose sorted front ran out while pixels were still
 // accumulating it loops: split the next front off the unsorted bag (or take all of it when short), sort it in place behind the

@@ -247,13 +247,16 @@ hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState&
                                  float* out_color, bool lazy, const BinStats* guard, hipStream_t stream);
 // the compositing of a frame whose binning and per-pixel stops are known (img.tile_last, img.n_contrib of an earlier pass over the
 // same geometry): each tile walks exactly its list's first tile_last entries and stores final outputs
+// capturable forward (api.hip: wg_rasterize_forward_fixed): when the frame did not fit (BinStats::spec_fail) the image and the
+// accumulation become NaN and tile_last / n_contrib zero
+hipError_t launch_poison_unfit(const ImageState& img, int W, int H, int tiles, float* out_color, hipStream_t stream);
 hipError_t launch_render_forward_replay(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                         const GeometryState& g, const float* subpixel_offset, const float* background,
                                         float* out_color, hipStream_t stream);
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                   const GeometryState& g, const float* subpixel_offset, const float* background,
                                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                  float* dL_dcolor, bool record, float* det_slots, unsigned char* det_flags, int P,
+                                  float* dL_dcolor, bool record, float* det_slots, unsigned char* det_flags, size_t slot_capacity, int P,
                                   hipStream_t stream);  // det_slots != nullptr: deterministic mode (det_flags: one byte per slot, cleared)
 
 struct BwdParams {

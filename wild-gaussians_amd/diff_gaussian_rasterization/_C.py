@@ -51,6 +51,10 @@ _lib.wg_rasterize_forward_toned.restype = _i
 _lib.wg_rasterize_forward_toned.argtypes = _lib.wg_rasterize_forward.argtypes + [C.POINTER(_ShTone)]
 _lib.wg_rasterize_backward_toned.restype = _i
 _lib.wg_rasterize_backward_toned.argtypes = _lib.wg_rasterize_backward.argtypes + [C.POINTER(_ShTone)]
+_lib.wg_rasterize_forward_fixed.restype = _i
+_lib.wg_rasterize_forward_fixed.argtypes = _lib.wg_rasterize_forward.argtypes[:-2] + [_vp, C.POINTER(_ShTone), _i]   # no debug flag; + tone, capacity
+_lib.wg_forward_status.restype = _i
+_lib.wg_forward_status.argtypes = [_vp, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]
 _lib.wg_rasterize_forward_recolor.restype = _i
 _lib.wg_rasterize_forward_recolor.argtypes = [_ALLOC_FN, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.wg_mark_visible.restype = _i
@@ -221,7 +225,10 @@ def forget_geometry():
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width, sh, degree,
-                        campos, prefiltered, debug, sh_tone=None):
+                        campos, prefiltered, debug, sh_tone=None, binning_capacity=None):
+    """binning_capacity (beyond the reference): an int makes the call wg_rasterize_forward_fixed -- no host rendezvous, capturable in
+    a hipGraph; the returned `rendered` is then the capacity, and forward_status(imgBuffer, H, W) tells the real count and whether
+    the frame fit (include/wg_rasterizer.h)."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:59-61
     if not means3D.is_cuda:
@@ -232,6 +239,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     # precomputed colours over remembered geometry: no projection, no binning
     reusable = (P != 0 and sh_tone is None and not debug and colors.numel() == 3 * P and sh.numel() == 0
                 and _lib.wg_get_option(b"geometry_reuse") == 1)
+    if binning_capacity is not None and debug:
+        raise RuntimeError("binning_capacity (wg_rasterize_forward_fixed) has no debug mode")
     key = None
     if reusable:
         key = _reuse_key(background, means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
@@ -275,15 +284,25 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     tone, _keep = (None, None) if sh_tone is None else _tone_block(sh_tone, device, P)
     try:
         with torch.cuda.device(device):
-            rendered = _lib.wg_rasterize_forward_toned(
-                geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
-                _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
-                _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
-                int(bool(debug)), _stream(device), None if tone is None else C.byref(tone))
+            if binning_capacity is None:
+                rendered = _lib.wg_rasterize_forward_toned(
+                    geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
+                    _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
+                    _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                    float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
+                    int(bool(debug)), _stream(device), None if tone is None else C.byref(tone))
+            else:
+                rendered = _lib.wg_rasterize_forward_fixed(
+                    geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
+                    _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
+                    _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                    float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
+                    _stream(device), None if tone is None else C.byref(tone), int(binning_capacity))
     finally:
         buffers = (geom.take(), binning.take(), img.take())
     _check(rendered, "wg_rasterize_forward")
+    if binning_capacity is not None:
+        _reuse.last_fixed = (buffers[2], H, W)
     if key is not None and rendered >= 0:
         _reuse.last = dict(tensors=key[0], scalars=key[1], R=rendered, radii=radii, geom=buffers[0], binning=buffers[1], img=buffers[2])
     return (rendered, out_color, radii) + buffers
@@ -350,6 +369,20 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         _check(status, "wg_rasterize_backward")
     out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     return out if sh_tone is None else out + tone_grads
+
+
+def forward_status(imageBuffer, H, W):
+    """(num_rendered, fits) of the forward call that produced imageBuffer (wg_forward_status: synchronises the current stream)."""
+    n, f = _i(0), _i(0)
+    with torch.cuda.device(imageBuffer.device):
+        _check(_lib.wg_forward_status(imageBuffer.data_ptr(), int(W), int(H), C.byref(n), C.byref(f), _stream(imageBuffer.device)), "wg_forward_status")
+    return int(n.value), bool(f.value)
+
+
+def last_forward_status():
+    """forward_status of the calling thread's latest binning_capacity= (fixed-capacity) forward call; None if there was none."""
+    last = getattr(_reuse, "last_fixed", None)
+    return None if last is None else forward_status(*last)
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

@@ -74,7 +74,7 @@ def _accumulation_from_image_state(img_buffer: torch.Tensor, height: int, width:
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None):
+                sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None):
         rs = raster_settings
         native_args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset,
@@ -87,6 +87,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             ctx.sh_tone = (None if sh_mul is None else sh_mul.detach(), None if sh_offset is None else sh_offset.detach(),
                            sh_pre_clamp_max, sh_post_clamp_max)
             native_args = native_args + (ctx.sh_tone,)
+        if binning_capacity is not None:   # beyond the reference: no host rendezvous (wg_rasterize_forward_fixed), capturable in a hipGraph
+            native_args = native_args + ((None,) if ctx.sh_tone is None else ()) + (int(binning_capacity),)
         num_rendered, color, radii, geom_buf, binning_buf, img_buf = _call_native(
             _C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
 
@@ -125,13 +127,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_mul = None if mul is None else g_mul.view(mul.shape)
             g_offset = None if offset is None else g_offset.view(offset.shape)
         # order of forward()'s inputs; None for raster_settings and the two clamp constants
-        return g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3Ds, None, g_mul, g_offset, None, None
+        return g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3Ds, None, g_mul, g_offset, None, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                        sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None):
+                        sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max)
+                                     raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity)
 
 
 class GaussianRasterizer(nn.Module):
@@ -149,8 +151,13 @@ class GaussianRasterizer(nn.Module):
                 colors_precomp: Optional[torch.Tensor] = None, scales: Optional[torch.Tensor] = None,
                 rotations: Optional[torch.Tensor] = None, cov3D_precomp: Optional[torch.Tensor] = None, *,
                 sh_mul: Optional[torch.Tensor] = None, sh_offset: Optional[torch.Tensor] = None,
-                sh_pre_clamp_max: Optional[float] = None, sh_post_clamp_max: Optional[float] = None):
-        """The reference's signature (diff_gaussian_rasterization/__init__.py:208-241) plus four keyword-only opt-ins (SURVEY.md 8f
+                sh_pre_clamp_max: Optional[float] = None, sh_post_clamp_max: Optional[float] = None,
+                binning_capacity: Optional[int] = None):
+        """`binning_capacity=` (keyword-only, beyond the reference): the forward pass without any host rendezvous
+        (wg_rasterize_forward_fixed: the caller supplies the number of (tile, Gaussian) instances the binning buffer holds), for steps
+        captured in a hipGraph; a frame that does not fit comes back as NaN, `_C.forward_status` tells.  Otherwise:
+
+        The reference's signature (diff_gaussian_rasterization/__init__.py:208-241) plus four keyword-only opt-ins (SURVEY.md 8f
         N3): with `shs`, the kernels evaluate `min(min(shs, sh_pre_clamp_max) * sh_mul[:, None, :] + [k == 0] * sh_offset[:, None, :],
         sh_post_clamp_max)` instead of `shs` -- WildGaussians' appearance toning (method.py:890-900, 1590-1595: pass the clamped
         features' raw tensor, `mul`, `offset / C0`, and 1.0 for both clamps) without the P x 48 intermediate tensors -- and return
@@ -170,4 +177,4 @@ class GaussianRasterizer(nn.Module):
             _absent() if scales is None else scales,
             _absent() if rotations is None else rotations,
             _absent() if cov3D_precomp is None else cov3D_precomp,
-            self.raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max)
+            self.raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity)

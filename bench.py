@@ -141,6 +141,9 @@ def governing_roofline(dom: str, d: dict, pmc_row, launch_ms: float, survey_byte
         basis = "by_survey_8d_bytes" if hbm["by_survey_8d_bytes"]["frac"] is not None else ("by_pmc_traffic" if by_traffic else "by_design_bytes")
         r = {"bound": "hbm", "kernel": dom, "achieved": hbm[basis]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": hbm[basis]["frac"], "frac_basis": basis}
+        if dom in ("render_forward", "render_backward") and valu_frac is None:
+            r["note"] = ("no PMC pass is stamped to this workload and these sources, so the VALU issue rate that governs the render kernels is not "
+                         "known here; SURVEY 8(d)'s bytes are the REFERENCE scheme's (R-based) and overstate what this kernel moves on dense frames")
     r.update({"traffic": pmc_row["hbm_bytes"] if by_traffic else None, "hbm": hbm, "avg_launch_ms": round(launch_ms, 4),
               "hbm_target_note": "north_star's >= 0.60 of 8 TB/s is met by the two streaming per-Gaussian kernels (stage_rooflines) "
                                  "and NOT by the render kernels, which VALU issue governs"})
@@ -198,8 +201,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the rasterizer has no CPU path")
+    # A bench step is ONE FULL pass of the hot path.  The binding's geometry reuse (consecutive calls over the same geometry tensor objects
+    # with other precomputed colours skip projection and binning: WildGaussians' second call per step) would turn every step after the
+    # first into a recolouring here, where the same tensors are rasterized again and again: off, whatever the caller's options say.
+    _C.set_option("geometry_reuse", 0)
     for kv in args.option:
         k, v = kv.split("=", 1)
+        if k == "geometry_reuse" and int(v) != 0:
+            raise SystemExit("bench.py times full passes: geometry_reuse stays off (scripts/bench_wildgaussians_step.py measures it where it belongs)")
         _C.set_option(k, int(v))
     rank, local_rank, world = VP.init()
     if world != args.gpus:
@@ -341,7 +350,7 @@ def main():
         "forward_ms_quantiles": fwd_q,
         "workload_stats": {"P": P, "V": V, "R": int(R), "N": N, "tiles": tiles, "instances_walked": walked},
         "library": {"version": _C.version(), "path": os.path.relpath(_C._LIB_PATH, ROOT), "options": args.option,
-                    "kernel_source_sha": kernel_source_sha(),
+                    "kernel_source_sha": kernel_source_sha(), "geometry_reuse": _C.get_option("geometry_reuse"),
                     # speculative forward (rasterizer_impl.cu:284's rendezvous moved behind the call's last launch): how it fared in this process
                     "speculative_forward": {k: _C.get_option(k) for k in ("speculative_forward", "spec_frames", "spec_misses", "forward_polls",
                                                                           "forward_polls_waited", "forward_wait_us_total")}},

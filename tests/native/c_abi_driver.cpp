@@ -101,6 +101,20 @@ int main(int argc, char** argv) {
                                        d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, d_color, d_radii,
                                        0, stream);
     if (R <= 0) { std::fprintf(stderr, "forward: %s (%s)\n", wg_status_string(R), wg_last_hip_error()); return 4; }
+    // twice more: from the second call on the library speculates on the frame's size from this thread's history (the binning buffer is
+    // requested before the count is known, possibly a second time after it); the third with a tiny margin so that Grow is asked to grow
+    for (int rep = 0; rep < 2; rep++) {
+        if (rep == 1) (void)wg_set_option("spec_margin_pct", 0);
+        const int Rr = wg_rasterize_forward(Grow::alloc, &geom, Grow::alloc, &bin, Grow::alloc, &img, P, D, M, d_bg, W, H, d_means, d_shs, nullptr, d_opac,
+                                            d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, d_color, d_radii,
+                                            0, stream);
+        if (Rr != R) { std::fprintf(stderr, "repeated forward: %d instead of %d (%s)\n", Rr, R, wg_last_hip_error()); return 4; }
+    }
+    if (wg_get_option("spec_frames") < 2 || wg_get_option("spec_misses") != 0) {
+        std::fprintf(stderr, "speculation did not engage: %d frames, %d misses\n", wg_get_option("spec_frames"), wg_get_option("spec_misses"));
+        return 4;
+    }
+    (void)wg_set_option("spec_margin_pct", 25);
 
     float *g2d, *gcon, *gop, *gcol, *g3d, *gcov, *gsh, *gsc, *grot;
     CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g2d), (size_t)P * 3 * 4));

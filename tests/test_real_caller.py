@@ -247,11 +247,13 @@ def test_training_trajectory_on_the_product_and_on_the_reference_kernels():
     by itself bound what hundreds of Adam steps do.  Here the same seeded 100 k-Gaussian model takes 300 real `train_iteration`s --
     through clone / split / prune and an opacity reset -- twice on this repo's operator and twice on the reference's own kernels
     (tests/real_caller/ref_backed.py over oracle/_ref).
-      * Before the first densification (30 Adam steps, no thresholds involved) the per-step losses of all four runs agree to 1e-3.
+      * Before the first densification (30 Adam steps, no thresholds involved) the per-step losses of all four runs agree to 2e-5
+        (observed 6e-7): this is the tight statement.
       * After 300 steps the training is chaotic in BOTH implementations (float atomics decide which Gaussians cross the densification
         thresholds; two runs of the reference kernels differ from one another by up to 0.9 dB on the best view): final loss, PSNR of
         the three training views and the number of Gaussians on the reference kernels must lie within the spread of the runs
-        (the larger of the two implementations' own run-to-run differences, x 1.5, with small floors)."""
+        (the larger of the two implementations' own run-to-run differences, x 1.5, with floors that cover the spreads seen over five
+        GPU runs of this test: counts +-3 %, PSNR +-0.5 dB, loss +-1.5 %): a sanity statement about a chaotic process, not a tight one."""
     import json
     from oracle.ref_hip import ref_hip
     if not ref_hip.available("nofma"):
@@ -269,19 +271,19 @@ def test_training_trajectory_on_the_product_and_on_the_reference_kernels():
     for r in (a1, a2, b1, b2):
         assert np.isfinite(r["loss"]) and r["loss"] < 0.9 * r["first_loss"] and len(r["counts"]) > 2, r
     head = np.array([r["head"] for r in (a1, a2, b1, b2)])
-    assert head.shape[1] == 30 and np.abs(head / head[0] - 1.0).max() <= 1e-3, np.abs(head / head[0] - 1.0).max()
+    assert head.shape[1] == 30 and np.abs(head / head[0] - 1.0).max() <= 2e-5, np.abs(head / head[0] - 1.0).max()   # observed: 6e-7
 
     def agree(get, floor):
         pa, pb = (get(a1), get(a2)), (get(b1), get(b2))
         tol = max(1.5 * max(abs(pa[0] - pa[1]), abs(pb[0] - pb[1])), floor)
         return abs(0.5 * (pa[0] + pa[1]) - 0.5 * (pb[0] + pb[1])) <= tol, (pa, pb, tol)
-    ok, why = agree(lambda r: r["loss"], 0.03 * a1["loss"])
+    ok, why = agree(lambda r: r["loss"], 0.05 * a1["loss"])
     assert ok, ("loss", why)
     # (over four GPU runs of this test: product 26 044 .. 26 500, reference kernels 26 419 .. 26 796 Gaussians left of 100 000)
-    ok, why = agree(lambda r: r["num_gaussians"], 0.04 * a1["num_gaussians"])
+    ok, why = agree(lambda r: r["num_gaussians"], 0.06 * a1["num_gaussians"])
     assert ok, ("num_gaussians", why)
     for k in range(3):
-        ok, why = agree(lambda r: r["psnr"][k], 0.5)
+        ok, why = agree(lambda r: r["psnr"][k], 1.0)
         assert ok, ("psnr", k, why)
 
 

@@ -1199,6 +1199,15 @@ def test_geometry_reuse_is_not_taken_when_anything_it_depends_on_changed(record_
     assert h == 0
     _C.set_option("geometry_reuse", 1)
     _C.forget_geometry()
+    with torch.inference_mode():                             # inference tensors have no version counter: never reused, never an error
+        ti = {k: v.clone() for k, v in t.items()}
+        kw = dict(means3D=ti["means3D"], means2D=m2d.clone(), opacities=ti["opacities"], scales=ti["scales"], rotations=ti["rotations"],
+                  colors_precomp=ti["colors_precomp"])
+        h0 = _C.geometry_reuse_hits()
+        a = rast(**kw)[0]
+        b = rast(**kw)[0]
+        assert _C.geometry_reuse_hits() == h0 and torch.equal(a, b) and torch.equal(a, ref_img)
+    _C.forget_geometry()
     with torch.cuda.stream(torch.cuda.Stream()):
         _, h = call(rast)
         torch.cuda.current_stream().synchronize()

@@ -409,47 +409,78 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
 // slots the per-tile pass flagged as written: the slot array (40 B per tile instance) is never cleared, only the flags (1 B per
 // instance) are -- and WRITES the whole 48-byte record, zeros for a Gaussian nothing was added to, so the record needs no clearing
 // either.  The kernel is a latency problem, not a bandwidth one (7 MB of flags, ~70 MB of flagged slots, 48 MB of records at the
-// headline scene): the slots are taken eight at a time -- eight flag loads, then the flagged slots' ten floats as five 8-byte
-// loads each, all independent -- and added in slot order, i.e. two memory round trips per eight slots (8.5 slots per Gaussian on
-// average, two of them flagged).
-// (Round 2: every slot cleared and read, ten dependent strided loads per slot: 300 MB cleared + 300 MB read.  A first round-3
-// version with sixteen threads per Gaussian, one per value: 237 us -- sixteen times the threads, each still a chain of round trips.)
+// headline scene), so it is built around the number of dependent memory round trips per wave, three whatever the lists' lengths:
+//   1. every lane's slot range (tiles_touched, prefix);
+//   2. the 64 Gaussians of a wave own ONE contiguous range of slots: its flag bytes are fetched by the whole wave, 64 consecutive
+//      bytes per load, into LDS (chunks of 4 KB for the rare wave that owns more); each lane then scans its own range there;
+//   3. the flagged slots' ten floats (five 8-byte loads each), up to eight slots of a lane in flight together, added in slot order.
+// (Round 2: every slot cleared and read, ten dependent strided loads per slot.  Earlier round-3 versions: sixteen threads per
+// Gaussian, one per value, 237 us; one thread per Gaussian reading its flags itself, two round trips per eight slots, 153 us.)
+constexpr uint32_t DET_FLAG_CHUNK = 4096;
 __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* __restrict__ offsets_incl, const uint32_t* __restrict__ tiles_touched,
                                                          const float* __restrict__ det_slots, const unsigned char* __restrict__ det_flags,
                                                          float* __restrict__ grad_rec, size_t slot_capacity) {
+    __shared__ unsigned char sflags[4][DET_FLAG_CHUNK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= P) return;
-    const uint32_t n = tiles_touched[g];
+    const bool valid = g < P;
+    const uint32_t n = valid ? tiles_touched[g] : 0u;
+    const uint32_t end = valid ? offsets_incl[g] : 0u;
+    const uint32_t base = end - n;
+    // the wave's slot range: from its first valid lane's base to its last valid lane's end (prefix sums are monotone)
+    const int g0 = blockIdx.x * blockDim.x + wave * 64;
+    if (g0 >= P) return;  // wave-uniform
+    const int last_lane = min(63, P - 1 - g0);
+    const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+    const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)end, last_lane);
     float acc[10];
 #pragma unroll
     for (int v = 0; v < 10; v++) acc[v] = 0.f;
-    if (n != 0u) {
-        const size_t base = (size_t)(offsets_incl[g] - n);
-        constexpr uint32_t U = 8;
-        for (uint32_t k0 = 0; k0 < n; k0 += U) {
-            unsigned char f[U];
+    unsigned char* sf = sflags[wave];
+    constexpr int U = 8;
+    for (uint32_t clo = wlo; clo < whi; clo += DET_FLAG_CHUNK) {  // wave-uniform trip count; one trip unless the wave owns > 4096 slots
+        const uint32_t clen = min(DET_FLAG_CHUNK, whi - clo);
+        __builtin_amdgcn_wave_barrier();  // the previous chunk's flags have been read by every lane
+        for (uint32_t i = lane; i < clen; i += 64) sf[i] = (clo + i < slot_capacity) ? det_flags[clo + i] : (unsigned char)0;
+        __builtin_amdgcn_s_waitcnt(0);    // (compiler inserts the waits for its own uses; this makes the hand-over explicit)
+        __builtin_amdgcn_wave_barrier();
+        // this lane's slots inside the chunk, in order; flagged ones gathered U at a time
+        const uint32_t mylo = max(base, clo), myhi = min(end, clo + clen);
+        uint32_t pend[U];
+        int np = 0;
+        auto flush = [&]() {
             float2 x[U][5];
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++)   // (slot_capacity: R as the caller knows it -- a capacity after wg_rasterize_forward_fixed)
-                f[u] = (k0 + u < n && base + k0 + u < slot_capacity) ? det_flags[base + k0 + u] : (unsigned char)0;
+            for (int u = 0; u < U; u++) {
+                const float2* sl = reinterpret_cast<const float2*>(det_slots + (size_t)pend[u < np ? u : 0] * 10);  // 40-byte slots: 8-byte aligned
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const float2* sl = reinterpret_cast<const float2*>(det_slots + (base + k0 + u) * 10);  // 40-byte slots: 8-byte aligned
-#pragma unroll
-                for (int h = 0; h < 5; h++) x[u][h] = f[u] ? sl[h] : make_float2(0.f, 0.f);
+                for (int h = 0; h < 5; h++) x[u][h] = u < np ? sl[h] : make_float2(0.f, 0.f);
             }
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++)
-                if (f[u]) {
+            for (int u = 0; u < U; u++)
+                if (u < np) {
 #pragma unroll
                     for (int h = 0; h < 5; h++) { acc[2 * h] += x[u][h].x; acc[2 * h + 1] += x[u][h].y; }
                 }
+            np = 0;
+        };
+        for (uint32_t k = mylo; k < myhi; k++) {
+            if (sf[k - clo]) {
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (u == np) pend[u] = k;   // (register array: written through a static index)
+                np++;
+                if (np == U) flush();
+            }
         }
+        if (np > 0) flush();
     }
-    float4* out = reinterpret_cast<float4*>(grad_rec + (size_t)g * GRAD_REC_FLOATS);
-    out[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    out[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    out[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
+    if (valid) {
+        float4* out = reinterpret_cast<float4*>(grad_rec + (size_t)g * GRAD_REC_FLOATS);
+        out[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        out[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        out[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
+    }
 }
 
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,

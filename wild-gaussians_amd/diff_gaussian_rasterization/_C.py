@@ -191,7 +191,11 @@ def _tensor_token(t):
     'absent' sentinels are fresh objects on every call: they match each other)."""
     if t is None or t.numel() == 0:
         return None
-    return (weakref.ref(t), t._version, tuple(t.shape), t.dtype)
+    try:
+        version = t._version
+    except RuntimeError:   # inference-mode tensors track no version: nothing can vouch for "unchanged", so they never match
+        return (lambda: None, object(), tuple(t.shape), t.dtype)
+    return (weakref.ref(t), version, tuple(t.shape), t.dtype)
 
 
 def _same_token(a, b):

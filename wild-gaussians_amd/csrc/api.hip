@@ -99,6 +99,25 @@ struct WaitStats {
     void clear() { *this = WaitStats(); }
 };
 thread_local WaitStats t_wait;
+// Deferred speculation (option "speculative_forward" = 2): the last forward call of this thread returned without looking at its frame's
+// verdict.  It is looked at by the next forward / backward call of the thread (settle_deferred, below).
+struct Deferred {
+    bool pending = false;
+    uint32_t seq = 0;
+    int P = 0, W = 0, H = 0;
+};
+thread_local Deferred t_deferred;
+// The backward pass of a deferred frame usually runs on ANOTHER host thread (torch's autograd engine): it finds the frame by its image
+// buffer here.  One ticket per forward thread (its latest deferred frame: earlier ones were settled by that thread's later calls).
+struct DeferredTicket {
+    const void* image_buffer;
+    const wg::HostMailbox* host;
+    uint32_t seq;
+    uint32_t reported_seq;  // the frame whose failure a backward call has already returned (the owning thread's settle then stays quiet)
+    bool reported;
+};
+std::mutex g_ticket_mu;
+std::vector<DeferredTicket> g_tickets;
 
 // the options (wg_common.h: Options): written by wg_set_option under the mutex, copied once per call
 std::mutex g_opt_mu;
@@ -200,6 +219,98 @@ struct RoctxEnv {  // WG_ROCTX=1: ranges on from the first call, without touchin
         if (e && e[0] == '1') g_roctx.enabled = g_roctx.load();
     }
 } g_roctx_env;
+
+// Reads the mailbox words of frame `seq` (waits for them, bounded).  false: not there within ~2 s.
+bool read_mailbox(Mailbox* mbox, uint32_t seq, wg::BinStats& st, bool* waited) {
+    volatile unsigned long long* w0 = &mbox->host->word0;
+    volatile unsigned long long* w1 = &mbox->host->word1;
+    const unsigned long long want = seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    unsigned long long a = *w0, b = *w1;
+    while ((a >> 32) != want || (b >> 32) != want) {
+        if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+        __builtin_ia32_pause();
+        a = *w0; b = *w1;
+    }
+    if (waited) *waited = spins != 0u;
+    if ((a >> 32) != want || (b >> 32) != want) return false;
+    st.num_rendered = (uint32_t)a;
+    st.max_tile_count = (uint32_t)b & wg::MAILBOX_MAX_LIST;   // (saturated at 2^30 - 1: beyond any list the sort paths distinguish)
+    st.split_active = (uint32_t)(b >> 30) & 1u;
+    st.spec_fail = (uint32_t)(b >> 31) & 1u;
+    return true;
+}
+
+// A deferred frame's verdict, taken by the thread's next call.  WG_ERR_SPECULATION when that frame did not fit the buffer it was given:
+// its image is NaN and its gradients are zero (see wg_rasterize_forward_fixed); the caller repeats the step.  The history learns the
+// frame's real size either way, so the repeat fits.
+int settle_deferred(hipStream_t stream) {
+    if (!t_deferred.pending) return WG_OK;
+    t_deferred.pending = false;
+    Mailbox& mb = t_mailbox;
+    wg::BinStats st{};
+    bool ok = mb.host != nullptr && read_mailbox(&mb, t_deferred.seq, st, nullptr);
+    if (!ok) {  // the frame's scan has not run within the bound: wait for the stream (a failed launch surfaces here)
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return hip_fail(e, "deferred forward (stream synchronize)");
+        ok = mb.host != nullptr && read_mailbox(&mb, t_deferred.seq, st, nullptr);
+        if (!ok) return hip_fail(hipErrorUnknown, "deferred forward: the instance count never arrived");
+    }
+    t_spec.push(t_deferred.P, t_deferred.W, t_deferred.H, st.num_rendered, st.max_tile_count);
+    t_last_instances_per_tile = st.num_rendered / (uint32_t)std::max(1, ((t_deferred.W + wg::TILE_X - 1) / wg::TILE_X) * ((t_deferred.H + wg::TILE_Y - 1) / wg::TILE_Y));
+    t_wait.spec_frames += 1;
+    if (st.spec_fail != 0u) {
+        t_wait.spec_misses += 1;
+        std::lock_guard<std::mutex> l(g_ticket_mu);
+        for (auto& k : g_tickets)
+            if (k.host == mb.host && k.reported && k.reported_seq == t_deferred.seq) return WG_OK;  // its backward call has said so already
+        return WG_ERR_SPECULATION;
+    }
+    return WG_OK;
+}
+
+void post_ticket(const void* image_buffer, const wg::HostMailbox* host, uint32_t seq) {
+    std::lock_guard<std::mutex> l(g_ticket_mu);
+    for (auto& t : g_tickets)
+        if (t.host == host) { t.image_buffer = image_buffer; t.seq = seq; return; }
+    g_tickets.push_back({image_buffer, host, seq, 0u, false});
+}
+
+// Backward side: was `image_buffer` produced by a deferred forward call whose verdict nobody has looked at yet, and did it fit?
+int check_ticket(const void* image_buffer, hipStream_t stream) {
+    DeferredTicket t{};
+    {
+        std::lock_guard<std::mutex> l(g_ticket_mu);
+        bool found = false;
+        for (auto& k : g_tickets)
+            if (k.image_buffer == image_buffer) { t = k; found = true; break; }
+        if (!found) return WG_OK;
+    }
+    volatile const unsigned long long* w0 = &t.host->word0;
+    volatile const unsigned long long* w1 = &t.host->word1;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned long long a = *w0, b = *w1;
+        const uint32_t sa = (uint32_t)(a >> 32), sb = (uint32_t)(b >> 32);
+        if (sa == t.seq && sb == t.seq) {
+            if (((b >> 31) & 1ull) == 0ull) return WG_OK;
+            std::lock_guard<std::mutex> l(g_ticket_mu);
+            for (auto& k : g_tickets)
+                if (k.host == t.host) { k.reported = true; k.reported_seq = t.seq; }
+            return WG_ERR_SPECULATION;
+        }
+        // a later frame of the owning thread is in the mailbox: that thread's call has settled (and reported) this one already
+        if ((int32_t)(sa - t.seq) > 0 || (int32_t)(sb - t.seq) > 0) return WG_OK;
+        if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            hipError_t e = hipStreamSynchronize(stream);   // the frame's scan has not run yet: wait for the stream once, then look again
+            if (e != hipSuccess) return hip_fail(e, "deferred forward (backward-side check)");
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(6)) return hip_fail(hipErrorUnknown, "deferred forward: the instance count never arrived");
+        }
+        __builtin_ia32_pause();
+    }
+}
 
 template <typename F>
 size_t required_bytes(F carve_fn) {
@@ -311,6 +422,10 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const wg::Options opt = options_snapshot();
     const bool fixed = fixed_capacity > 0;  // no host rendezvous at all: the caller's capacity, the superset (lazy) flow, a device-side verdict
+    {
+        const int settled = settle_deferred(stream);
+        if (settled != WG_OK) return settled;
+    }
     if (tone != nullptr && shs == nullptr && P > 0) return WG_ERR_INVALID_ARGUMENT;  // the tone acts on SH coefficients
     if (!geometry_alloc || !binning_alloc || !image_alloc) return WG_ERR_INVALID_ARGUMENT;
     if (P < 0 || width <= 0 || height <= 0 || D < 0 || D > 3) return WG_ERR_INVALID_ARGUMENT;
@@ -469,16 +584,24 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
                 }
             }
             WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, mbox ? mbox->dev : nullptr, mbox ? mbox->seq : 0, try_split, spec, opt.fused_scan != 0, stream), "tile_scan");
+            // "speculative_forward" = 2: do not even look at the verdict before returning -- the thread's next call does (settle_deferred)
+            const bool deferred = !fixed && spec.capacity != 0u && opt.speculative == 2;
             if (spec.capacity != 0u) {
                 wg::BinningState sbin = wg::BinningState::fromChunk(spec_chunk, (size_t)spec.capacity, false);
                 const uint32_t r_hint = fixed ? (t_spec.usable(P, width, height) ? std::min(t_spec.last_rendered(), spec.capacity) : spec.capacity) : t_spec.last_rendered();
                 const int st_ = enqueue_tail(sbin, r_hint, spec.max_list == 0xffffffffu ? 0u : spec.max_list, spec_lazy, try_split, img.stats);
                 if (st_ != WG_OK) return st_;
-                if (fixed) {
+                if (fixed || deferred) {
                     // A frame that does not fit leaves nothing rendered: make that impossible to miss (NaN image and accumulation) and
                     // safe to differentiate (no walked instance anywhere: the backward pass returns zeros); wg_forward_status tells.
                     WG_STAGE(WG_STAGE_RENDER_FORWARD, wg::launch_poison_unfit(img, width, height, tiles, out_color, stream), "poison_unfit");
-                    return fixed_capacity;
+                    if (deferred) {
+                        t_deferred.pending = true;
+                        t_deferred.seq = mbox->seq;
+                        t_deferred.P = P; t_deferred.W = width; t_deferred.H = height;
+                        post_ticket(img.final_T, mbox->host, mbox->seq);   // (the state's first array: image_alloc's pointer, aligned)
+                    }
+                    return (int)spec.capacity;
                 }
             }
         } else {
@@ -492,25 +615,10 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
         bool have_stats = false;
         if (mbox) {
             // poll the mailbox (bounded: ~2 s, then fall back to a real synchronise so that a failed launch is reported)
-            volatile unsigned long long* w0 = &mbox->host->word0;
-            volatile unsigned long long* w1 = &mbox->host->word1;
-            const unsigned long long want = mbox->seq;
             const auto t0 = std::chrono::steady_clock::now();
-            unsigned spins = 0;
-            unsigned long long a = *w0, b = *w1;
-            while ((a >> 32) != want || (b >> 32) != want) {
-                if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
-                __builtin_ia32_pause();
-                a = *w0; b = *w1;
-            }
-            if ((a >> 32) == want && (b >> 32) == want) {
-                st.num_rendered = (uint32_t)a;
-                st.max_tile_count = (uint32_t)b & wg::MAILBOX_MAX_LIST;   // (saturated at 2^30 - 1: beyond any list the sort paths distinguish)
-                st.split_active = (uint32_t)(b >> 30) & 1u;
-                st.spec_fail = (uint32_t)(b >> 31) & 1u;
-                have_stats = true;
-            }
-            t_wait.record(spins != 0u, std::chrono::steady_clock::now() - t0, spec.capacity != 0u);
+            bool waited = false;
+            have_stats = read_mailbox(mbox, mbox->seq, st, &waited);
+            t_wait.record(waited, std::chrono::steady_clock::now() - t0, spec.capacity != 0u);
         }
         if (have_stats) {
             e = hipSuccess;
@@ -621,6 +729,11 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
                                 float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const wg::Options opt = options_snapshot();
+    if (image_buffer != nullptr) {   // a deferred forward call's verdict, before anything is differentiated (found by its image buffer: the
+        const void* key = reinterpret_cast<const void*>((reinterpret_cast<uintptr_t>(image_buffer) + wg::ALIGN - 1) & ~(uintptr_t)(wg::ALIGN - 1));
+        const int verdict = check_ticket(key, stream);   // backward pass usually runs on torch's autograd thread, not the forward's)
+        if (verdict != WG_OK) return verdict;
+    }
     const int g_grad_record = opt.grad_record;
     if (tone != nullptr && P > 0) {
         if (shs == nullptr) return WG_ERR_INVALID_ARGUMENT;
@@ -770,7 +883,11 @@ int wg_set_option(const char* name, int value) {
     if (std::strcmp(name, "grad_record") == 0) { o.grad_record = value != 0; return WG_OK; }
     if (std::strcmp(name, "geometry_reuse") == 0) { o.geometry_reuse = value != 0; return WG_OK; }
     if (std::strcmp(name, "fused_scan") == 0) { o.fused_scan = value != 0; return WG_OK; }
-    if (std::strcmp(name, "speculative_forward") == 0) { o.speculative = value != 0; t_spec.clear(); t_wait.clear(); return WG_OK; }
+    if (std::strcmp(name, "speculative_forward") == 0) {  // (a deferred frame still pending is dropped: its verdict goes unread)
+        if (value < 0 || value > 2) return WG_ERR_INVALID_ARGUMENT;
+        o.speculative = value; t_spec.clear(); t_wait.clear(); t_deferred.pending = false;
+        return WG_OK;
+    }
     if (std::strcmp(name, "spec_margin_pct") == 0) { if (value < 0 || value > 1000) return WG_ERR_INVALID_ARGUMENT; o.spec_margin_pct = value; return WG_OK; }
     if (std::strcmp(name, "deterministic_backward") == 0) { o.deterministic_backward = value != 0; return WG_OK; }
     if (std::strcmp(name, "band_list_min_p") == 0) { o.band_list_min_p = value > 0 ? value : 1; return WG_OK; }
@@ -880,6 +997,8 @@ const char* wg_status_string(int status) {
         case WG_ERR_ALLOC: return "scratch allocator returned NULL";
         case WG_ERR_HIP: return "HIP runtime error";
         case WG_ERR_OVERFLOW: return "more than 2^31-1 tile instances";
+        case WG_ERR_SPECULATION: return "the previous forward call of this thread (deferred speculation) did not fit its predicted binning buffer: "
+                                        "its image is NaN and its gradients are zero -- repeat the step";
         default: return status > 0 ? "ok (num_rendered)" : "unknown error";
     }
 }

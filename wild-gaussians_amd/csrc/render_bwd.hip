@@ -37,6 +37,12 @@ constexpr int BATCH = 64;
 //                  0.4276 ms -- the four s_or_b64 sit on the scalar chain between the strips' branches.
 //   (A third idea, the butterfly's two select levels as bank-masked DPP adds, does not exist on this ISA: a DPP bank is four
 //    CONSECUTIVE lanes of a row, not lane % 4, so a bank mask cannot address the odd lanes.)
+//   WG_BWD_PAIR    two instances' reductions in ONE butterfly of twenty values (45 VALU against 2 x 34): the first contributing
+//                  instance's ten sums are parked in a second register set, the next one reduces both.  Parity-green, 92 VGPRs,
+//                  0.4121 -> 0.4124 ms: the reduction costs its dependent chain, not its instruction count (EXPERIMENTS.md R3.1).
+#ifndef WG_BWD_PAIR
+#define WG_BWD_PAIR 0
+#endif
 #ifndef WG_BWD_PK
 #define WG_BWD_PK 0
 #endif
@@ -95,6 +101,44 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
     return y;
 }
 
+
+template <int PATTERN>
+__device__ __forceinline__ float swz_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), PATTERN));
+}
+
+// Butterfly reduction of TWENTY per-lane values (two instances' ten sums: a0..a9, b0..b9 = values 0..19).  On return lane l holds the
+// full-wave total of value index 4 m + 2 bit4(l) + bit5(l), with m = 2 bit1(l) + bit0(l) when bit2(l) == 0 and m = 4 when bit2(l) == 1
+// (bit 3 does not matter; with bit 2 set, neither do bits 0 and 1: those lanes hold copies).
+__device__ __forceinline__ float butterfly20(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8, float a9,
+                                             float b0, float b1, float b2, float b3, float b4, float b5, float b6, float b7, float b8, float b9,
+                                             int lane) {
+    // xor 32: twenty -> ten;  w_k = v_{2k + bit5}
+    const float w0 = pair_x32(a0, a1), w1 = pair_x32(a2, a3), w2 = pair_x32(a4, a5), w3 = pair_x32(a6, a7), w4 = pair_x32(a8, a9);
+    const float w5 = pair_x32(b0, b1), w6 = pair_x32(b2, b3), w7 = pair_x32(b4, b5), w8 = pair_x32(b6, b7), w9 = pair_x32(b8, b9);
+    // xor 16: ten -> five;  u_m = w_{2m + bit4}
+    const float u0 = pair_x16(w0, w1), u1 = pair_x16(w2, w3), u2 = pair_x16(w4, w5), u3 = pair_x16(w6, w7), u4 = pair_x16(w8, w9);
+    // xor 1: five -> three;  x0 = u_{bit0}, x1 = u_{2 + bit0}, x2 = u4
+    const bool bit0 = lane & 1;
+    const float k0 = bit0 ? u1 : u0, s0 = bit0 ? u0 : u1;
+    const float k1 = bit0 ? u3 : u2, s1 = bit0 ? u2 : u3;
+    const float x0 = k0 + dpp_f<0xB1>(s0);
+    const float x1 = k1 + dpp_f<0xB1>(s1);
+    const float x2 = u4 + dpp_f<0xB1>(u4);
+    // xor 2: three -> two;  y0 = x_{bit1}, y1 = x2
+    const bool bit1 = lane & 2;
+    const float k2 = bit1 ? x1 : x0, s2 = bit1 ? x0 : x1;
+    const float y0 = k2 + dpp_f<0x4E>(s2);
+    const float y1 = x2 + dpp_f<0x4E>(x2);
+    // xor 4 (ds_swizzle through the LDS crossbar: no VALU slot for the exchange itself): two -> one;  z = bit2 ? y1 : y0
+    const bool bit2 = lane & 4;
+    const float k3 = bit2 ? y1 : y0, s3 = bit2 ? y0 : y1;
+    float z = k3 + swz_f<0x101F>(s3);
+    // lanes l and l ^ 8 of each row
+    z += dpp_f<0x128>(z);
+    return z;
+}
+
 // RECORD (default, wg_set_option("grad_record")): the ten reduced values of an instance go, unscaled, to ONE 48-byte gradient
 // record of its Gaussian (grad_rec[12 id + k], k = the value's index; wg_common.h: GRAD_REC_*) -- one L2 line per instance (two for
 // a quarter of the records) instead of partial lines of four arrays, and the per-Gaussian factors (opacity, 0.5 W,
@@ -147,6 +191,12 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
     else { abase = dL_dopacity; astride = 1; }
     // values 8 and 9 (bit1 set) are replicated over bits 0 and 4: let only the bit0 == bit4 == 0 copy issue
     const bool issue = owner && !((lane & 2) && (lane & 17));
+    // the paired reduction's lane -> value map (butterfly20): value index 0..19, ten per instance
+    const int m20 = (lane & 4) ? 4 : 2 * ((lane >> 1) & 1) + (lane & 1);
+    const int vidx20 = 4 * m20 + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
+    const bool issue20 = (lane & 8) == 0 && (!(lane & 4) || (lane & 3) == 0);
+    const bool second20 = vidx20 >= 10;                                   // this lane's value belongs to the PARKED (earlier) instance
+    float* const abase20 = grad_rec + (vidx20 - (second20 ? 10 : 0));
     // constant factor of this lane's value (see the per-pair sums below); values 3..8 also carry the splat's opacity
     const bool oscale = vidx >= 3 && vidx <= 8;
     constexpr float INV_L = 1.0f / WG_LOG2E;  // u, v above carry a factor -log2(e)
@@ -215,6 +265,7 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
 #define sxy p3.y
 #define syy p4.x
 #define sq p4.y
+#define PARKED_VALUES q0.x, q0.y, q1.x, q2.x, q2.y, q1.y, q3.x, q3.y, q4.x, q4.y
 #else
 #define acr p0.x
 #define acg p0.y
@@ -226,8 +277,13 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
 #define sxy p3.y
 #define syy p4.x
 #define sq p4.y
+#define PARKED_VALUES q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y, q4.x, q4.y
 #endif
 
+    constexpr bool PAIR = WG_BWD_PAIR && RECORD && !DET;
+    f2 q0 = {0.f, 0.f}, q1 = {0.f, 0.f}, q2 = {0.f, 0.f}, q3 = {0.f, 0.f}, q4 = {0.f, 0.f};  // PAIR: the parked instance's ten sums ...
+    float parked_id = 0.f;                                                                 // ... and its Gaussian id (as the record carries it)
+    bool parked = false;                                                                   // wave-uniform
     for (int hi = hi0; hi > 0; hi -= BATCH) {
         // lane l stages the instance at list position hi-1-l (back to front, backward.cu:517)
         const int posl = hi - 1 - lane;
@@ -375,6 +431,21 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
 #else
             if (__ballot(any) == 0ull) continue;
 #endif
+            if (PAIR) {
+                if (!parked) {  // park this instance's sums; the next contributing instance reduces both
+                    q0 = p0; q1 = p1; q2 = p2; q3 = p3; q4 = p4;
+                    parked_id = r1.z;
+                    parked = true;
+                } else {
+                    // (the accumulator NAMES differ between the packed and the scalar layout: go through them)
+                    const float t20 = butterfly20(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, PARKED_VALUES, lane);
+                    if (issue20) unsafeAtomicAdd(abase20 + (size_t)__float_as_uint(second20 ? parked_id : r1.z) * GRAD_REC_FLOATS, t20);
+                    parked = false;
+                }
+                asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\tv_mov_b64 %4, 0"
+                             : "=v"(p0), "=v"(p1), "=v"(p2), "=v"(p3), "=v"(p4));
+                continue;
+            }
             const float total = butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
             if (DET) {
                 if (issue) {
@@ -392,8 +463,13 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
                          : "=v"(p0), "=v"(p1), "=v"(p2), "=v"(p3), "=v"(p4));
         }
     }
+    if (PAIR && parked) {  // an odd one left: its own butterfly
+        const float total = butterfly10(PARKED_VALUES, lane);
+        if (issue) unsafeAtomicAdd(abase + (size_t)__float_as_uint(parked_id) * GRAD_REC_FLOATS, total);
+    }
 }
 
+#undef PARKED_VALUES
 #undef acr
 #undef acg
 #undef acb

@@ -403,3 +403,27 @@ def test_fused_optimizer_is_a_torch_adam_and_refuses_what_it_does_not_implement(
         FusedAdam([p], amsgrad=True)
     with pytest.raises(NotImplementedError):
         FusedAdam([p], betas=(0.3, 0.999)).step()
+
+
+def test_geometry_reuse_tokens_are_by_object_and_version_never_by_address():
+    """The binding's geometry reuse (diff_gaussian_rasterization/_C.py) decides "the same geometry as the last call" from tensor OBJECTS
+    and autograd version counters.  Pure host logic, checked on CPU tensors."""
+    from diff_gaussian_rasterization import _C
+    a = torch.zeros(5, 3)
+    ta = _C._tensor_token(a)
+    assert _C._same_token(ta, _C._tensor_token(a))
+    assert not _C._same_token(ta, _C._tensor_token(a.clone()))            # equal values, another object
+    a.add_(1.0)                                                           # an in-place write bumps the version
+    assert not _C._same_token(ta, _C._tensor_token(a))
+    tb = _C._tensor_token(a)
+    view = a[:]                                                           # a view is another object (and may be another shape)
+    assert not _C._same_token(tb, _C._tensor_token(view))
+    assert _C._tensor_token(torch.Tensor([])) is None and _C._same_token(None, None) and not _C._same_token(tb, None)
+    b = torch.zeros(5, 3)
+    tb2 = _C._tensor_token(b)
+    del b                                                                 # a dead tensor matches nothing, whatever lands at its address
+    c = torch.zeros(5, 3)
+    assert not _C._same_token(tb2, _C._tensor_token(c))
+    with torch.inference_mode():                                          # no version counter: never "the same"
+        d = torch.zeros(5, 3)
+        assert not _C._same_token(_C._tensor_token(d), _C._tensor_token(d))

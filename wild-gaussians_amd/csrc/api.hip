@@ -47,6 +47,18 @@ struct StageProfiler {
 };
 StageProfiler g_prof;
 
+// The backward pass of a deferred frame usually runs on ANOTHER host thread (torch's autograd engine): it finds the frame by its image
+// buffer here.  One ticket per forward thread (its latest deferred frame: earlier ones were settled by that thread's later calls).
+struct DeferredTicket {
+    const void* image_buffer;
+    const wg::HostMailbox* host;
+    uint32_t seq;
+    uint32_t reported_seq;  // the frame whose failure a backward call has already returned (the owning thread's settle then stays quiet)
+    bool reported;
+};
+std::mutex g_ticket_mu;
+std::vector<DeferredTicket> g_tickets;
+
 // One pinned mailbox per host thread (see wg::HostMailbox).  nullptr if pinned memory is unavailable: the forward pass
 // then falls back to hipMemcpyAsync + hipStreamSynchronize.
 struct Mailbox {
@@ -55,7 +67,14 @@ struct Mailbox {
     uint32_t seq = 0;
     bool tried = false;
     ~Mailbox() {
-        if (host) (void)hipHostFree(host);
+        if (!host) return;
+        {   // a thread that ends takes its deferred-frame ticket with it: nobody may look into the mailbox after it is freed
+            std::lock_guard<std::mutex> l(g_ticket_mu);
+            for (size_t i = 0; i < g_tickets.size();)
+                if (g_tickets[i].host == host) g_tickets.erase(g_tickets.begin() + (long)i);
+                else i++;
+        }
+        (void)hipHostFree(host);
     }
 };
 thread_local Mailbox t_mailbox;
@@ -107,17 +126,6 @@ struct Deferred {
     int P = 0, W = 0, H = 0;
 };
 thread_local Deferred t_deferred;
-// The backward pass of a deferred frame usually runs on ANOTHER host thread (torch's autograd engine): it finds the frame by its image
-// buffer here.  One ticket per forward thread (its latest deferred frame: earlier ones were settled by that thread's later calls).
-struct DeferredTicket {
-    const void* image_buffer;
-    const wg::HostMailbox* host;
-    uint32_t seq;
-    uint32_t reported_seq;  // the frame whose failure a backward call has already returned (the owning thread's settle then stays quiet)
-    bool reported;
-};
-std::mutex g_ticket_mu;
-std::vector<DeferredTicket> g_tickets;
 
 // the options (wg_common.h: Options): written by wg_set_option under the mutex, copied once per call
 std::mutex g_opt_mu;

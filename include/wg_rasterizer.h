@@ -299,7 +299,7 @@ const char* wg_stage_name(int stage);
  * their order -- and the last bits of the gradients -- vary from run to run (as in the reference, whose atomics are per pixel).
  * With 1 every (tile, Gaussian) instance stores its ten wave-reduced sums into a slot of its own and a per-Gaussian kernel adds
  * the slots in a fixed order: bit-identical gradients run to run, at 41 B of stream-ordered scratch per tile instance and about
- * 12.5 % of the train step (972 -> 850 iter/s at the headline scene; 27 % in round 2).  Values agree with the default mode to rounding
+ * 12 % of the train step (985 -> 869 iter/s at the headline scene; 27 % in round 2).  Values agree with the default mode to rounding
  * (2e-6 of an array's largest magnitude). */
 /* "box_count" (-1 automatic / 0 / 1, default -1: on for large scenes and after a dense frame, like the split): the per-tile instance
  * counts are made from a difference grid (four LDS atomics per Gaussian: its rectangle's corners) and two prefix passes instead of

@@ -789,7 +789,7 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
         StageScope scope_(WG_STAGE_RENDER_BACKWARD, stream);
         const size_t slot_bytes = (((size_t)R * 10 * sizeof(float)) + 255) & ~(size_t)255;
         hipError_t e = wg::run_scan(geom, P, stream);
-        if (e == hipSuccess) e = hipMallocAsync(reinterpret_cast<void**>(&det_slots), slot_bytes + (size_t)R, stream);
+        if (e == hipSuccess) e = hipMallocAsync(reinterpret_cast<void**>(&det_slots), slot_bytes + (size_t)R + 4, stream);  // (+4: the flags are read as 32-bit words)
         if (e == hipSuccess) {
             det_flags = reinterpret_cast<unsigned char*>(det_slots) + slot_bytes;
             e = hipMemsetAsync(det_flags, 0, (size_t)R, stream);

@@ -17,6 +17,7 @@
 // The gradient arithmetic is the reference's hand-derived backward, not autograd of the forward:
 // straight-through min(0.99,.), NDC-scaled dL_dmean2D (0.5*W, 0.5*H), abs-gradient in .z
 // (backward.cu:593-595), conic gradient in .x/.y/.w of a float4 (backward.cu:598-600).
+#include <algorithm>
 #include "wg_common.h"
 #include "wg_alpha.h"
 
@@ -496,7 +497,7 @@ constexpr uint32_t DET_FLAG_CHUNK = 4096;
 __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* __restrict__ offsets_incl, const uint32_t* __restrict__ tiles_touched,
                                                          const float* __restrict__ det_slots, const unsigned char* __restrict__ det_flags,
                                                          float* __restrict__ grad_rec, size_t slot_capacity) {
-    __shared__ unsigned char sflags[4][DET_FLAG_CHUNK];
+    __shared__ __attribute__((aligned(16))) unsigned char sflags[4][DET_FLAG_CHUNK + 16];   // (+ the word-alignment shift)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = g < P;
@@ -517,10 +518,31 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* 
     for (uint32_t clo = wlo; clo < whi; clo += DET_FLAG_CHUNK) {  // wave-uniform trip count; one trip unless the wave owns > 4096 slots
         const uint32_t clen = min(DET_FLAG_CHUNK, whi - clo);
         __builtin_amdgcn_wave_barrier();  // the previous chunk's flags have been read by every lane
-        for (uint32_t i = lane; i < clen; i += 64) sf[i] = (clo + i < slot_capacity) ? det_flags[clo + i] : (unsigned char)0;
-        __builtin_amdgcn_s_waitcnt(0);    // (compiler inserts the waits for its own uses; this makes the hand-over explicit)
+        // the chunk's flag bytes as aligned 32-bit words, four loads per lane in flight before the first is stored (a plain byte loop
+        // was one memory round trip per 64 bytes: nine in a row for an average wave)
+        {
+            const uint32_t a0 = clo & ~3u, shift = clo - a0;                   // word-aligned start; sf[] is indexed from a0
+            const uint32_t words = (shift + clen + 3u) >> 2;
+            const uint32_t cap_words = (uint32_t)std::min<size_t>((slot_capacity + 3) >> 2, 0xffffffffu);   // (the allocation is padded to 256 B)
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(det_flags) + (a0 >> 2);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(sf);
+            for (uint32_t i0 = 0; i0 < words; i0 += 256) {   // wave-uniform
+                uint32_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + 64u * u + lane;
+                    v[u] = (i < words && (a0 >> 2) + i < cap_words) ? src[i] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + 64u * u + lane;
+                    if (i < words) dst[i] = v[u];
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         // this lane's slots inside the chunk, in order; flagged ones gathered U at a time
+        const uint32_t sbase = clo & ~3u;   // sf[k - sbase] is slot k's flag
         const uint32_t mylo = max(base, clo), myhi = min(end, clo + clen);
         uint32_t pend[U];
         int np = 0;
@@ -541,7 +563,7 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* 
             np = 0;
         };
         for (uint32_t k = mylo; k < myhi; k++) {
-            if (sf[k - clo]) {
+            if (sf[k - sbase]) {
 #pragma unroll
                 for (int u = 0; u < U; u++)
                     if (u == np) pend[u] = k;   // (register array: written through a static index)

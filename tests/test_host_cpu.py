@@ -95,6 +95,46 @@ def test_invalid_arguments_are_rejected_before_any_device_work(lib):
     assert lib.wg_mark_visible(0, None, None, None, None, None) == 0
 
 
+def test_round3_entry_points_reject_invalid_arguments_before_any_device_work(lib):
+    """wg_rasterize_forward_fixed / _recolor / wg_forward_status: the same rule as the forward pass -- no allocator callback and no
+    HIP call before the arguments have been checked (this test runs on a box without a GPU)."""
+    ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    called = []
+    cb = ALLOC(lambda n, u: called.append(n) or 0)
+    one = C.c_void_p(16)
+    lib.wg_rasterize_forward_fixed.restype = i
+    lib.wg_rasterize_forward_fixed.argtypes = [ALLOC, vp, ALLOC, vp, ALLOC, vp, i, i, i, vp, i, i, vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp,
+                                               f, f, f, vp, i, vp, vp, vp, vp, i]
+
+    def fixed(capacity, P=10, W=64, H=64, colors=one):
+        return lib.wg_rasterize_forward_fixed(cb, None, cb, None, cb, None, P, 0, 0, one, W, H, one, None, colors, one, one, 1.0, one, None,
+                                              one, one, one, 1.0, 1.0, 0.1, None, 0, one, None, None, None, capacity)
+    assert fixed(0) == -1 and fixed(-5) == -1       # the capacity is the caller's to give
+    assert fixed(1024, P=-1) == -1 and fixed(1024, W=0) == -1 and fixed(1024, colors=None) == -1
+    assert fixed(1024, W=16 * 400, H=16 * 400) == -1  # 160 000 tiles: more than the LDS binning the capturable flow is restricted to
+
+    lib.wg_rasterize_forward_recolor.restype = i
+    lib.wg_rasterize_forward_recolor.argtypes = [ALLOC, vp, vp, vp, vp, i, i, vp, i, i, vp, vp, vp, vp, vp]
+
+    def recolor(alloc=cb, geom=one, binning=one, image=one, P=10, R=5, bg=one, W=64, H=64, colors=one, out=one):
+        return lib.wg_rasterize_forward_recolor(alloc, None, geom, binning, image, P, R, bg, W, H, colors, None, out, None, None)
+    for kw in (dict(alloc=C.cast(None, ALLOC)), dict(geom=None), dict(binning=None), dict(image=None), dict(P=0), dict(R=-1), dict(bg=None),
+               dict(W=0), dict(H=-2), dict(colors=None), dict(out=None)):
+        assert recolor(**kw) == -1, kw
+    assert recolor() == -2 and called == [called[0]]   # valid arguments: the allocator is asked once, returns NULL -> WG_ERR_ALLOC
+    del called[:]
+
+    lib.wg_forward_status.restype, lib.wg_forward_status.argtypes = i, [vp, i, i, vp, vp, vp]
+    assert lib.wg_forward_status(None, 64, 64, None, None, None) == -1
+    assert lib.wg_forward_status(one, 0, 64, None, None, None) == -1
+    lib.wg_image_accumulation_offset.restype, lib.wg_image_accumulation_offset.argtypes = C.c_size_t, [i, i]
+    lib.wg_image_buffer_size.restype, lib.wg_image_buffer_size.argtypes = C.c_size_t, [i, i]
+    off = lib.wg_image_accumulation_offset(1920, 1080)
+    assert off % 256 == 0 and off + 1920 * 1080 * 4 <= lib.wg_image_buffer_size(1920, 1080)
+    assert not called
+
+
 def test_python_surface_matches_the_reference_operator():
     import diff_gaussian_rasterization as dgr
     assert dgr.GaussianRasterizationSettings._fields == (

@@ -41,6 +41,13 @@ constexpr int BATCH = 64;
 //   WG_BWD_PAIR    two instances' reductions in ONE butterfly of twenty values (45 VALU against 2 x 34): the first contributing
 //                  instance's ten sums are parked in a second register set, the next one reduces both.  Parity-green, 92 VGPRs,
 //                  0.4121 -> 0.4124 ms: the reduction costs its dependent chain, not its instruction count (EXPERIMENTS.md R3.1).
+//   WG_BWD_MFMA    the ten sums reduced on the MATRIX pipe, which this kernel otherwise leaves idle: ten v_mfma_f32_16x16x4_f32 (A = one
+//                  value's 64 partial sums, B = a 0/1 selector that routes it to column k of ONE 16x16 accumulator) sum over the four
+//                  16-lane rows, three adds fold the accumulator's four registers, an eleventh MFMA sums the rows again: value k's
+//                  total lands in lane k.  3 VALU instead of 34 per contributing instance, ten selector VGPRs.
+#ifndef WG_BWD_MFMA
+#define WG_BWD_MFMA 0
+#endif
 #ifndef WG_BWD_PAIR
 #define WG_BWD_PAIR 0
 #endif
@@ -102,6 +109,43 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
     return y;
 }
 
+
+// The same reduction on the matrix pipe (v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] B[k][j]; A[i][k] and B[k][j] live in lane
+// 16 k + i resp. 16 k + j, D[i][j] in lane 16 (i / 4) + j, register i % 4).  With A = value v's per-lane sums and B = sel[v] =
+// (lane % 16 == v), ten accumulating MFMAs leave D[i][v] = the sum of value v over the lanes {i, 16 + i, 32 + i, 48 + i}; adding the
+// four registers gives, in lane 16 g + v, value v summed over the lanes with lane % 16 in [4 g, 4 g + 4); one more MFMA (A = sel[0]:
+// row 0 only, B = those sums) adds the four g: lane v (v < 10) holds the wave total of value v.  Products are x * 1 and x * 0, sums are
+// fp32: the same totals as butterfly10() up to the order of the additions.  (x * 0 is NaN for an infinite x: one non-finite sum spreads to all ten -- the
+// gradient of such an instance is lost either way.)
+typedef float f4 __attribute__((ext_vector_type(4)));
+struct MfmaSel { float s0, s1, s2, s3, s4, s5, s6, s7, s8, s9; };
+__device__ __forceinline__ MfmaSel mfma_selectors(int lane) {
+    MfmaSel m;
+    const int j = lane & 15;
+    m.s0 = j == 0 ? 1.f : 0.f; m.s1 = j == 1 ? 1.f : 0.f; m.s2 = j == 2 ? 1.f : 0.f; m.s3 = j == 3 ? 1.f : 0.f; m.s4 = j == 4 ? 1.f : 0.f;
+    m.s5 = j == 5 ? 1.f : 0.f; m.s6 = j == 6 ? 1.f : 0.f; m.s7 = j == 7 ? 1.f : 0.f; m.s8 = j == 8 ? 1.f : 0.f; m.s9 = j == 9 ? 1.f : 0.f;
+    // opaque: the compiler must keep them in registers, not rebuild them (v_cmp + v_cndmask each) in front of every MFMA
+    asm volatile("" : "+v"(m.s0), "+v"(m.s1), "+v"(m.s2), "+v"(m.s3), "+v"(m.s4), "+v"(m.s5), "+v"(m.s6), "+v"(m.s7), "+v"(m.s8), "+v"(m.s9));
+    return m;
+}
+__device__ __forceinline__ float reduce10_mfma(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8,
+                                               float v9, const MfmaSel& m) {
+    f4 d = {0.f, 0.f, 0.f, 0.f};
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, m.s0, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, m.s1, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, m.s2, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, m.s3, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v4, m.s4, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v5, m.s5, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v6, m.s6, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v7, m.s7, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v8, m.s8, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v9, m.s9, d, 0, 0, 0);
+    const float t = (d[0] + d[1]) + (d[2] + d[3]);
+    f4 e = {0.f, 0.f, 0.f, 0.f};
+    e = __builtin_amdgcn_mfma_f32_16x16x4f32(m.s0, t, e, 0, 0, 0);
+    return e[0];
+}
 
 template <int PATTERN>
 __device__ __forceinline__ float swz_f(float v) {
@@ -181,8 +225,14 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
 
     // which of the ten reduced values this lane owns after butterfly10(), and where it accumulates it:
     //   0,1,2 -> dL_dcolor[3id + k]; 3,4,5 -> dL_dmean2D[3id + k-3]; 6,7,8 -> dL_dconic[4id + {0,1,3}]; 9 -> dL_dopacity[id]
+#if WG_BWD_MFMA
+    const int vidx = lane < 10 ? lane : 0;  // reduce10_mfma(): value k's total in lane k
+    const bool owner = lane < 10;
+    const MfmaSel msel = mfma_selectors(lane);
+#else
     const int vidx = (lane & 2) ? 8 + ((lane >> 5) & 1) : 4 * (lane & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
     const bool owner = (lane & 12) == 0;  // lanes with bits 2,3 clear: one lane per value (two spare for value 8/9 copies)
+#endif
     float* abase;
     uint32_t astride;
     if (RECORD) { abase = grad_rec + vidx; astride = GRAD_REC_FLOATS; }
@@ -191,7 +241,11 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
     else if (vidx < 9) { abase = dL_dconic + (vidx == 8 ? 3 : vidx - 6); astride = 4; }
     else { abase = dL_dopacity; astride = 1; }
     // values 8 and 9 (bit1 set) are replicated over bits 0 and 4: let only the bit0 == bit4 == 0 copy issue
+#if WG_BWD_MFMA
+    const bool issue = owner;
+#else
     const bool issue = owner && !((lane & 2) && (lane & 17));
+#endif
     // the paired reduction's lane -> value map (butterfly20): value index 0..19, ten per instance
     const int m20 = (lane & 4) ? 4 : 2 * ((lane >> 1) & 1) + (lane & 1);
     const int vidx20 = 4 * m20 + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
@@ -447,7 +501,11 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
                              : "=v"(p0), "=v"(p1), "=v"(p2), "=v"(p3), "=v"(p4));
                 continue;
             }
+#if WG_BWD_MFMA
+            const float total = reduce10_mfma(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, msel);
+#else
             const float total = butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
+#endif
             if (DET) {
                 if (issue) {
                     const uint32_t slot = __float_as_uint(r1.z);

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B builds of kernel variants (wild-gaussians_amd/build.py: WG_BUILD_VARIANT / WG_FILE_FLAGS), built HERE (hipcc cross-compiles),
 # benchmarked on the GPU box by scripts/ab_run.sh.   usage: scripts/ab_variants.sh name1 "file.hip:-DFLAG=1 ..." [name2 "..."] ...
+# (rejected render_bwd.hip variants live in experiments/r3_render_bwd_variants.patch: git apply it first)
 set -e
 cd "$(dirname "$0")/.."
 while [ $# -ge 2 ]; do

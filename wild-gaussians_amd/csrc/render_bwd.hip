@@ -25,39 +25,9 @@ namespace wg {
 
 constexpr int BATCH = 64;
 
-// A/B knobs of this kernel (scripts/ab_variants.sh + scripts/ab_run.sh; numbers in EXPERIMENTS.md, round 3).  Both are OFF: measured, lost.
-//   WG_BWD_PK      the per-pair arithmetic on float PAIRS of one pixel -- (dx,dy), (xx,xy), (u,v) and the accumulator pairs
-//                  (acr,acg) (sx,sy) (sxx,sxy) (syy,sq) -- as v_pk_add/mul/fma_f32 with the shared multiplier broadcast by op_sel
-//                  (packing WITHIN a pixel keeps the per-strip skip granularity that packing strip pairs lost).
-//                  Same products, same fused multiply-adds.  12 instead of 14 VALU per strip evaluation, 23 instead of 29 per
-//                  contributing strip (9 of them packed) -- and 0.4218 -> 0.4367 ms, at 5 or at 6 waves per SIMD alike: in this
-//                  dependent mix a v_pk_*_f32 occupies its SIMD for about two plain VALU slots (MI355X_MICROARCH.md calls packed
-//                  f32 "an anti-lever" beside other work too), so an instruction count that falls by a fifth buys nothing.
-//   WG_BWD_ANYMASK "did any lane contribute to this instance" as an OR of the strips' lane masks in SGPRs instead of a per-lane flag
-//                  that hipcc turns back into a mask with v_cndmask + v_cmp (2 VALU per visited instance): bit-identical, 0.4218 ->
-//                  0.4276 ms -- the four s_or_b64 sit on the scalar chain between the strips' branches.
-//   (A third idea, the butterfly's two select levels as bank-masked DPP adds, does not exist on this ISA: a DPP bank is four
-//    CONSECUTIVE lanes of a row, not lane % 4, so a bank mask cannot address the odd lanes.)
-//   WG_BWD_PAIR    two instances' reductions in ONE butterfly of twenty values (45 VALU against 2 x 34): the first contributing
-//                  instance's ten sums are parked in a second register set, the next one reduces both.  Parity-green, 92 VGPRs,
-//                  0.4121 -> 0.4124 ms: the reduction costs its dependent chain, not its instruction count (EXPERIMENTS.md R3.1).
-//   WG_BWD_MFMA    the ten sums reduced on the MATRIX pipe, which this kernel otherwise leaves idle: ten v_mfma_f32_16x16x4_f32 (A = one
-//                  value's 64 partial sums, B = a 0/1 selector that routes it to column k of ONE 16x16 accumulator) sum over the four
-//                  16-lane rows, three adds fold the accumulator's four registers, an eleventh MFMA sums the rows again: value k's
-//                  total lands in lane k.  3 VALU instead of 34 per contributing instance, ten selector VGPRs.
-#ifndef WG_BWD_MFMA
-#define WG_BWD_MFMA 0
-#endif
-#ifndef WG_BWD_PAIR
-#define WG_BWD_PAIR 0
-#endif
-#ifndef WG_BWD_PK
-#define WG_BWD_PK 0
-#endif
-#ifndef WG_BWD_ANYMASK
-#define WG_BWD_ANYMASK 0
-#endif
-
+// Measured and rejected variants of this kernel (packed f32 per-pair math, scalar any-mask, two instances per butterfly, the reduction
+// on the matrix pipe, forced occupancy) are NOT in this file: experiments/r3_render_bwd_variants.patch adds them back as compile-time
+// knobs for scripts/ab_variants.sh; their numbers are in EXPERIMENTS.md (R3.1).
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <int CTRL>
@@ -110,80 +80,6 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
 }
 
 
-// The same reduction on the matrix pipe (v_mfma_f32_16x16x4_f32: D[i][j] += sum_k A[i][k] B[k][j]; A[i][k] and B[k][j] live in lane
-// 16 k + i resp. 16 k + j, D[i][j] in lane 16 (i / 4) + j, register i % 4).  With A = value v's per-lane sums and B = sel[v] =
-// (lane % 16 == v), ten accumulating MFMAs leave D[i][v] = the sum of value v over the lanes {i, 16 + i, 32 + i, 48 + i}; adding the
-// four registers gives, in lane 16 g + v, value v summed over the lanes with lane % 16 in [4 g, 4 g + 4); one more MFMA (A = sel[0]:
-// row 0 only, B = those sums) adds the four g: lane v (v < 10) holds the wave total of value v.  Products are x * 1 and x * 0, sums are
-// fp32: the same totals as butterfly10() up to the order of the additions.  (x * 0 is NaN for an infinite x: one non-finite sum spreads to all ten -- the
-// gradient of such an instance is lost either way.)
-typedef float f4 __attribute__((ext_vector_type(4)));
-struct MfmaSel { float s0, s1, s2, s3, s4, s5, s6, s7, s8, s9; };
-__device__ __forceinline__ MfmaSel mfma_selectors(int lane) {
-    MfmaSel m;
-    const int j = lane & 15;
-    m.s0 = j == 0 ? 1.f : 0.f; m.s1 = j == 1 ? 1.f : 0.f; m.s2 = j == 2 ? 1.f : 0.f; m.s3 = j == 3 ? 1.f : 0.f; m.s4 = j == 4 ? 1.f : 0.f;
-    m.s5 = j == 5 ? 1.f : 0.f; m.s6 = j == 6 ? 1.f : 0.f; m.s7 = j == 7 ? 1.f : 0.f; m.s8 = j == 8 ? 1.f : 0.f; m.s9 = j == 9 ? 1.f : 0.f;
-    // opaque: the compiler must keep them in registers, not rebuild them (v_cmp + v_cndmask each) in front of every MFMA
-    asm volatile("" : "+v"(m.s0), "+v"(m.s1), "+v"(m.s2), "+v"(m.s3), "+v"(m.s4), "+v"(m.s5), "+v"(m.s6), "+v"(m.s7), "+v"(m.s8), "+v"(m.s9));
-    return m;
-}
-__device__ __forceinline__ float reduce10_mfma(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8,
-                                               float v9, const MfmaSel& m) {
-    f4 d = {0.f, 0.f, 0.f, 0.f};
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, m.s0, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, m.s1, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, m.s2, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, m.s3, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v4, m.s4, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v5, m.s5, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v6, m.s6, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v7, m.s7, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v8, m.s8, d, 0, 0, 0);
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(v9, m.s9, d, 0, 0, 0);
-    const float t = (d[0] + d[1]) + (d[2] + d[3]);
-    f4 e = {0.f, 0.f, 0.f, 0.f};
-    e = __builtin_amdgcn_mfma_f32_16x16x4f32(m.s0, t, e, 0, 0, 0);
-    return e[0];
-}
-
-template <int PATTERN>
-__device__ __forceinline__ float swz_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), PATTERN));
-}
-
-// Butterfly reduction of TWENTY per-lane values (two instances' ten sums: a0..a9, b0..b9 = values 0..19).  On return lane l holds the
-// full-wave total of value index 4 m + 2 bit4(l) + bit5(l), with m = 2 bit1(l) + bit0(l) when bit2(l) == 0 and m = 4 when bit2(l) == 1
-// (bit 3 does not matter; with bit 2 set, neither do bits 0 and 1: those lanes hold copies).
-__device__ __forceinline__ float butterfly20(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, float a8, float a9,
-                                             float b0, float b1, float b2, float b3, float b4, float b5, float b6, float b7, float b8, float b9,
-                                             int lane) {
-    // xor 32: twenty -> ten;  w_k = v_{2k + bit5}
-    const float w0 = pair_x32(a0, a1), w1 = pair_x32(a2, a3), w2 = pair_x32(a4, a5), w3 = pair_x32(a6, a7), w4 = pair_x32(a8, a9);
-    const float w5 = pair_x32(b0, b1), w6 = pair_x32(b2, b3), w7 = pair_x32(b4, b5), w8 = pair_x32(b6, b7), w9 = pair_x32(b8, b9);
-    // xor 16: ten -> five;  u_m = w_{2m + bit4}
-    const float u0 = pair_x16(w0, w1), u1 = pair_x16(w2, w3), u2 = pair_x16(w4, w5), u3 = pair_x16(w6, w7), u4 = pair_x16(w8, w9);
-    // xor 1: five -> three;  x0 = u_{bit0}, x1 = u_{2 + bit0}, x2 = u4
-    const bool bit0 = lane & 1;
-    const float k0 = bit0 ? u1 : u0, s0 = bit0 ? u0 : u1;
-    const float k1 = bit0 ? u3 : u2, s1 = bit0 ? u2 : u3;
-    const float x0 = k0 + dpp_f<0xB1>(s0);
-    const float x1 = k1 + dpp_f<0xB1>(s1);
-    const float x2 = u4 + dpp_f<0xB1>(u4);
-    // xor 2: three -> two;  y0 = x_{bit1}, y1 = x2
-    const bool bit1 = lane & 2;
-    const float k2 = bit1 ? x1 : x0, s2 = bit1 ? x0 : x1;
-    const float y0 = k2 + dpp_f<0x4E>(s2);
-    const float y1 = x2 + dpp_f<0x4E>(x2);
-    // xor 4 (ds_swizzle through the LDS crossbar: no VALU slot for the exchange itself): two -> one;  z = bit2 ? y1 : y0
-    const bool bit2 = lane & 4;
-    const float k3 = bit2 ? y1 : y0, s3 = bit2 ? y0 : y1;
-    float z = k3 + swz_f<0x101F>(s3);
-    // lanes l and l ^ 8 of each row
-    z += dpp_f<0x128>(z);
-    return z;
-}
-
 // RECORD (default, wg_set_option("grad_record")): the ten reduced values of an instance go, unscaled, to ONE 48-byte gradient
 // record of its Gaussian (grad_rec[12 id + k], k = the value's index; wg_common.h: GRAD_REC_*) -- one L2 line per instance (two for
 // a quarter of the records) instead of partial lines of four arrays, and the per-Gaussian factors (opacity, 0.5 W,
@@ -195,16 +91,8 @@ __device__ __forceinline__ float butterfly20(float a0, float a1, float a2, float
 // into which the ten lanes STORE the wave-reduced sums; det_reduce_kernel then adds a Gaussian's slots in slot order into its
 // gradient record.  Same sums as the atomic path up to the order of a Gaussian's per-tile terms, which is now fixed: two runs
 // give bit-identical gradients.
-#ifndef WG_BWD_WAVES
-#define WG_BWD_WAVES 0
-#endif
-#if WG_BWD_WAVES
-#define WG_BWD_OCC __attribute__((amdgpu_waves_per_eu(WG_BWD_WAVES, WG_BWD_WAVES)))
-#else
-#define WG_BWD_OCC
-#endif
 template <bool RECORD, bool DET = false>
-__global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
+__global__ void __launch_bounds__(64) render_backward_kernel(
     int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_last,
@@ -225,14 +113,8 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
 
     // which of the ten reduced values this lane owns after butterfly10(), and where it accumulates it:
     //   0,1,2 -> dL_dcolor[3id + k]; 3,4,5 -> dL_dmean2D[3id + k-3]; 6,7,8 -> dL_dconic[4id + {0,1,3}]; 9 -> dL_dopacity[id]
-#if WG_BWD_MFMA
-    const int vidx = lane < 10 ? lane : 0;  // reduce10_mfma(): value k's total in lane k
-    const bool owner = lane < 10;
-    const MfmaSel msel = mfma_selectors(lane);
-#else
     const int vidx = (lane & 2) ? 8 + ((lane >> 5) & 1) : 4 * (lane & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
     const bool owner = (lane & 12) == 0;  // lanes with bits 2,3 clear: one lane per value (two spare for value 8/9 copies)
-#endif
     float* abase;
     uint32_t astride;
     if (RECORD) { abase = grad_rec + vidx; astride = GRAD_REC_FLOATS; }
@@ -241,26 +123,13 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
     else if (vidx < 9) { abase = dL_dconic + (vidx == 8 ? 3 : vidx - 6); astride = 4; }
     else { abase = dL_dopacity; astride = 1; }
     // values 8 and 9 (bit1 set) are replicated over bits 0 and 4: let only the bit0 == bit4 == 0 copy issue
-#if WG_BWD_MFMA
-    const bool issue = owner;
-#else
     const bool issue = owner && !((lane & 2) && (lane & 17));
-#endif
-    // the paired reduction's lane -> value map (butterfly20): value index 0..19, ten per instance
-    const int m20 = (lane & 4) ? 4 : 2 * ((lane >> 1) & 1) + (lane & 1);
-    const int vidx20 = 4 * m20 + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
-    const bool issue20 = (lane & 8) == 0 && (!(lane & 4) || (lane & 3) == 0);
-    const bool second20 = vidx20 >= 10;                                   // this lane's value belongs to the PARKED (earlier) instance
-    float* const abase20 = grad_rec + (vidx20 - (second20 ? 10 : 0));
     // constant factor of this lane's value (see the per-pair sums below); values 3..8 also carry the splat's opacity
     const bool oscale = vidx >= 3 && vidx <= 8;
     constexpr float INV_L = 1.0f / WG_LOG2E;  // u, v above carry a factor -log2(e)
     const float vscale = vidx == 3 ? ddelx_dx * INV_L : vidx == 4 ? ddely_dy * INV_L : vidx == 5 ? INV_L : (vidx >= 6 && vidx <= 8) ? -0.5f : 1.0f;
 
     float pfx[4], pfy[4], T[4], tfb[4], dLr[4], dLg[4], dLb[4], recd[4];
-#if WG_BWD_PK
-    f2 pf[4], dLrg[4];  // (pfx, pfy) and (dL_dred, dL_dgreen) of the lane's four pixels as register pairs
-#endif
     int last[4];
     StripBounds sb;
 #pragma unroll
@@ -282,10 +151,6 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
         pfy[s] = (float)py + off.y;
         tfb[s] = -T[s] * (bg0 * dLr[s] + bg1 * dLg[s] + bg2 * dLb[s]);  // -T_final * <bg, dL_dpixel>
         recd[s] = 0.f;
-#if WG_BWD_PK
-        pf[s] = f2{pfx[s], pfy[s]};
-        dLrg[s] = f2{dLr[s], dLg[s]};
-#endif
         const float inf = __builtin_huge_valf();
         sb.x0[s] = wave_min_uniform(inside ? pfx[s] : inf);
         sb.x1[s] = wave_max_uniform(inside ? pfx[s] : -inf);
@@ -308,20 +173,6 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
     // the ten sums live in five register PAIRS, so that clearing them after a reduction is five v_mov_b64 instead of ten v_mov_b32
     // (backward 0.4272 -> 0.4234 ms; the names below are the pairs' halves)
     f2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, p3 = {0.f, 0.f}, p4 = {0.f, 0.f};
-#if WG_BWD_PK
-    // pairs that share a multiplier: (acr, acg) += w (dLr, dLg);  (sx, sy) += q (u, v);  (sxx, sxy) += q (xx, xy);  (syy, sq) += q (yy, 1)
-#define acr p0.x
-#define acg p0.y
-#define acb p1.x
-#define sab p1.y
-#define sx p2.x
-#define sy p2.y
-#define sxx p3.x
-#define sxy p3.y
-#define syy p4.x
-#define sq p4.y
-#define PARKED_VALUES q0.x, q0.y, q1.x, q2.x, q2.y, q1.y, q3.x, q3.y, q4.x, q4.y
-#else
 #define acr p0.x
 #define acg p0.y
 #define acb p1.x
@@ -332,13 +183,7 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
 #define sxy p3.y
 #define syy p4.x
 #define sq p4.y
-#define PARKED_VALUES q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y, q4.x, q4.y
-#endif
 
-    constexpr bool PAIR = WG_BWD_PAIR && RECORD && !DET;
-    f2 q0 = {0.f, 0.f}, q1 = {0.f, 0.f}, q2 = {0.f, 0.f}, q3 = {0.f, 0.f}, q4 = {0.f, 0.f};  // PAIR: the parked instance's ten sums ...
-    float parked_id = 0.f;                                                                 // ... and its Gaussian id (as the record carries it)
-    bool parked = false;                                                                   // wave-uniform
     for (int hi = hi0; hi > 0; hi -= BATCH) {
         // lane l stages the instance at list position hi-1-l (back to front, backward.cu:517)
         const int posl = hi - 1 - lane;
@@ -393,66 +238,14 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
             //   dL_dmean2D.y = -o * 0.5H * sum(q v)           dL_dconic.xy = -0.5 o * sum(q dx dy)
             //   dL_dmean2D.z =  o * sum(|q| (0.5W |u| + 0.5H |v|))   dL_dconic.yy = -0.5 o * sum(q dy dy)
             //   dL_dopacity  = sum(q)
-#if WG_BWD_ANYMASK
-            uint64_t anym = 0ull;
-#else
             bool any = false;
-#endif
-#if WG_BWD_PK
-            const f2 mxy = {r0.x, r0.y}, gzw = {gb.z, gb.w};
-#endif
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 if (((reach[s] >> j) & 1ull) == 0ull) continue;  // wave-uniform
-#if WG_BWD_PK
-                // eval_alpha() on pairs: the same differences, products and fused multiply-adds, two per instruction
-                const f2 d = mxy - pf[s];                       // (dx, dy)
-                const f2 xq = f2{d.x, d.x} * d;                 // (dx dx, dx dy)
-                const float yy = d.y * d.y;
-                const float pw2 = sc.ca * xq.x + sc.cb * xq.y + sc.cc * yy;
-                const float G = __builtin_amdgcn_exp2f(pw2);
-                const float alpha = fminf(0.99f, sc.o * G);
-                const bool pass = pw2 <= 0.0f && alpha >= (1.0f / 255.0f);
-                const bool contrib = pos < last[s] && pass;
-#if WG_BWD_ANYMASK
-                anym |= __builtin_amdgcn_ballot_w64(contrib);   // (HIP's __ballot goes through a zero-extended compare: v_cndmask + v_cmp)
-#endif
-                if (contrib) {
-#if !WG_BWD_ANYMASK
-                    any = true;
-#endif
-                    const float a = alpha;
-                    const float inv = __builtin_amdgcn_rcpf(1.0f - a);
-                    const float Tn = T[s] * inv;
-                    T[s] = Tn;
-                    const float w = a * Tn;
-                    p0 += f2{w, w} * dLrg[s];
-                    acb += w * dLb[s];
-                    const float cd = colr * dLrg[s].x + colg * dLrg[s].y + colb * dLb[s];
-                    const float diff = cd - recd[s];
-                    recd[s] += a * diff;
-                    const float dLda = diff * Tn + tfb[s] * inv;
-                    const float q = G * dLda;
-                    const f2 cross = f2{r0.w, r0.w} * f2{d.y, d.x};   // cb (dy, dx)
-                    const f2 uv = gzw * d + cross;                    // (2ca dx + cb dy, 2cc dy + cb dx), the scalar build's roundings
-                    const f2 qq = {q, q};
-                    p2 += qq * uv;
-                    sab += fabsf(q) * (ddelx_dx * fabsf(uv.x) + ddely_dy * fabsf(uv.y));
-                    p3 += qq * xq;
-                    p4 += qq * f2{yy, 1.0f};
-                }
-            }
-#else
                 PairEval e;
                 const bool pass = eval_alpha(sc, pfx[s], pfy[s], e);
-#if WG_BWD_ANYMASK
-                const bool contrib = pos < last[s] && pass;
-                anym |= __builtin_amdgcn_ballot_w64(contrib);   // (HIP's __ballot goes through a zero-extended compare: v_cndmask + v_cmp)
-                if (contrib) {
-#else
                 if (pos < last[s] && pass) {
                     any = true;
-#endif
                     const float a = e.alpha;
                     const float inv = __builtin_amdgcn_rcpf(1.0f - a);
                     const float Tn = T[s] * inv;  // T / (1 - alpha), backward.cu:548
@@ -480,32 +273,8 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
                     syy += q * e.yy;
                 }
             }
-#endif
-#if WG_BWD_ANYMASK
-            if (anym == 0ull) continue;
-#else
             if (__ballot(any) == 0ull) continue;
-#endif
-            if (PAIR) {
-                if (!parked) {  // park this instance's sums; the next contributing instance reduces both
-                    q0 = p0; q1 = p1; q2 = p2; q3 = p3; q4 = p4;
-                    parked_id = r1.z;
-                    parked = true;
-                } else {
-                    // (the accumulator NAMES differ between the packed and the scalar layout: go through them)
-                    const float t20 = butterfly20(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, PARKED_VALUES, lane);
-                    if (issue20) unsafeAtomicAdd(abase20 + (size_t)__float_as_uint(second20 ? parked_id : r1.z) * GRAD_REC_FLOATS, t20);
-                    parked = false;
-                }
-                asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\tv_mov_b64 %4, 0"
-                             : "=v"(p0), "=v"(p1), "=v"(p2), "=v"(p3), "=v"(p4));
-                continue;
-            }
-#if WG_BWD_MFMA
-            const float total = reduce10_mfma(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, msel);
-#else
             const float total = butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
-#endif
             if (DET) {
                 if (issue) {
                     const uint32_t slot = __float_as_uint(r1.z);
@@ -522,13 +291,8 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
                          : "=v"(p0), "=v"(p1), "=v"(p2), "=v"(p3), "=v"(p4));
         }
     }
-    if (PAIR && parked) {  // an odd one left: its own butterfly
-        const float total = butterfly10(PARKED_VALUES, lane);
-        if (issue) unsafeAtomicAdd(abase + (size_t)__float_as_uint(parked_id) * GRAD_REC_FLOATS, total);
-    }
 }
 
-#undef PARKED_VALUES
 #undef acr
 #undef acg
 #undef acb

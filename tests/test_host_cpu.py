@@ -467,3 +467,15 @@ def test_geometry_reuse_tokens_are_by_object_and_version_never_by_address():
     with torch.inference_mode():                                          # no version counter: never "the same"
         d = torch.zeros(5, 3)
         assert not _C._same_token(_C._tensor_token(d), _C._tensor_token(d))
+    # the remembered call ends with the next backward call of the process (writes through `.data` move no version counter)
+    g = [torch.zeros(5, 3) for _ in range(9)]
+    key = (tuple(_C._tensor_token(t) for t in g), (1.0, 0.5, 0.5, 0.1, 32, 32, False, "cpu", 0))   # as _reuse_key builds it
+    try:
+        _C._reuse.last = dict(tensors=key[0], scalars=key[1], epoch=_C._reuse_epoch)
+        assert _C._reuse_lookup(key) is _C._reuse.last
+        g[0].data.add_(1.0)                                               # invisible to the token ...
+        assert _C._reuse_lookup(key) is _C._reuse.last
+        _C._reuse_epoch += 1                                              # ... which is why a backward call (it bumps the epoch) ends the reach
+        assert _C._reuse_lookup(key) is None
+    finally:
+        _C.forget_geometry()

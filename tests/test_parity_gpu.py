@@ -1199,6 +1199,13 @@ def test_geometry_reuse_is_not_taken_when_anything_it_depends_on_changed(record_
     assert h == 0
     _C.set_option("geometry_reuse", 1)
     _C.forget_geometry()
+    cg = t["colors_precomp"].clone().requires_grad_(True)     # a backward call ends the reach (optimisers write next, some through .data)
+    _, h = call(rast, colors_precomp=cg)
+    (img, _, _), h1 = call(rast, colors_precomp=cg)
+    img.sum().backward()
+    _, h2 = call(rast, colors_precomp=cg)
+    assert (h, h1, h2) == (0, 1, 0) and cg.grad is not None
+    _C.forget_geometry()
     with torch.inference_mode():                             # inference tensors have no version counter: never reused, never an error
         ti = {k: v.clone() for k, v in t.items()}
         kw = dict(means3D=ti["means3D"], means2D=m2d.clone(), opacities=ti["opacities"], scales=ti["scales"], rotations=ti["rotations"],

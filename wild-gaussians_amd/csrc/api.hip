@@ -60,7 +60,13 @@ std::mutex g_ticket_mu;
 std::vector<DeferredTicket> g_tickets;
 
 // One pinned mailbox per host thread (see wg::HostMailbox).  nullptr if pinned memory is unavailable: the forward pass
-// then falls back to hipMemcpyAsync + hipStreamSynchronize.
+// then falls back to hipMemcpyAsync + hipStreamSynchronize.  The pinned words outlive their thread: a thread that ends hands its
+// mailbox (with its sequence counter, which therefore never runs backwards) to a process-wide free list for the next thread that
+// needs one, and nothing is ever given back to the runtime -- a backward call on another thread may be polling those words at that
+// very moment (check_ticket), and thread-local destructors of a process that is shutting down run after the HIP runtime has gone.
+struct MailboxSlot { wg::HostMailbox* host; wg::HostMailbox* dev; uint32_t seq; };
+std::mutex g_mailbox_mu;
+std::vector<MailboxSlot> g_mailbox_free;
 struct Mailbox {
     wg::HostMailbox* host = nullptr;
     wg::HostMailbox* dev = nullptr;
@@ -68,13 +74,14 @@ struct Mailbox {
     bool tried = false;
     ~Mailbox() {
         if (!host) return;
-        {   // a thread that ends takes its deferred-frame ticket with it: nobody may look into the mailbox after it is freed
+        {   // the thread's deferred-frame ticket goes with it (its frames' verdicts were this thread's to report)
             std::lock_guard<std::mutex> l(g_ticket_mu);
             for (size_t i = 0; i < g_tickets.size();)
                 if (g_tickets[i].host == host) g_tickets.erase(g_tickets.begin() + (long)i);
                 else i++;
         }
-        (void)hipHostFree(host);
+        std::lock_guard<std::mutex> l(g_mailbox_mu);
+        g_mailbox_free.push_back({host, dev, seq});
     }
 };
 thread_local Mailbox t_mailbox;
@@ -110,7 +117,7 @@ struct WaitStats {
     uint64_t polls = 0, waited = 0, spec_frames = 0, spec_misses = 0;
     double wait_us = 0.0, last_wait_us = 0.0;
     template <typename D>
-    void record(bool spun, D d, bool) {
+    void record(bool spun, D d) {
         polls += 1;
         last_wait_us = std::chrono::duration<double, std::micro>(d).count();
         if (spun) { waited += 1; wait_us += last_wait_us; }
@@ -124,6 +131,7 @@ struct Deferred {
     bool pending = false;
     uint32_t seq = 0;
     int P = 0, W = 0, H = 0;
+    hipStream_t stream = nullptr;  // the stream the frame was enqueued on (the next call may come with another one)
 };
 thread_local Deferred t_deferred;
 
@@ -139,8 +147,17 @@ Mailbox* get_mailbox() {
     Mailbox& m = t_mailbox;
     if (!m.tried) {
         m.tried = true;
+        {
+            std::lock_guard<std::mutex> l(g_mailbox_mu);
+            if (!g_mailbox_free.empty()) {
+                const MailboxSlot s = g_mailbox_free.back();
+                g_mailbox_free.pop_back();
+                m.host = s.host; m.dev = s.dev; m.seq = s.seq;
+                m.host->need_far = 0u;
+            }
+        }
         void* h = nullptr;
-        if (hipHostMalloc(&h, sizeof(wg::HostMailbox), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        if (!m.host && hipHostMalloc(&h, sizeof(wg::HostMailbox), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
             void* d = nullptr;
             if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
                 m.host = static_cast<wg::HostMailbox*>(h);
@@ -253,9 +270,10 @@ bool read_mailbox(Mailbox* mbox, uint32_t seq, wg::BinStats& st, bool* waited) {
 // A deferred frame's verdict, taken by the thread's next call.  WG_ERR_SPECULATION when that frame did not fit the buffer it was given:
 // its image is NaN and its gradients are zero (see wg_rasterize_forward_fixed); the caller repeats the step.  The history learns the
 // frame's real size either way, so the repeat fits.
-int settle_deferred(hipStream_t stream) {
+int settle_deferred() {
     if (!t_deferred.pending) return WG_OK;
     t_deferred.pending = false;
+    const hipStream_t stream = t_deferred.stream;
     Mailbox& mb = t_mailbox;
     wg::BinStats st{};
     bool ok = mb.host != nullptr && read_mailbox(&mb, t_deferred.seq, st, nullptr);
@@ -286,6 +304,8 @@ void post_ticket(const void* image_buffer, const wg::HostMailbox* host, uint32_t
 }
 
 // Backward side: was `image_buffer` produced by a deferred forward call whose verdict nobody has looked at yet, and did it fit?
+// A ticket is checked once: the call that reads its verdict takes the address out of it (scratch addresses come back from the
+// caller's allocator for other frames).
 int check_ticket(const void* image_buffer, hipStream_t stream) {
     DeferredTicket t{};
     {
@@ -295,6 +315,15 @@ int check_ticket(const void* image_buffer, hipStream_t stream) {
             if (k.image_buffer == image_buffer) { t = k; found = true; break; }
         if (!found) return WG_OK;
     }
+    auto consume = [&](bool failed) {
+        std::lock_guard<std::mutex> l(g_ticket_mu);
+        for (auto& k : g_tickets)
+            if (k.host == t.host && k.seq == t.seq) {
+                k.image_buffer = nullptr;
+                if (failed) { k.reported = true; k.reported_seq = t.seq; }
+            }
+    };
+    // (t.host stays valid whatever its thread does meanwhile: mailboxes are pooled, never freed)
     volatile const unsigned long long* w0 = &t.host->word0;
     volatile const unsigned long long* w1 = &t.host->word1;
     const auto t0 = std::chrono::steady_clock::now();
@@ -303,14 +332,12 @@ int check_ticket(const void* image_buffer, hipStream_t stream) {
         const unsigned long long a = *w0, b = *w1;
         const uint32_t sa = (uint32_t)(a >> 32), sb = (uint32_t)(b >> 32);
         if (sa == t.seq && sb == t.seq) {
-            if (((b >> 31) & 1ull) == 0ull) return WG_OK;
-            std::lock_guard<std::mutex> l(g_ticket_mu);
-            for (auto& k : g_tickets)
-                if (k.host == t.host) { k.reported = true; k.reported_seq = t.seq; }
-            return WG_ERR_SPECULATION;
+            const bool failed = ((b >> 31) & 1ull) != 0ull;
+            consume(failed);
+            return failed ? WG_ERR_SPECULATION : WG_OK;
         }
         // a later frame of the owning thread is in the mailbox: that thread's call has settled (and reported) this one already
-        if ((int32_t)(sa - t.seq) > 0 || (int32_t)(sb - t.seq) > 0) return WG_OK;
+        if ((int32_t)(sa - t.seq) > 0 || (int32_t)(sb - t.seq) > 0) { consume(false); return WG_OK; }
         if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
             hipError_t e = hipStreamSynchronize(stream);   // the frame's scan has not run yet: wait for the stream once, then look again
             if (e != hipSuccess) return hip_fail(e, "deferred forward (backward-side check)");
@@ -431,7 +458,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
     const wg::Options opt = options_snapshot();
     const bool fixed = fixed_capacity > 0;  // no host rendezvous at all: the caller's capacity, the superset (lazy) flow, a device-side verdict
     {
-        const int settled = settle_deferred(stream);
+        const int settled = settle_deferred();
         if (settled != WG_OK) return settled;
     }
     if (tone != nullptr && shs == nullptr && P > 0) return WG_ERR_INVALID_ARGUMENT;  // the tone acts on SH coefficients
@@ -607,6 +634,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
                         t_deferred.pending = true;
                         t_deferred.seq = mbox->seq;
                         t_deferred.P = P; t_deferred.W = width; t_deferred.H = height;
+                        t_deferred.stream = stream;
                         post_ticket(img.final_T, mbox->host, mbox->seq);   // (the state's first array: image_alloc's pointer, aligned)
                     }
                     return (int)spec.capacity;
@@ -626,7 +654,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
             const auto t0 = std::chrono::steady_clock::now();
             bool waited = false;
             have_stats = read_mailbox(mbox, mbox->seq, st, &waited);
-            t_wait.record(waited, std::chrono::steady_clock::now() - t0, spec.capacity != 0u);
+            t_wait.record(waited, std::chrono::steady_clock::now() - t0);
         }
         if (have_stats) {
             e = hipSuccess;
@@ -769,8 +797,9 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     // grad_record (default): the per-tile pass accumulates into one 48-byte record per Gaussian (wg_common.h: GRAD_REC_FLOATS) inside the geometry buffer, cleared
     // here; the per-Gaussian kernel then WRITES the four arrays (they need no clearing by the caller).  Off: the arrays are the
     // accumulation targets and must arrive zeroed, as the reference demands of its caller (rasterize_points.cu:157-165).
-    // deterministic_backward: per-instance slots (stream-ordered scratch of 40 B per tile instance, cleared) + an ordered
-    // per-Gaussian sum instead of float atomics; needs the exclusive prefix of tiles_touched, which the LDS binning path never made
+    // deterministic_backward: per-instance slots (stream-ordered scratch of 40 B per tile instance + a flag byte each; only the flags
+    // are cleared) + an ordered per-Gaussian sum instead of float atomics; needs the prefix sum of tiles_touched, which the LDS
+    // binning path never made.
     // The record decision follows the OPTIONS alone (it is what the NULL checks above and the binding's allocation key on); only the
     // slot scratch, its scan and the ordered sum need instances to exist.  With nothing rendered the cleared record gives zeros.
     const bool det = opt.deterministic_backward != 0 && R > 0;

@@ -182,8 +182,12 @@ def _tone_block(sh_tone, device, P, grads=None):
 # same camera tensors and scalars and only other precomputed colours, it takes wg_rasterize_forward_recolor -- a copy of the
 # projected state with the new colours and the compositing along the parent's sorted lists; binning and image-state buffers are
 # shared with the parent call's (the per-pixel values are identical).  Identity is by object (weak references), never by address:
-# a freed tensor's address can be handed to a new one.
+# a freed tensor's address can be handed to a new one.  A write through `tensor.data` does not move the version counter, so the
+# remembered call also ends with the first BACKWARD call of the process after it (`_reuse_epoch`; on whatever thread autograd runs
+# it): between a step's backward pass and the next step's forward pass -- where optimisers and densification write -- nothing is
+# remembered.  A forward-only loop that edits geometry through `.data` between two renders of one camera calls forget_geometry().
 _reuse = threading.local()
+_reuse_epoch = 0   # bumped by every backward call (any thread; the GIL orders it)
 
 
 def _tensor_token(t):
@@ -215,7 +219,7 @@ def _reuse_key(background, means3D, opacity, scales, rotations, scale_modifier, 
 
 def _reuse_lookup(key):
     last = getattr(_reuse, "last", None)
-    if last is None or last["scalars"] != key[1] or len(last["tensors"]) != len(key[0]):
+    if last is None or last.get("epoch") != _reuse_epoch or last["scalars"] != key[1] or len(last["tensors"]) != len(key[0]):
         return None
     if not all(_same_token(a, b) for a, b in zip(last["tensors"], key[0])):
         return None
@@ -308,7 +312,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     if binning_capacity is not None:
         _reuse.last_fixed = (buffers[2], H, W)
     if key is not None and rendered >= 0:
-        _reuse.last = dict(tensors=key[0], scalars=key[1], R=rendered, radii=radii, geom=buffers[0], binning=buffers[1], img=buffers[2])
+        _reuse.last = dict(tensors=key[0], scalars=key[1], R=rendered, radii=radii, geom=buffers[0], binning=buffers[1], img=buffers[2],
+                           epoch=_reuse_epoch)
     return (rendered, out_color, radii) + buffers
 
 
@@ -317,6 +322,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, sh_tone=None):
     """With sh_tone (see rasterize_gaussians) two more tensors are appended to the result: dL_dsh_mul, dL_dsh_offset (None where the
     input was None), and dL_dsh is the gradient w.r.t. the raw coefficients."""
+    global _reuse_epoch
+    _reuse_epoch += 1   # what the forward calls remembered ends here (see "Geometry reuse" above)
     device = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)

@@ -332,6 +332,8 @@ def main():
         "loss_allreduced_last_step": None if args.forward_only else round(loss_stream.last(), 9),
         "loss_note": "loss = <image, cotangent> on the rasterizer's stream; its 4-byte all-reduce is queued asynchronously (wg_viewparallel.LossStream) "
                      "and covered by the device-wide synchronize that ends the timed region",
+        "host_note": "the interpreter's cycle collector runs before, not inside, each timed region (the host is in step with the GPU: "
+                     "a collector pause would be a GPU pause); every step's work is unchanged",
         "rccl_ranks_seen": job["rccl_ranks_seen"],
         "per_rank_ms_per_step": job["per_rank_ms_per_step"],
         "per_rank_device": job["per_rank_device"],

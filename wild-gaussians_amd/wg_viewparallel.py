@@ -176,18 +176,29 @@ def backend_name() -> str:
 def timed_region(fn, steps: int, device, keep=None) -> float:
     """bench.py's timing contract: barrier + device synchronize on both sides of exactly `steps` calls of fn, MAX over ranks.
     keep (a one-element list) receives this rank's own time, taken before it waits for the others."""
+    import gc
     import time
     sync = (lambda: torch.cuda.synchronize(device)) if torch.cuda.is_available() and device is not None and torch.device(device).type == "cuda" else (lambda: None)
-    barrier()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
-    sync()
-    if keep is not None:
-        keep[0] = time.perf_counter() - t0
-    barrier()
-    return max_over_ranks(time.perf_counter() - t0, device)
+    # The host is in step with the GPU here (a forward call returns the frame's exact instance count, i.e. waits for its scan), so a
+    # pause of the interpreter's cycle collector is a pause of the GPU, and with N ranks the slowest rank's pauses are everybody's:
+    # collect before the region, keep the collector off inside it (no work of a step is skipped; reference counting still frees).
+    gc_was_on = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        sync()
+        if keep is not None:
+            keep[0] = time.perf_counter() - t0
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0, device)
+    finally:
+        if gc_was_on:
+            gc.enable()
 
 
 def job_fields(world: int, steps: int, t_region: float, ranks_seen, baseline_iters_per_s: float | None = None) -> dict:

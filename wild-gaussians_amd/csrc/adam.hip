@@ -20,6 +20,8 @@ struct AdamBatch {
     int n;
 };
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const wg_adam_tensor& d) {
     g = d.weight_decay != 0.0f ? g + d.weight_decay * p : g;
     m = m + d.one_minus_beta1 * (g - m);          // exp_avg.lerp_(grad, 1 - beta1)   (weight < 0.5: start + weight * (end - start))
@@ -36,6 +38,40 @@ __global__ void __launch_bounds__(ADAM_THREADS) fused_adam_kernel(const AdamBatc
     const size_t base = (size_t)(blockIdx.x - batch.first_block[k]) * ADAM_PER_BLOCK;
     const bool vec = ((reinterpret_cast<uintptr_t>(d.param) | reinterpret_cast<uintptr_t>(d.grad) | reinterpret_cast<uintptr_t>(d.exp_avg) |
                        reinterpret_cast<uintptr_t>(d.exp_avg_sq)) & 15u) == 0;
+    // a workgroup wholly inside its tensor (all but the last of each): every thread requests its sixteen 16-byte loads before it
+    // computes or stores anything -- written as "load, update, store" per float4 the stores of one would sit between the loads of
+    // the next (the four arrays may alias as far as the compiler knows), with four loads in flight per thread instead of sixteen
+    if (vec && base + ADAM_PER_BLOCK <= d.numel) {
+        float* __restrict__ const P = d.param;
+        const float* __restrict__ const G = d.grad;
+        float* __restrict__ const M = d.exp_avg;
+        float* __restrict__ const V = d.exp_avg_sq;
+        float4 p[4], g[4], m[4], v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const size_t i = base + ((size_t)r * ADAM_THREADS + threadIdx.x) * ADAM_PER_THREAD;
+            p[r] = *reinterpret_cast<const float4*>(P + i);
+            const f4v gv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(G + i));   // read once, by nobody else
+            g[r] = make_float4(gv.x, gv.y, gv.z, gv.w);
+            m[r] = *reinterpret_cast<const float4*>(M + i);
+            v[r] = *reinterpret_cast<const float4*>(V + i);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            adam_one(p[r].x, g[r].x, m[r].x, v[r].x, d);
+            adam_one(p[r].y, g[r].y, m[r].y, v[r].y, d);
+            adam_one(p[r].z, g[r].z, m[r].z, v[r].z, d);
+            adam_one(p[r].w, g[r].w, m[r].w, v[r].w, d);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const size_t i = base + ((size_t)r * ADAM_THREADS + threadIdx.x) * ADAM_PER_THREAD;
+            *reinterpret_cast<float4*>(P + i) = p[r];
+            *reinterpret_cast<float4*>(M + i) = m[r];
+            *reinterpret_cast<float4*>(V + i) = v[r];
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const size_t i = base + ((size_t)r * ADAM_THREADS + threadIdx.x) * ADAM_PER_THREAD;

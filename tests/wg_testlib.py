@@ -26,8 +26,9 @@ def make_settings(cam, sh_degree, kernel_size=0.1, bg=None, subpixel_offset=None
 
 
 def run_hip(cloud, cam, sh_degree=3, kernel_size=0.1, bg=None, subpixel_offset=None, cotangent=None, scale_modifier=1.0,
-            device="cuda"):
-    """Forward (+ backward when a cotangent is given) through GaussianRasterizer; numpy results."""
+            device="cuda", binning_capacity=None):
+    """Forward (+ backward when a cotangent is given) through GaussianRasterizer; numpy results.  binning_capacity: the
+    fixed-capacity forward (wg_rasterize_forward_fixed)."""
     from diff_gaussian_rasterization import GaussianRasterizer
     rs = make_settings(cam, sh_degree, kernel_size, bg, subpixel_offset, scale_modifier, device=device)
     t = {k: to_dev(v, device).requires_grad_(cotangent is not None) for k, v in cloud.items()}
@@ -35,7 +36,7 @@ def run_hip(cloud, cam, sh_degree=3, kernel_size=0.1, bg=None, subpixel_offset=N
     rast = GaussianRasterizer(rs)
     color, radii, acc = rast(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t.get("shs"),
                              colors_precomp=t.get("colors_precomp"), scales=t.get("scales"), rotations=t.get("rotations"),
-                             cov3D_precomp=t.get("cov3D_precomp"))
+                             cov3D_precomp=t.get("cov3D_precomp"), **({} if binning_capacity is None else {"binning_capacity": binning_capacity}))
     out = dict(color=color.detach().cpu().numpy(), radii=radii.cpu().numpy(), accumulation=acc.detach().cpu().numpy())
     if cotangent is not None:
         color.backward(to_dev(cotangent, device))

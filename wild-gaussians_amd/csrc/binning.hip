@@ -560,25 +560,35 @@ __global__ void __launch_bounds__(64 * SCAN_WAVES) chunk_tile_scan_kernel(uint32
 // with the band = the XCD the dispatcher is observed to run the block on (block b -> XCD b % 8), an XCD's L2 only ever
 // holds its own eighth of the bucket array (< 4 MiB at 1080p) and lines leave it complete.  The band assignment is a
 // speed matter only: any placement gives the same buckets.
-// (Measured and dropped: (i) staging a workgroup's instances tile-major in LDS and writing them out in runs brought the
-// fabric writes down to the 30 MB of payload and was not faster at ~900 instances per tile (it is the kernel for dense
-// frames, below); (ii) per-band candidate lists built by the count kernel, so that a band's workgroup does not scan the whole
-// chunk, saved 2 us at 1 M Gaussians for 16 B/Gaussian of lists -- they are built from 2 M Gaussians on, where the eightfold
-// scan does matter.  With every store and atomic removed the kernel still takes 41 of its 52 us at 1 M: what is left is the
-// rectangle walk's instruction stream.)
-template <bool LISTS>  // candidates from the count kernel's band lists (large P) instead of the whole chunk
+// INSTANCE-parallel since round 3.  Rounds 1-2 walked rectangles: a (chunk, band) workgroup visited all of the chunk's Gaussians,
+// one per lane and round, sixteen predicated steps each, although only one in five has a row inside the band and a valid one emits
+// ~5 instances there -- 5 % of the lane-steps did anything (PMC: 1 500 vector instructions per wave for 450 emitted instances; with
+// every store and atomic removed that kernel still took 41 of its 52 us).  Now the workgroup (1) appends the Gaussians that do reach
+// its band to a list in LDS (clipped rectangle, entry, instance count), (2) scans the counts, and (3) deals the band's instances
+// out evenly: a thread takes a contiguous run of them, finds its first Gaussian with one binary search of the prefix and walks on
+// from there.  Every lane-step emits; a splat of 300 tiles is spread over the workgroup like any other run.  0.0575 -> 0.0478 ms
+// at the headline scene, bit-identical outputs (profiles/r3/ab_scatter_instance_parallel.txt); what is left is the L2's rate of
+// 4-byte store requests (~0.9 M per XCD) and the workgroups' start-up chain.  16 KB of list per workgroup: with 32 KB (eight
+// candidates per thread and pass) the kernel loses its occupancy and the whole gain.
+// (Measured and dropped earlier: staging a workgroup's instances tile-major in LDS and writing them out in runs brought the fabric
+// writes down to the 30 MB of payload and was not faster at ~900 instances per tile -- it is the kernel for dense frames, below.)
+constexpr int SC_PF = 4;                 // candidates a thread looks at per pass
+constexpr int SC_CAP = SC_PF * 256;      // list capacity of a pass (every candidate of the pass may reach the band)
+template <bool LISTS>
 __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4* __restrict__ rects, const float* __restrict__ depths,
                                                            const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ chunk_hist,
                                                            const uint16_t* __restrict__ band_list, const uint32_t* __restrict__ band_cnt,
                                                            uint32_t* __restrict__ bucket_ids, int gx, int tiles, int code_bits,
                                                            const SplitState* __restrict__ split, const BinStats* __restrict__ guard) {
     extern __shared__ uint32_t cursor[];
+    __shared__ uint32_t q_entry[SC_CAP], q_xy[SC_CAP], q_wh[SC_CAP], q_pre[SC_CAP];  // per listed Gaussian: entry, x0 | ya << 16, w | h << 16, exclusive prefix of w * h
+    __shared__ uint32_t q_n, wave_tot[4];
     if (guard && guard->spec_fail) return;  // workgroup-uniform
-    const int tid = threadIdx.x, band = blockIdx.x & 7, chunk = blockIdx.x >> 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, band = blockIdx.x & 7, chunk = blockIdx.x >> 3;
     const uint32_t near_code = split ? split->near_code : SPLIT_OFF;
-    const bool near_only = near_code != SPLIT_OFF;  // active split: only the near Gaussians are scattered (chunk_hist holds their prefix)
+    const bool near_only = near_code != SPLIT_OFF;
     const int q = tiles >> 3, rem = tiles & 7;
-    const int t0 = band * q + min(band, rem), t1 = t0 + q + (band < rem ? 1 : 0);  // this band's tiles [t0, t1)
+    const int t0 = band * q + min(band, rem), t1 = t0 + q + (band < rem ? 1 : 0);
     if (t0 >= t1) return;
     int begin, end;
     chunk_bounds(P, chunk, begin, end);
@@ -588,39 +598,110 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4*
     if (cn == 0) return;
     const uint32_t* hbase = chunk_hist + (size_t)chunk * tiles;
     for (int t = t0 + tid; t < t1; t += 256) cursor[t - t0] = tile_offset[t] + hbase[t];
-    __syncthreads();
-    const int y0 = t0 / gx, y1 = (t1 - 1) / gx;  // tile rows the band touches (first / last possibly partial)
-    for (int base = 0; base < cn; base += PF * 256) {
-        ushort4 r[PF];
-        uint32_t entry[PF];  // Gaussian id, with the coarse depth code above it when the ids leave room (wg_sort.h: depth_code)
-        int idx[PF];
+    const int y0 = t0 / gx, y1 = (t1 - 1) / gx;
+    for (int base = 0; base < cn; base += SC_CAP) {
+        if (tid == 0) q_n = 0;
+        __syncthreads();  // (the first pass: the cursors; later ones: the previous pass's list has been read)
+        // (1) the candidates that reach the band
+        ushort4 r[SC_PF];
+        uint32_t entry[SC_PF];
 #pragma unroll
-        for (int k = 0; k < PF; k++) {
+        for (int k = 0; k < SC_PF; k++) {
             const int i = base + k * 256 + tid;
-            idx[k] = i < cn ? begin + (LISTS ? (int)list[i] : i) : -1;
-        }
-#pragma unroll
-        for (int k = 0; k < PF; k++) {
-            const bool in = idx[k] >= 0;
-            r[k] = in ? rects[idx[k]] : make_ushort4(0, 0, 0, 0);
-            entry[k] = in ? (uint32_t)idx[k] : 0u;
-            if ((code_bits || near_only) && in) {
-                const uint32_t db = __float_as_uint(depths[idx[k]]);
+            const int idx = i < cn ? begin + (LISTS ? (int)list[i] : i) : -1;
+            r[k] = idx >= 0 ? rects[idx] : make_ushort4(0, 0, 0, 0);
+            entry[k] = idx >= 0 ? (uint32_t)idx : 0u;
+            if ((code_bits || near_only) && idx >= 0) {
+                const uint32_t db = __float_as_uint(depths[idx]);
                 if (code_bits) entry[k] |= depth_code(db, (uint32_t)code_bits) << (32 - code_bits);
-                if (near_only && depth_code(db, SPLIT_BITS) > near_code) r[k] = make_ushort4(0, 0, 0, 0);  // a far Gaussian: nothing to emit now
+                if (near_only && depth_code(db, SPLIT_BITS) > near_code) r[k] = make_ushort4(0, 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int k = 0; k < PF; k++) {
-            if (base + k * 256 >= cn) break;
+        for (int k = 0; k < SC_PF; k++) {
+            if (base + k * 256 >= cn) break;  // workgroup-uniform
             const int ya = max((int)r[k].y, y0), yb = min((int)r[k].w, y1 + 1);
-            for_each_tile<16>(r[k].z > r[k].x && yb > ya, r[k].x, ya, r[k].z, yb, (int)entry[k], [&](int x, int y, int id) {
+            const bool valid = r[k].z > r[k].x && yb > ya;
+            const uint64_t m = __ballot(valid);
+            if (m != 0ull) {  // wave-aggregated append
+                const int leader = __builtin_ctzll(m);
+                uint32_t wbase = 0;
+                if (lane == leader) wbase = atomicAdd(&q_n, (uint32_t)__builtin_popcountll(m));
+                wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, leader);
+                if (valid) {
+                    const uint32_t pos = wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    q_entry[pos] = entry[k];
+                    q_xy[pos] = (uint32_t)r[k].x | ((uint32_t)ya << 16);
+                    q_wh[pos] = (uint32_t)(r[k].z - r[k].x) | ((uint32_t)(yb - ya) << 16);
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t n = q_n;
+        if (n == 0u) continue;  // workgroup-uniform
+        // (2) exclusive prefix of the listed Gaussians' instance counts: SC_PF consecutive entries per thread
+        uint32_t c[SC_PF], sum = 0;
+#pragma unroll
+        for (int e = 0; e < SC_PF; e++) {
+            const uint32_t j = (uint32_t)SC_PF * (uint32_t)tid + e;
+            const uint32_t wh = j < n ? q_wh[j] : 0u;
+            c[e] = (wh & 0xffffu) * (wh >> 16);
+            sum += c[e];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - sum, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const uint32_t wt = wave_tot[w];
+            if (w < wave) before += wt;
+            total += wt;
+        }
+#pragma unroll
+        for (int e = 0; e < SC_PF; e++) {
+            const uint32_t j = (uint32_t)SC_PF * (uint32_t)tid + e;
+            if (j < n) q_pre[j] = before;
+            before += c[e];
+        }
+        __syncthreads();
+        // (3) the band's `total` instances of this pass, a contiguous run per thread
+        const uint32_t run = (total + 255u) >> 8;
+        uint32_t i = min(total, run * (uint32_t)tid);
+        const uint32_t i_end = min(total, i + run);
+        if (i < i_end) {
+            uint32_t lo = 0, hi = n - 1;  // the last listed Gaussian whose prefix is <= i (counts are >= 1: prefixes strictly increase)
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if (q_pre[mid] <= i) lo = mid; else hi = mid - 1u;
+            }
+            uint32_t j = lo;
+            uint32_t xy = q_xy[j], wh = q_wh[j], ent = q_entry[j];
+            int x0 = (int)(xy & 0xffffu), w = (int)(wh & 0xffffu);
+            const uint32_t o = i - q_pre[j];
+            int y = (int)(xy >> 16) + (int)(o / (uint32_t)w), x = x0 + (int)(o % (uint32_t)w);
+            int yb = (int)(xy >> 16) + (int)(wh >> 16);
+            for (; i < i_end; i++) {
                 const int t = y * gx + x;
                 if (t >= t0 && t < t1) {
                     const uint32_t pos = atomicAdd(&cursor[t - t0], 1u);
-                    bucket_ids[pos] = (uint32_t)id;  // 4 bytes per instance; the exact depth is gathered at sort time
+                    bucket_ids[pos] = ent;
                 }
-            });
+                if (++x == x0 + w) {
+                    x = x0;
+                    if (++y == yb && i + 1u < i_end) {  // on to the next listed Gaussian
+                        j++;
+                        xy = q_xy[j]; wh = q_wh[j]; ent = q_entry[j];
+                        x0 = x = (int)(xy & 0xffffu); w = (int)(wh & 0xffffu);
+                        y = (int)(xy >> 16); yb = y + (int)(wh >> 16);
+                    }
+                }
+            }
         }
     }
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """How evenly do the forward render kernel's waves load the SIMDs?  Needs a library built with -DWG_FWD_PROBE=1 for render_fwd.hip
-(scripts/ab_variants.sh probe "render_fwd.hip:-DWG_FWD_PROBE=1"; WG_RASTERIZER_LIB points at it): every wave records its start / end
+(git apply experiments/r3_forward_probe.patch; scripts/ab_variants.sh probe "render_fwd.hip:-DWG_FWD_PROBE=1"; WG_RASTERIZER_LIB points
+at it; git apply -R ... afterwards: the probe is not part of the product source): every wave records its start / end
 on the 100 MHz real-time counter and the SIMD it ran on.  One wave per tile, all ~8 k waves resident at once (8 per SIMD): the kernel
 ends when the SIMD with the largest SUM of tile costs ends.
 

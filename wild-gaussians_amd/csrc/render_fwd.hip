@@ -229,13 +229,6 @@ __device__ void fwd_store(const FwdTile& st, bool complete, int W, int H, int ti
 #else
 #define WG_FWD_OCC
 #endif
-#ifdef WG_FWD_PROBE
-// scheduling probe (scripts/probe_forward_balance.py): per wave its start / end on the 100 MHz real-time counter and where it ran
-__device__ unsigned long long wg_probe[4 * 65536];
-extern "C" int wg_probe_fetch(void* dst, size_t bytes) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wg_probe), bytes < sizeof(wg_probe) ? bytes : sizeof(wg_probe), 0, hipMemcpyDeviceToHost);
-}
-#endif
 __global__ void __launch_bounds__(64) WG_FWD_OCC render_forward_kernel(
     int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
@@ -244,9 +237,6 @@ __global__ void __launch_bounds__(64) WG_FWD_OCC render_forward_kernel(
     float* __restrict__ out_color, const BinStats* __restrict__ guard, int replay, float* __restrict__ accum) {
     __shared__ float4 lds[BATCH * 3];
     if (guard && guard->spec_fail) return;  // speculative forward (api.hip): the frame did not fit what was enqueued; the host re-issues
-#ifdef WG_FWD_PROBE
-    const unsigned long long probe_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
     const int tile = xcd_tile(blockIdx.x, tiles);
     const int lane = threadIdx.x;
     FwdTile st;
@@ -260,15 +250,6 @@ __global__ void __launch_bounds__(64) WG_FWD_OCC render_forward_kernel(
     const bool complete = st.strips_alive == 0 || end == n || replay != 0;
     fwd_store(st, complete, W, H, tile, lane, bg, final_T, n_contrib, tile_last, out_color, accum);
     if (tile_state && lane == 0) tile_state[tile] = complete ? 0xffffffffu : (uint32_t)end;
-#ifdef WG_FWD_PROBE
-    if (lane == 0 && blockIdx.x < 65536) {
-        wg_probe[4 * blockIdx.x] = probe_t0;
-        wg_probe[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-        wg_probe[4 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |   // XCC_ID
-                                       (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));                      // HW_ID
-        wg_probe[4 * blockIdx.x + 3] = (unsigned long long)tile;
-    }
-#endif
 }
 
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,

@@ -479,3 +479,19 @@ def test_geometry_reuse_tokens_are_by_object_and_version_never_by_address():
         assert _C._reuse_lookup(key) is None
     finally:
         _C.forget_geometry()
+
+
+def test_experiment_patches_still_apply():
+    """experiments/*.patch hold the measured-and-rejected kernel variants (EXPERIMENTS.md) out of the product sources; they must keep
+    applying to the tree they are filed next to, or the A/Bs they document cannot be repeated."""
+    import glob
+    import shutil
+    import subprocess
+    if shutil.which("git") is None:
+        pytest.skip("git not available")
+    patches = sorted(glob.glob(os.path.join(ROOT, "experiments", "*.patch")))
+    assert patches
+    for p in patches:
+        r = subprocess.run(["git", "apply", "--check", p], cwd=ROOT, capture_output=True, text=True)
+        assert r.returncode == 0, f"{os.path.basename(p)} no longer applies:\n{r.stderr}"
+

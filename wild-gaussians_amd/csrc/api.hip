@@ -560,16 +560,16 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
         if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, code_bits, opt.lazy, try_split, guard, stream), "tile_sort_lazy");
         else WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, geom, tiles, longest, guard, stream), "tile_sort");
         WG_STAGE(WG_STAGE_RENDER_FORWARD,
-                 wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, lazy, guard, stream),
+                 wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, lazy, opt.exact_compositing != 0, guard, stream),
                  "render_forward");
         if (lazy) {
             WG_STAGE(WG_STAGE_RENDER_FIXUP,
-                     wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, try_split, 0, (wg::HostMailbox*)nullptr, guard, stream),
+                     wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, try_split, 0, opt.exact_compositing != 0, (wg::HostMailbox*)nullptr, guard, stream),
                      "render_fixup");
             if (far) {  // both return at once unless some tile ran out of near instances with pixels still accumulating
                 WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter_far(P, geom, img, bin, gx, tiles, code_bits, guard, stream), "tile_scatter_far");
                 WG_STAGE(WG_STAGE_RENDER_FIXUP,
-                         wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, true, 1, mbox ? mbox->dev : (wg::HostMailbox*)nullptr, guard, stream),
+                         wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, true, 1, opt.exact_compositing != 0, mbox ? mbox->dev : (wg::HostMailbox*)nullptr, guard, stream),
                          "render_fixup_far");
             }
         }
@@ -715,7 +715,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
         if (huge_frame) WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_ranges(num_rendered, bin, img, tiles, stream), "tile_ranges");
     }
     WG_STAGE(WG_STAGE_RENDER_FORWARD,
-             wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, false, nullptr, stream),
+             wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, false, opt.exact_compositing != 0, nullptr, stream),
              "render_forward");
     return num_rendered;
 }
@@ -736,7 +736,7 @@ int wg_rasterize_forward_recolor(wg_alloc_fn geometry_alloc, void* geometry_user
     wg::GeometryState geom = wg::GeometryState::fromChunk(chunk, (size_t)P, false);
     WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_recolor(P, parent, geom, colors_precomp, radii, stream), "recolor");
     WG_STAGE(WG_STAGE_RENDER_FORWARD,
-             wg::launch_render_forward_replay(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, stream),
+             wg::launch_render_forward_replay(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, options_snapshot().exact_compositing != 0, stream),
              "render_forward_replay");
     return R;
 }
@@ -837,7 +837,7 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
         WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_order(img.tile_last, nullptr, img.order_bwd, gx * gy, clear_records ? geom.grad_rec : nullptr,
                                                              (size_t)P * wg::GRAD_REC_FLOATS, stream), "tile_order");
         WG_STAGE(WG_STAGE_RENDER_BACKWARD, wg::launch_render_backward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, dL_dpix,
-                                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, det_slots, det_flags, (size_t)R, P, stream),
+                                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, opt.exact_compositing != 0, det_slots, det_flags, (size_t)R, P, stream),
                  "render_backward");
     }
 
@@ -918,6 +918,7 @@ int wg_set_option(const char* name, int value) {
     if (std::strcmp(name, "force_global_sort") == 0) { o.force_global_sort = value != 0; return WG_OK; }
     if (std::strcmp(name, "host_mailbox") == 0) { o.use_mailbox = value != 0; return WG_OK; }
     if (std::strcmp(name, "grad_record") == 0) { o.grad_record = value != 0; return WG_OK; }
+    if (std::strcmp(name, "exact_compositing") == 0) { o.exact_compositing = value != 0; return WG_OK; }
     if (std::strcmp(name, "geometry_reuse") == 0) { o.geometry_reuse = value != 0; return WG_OK; }
     if (std::strcmp(name, "fused_scan") == 0) { o.fused_scan = value != 0; return WG_OK; }
     if (std::strcmp(name, "speculative_forward") == 0) {  // (a deferred frame still pending is dropped: its verdict goes unread)
@@ -969,6 +970,7 @@ int wg_get_option(const char* name) {
     if (std::strcmp(name, "forward_wait_us_last") == 0) return (int)std::min(t_wait.last_wait_us, 2147483647.0);
     const wg::Options o = options_snapshot();
     if (std::strcmp(name, "grad_record") == 0) return o.grad_record;
+    if (std::strcmp(name, "exact_compositing") == 0) return o.exact_compositing;
     if (std::strcmp(name, "geometry_reuse") == 0) return o.geometry_reuse;
     if (std::strcmp(name, "fused_scan") == 0) return o.fused_scan;
     if (std::strcmp(name, "speculative_forward") == 0) return o.speculative;

@@ -91,8 +91,20 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
 // into which the ten lanes STORE the wave-reduced sums; det_reduce_kernel then adds a Gaussian's slots in slot order into its
 // gradient record.  Same sums as the atomic path up to the order of a Gaussian's per-tile terms, which is now fixed: two runs
 // give bit-identical gradients.
-template <bool RECORD, bool DET = false>
-__global__ void __launch_bounds__(64) render_backward_kernel(
+// EXACT (Options::exact_compositing): the forward kernel took every skip decision on the reference's own arithmetic (wg_alpha.h:
+// eval_alpha_exact).  This kernel keeps the fast evaluation (its values only have to be accurate) but must take the SAME decisions, so
+// a pair whose fast values are within a proven error band of a threshold is re-evaluated with that arithmetic (a rare,
+// wave-uniform branch; ~10^3 pairs of ~10^9 per frame) and its decision, alpha and G are taken from there.
+#ifndef WG_BWD_WAVES
+#define WG_BWD_WAVES 0
+#endif
+#if WG_BWD_WAVES
+#define WG_BWD_OCC __attribute__((amdgpu_waves_per_eu(WG_BWD_WAVES, WG_BWD_WAVES)))
+#else
+#define WG_BWD_OCC
+#endif
+template <bool RECORD, bool DET = false, bool EXACT = false>
+__global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
     int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_last,
@@ -243,7 +255,22 @@ __global__ void __launch_bounds__(64) render_backward_kernel(
             for (int s = 0; s < 4; s++) {
                 if (((reach[s] >> j) & 1ull) == 0ull) continue;  // wave-uniform
                 PairEval e;
-                const bool pass = eval_alpha(sc, pfx[s], pfy[s], e);
+                bool pass;
+                if (EXACT) {
+                    float margin, band;
+                    pass = eval_alpha_banded(sc, pfx[s], pfy[s], e, margin, band);
+                    const bool fragile = pos < last[s] && fabsf(margin) < band;
+                    if (__ballot(fragile) != 0ull) {  // rare: the reference's arithmetic on the record as preprocess wrote it
+                        const size_t r = 3 * (size_t)point_list[range.x + pos];
+                        float4 q0 = splats[r], q1 = splats[r + 1];
+                        halve_conic(q0, q1);
+                        float dx, dy, G, alpha;
+                        const bool px = eval_alpha_exact(exact_coef_of(q0, q1), pfx[s], pfy[s], dx, dy, G, alpha);
+                        if (fragile) { pass = px; e.G = G; e.alpha = alpha; }
+                    }
+                } else {
+                    pass = eval_alpha(sc, pfx[s], pfy[s], e);
+                }
                 if (pos < last[s] && pass) {
                     any = true;
                     const float a = e.alpha;
@@ -406,15 +433,16 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* 
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                   const GeometryState& g, const float* subpixel_offset, const float* background,
                                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                  float* dL_dcolor, bool record, float* det_slots, unsigned char* det_flags, size_t slot_capacity, int P,
+                                  float* dL_dcolor, bool record, bool exact, float* det_slots, unsigned char* det_flags, size_t slot_capacity, int P,
                                   hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
-#define WG_LAUNCH(REC, DET)                                                                                                                 \
-    hipLaunchKernelGGL((render_backward_kernel<REC, DET>), dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.order_bwd, img.ranges,     \
+#define WG_LAUNCH2(REC, DET, EX)                                                                                                            \
+    hipLaunchKernelGGL((render_backward_kernel<REC, DET, EX>), dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.order_bwd, img.ranges,     \
                        b.point_list, g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.final_T, img.n_contrib,    \
                        img.tile_last, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, g.grad_rec, g.rects, g.point_offsets,         \
                        g.tiles_touched, det_slots, det_flags)
+#define WG_LAUNCH(REC, DET) do { if (exact) WG_LAUNCH2(REC, DET, true); else WG_LAUNCH2(REC, DET, false); } while (0)
     if (det_slots) {
         WG_LAUNCH(true, true);
         hipLaunchKernelGGL(det_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, g.point_offsets, g.tiles_touched, det_slots, det_flags,
@@ -422,6 +450,7 @@ hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState
     } else if (record) WG_LAUNCH(true, false);
     else WG_LAUNCH(false, false);
 #undef WG_LAUNCH
+#undef WG_LAUNCH2
     return hipGetLastError();
 }
 

@@ -78,7 +78,10 @@ __device__ void fwd_init(FwdTile& st, int W, int H, int gx, int tile, int lane, 
 }
 
 // lds: BATCH * 3 float4 of the wave's own LDS.  list = the tile's sorted instance list (point_list + range.x).
-template <bool WGB>
+// EXACT (Options::exact_compositing): every value a skip / stop decision is taken on -- power, alpha, T -- is computed with the
+// reference's own float32 operations (wg_alpha.h: eval_alpha_exact), so n_contrib, final_T and the set of blended instances are the
+// reference's bit for bit; only the colour sums keep their fused multiply-adds (<= 1e-6 of a pixel).
+template <bool WGB, bool EXACT>
 __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, const uint32_t* __restrict__ list, const float4* __restrict__ splats,
                          int pos_begin, int pos_end) {
     const int n = pos_end - pos_begin;
@@ -118,7 +121,7 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
         // correctness.  WGB (legal only when the workgroup IS the wave) keeps the s_barrier-free __syncthreads() of the one-wave
         // kernel anyway: hipcc schedules and allocates the compositing loop measurably better around it (0.325 vs 0.340 ms).
         if (WGB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
-        scale_conic(s0, s1);
+        if (EXACT) halve_conic(s0, s1); else scale_conic(s0, s1);
         lds[3 * lane] = s0;
         lds[3 * lane + 1] = s1;
         lds[3 * lane + 2] = s2;
@@ -140,9 +143,10 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
         while (todo != 0ull) {
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const float4 r0 = lds[3 * j];      // mx, my, ca, cb
-            const float4 r1 = lds[3 * j + 1];  // cc, opacity, -, red
+            const float4 r0 = lds[3 * j];      // mx, my, ca, cb        (EXACT: mx, my, -0.5 conic.x, conic.y)
+            const float4 r1 = lds[3 * j + 1];  // cc, opacity, -, red   (EXACT: -0.5 conic.z, ...)
             const SplatCoef sc = coef_of(r0, r1);
+            const ExactCoef xc = exact_coef_of(r0, r1);
             // green, blue: requested with the rest of the record (inside the blend branch it was an LDS round trip on every blending
             // strip's dependency chain: 0.288 -> 0.2815 ms)
             const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
@@ -151,12 +155,20 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 if (((reach[s] >> j) & 1ull) == 0ull) continue;  // wave-uniform
-                PairEval e;
-                const bool pass = eval_alpha(sc, pfx[s], pfy[s], e);
-                const float alpha = e.alpha;
+                bool pass;
+                float alpha;
+                if (EXACT) {
+                    float dx, dy, G;
+                    pass = eval_alpha_exact(xc, pfx[s], pfy[s], dx, dy, G, alpha);
+                } else {
+                    PairEval e;
+                    pass = eval_alpha(sc, pfx[s], pfy[s], e);
+                    alpha = e.alpha;
+                }
                 if (((alive >> s) & 1u) && pass) {
                     const float w = alpha * T[s];
-                    const float test_T = T[s] - w;  // T (1 - alpha), forward.cu:367, one rounding step apart
+                    // T (1 - alpha), forward.cu:367: as spelled there (EXACT), or one rounding step apart
+                    const float test_T = EXACT ? ref_test_T(T[s], alpha) : T[s] - w;
                     if (test_T < 0.0001f) {
                         alive &= ~(1u << s);  // done (forward.cu:368-372): this instance is not blended
                     } else {
@@ -229,6 +241,7 @@ __device__ void fwd_store(const FwdTile& st, bool complete, int W, int H, int ti
 #else
 #define WG_FWD_OCC
 #endif
+template <bool EXACT>
 __global__ void __launch_bounds__(64) WG_FWD_OCC render_forward_kernel(
     int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
@@ -244,7 +257,7 @@ __global__ void __launch_bounds__(64) WG_FWD_OCC render_forward_kernel(
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const int end = seg_end ? min(n, (int)seg_end[tile]) : n;
-    fwd_walk<true>(st, lds, lane, point_list + range.x, splats, 0, end);
+    fwd_walk<true, EXACT>(st, lds, lane, point_list + range.x, splats, 0, end);
     // replay (geometry reuse): seg_end is the tile's walked length of an earlier pass over the same geometry -- nothing behind it
     // contributes, so the tile is complete whatever is left of the list
     const bool complete = st.strips_alive == 0 || end == n || replay != 0;
@@ -254,23 +267,29 @@ __global__ void __launch_bounds__(64) WG_FWD_OCC render_forward_kernel(
 
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                  const GeometryState& g, const float* subpixel_offset, const float* background,
-                                 float* out_color, bool lazy, const BinStats* guard, hipStream_t stream) {
+                                 float* out_color, bool lazy, bool exact, const BinStats* guard, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(render_forward_kernel, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats,
-                       reinterpret_cast<const float2*>(subpixel_offset), background, lazy ? img.seg_end : (const uint32_t*)nullptr,
-                       lazy ? img.tile_state : (uint32_t*)nullptr, img.final_T, img.n_contrib, img.tile_last, out_color, guard, 0, img.accum);
+#define WG_LAUNCH(EX)                                                                                                                       \
+    hipLaunchKernelGGL(render_forward_kernel<EX>, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats,   \
+                       reinterpret_cast<const float2*>(subpixel_offset), background, lazy ? img.seg_end : (const uint32_t*)nullptr,        \
+                       lazy ? img.tile_state : (uint32_t*)nullptr, img.final_T, img.n_contrib, img.tile_last, out_color, guard, 0, img.accum)
+    if (exact) WG_LAUNCH(true); else WG_LAUNCH(false);
+#undef WG_LAUNCH
     return hipGetLastError();
 }
 
 hipError_t launch_render_forward_replay(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                         const GeometryState& g, const float* subpixel_offset, const float* background,
-                                        float* out_color, hipStream_t stream) {
+                                        float* out_color, bool exact, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(render_forward_kernel, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats,
-                       reinterpret_cast<const float2*>(subpixel_offset), background, (const uint32_t*)img.tile_last, (uint32_t*)nullptr,
-                       img.final_T, img.n_contrib, img.tile_last, out_color, (const BinStats*)nullptr, 1, img.accum);
+#define WG_LAUNCH(EX)                                                                                                                       \
+    hipLaunchKernelGGL(render_forward_kernel<EX>, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats,   \
+                       reinterpret_cast<const float2*>(subpixel_offset), background, (const uint32_t*)img.tile_last, (uint32_t*)nullptr,   \
+                       img.final_T, img.n_contrib, img.tile_last, out_color, (const BinStats*)nullptr, 1, img.accum)
+    if (exact) WG_LAUNCH(true); else WG_LAUNCH(false);
+#undef WG_LAUNCH
     return hipGetLastError();
 }
 
@@ -297,6 +316,7 @@ hipError_t launch_poison_unfit(const ImageState& img, int W, int H, int tiles, f
 // accumulating it loops: split the next front off the unsorted bag (or take all of it when short), sort it in place behind the
 // part already consumed, let wave 0 resume the walk over it -- until every pixel has stopped or the list is exhausted.  The
 // final list prefix is in exactly the order a full sort gives, so n_contrib / tile_last / the backward pass are unaffected.
+template <bool EXACT>
 __global__ void __launch_bounds__(256) render_fixup_kernel(
     int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, uint32_t* point_list, const uint32_t* __restrict__ bucket_ids,
     const float* __restrict__ depths, const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset,
@@ -345,7 +365,7 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
         __threadfence_block();
         __syncthreads();  // the sorted segment is visible to wave 0
         if (walker) {
-            fwd_walk<false>(st, lds, tid, list, splats, (int)done, (int)(done + F));
+            fwd_walk<false, EXACT>(st, lds, tid, list, splats, (int)done, (int)(done + F));
             if (tid == 0) s_complete = (st.strips_alive == 0 || done + F == n) ? 1 : 0;
         }
         done += F;
@@ -368,13 +388,17 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
 
 hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
                                const float* subpixel_offset, const float* background, float* out_color, const LazyConfig& g_lazy,
-                               bool split, int phase, HostMailbox* mailbox_dev, const BinStats* guard, hipStream_t stream) {
+                               bool split, int phase, bool exact, HostMailbox* mailbox_dev, const BinStats* guard, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(render_fixup_kernel, dim3(tiles), dim3(256), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, b.bucket_ids,
-                       g.depths, g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.tile_state, img.final_T,
-                       img.n_contrib, img.tile_last, out_color, 1536u < g_lazy.cap ? 1536u : (g_lazy.cap * 3u) / 4u, g_lazy.cap < FRONT_CAP ? g_lazy.cap : FRONT_CAP,
-                       code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu, split ? img.tile_near : (const uint32_t*)nullptr, img.split, phase, mailbox_dev, guard, img.accum);
+#define WG_LAUNCH(EX)                                                                                                                       \
+    hipLaunchKernelGGL(render_fixup_kernel<EX>, dim3(tiles), dim3(256), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, b.bucket_ids, \
+                       g.depths, g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.tile_state, img.final_T,      \
+                       img.n_contrib, img.tile_last, out_color, 1536u < g_lazy.cap ? 1536u : (g_lazy.cap * 3u) / 4u,                       \
+                       g_lazy.cap < FRONT_CAP ? g_lazy.cap : FRONT_CAP, code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu,           \
+                       split ? img.tile_near : (const uint32_t*)nullptr, img.split, phase, mailbox_dev, guard, img.accum)
+    if (exact) WG_LAUNCH(true); else WG_LAUNCH(false);
+#undef WG_LAUNCH
     return hipGetLastError();
 }
 

@@ -51,6 +51,97 @@ __device__ __forceinline__ bool eval_alpha(const SplatCoef& c, float pfx, float 
     return p2 <= 0.0f && e.alpha >= (1.0f / 255.0f);
 }
 
+// ---- decision-exact compositing (Options::exact_compositing, default on) ------------------------------------------------------------
+// The skips of forward.cu:356-372 / backward.cu:536-546 are threshold decisions on float32 values; a value that differs from the
+// reference's in its last bits lands on the other side of a threshold once in ~10^8 pairs, and one flipped decision moves a pixel by
+// up to ~1e-2 (the instance at which a pixel stops is not blended at all) and T, n_contrib and every later decision of that pixel
+// with it.  So the values the decisions are taken on are computed HERE WITH THE REFERENCE'S OWN ARITHMETIC, operation for operation:
+//   power = -0.5f * (con.x * d.x * d.x + con.z * d.y * d.y) - con.y * d.x * d.y      (forward.cu:359, unfused, in that order)
+//   alpha = min(0.99f, con.w * exp(power))                                             (forward.cu:364)
+//   test_T = T * (1 - alpha)                                                           (forward.cu:367)
+// with `exp` = the float32 expansion llvm emits for it on gfx950 (AMDGPULegalizerInfo / SITargetLowering: lowerFExp; it is what the
+// reference's sources compile to with hipcc, oracle/ref_hip/Makefile: "nofma" build, and what oracle/_ref's disassembly shows):
+//   ph = x * log2e;  e = rint(ph);  pl = fma(x, log2e, -ph);  pl = fma(x, 0x1.4ae0bep-26, pl);  r = ldexp(v_exp_f32((ph - e) + pl), (int)e)
+// The parked record carries -0.5 * conic.x and -0.5 * conic.z: a multiplication by -0.5 is exact and commutes with every rounding
+// in the expression above, so  fl(fl(hA dx) dx) + fl(fl(hC dy) dy)  is bit for bit  -0.5f * (fl(fl(A dx) dx) + fl(fl(C dy) dy)).
+struct ExactCoef {
+    float mx, my;
+    float hA, B, hC;  // -0.5 conic.x, conic.y, -0.5 conic.z
+    float o;
+};
+__device__ __forceinline__ void halve_conic(float4& r0, float4& r1) {
+    r0.z = -0.5f * r0.z;
+    r1.x = -0.5f * r1.x;
+}
+__device__ __forceinline__ ExactCoef exact_coef_of(const float4 r0, const float4 r1) {  // from a record parked by halve_conic()
+    ExactCoef c;
+    c.mx = r0.x; c.my = r0.y; c.hA = r0.z; c.B = r0.w; c.hC = r1.x; c.o = r1.y;
+    return c;
+}
+// exp(x) for x <= 0 as the reference build computes it.  The expansion's two range selects are dropped: x > 88.7 cannot occur, and
+// below -103 (where it returns 0) the clamp keeps ldexp's result a denormal: either way alpha < 1/255 and the pair is skipped.
+__device__ __forceinline__ float ref_expf_nonpos(float x) {
+#pragma clang fp contract(off)
+    x = fmaxf(x, -104.0f);
+    const float c = 0x1.715476p+0f, cc = 0x1.4ae0bep-26f;
+    const float ph = x * c;
+    const float e = __builtin_rintf(ph);
+    float pl = __builtin_fmaf(x, c, -ph);
+    pl = __builtin_fmaf(x, cc, pl);
+    const float a = (ph - e) + pl;
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+}
+// the reference's power for a pixel at (pfx, pfy); d = mean - pixel (forward.cu:357)
+__device__ __forceinline__ float ref_power(const ExactCoef& c, float dx, float dy) {
+#pragma clang fp contract(off)
+    const float t2 = (c.hA * dx) * dx;
+    const float t4 = (c.hC * dy) * dy;
+    const float s = t2 + t4;
+    const float t6 = (c.B * dx) * dy;
+    return s - t6;
+}
+// Returns the reference's decision for the pair (power <= 0 and alpha >= 1/255) and its alpha, G = exp(power), dx, dy.
+__device__ __forceinline__ bool eval_alpha_exact(const ExactCoef& c, float pfx, float pfy, float& dx, float& dy, float& G, float& alpha) {
+#pragma clang fp contract(off)
+    dx = c.mx - pfx;
+    dy = c.my - pfy;
+    const float power = ref_power(c, dx, dy);
+    G = ref_expf_nonpos(power);
+    alpha = fminf(0.99f, c.o * G);
+    return !(power > 0.0f) && !(alpha < (1.0f / 255.0f));
+}
+
+// The fast evaluation (eval_alpha) with the distance of its two decisions from their thresholds:
+//   margin = min(255 alpha - 1, -p2)   (>= 0: the pair passes both skips),    band = BAND_C |S| + BAND_C0,  S = ca xx + cc yy.
+// |margin| >= band  =>  the reference's arithmetic takes the same decision, because the two evaluations cannot differ by more:
+//   * exponent, in log2 units: the fast form rounds 5 times, the reference's 4 (+ the conversion), each by <= 2^-24 of the term it
+//     forms, so |p2 - log2(e) power_ref| <= 9 * 2^-24 * M,  M = |ca| xx + |cb xy| + |cc| yy = |S| + |cb xy| <= 2 |S| + |p2|;
+//     a pair near either threshold has |p2| <= log2(255) + 0.1, hence <= 1.1e-6 |S| + 4.4e-6;
+//   * v_exp_f32 against the expansion's own v_exp_f32 + ldexp, o * G, 255 alpha - 1: 1 ulp each, <= 6e-7 in log2 units;
+//   * 255 alpha - 1 moves by ln 2 (< 1) times the exponent's error.
+// The constants carry a factor 2 on top.  (margin clearly negative on one side decides the pair whatever the other side says.)
+constexpr float BAND_C = 2.5e-6f, BAND_C0 = 1.0e-5f;
+__device__ __forceinline__ bool eval_alpha_banded(const SplatCoef& c, float pfx, float pfy, PairEval& e, float& margin, float& band) {
+    e.dx = c.mx - pfx;
+    e.dy = c.my - pfy;
+    e.xx = e.dx * e.dx;
+    e.xy = e.dx * e.dy;
+    e.yy = e.dy * e.dy;
+    const float S = __builtin_fmaf(c.ca, e.xx, c.cc * e.yy);
+    const float p2 = __builtin_fmaf(c.cb, e.xy, S);
+    e.G = __builtin_amdgcn_exp2f(p2);
+    e.alpha = fminf(0.99f, c.o * e.G);
+    band = __builtin_fmaf(BAND_C, fabsf(S), BAND_C0);
+    margin = fminf(__builtin_fmaf(e.alpha, 255.0f, -1.0f), -p2);
+    return margin >= 0.0f;
+}
+
+__device__ __forceinline__ float ref_test_T(float T, float alpha) {
+#pragma clang fp contract(off)
+    const float om = 1.0f - alpha;
+    return T * om;
+}
+
 // XCD-aware block -> tile map: blocks are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), so
 // XCD x receives the contiguous band of tiles [x*q + min(x,rem), ...): its private L2 only ever sees the
 // splat records of that band.  Bijective for any tile count.

@@ -225,6 +225,10 @@ struct Options {
     int fused_scan = 0;               // column scan + tile scan in one launch (last-workgroup hand-over); see EXPERIMENTS.md for the A/B
     int geometry_reuse = 1;           // read by the torch binding (_C.py): consecutive calls over identical geometry and camera share
                                       // the projection and the binning of the first (wg_rasterize_forward_recolor)
+    int exact_compositing = 1;        // 1: the render kernels take every skip / stop decision (power > 0, alpha < 1/255, T (1 - alpha) < 1e-4) on values
+                                      // computed with the reference's own float32 operations (wg_alpha.h): n_contrib, final_T and the blended set are
+                                      // the reference's bit for bit.  0: exp2 of a pre-scaled fused form (round 1-3; ~2 ppm of pixels flip).  Must not
+                                      // change between a frame's forward and backward call.
     int grad_record = 1;              // 0: the per-tile backward accumulates into the four arrays themselves (A/B)
     int deterministic_backward = 0;   // 1: per-instance slots + an ordered per-Gaussian sum instead of float atomics (bit-reproducible)
     int near_split = -1;              // near / far split of dense frames: -1 automatic (P >= band_list_min_p or a dense previous frame, and >= SPLIT_DENSE_AVG =
@@ -239,12 +243,12 @@ hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, c
 // phase 0: the near bag (all of the bucket without a split); phase 1: the far bag of the tiles that asked for it
 hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
                                const float* subpixel_offset, const float* background, float* out_color, const LazyConfig& lazy,
-                               bool split, int phase, HostMailbox* mailbox_dev, const BinStats* guard, hipStream_t stream);
+                               bool split, int phase, bool exact, HostMailbox* mailbox_dev, const BinStats* guard, hipStream_t stream);
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
                             const BinStats* guard, hipStream_t stream);
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                  const GeometryState& g, const float* subpixel_offset, const float* background,
-                                 float* out_color, bool lazy, const BinStats* guard, hipStream_t stream);
+                                 float* out_color, bool lazy, bool exact, const BinStats* guard, hipStream_t stream);
 // the compositing of a frame whose binning and per-pixel stops are known (img.tile_last, img.n_contrib of an earlier pass over the
 // same geometry): each tile walks exactly its list's first tile_last entries and stores final outputs
 // capturable forward (api.hip: wg_rasterize_forward_fixed): when the frame did not fit (BinStats::spec_fail) the image and the
@@ -252,11 +256,11 @@ hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState&
 hipError_t launch_poison_unfit(const ImageState& img, int W, int H, int tiles, float* out_color, hipStream_t stream);
 hipError_t launch_render_forward_replay(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                         const GeometryState& g, const float* subpixel_offset, const float* background,
-                                        float* out_color, hipStream_t stream);
+                                        float* out_color, bool exact, hipStream_t stream);
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                   const GeometryState& g, const float* subpixel_offset, const float* background,
                                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                  float* dL_dcolor, bool record, float* det_slots, unsigned char* det_flags, size_t slot_capacity, int P,
+                                  float* dL_dcolor, bool record, bool exact, float* det_slots, unsigned char* det_flags, size_t slot_capacity, int P,
                                   hipStream_t stream);  // det_slots != nullptr: deterministic mode (det_flags: one byte per slot, cleared)
 
 struct BwdParams {

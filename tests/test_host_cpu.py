@@ -483,15 +483,32 @@ def test_geometry_reuse_tokens_are_by_object_and_version_never_by_address():
 
 def test_experiment_patches_still_apply():
     """experiments/*.patch hold the measured-and-rejected kernel variants (EXPERIMENTS.md) out of the product sources; they must keep
-    applying to the tree they are filed next to, or the A/Bs they document cannot be repeated."""
+    applying, or the A/Bs they document cannot be repeated: those filed at the top level to the current tree, those under
+    experiments/at_<commit>/ to the tree of that commit (the round they were measured in; checked on the files they touch)."""
     import glob
+    import re
     import shutil
     import subprocess
-    if shutil.which("git") is None:
-        pytest.skip("git not available")
+    import tempfile
+    if shutil.which("git") is None or subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True).returncode != 0:
+        pytest.skip("git (or the history) not available")
     patches = sorted(glob.glob(os.path.join(ROOT, "experiments", "*.patch")))
     assert patches
     for p in patches:
         r = subprocess.run(["git", "apply", "--check", p], cwd=ROOT, capture_output=True, text=True)
         assert r.returncode == 0, f"{os.path.basename(p)} no longer applies:\n{r.stderr}"
-
+    for d in sorted(glob.glob(os.path.join(ROOT, "experiments", "at_*"))):
+        sha = os.path.basename(d)[3:]
+        if subprocess.run(["git", "cat-file", "-e", sha + "^{commit}"], cwd=ROOT, capture_output=True).returncode != 0:
+            pytest.skip(f"commit {sha} not in this clone")
+        for p in sorted(glob.glob(os.path.join(d, "*.patch"))):
+            files = sorted(set(re.findall(r"^(?:diff --git a/(\S+) b/|--- a/(\S+))", open(p).read(), flags=re.M)))
+            files = sorted({a or b for a, b in files})
+            with tempfile.TemporaryDirectory() as tmp:
+                for f in files:
+                    blob = subprocess.run(["git", "show", f"{sha}:{f}"], cwd=ROOT, capture_output=True)
+                    if blob.returncode == 0:   # (a file the patch creates does not exist at the base)
+                        os.makedirs(os.path.dirname(os.path.join(tmp, f)), exist_ok=True)
+                        open(os.path.join(tmp, f), "wb").write(blob.stdout)
+                r = subprocess.run(["git", "apply", "--check", p], cwd=tmp, capture_output=True, text=True)
+                assert r.returncode == 0, f"{os.path.relpath(p, ROOT)} does not apply to {sha}:\n{r.stderr}"

@@ -315,9 +315,16 @@ const char* wg_stage_name(int stage);
  * speculative frame holds the recent frames' largest instance count plus this margin.  Setting "speculative_forward" also clears the
  * calling thread's frame history and the read-only counters wg_get_option reports for it: "spec_frames", "spec_misses",
  * "forward_polls", "forward_polls_waited", "forward_wait_us_total", "forward_wait_us_last".
- * "geometry_reuse" (1/0, default 1): read by the torch binding only (wg_rasterize_forward_recolor is always available).
+ * "geometry_reuse" (0/1, default 0 since round 4): read by the torch binding only (wg_rasterize_forward_recolor is always available);
+ * opt-in because a write through `tensor.data` is invisible to the binding's identity check (diff_gaussian_rasterization/_C.py).
  * "fused_scan" (0/1, default 0): the column scan and the tile scan of the binning in one launch (measured slower on MI355X: the
  * device-scope hand-over costs more than the launch it saves). */
+/* "exact_compositing" (1/0, default 1): the render kernels take every skip / stop decision of forward.cu:356-372 and backward.cu:536-546
+ * (power > 0, alpha < 1/255, T (1 - alpha) < 1e-4) on values computed with the reference's own float32 operations, in its order, unfused,
+ * with the float32 `exp` expansion hipcc emits for the reference's sources: n_contrib, final_T and the set of blended instances are
+ * bit for bit those of the reference built with -ffp-contract=off; the image differs by the colour sums' fused multiply-adds (~2e-7).
+ * 0: exp2 of a pre-scaled fused form (rounds 1-3: about 2 pixels per million land on the other side of a threshold); 5 % faster.
+ * Must not change between a frame's forward and its backward call. */
 /* "roctx" (0/1, default 0; WG_ROCTX=1 in the environment switches it on from the first call): a roctx range around every stage
  * ("wg:K1 preprocess" ... "wg:K10-K11 preprocess_backward"), for `rocprofv3 --marker-trace --kernel-trace`.  The marker library is
  * dlopen()ed on demand; WG_ERR_INVALID_ARGUMENT if none is found. */

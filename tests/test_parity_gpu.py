@@ -925,7 +925,8 @@ def record_option():
     yield _C
     _C.set_option("grad_record", 1)
     _C.set_option("deterministic_backward", 0)
-    _C.set_option("geometry_reuse", 1)
+    _C.set_option("geometry_reuse", _C.GEOMETRY_REUSE_DEFAULT)
+    _C.forget_geometry()
 
 
 def test_gradient_record_and_in_place_accumulation_agree(oracle, record_option):
@@ -1101,7 +1102,7 @@ def test_speculative_forward_gives_the_classic_results_and_falls_back_when_a_fra
 
 @pytest.mark.parametrize("scene", ["sparse", "dense_lazy", "near_far"])
 def test_geometry_reuse_gives_what_two_separate_calls_give(record_option, scene):
-    """Option "geometry_reuse" (default 1): WildGaussians rasterizes the same Gaussians through the same camera
+    """Option "geometry_reuse" (opt-in): WildGaussians rasterizes the same Gaussians through the same camera
     with raw and then with toned colours (method.py:1573-1611).  The second call -- same geometry tensor OBJECTS at the same version,
     same settings, other precomputed colours -- copies the projected state with the new colours and composites along the first
     call's sorted lists (wg_rasterize_forward_recolor): no projection, no binning.  Images, accumulation and radii are bit-identical to
@@ -1144,7 +1145,7 @@ def test_geometry_reuse_gives_what_two_separate_calls_give(record_option, scene)
     finally:
         _C.set_option("near_split", -1)
         _C.set_option("near_per_tile", 0)
-        _C.set_option("geometry_reuse", 1)
+        _C.set_option("geometry_reuse", _C.GEOMETRY_REUSE_DEFAULT)
     assert (hits_off, hits_on) == (0, 1)
     assert not np.array_equal(a["img1"], a["img2"]) and a["img2"].any()
     for k in a:
@@ -1171,10 +1172,16 @@ def test_geometry_reuse_is_not_taken_when_anything_it_depends_on_changed(record_
         out = rast(**kw)
         return out, _C.geometry_reuse_hits() - h0
     rast = GaussianRasterizer(rs)
-    (ref_img, _, _), h = call(rast)
+    assert _C.get_option("geometry_reuse") == 0              # opt-in: by default nothing is ever remembered
+    (ref_img, ref_radii, _), h = call(rast)
+    (img, _, _), h1 = call(rast)
+    assert (h, h1) == (0, 0) and torch.equal(img, ref_img)
+    _C.set_option("geometry_reuse", 1)
+    (_, radii_a, _), h = call(rast)
     assert h == 0
-    (img, _, _), h = call(rast)
+    (img, radii_b, _), h = call(rast)
     assert h == 1 and torch.equal(img, ref_img)
+    assert radii_b is not radii_a and radii_b.data_ptr() != radii_a.data_ptr() and torch.equal(radii_a, radii_b)   # a fresh tensor per call
     t["means3D"].mul_(1.0)                                   # an in-place write: same object, new version
     (img, _, _), h = call(rast)
     assert h == 0 and torch.equal(img, ref_img)
@@ -1197,7 +1204,25 @@ def test_geometry_reuse_is_not_taken_when_anything_it_depends_on_changed(record_
     _, h = call(rast)
     _, h = call(rast)
     assert h == 0
+    # the hole that makes the option opt-in: a write through .data moves no version counter.  With the option at its default the
+    # edited geometry is rendered; with it on, the caller has promised not to do this (or to call forget_geometry())
+    t["means3D"].data.mul_(1.25)
+    (img_moved, _, _), h = call(rast)
+    t["means3D"].data.div_(1.25)
+    assert h == 0 and not torch.equal(img_moved, ref_img)
     _C.set_option("geometry_reuse", 1)
+    _C.forget_geometry()
+    _, h = call(rast, binning_capacity=None)
+    for opts, kw in ((dict(speculative_forward=2), {}), ({}, dict(binning_capacity=4_000_000))):   # a parent whose verdict is not in is never remembered
+        for k, v in opts.items():
+            _C.set_option(k, v)
+        try:
+            _C.forget_geometry()
+            _, h = call(rast, **kw)
+            _, h2 = call(rast)
+            assert (h, h2) == (0, 0), (opts, kw)
+        finally:
+            _C.set_option("speculative_forward", 1)
     _C.forget_geometry()
     cg = t["colors_precomp"].clone().requires_grad_(True)     # a backward call ends the reach (optimisers write next, some through .data)
     _, h = call(rast, colors_precomp=cg)
@@ -1339,7 +1364,7 @@ def test_fixed_capacity_forward_needs_no_host_rendezvous_and_can_be_captured_in_
                 a, b = grads[pos], ref[i][k]
                 assert float((a - b.view_as(a)).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-30, k
     finally:
-        _C.set_option("geometry_reuse", 1)
+        _C.set_option("geometry_reuse", _C.GEOMETRY_REUSE_DEFAULT)
 
 
 def test_backward_run_to_run_spread_is_at_rounding_level():

@@ -60,7 +60,7 @@ __device__ __forceinline__ bool eval_alpha(const SplatCoef& c, float pfx, float 
 //   alpha = min(0.99f, con.w * exp(power))                                             (forward.cu:364)
 //   test_T = T * (1 - alpha)                                                           (forward.cu:367)
 // with `exp` = the float32 expansion llvm emits for it on gfx950 (AMDGPULegalizerInfo / SITargetLowering: lowerFExp; it is what the
-// reference's sources compile to with hipcc, oracle/ref_hip/Makefile: "nofma" build, and what oracle/_ref's disassembly shows):
+// reference's own sources compile to with hipcc and -ffp-contract=off -- the checker build the tests hold this to, whose disassembly shows it):
 //   ph = x * log2e;  e = rint(ph);  pl = fma(x, log2e, -ph);  pl = fma(x, 0x1.4ae0bep-26, pl);  r = ldexp(v_exp_f32((ph - e) + pl), (int)e)
 // The parked record carries -0.5 * conic.x and -0.5 * conic.z: a multiplication by -0.5 is exact and commutes with every rounding
 // in the expression above, so  fl(fl(hA dx) dx) + fl(fl(hC dy) dy)  is bit for bit  -0.5f * (fl(fl(A dx) dx) + fl(fl(C dy) dy)).

@@ -223,8 +223,8 @@ struct Options {
     int speculative = 1;              // speculative forward (api.hip): enqueue everything behind the instance count before it is known
     int spec_margin_pct = 25;         //   binning buffer = the recent frames' largest count + this margin
     int fused_scan = 0;               // column scan + tile scan in one launch (last-workgroup hand-over); see EXPERIMENTS.md for the A/B
-    int geometry_reuse = 1;           // read by the torch binding (_C.py): consecutive calls over identical geometry and camera share
-                                      // the projection and the binning of the first (wg_rasterize_forward_recolor)
+    int geometry_reuse = 0;           // read by the torch binding (_C.py; opt-in since round 4): consecutive calls over identical geometry and
+                                      // camera share the projection and the binning of the first (wg_rasterize_forward_recolor)
     int exact_compositing = 1;        // 1: the render kernels take every skip / stop decision (power > 0, alpha < 1/255, T (1 - alpha) < 1e-4) on values
                                       // computed with the reference's own float32 operations (wg_alpha.h): n_contrib, final_T and the blended set are
                                       // the reference's bit for bit.  0: exp2 of a pre-scaled fused form (round 1-3; ~2 ppm of pixels flip).  Must not

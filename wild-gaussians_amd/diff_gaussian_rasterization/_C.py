@@ -175,18 +175,53 @@ def _tone_block(sh_tone, device, P, grads=None):
 
 
 # ----------------------------------------------------------------------------------------------------------
-# Geometry reuse across consecutive calls (option "geometry_reuse", default on).  WildGaussians rasterizes the same Gaussians
-# through the same camera twice per step -- raw colours, then toned colours (method.py:1573-1611), a third time for depth -- and the
-# reference projects, bins and sorts each time.  The binding remembers the LAST full forward call of the calling thread: when the
-# next call hands over the very same geometry tensors (same Python objects, same autograd versions: nothing wrote to them), the
-# same camera tensors and scalars and only other precomputed colours, it takes wg_rasterize_forward_recolor -- a copy of the
-# projected state with the new colours and the compositing along the parent's sorted lists; binning and image-state buffers are
-# shared with the parent call's (the per-pixel values are identical).  Identity is by object (weak references), never by address:
-# a freed tensor's address can be handed to a new one.  A write through `tensor.data` does not move the version counter, so the
-# remembered call also ends with the first BACKWARD call of the process after it (`_reuse_epoch`; on whatever thread autograd runs
-# it): between a step's backward pass and the next step's forward pass -- where optimisers and densification write -- nothing is
-# remembered.  A forward-only loop that edits geometry through `.data` between two renders of one camera calls forget_geometry().
-_reuse = threading.local()
+# Geometry reuse across consecutive calls (option "geometry_reuse", OPT-IN since round 4: default off).  WildGaussians rasterizes the
+# same Gaussians through the same camera twice per step -- raw colours, then toned colours (method.py:1573-1611), a third time for
+# depth -- and the reference projects, bins and sorts each time.  With the option on the binding remembers the LAST full forward call
+# of the calling thread: when the next call hands over the very same geometry tensors (same Python objects, same autograd versions,
+# same data pointers: nothing wrote to them that autograd knows of), the same camera tensors and scalars and only other precomputed
+# colours, it takes wg_rasterize_forward_recolor -- a copy of the projected state with the new colours and the compositing along the
+# parent's sorted lists; binning and image-state buffers are shared with the parent call's (the per-pixel values are identical).
+# Identity is by object (weak references), never by address alone: a freed tensor's address can be handed to a new one.
+# WHY OPT-IN: a write through `tensor.data` (or `set_()` to equal-shaped storage at the same address) moves no version counter, and the
+# binding cannot see it without reading the data back.  The remembered call ends with the first BACKWARD call of the process after it
+# (`_reuse_epoch`; on whatever thread autograd runs it), so a training step -- forward calls, backward, optimiser -- is safe; a
+# forward-only loop that edits geometry through `.data` between two renders of one camera is not, and a drop-in must not depend on its
+# caller never doing that.  Callers that switch it on (wg_integration.apply_optins does) make that promise, or call forget_geometry().
+# A parent call whose frame may turn out not to have fit (binning_capacity=, speculative_forward = 2) is never remembered: its child
+# would composite along empty lists and return a clean background image where the contract says NaN.
+GEOMETRY_REUSE_DEFAULT = 0
+
+
+class _ReuseState:
+    def __init__(self):
+        self.last = None        # the remembered forward call (strong references to its scratch buffers)
+        self.hits = 0
+        self.last_fixed = None
+
+
+class _PerThread:
+    """`_reuse.<attr>` = the calling thread's _ReuseState.  A plain registry instead of threading.local, so that a backward call
+    (usually on autograd's thread) can drop EVERY thread's stale entry -- and with it the references that keep a frame's scratch
+    buffers alive until that thread's next forward call."""
+    _states = {}
+
+    @classmethod
+    def state(cls):
+        ident = threading.get_ident()
+        s = cls._states.get(ident)
+        if s is None:
+            s = cls._states[ident] = _ReuseState()
+        return s
+
+    def __getattr__(self, name):
+        return getattr(self.state(), name)
+
+    def __setattr__(self, name, value):
+        setattr(self.state(), name, value)
+
+
+_reuse = _PerThread()
 _reuse_epoch = 0   # bumped by every backward call (any thread; the GIL orders it)
 
 
@@ -199,7 +234,7 @@ def _tensor_token(t):
         version = t._version
     except RuntimeError:   # inference-mode tensors track no version: nothing can vouch for "unchanged", so they never match
         return (lambda: None, object(), tuple(t.shape), t.dtype)
-    return (weakref.ref(t), version, tuple(t.shape), t.dtype)
+    return (weakref.ref(t), version, tuple(t.shape), t.dtype, t.data_ptr(), tuple(t.stride()))
 
 
 def _same_token(a, b):
@@ -218,7 +253,7 @@ def _reuse_key(background, means3D, opacity, scales, rotations, scale_modifier, 
 
 
 def _reuse_lookup(key):
-    last = getattr(_reuse, "last", None)
+    last = _reuse.last
     if last is None or last.get("epoch") != _reuse_epoch or last["scalars"] != key[1] or len(last["tensors"]) != len(key[0]):
         return None
     if not all(_same_token(a, b) for a, b in zip(last["tensors"], key[0])):
@@ -267,8 +302,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             finally:
                 child = geom.take()
             _check(rendered, "wg_rasterize_forward_recolor")
-            _reuse.hits = getattr(_reuse, "hits", 0) + 1
-            return (rendered, out_color, last["radii"], child, last["binning"], last["img"])
+            _reuse.hits += 1
+            # (a fresh radii tensor, as every call of the reference returns: 4 bytes per Gaussian)
+            return (rendered, out_color, last["radii"].clone(), child, last["binning"], last["img"])
     else:
         _reuse.last = None   # any other kind of call ends the remembered one's reach
 
@@ -311,7 +347,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     _check(rendered, "wg_rasterize_forward")
     if binning_capacity is not None:
         _reuse.last_fixed = (buffers[2], H, W)
-    if key is not None and rendered >= 0:
+    # (never a parent whose verdict is not in yet: see "Geometry reuse" above)
+    if key is not None and rendered >= 0 and binning_capacity is None and _lib.wg_get_option(b"speculative_forward") != 2:
         _reuse.last = dict(tensors=key[0], scalars=key[1], R=rendered, radii=radii, geom=buffers[0], binning=buffers[1], img=buffers[2],
                            epoch=_reuse_epoch)
     return (rendered, out_color, radii) + buffers
@@ -323,7 +360,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     """With sh_tone (see rasterize_gaussians) two more tensors are appended to the result: dL_dsh_mul, dL_dsh_offset (None where the
     input was None), and dL_dsh is the gradient w.r.t. the raw coefficients."""
     global _reuse_epoch
-    _reuse_epoch += 1   # what the forward calls remembered ends here (see "Geometry reuse" above)
+    _reuse_epoch += 1   # what the forward calls remembered ends here (see "Geometry reuse" above) ...
+    for st in list(_PerThread._states.values()):   # ... and so do the references that kept those frames' scratch alive (any thread's)
+        st.last = None
     device = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
@@ -392,7 +431,7 @@ def forward_status(imageBuffer, H, W):
 
 def last_forward_status():
     """forward_status of the calling thread's latest binning_capacity= (fixed-capacity) forward call; None if there was none."""
-    last = getattr(_reuse, "last_fixed", None)
+    last = _reuse.last_fixed
     return None if last is None else forward_status(*last)
 
 
@@ -467,7 +506,7 @@ def set_option(name: str, value: int) -> None:
 
 def geometry_reuse_hits() -> int:
     """How many calls of this thread took the geometry-reuse path so far."""
-    return getattr(_reuse, "hits", 0)
+    return _reuse.hits
 
 
 def get_option(name: str) -> int:

@@ -17,6 +17,9 @@ needs the few-line edits INTEGRATION.md lists.  What IS swapped, each with the r
   activations           `GaussianModel.get_gaussians` (method.py:1060-1086)          -> wg_fused_gaussians.activate (same dict)
   eval_sh               `method.eval_sh` (method.py:493-548, called at :1564, :1597) -> wg_fused_gaussians.eval_sh; calls it does not cover
                         (degree 4, a channel count other than 3, CPU tensors) go to the original function
+  geometry_reuse        library option "geometry_reuse" = 1 (opt-in since round 4): the toned and depth calls of `_render_internal`
+                        (method.py:1573-1631) ride on the raw call's projection and binning.  The caller's training loop qualifies
+                        (it writes geometry only between a backward pass and the next forward pass); undo() switches it off again
 """
 from __future__ import annotations
 
@@ -24,7 +27,7 @@ import torch
 
 
 def apply_optins(method_module, model=None, ssim: bool = True, adam: bool = True, densification_stats: bool = True, activations: bool = True,
-                 eval_sh: bool = True):
+                 eval_sh: bool = True, geometry_reuse: bool = True):
     """-> a function that restores everything that was replaced.  `model`: an already constructed GaussianModel (e.g.
     `WildGaussians(...).model`) whose existing optimizer should be adopted too."""
     import wg_fused_gaussians as FG
@@ -76,8 +79,18 @@ def apply_optins(method_module, model=None, ssim: bool = True, adam: bool = True
             return FG.eval_sh(d, sh, dirs)
         swap(method_module, "eval_sh", fused_eval_sh)
 
+    reuse_before = None
+    if geometry_reuse:
+        from diff_gaussian_rasterization import _C
+        reuse_before = _C.get_option("geometry_reuse")
+        _C.set_option("geometry_reuse", 1)
+
     def undo():
         while saved:
             obj, name, old = saved.pop()
             setattr(obj, name, old)
+        if reuse_before is not None:
+            from diff_gaussian_rasterization import _C
+            _C.set_option("geometry_reuse", reuse_before)
+            _C.forget_geometry()
     return undo

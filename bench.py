@@ -150,6 +150,22 @@ def governing_roofline(dom: str, d: dict, pmc_row, launch_ms: float, survey_byte
     return r
 
 
+def host_step_summary(stamps) -> dict:
+    """Where the timed region's time went, step by step, from the host clock read after every call inside it (the host is in step with
+    the GPU: a forward call returns behind its frame's scan).  The mean of these is ms_per_step up to the closing synchronize."""
+    d = [1e3 * (b - a) for a, b in zip(stamps[:-1], stamps[1:])]
+    if not d:
+        return {}
+    srt = sorted(d)
+    out = {"p50": round(srt[len(srt) // 2], 4), "min": round(srt[0], 4), "max": round(srt[-1], 4), "argmax": int(d.index(srt[-1])),
+           "mean": round(sum(d) / len(d), 4), "steps_over_1.25x_p50": int(sum(1 for x in d if x > 1.25 * srt[len(srt) // 2]))}
+    if len(d) <= 64:
+        out["series"] = [round(x, 3) for x in d]
+    else:
+        out["first_8"] = [round(x, 3) for x in d[:8]]
+    return out
+
+
 def self_launch(n: int):
     """`python bench.py --gpus N` without a launcher: replace this process by `torch.distributed.run` with N ranks of the same
     command line (one process per GPU, rendezvous on 127.0.0.1, a free port).  With fewer than N devices visible (the 1-GPU test
@@ -185,6 +201,7 @@ def main():
     ap.add_argument("--scale-mult", type=float, default=1.0, help="multiply the Gaussian scales (denser per-tile lists; 1.0 = SURVEY 8d recipe)")
     ap.add_argument("--forward-only", action="store_true", help="stress mode: time only the forward pass (e.g. 10M Gaussians @ 4K)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (parity + CPU timing)")
+    ap.add_argument("--no-camera-sequence", action="store_true", help="skip the eight-camera sequence block (speculation misses over differing frames)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events in the timed region")
     ap.add_argument("--baseline-iters-per-s", type=float, default=None,
                     help="the 1-GPU value of this metric: the line then carries scaling_efficiency = value / (N * baseline)")
@@ -254,26 +271,34 @@ def main():
 
     t_train_local = [0.0]
 
-    def timed(fn, steps, keep=None):   # barrier + synchronize on both sides of exactly `steps` calls, max over ranks
-        return VP.timed_region(fn, steps, device, keep)
+    def timed(fn, steps, keep=None, stamps=None):   # barrier + synchronize on both sides of exactly `steps` calls, max over ranks
+        return VP.timed_region(fn, steps, device, keep, stamps)
 
     if args.forward_only:
         train_step = fwd_step
-    for _ in range(args.warmup):
-        train_step()
-    torch.cuda.synchronize(device)
-    # timed region: exactly K steps, no instrumentation inside (recording a HIP event costs ~15 us on this stack, and a
-    # step would carry 16 of them)
-    t_train = timed(train_step, args.steps, keep=t_train_local)
-    # per-stage durations: the same K steps once more with a pair of HIP events recorded around every stage, on the stream
-    # the kernels are launched on (wg_profile_* in the C-ABI library)
+    # Order of the passes.  The per-stage pass (the same K steps with a pair of HIP events around every stage, on the stream the
+    # kernels are launched on: wg_profile_* in the C-ABI library) runs FIRST, the W warm-up steps and the timed region after it.
+    # Why: a fresh process starts on an idle GPU, and the device needs ~30 ms of load to reach its steady clocks -- with the driver's
+    # `--steps 20 --warmup 5` the timed region WAS that ramp (round 3: mean 1.07 ms vs p50 1.00; round 4's host-clock series of the
+    # region, `timed_region_host_ms`: 1.20 ms at step 3 falling monotonically to 1.07 at step 19, profiles/r4/driver_cmd_series.txt).
+    # Nothing is dropped from the timed region: W untimed steps, then exactly K full steps between barrier + synchronize pairs.
     stages = {}
+    t_train_profiled = None
     if not args.no_profile:
+        train_step()                      # (first call of the process: lazy initialisations stay out of the stage times)
+        torch.cuda.synchronize(device)
         _C.profile_reset()
         _C.profile_enable(True)
         t_train_profiled = timed(train_step, args.steps)
         stages = _C.profile_read()
         _C.profile_enable(False)
+    for _ in range(args.warmup):
+        train_step()
+    torch.cuda.synchronize(device)
+    # timed region: exactly K steps, no instrumentation inside (recording a HIP event costs ~15 us on this stack, and a
+    # step would carry 16 of them)
+    host_stamps = []
+    t_train = timed(train_step, args.steps, keep=t_train_local, stamps=host_stamps)
 
     # per-step distribution (median and p10/p90): one event pair per step, a third pass of the same K steps
     def step_quantiles(fn, steps):
@@ -332,6 +357,8 @@ def main():
         "loss_allreduced_last_step": None if args.forward_only else round(loss_stream.last(), 9),
         "loss_note": "loss = <image, cotangent> on the rasterizer's stream; its 4-byte all-reduce is queued asynchronously (wg_viewparallel.LossStream) "
                      "and covered by the device-wide synchronize that ends the timed region",
+        "pass_order": ("per-stage event pass (K steps)" if not args.no_profile else "") + " -> W warm-up steps -> timed region (K steps) -> per-step quantile "
+                      "pass -> forward-only passes: the GPU reaches its steady clocks before the timed region, see bench.py",
         "host_note": "the interpreter's cycle collector runs before, not inside, each timed region (the host is in step with the GPU: "
                      "a collector pause would be a GPU pause); every step's work is unchanged",
         "rccl_ranks_seen": job["rccl_ranks_seen"],
@@ -349,6 +376,7 @@ def main():
         "forward_mpix_per_s": round(fwd_fps * N / 1e6, 1),
         "forward_ms": round(1000.0 * t_fwd / args.steps, 4),
         "step_ms_quantiles": step_q,
+        "timed_region_host_ms": host_step_summary(host_stamps),
         "forward_ms_quantiles": fwd_q,
         "workload_stats": {"P": P, "V": V, "R": int(R), "N": N, "tiles": tiles, "instances_walked": walked},
         "library": {"version": _C.version(), "path": os.path.relpath(_C._LIB_PATH, ROOT), "options": args.option,
@@ -406,6 +434,53 @@ def main():
                 if all(k in pmc for k in names if per_stage[k] > 0 and k != "tile_ranges"):
                     pipe[nm + "_hbm_traffic_GBps"] = round(sum(pmc[k]["hbm_bytes"] for k in names if k in pmc) / (tt * 1e-3) / 1e9, 1)
         out["pipeline_roofline"] = pipe
+
+    if world == 1 and not args.forward_only and not args.no_camera_sequence:
+        # BASELINE config 4's eight cameras (the base camera yawed by 0..35 degrees: R falls from 7.4 M to 3.5 M) cycled on ONE GPU:
+        # what the speculative forward costs when consecutive frames differ.  The headline loop above renders one frame over and over,
+        # where a prediction can never miss; here the thread's frame history starts empty, the first cycle has to learn the sizes
+        # (a frame with more instances than predicted + margin re-issues its tail: a "miss"), later cycles run on the learnt maximum.
+        cams = VP.view_cameras(8, W, H)
+        rasts = [GaussianRasterizer(make_settings(c, deg, device=device)) for c in cams]
+
+        def seq_step(i):
+            for v in t.values():
+                v.grad = None
+            means2D.grad = None
+            color = rasts[i % 8](means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t.get("shs"),
+                                 colors_precomp=t.get("colors_precomp"), scales=t["scales"], rotations=t["rotations"])[0]
+            color.backward(cot)
+        spec_mode = _C.get_option("speculative_forward")
+        _C.set_option("speculative_forward", spec_mode)   # clears this thread's frame history and counters
+        counter = [0]
+
+        def seq_fn():
+            seq_step(counter[0])
+            counter[0] += 1
+        t_cold = timed(seq_fn, 8)                          # first cycle: nothing learnt yet
+        cold = {k: _C.get_option(k) for k in ("spec_frames", "spec_misses")}
+        t_seq = timed(seq_fn, args.steps)
+        warm = {k: _C.get_option(k) for k in ("spec_frames", "spec_misses")}
+        _C.set_option("speculative_forward", 0)
+        counter[0] = 0
+        timed(seq_fn, 8)
+        t_seq_classic = timed(seq_fn, args.steps)
+        _C.set_option("speculative_forward", spec_mode)
+        out["camera_sequence"] = {
+            "what": "the eight config-4 cameras cycled (fwd+bwd, one frame per step) on this GPU; frame history cleared first",
+            "first_cycle": {"steps": 8, "ms_per_step": round(1e3 * t_cold / 8, 4), **cold},
+            "steady": {"steps": args.steps, "ms_per_step": round(1e3 * t_seq / args.steps, 4), "iters_per_s": round(args.steps / t_seq, 2),
+                       "spec_frames": warm["spec_frames"] - cold["spec_frames"], "spec_misses": warm["spec_misses"] - cold["spec_misses"]},
+            "steady_without_speculation": {"ms_per_step": round(1e3 * t_seq_classic / args.steps, 4)},
+        }
+        with torch.no_grad():
+            Rs = []
+            for r8 in rasts:
+                rs8 = r8.raster_settings
+                Rs.append(int(_C.rasterize_gaussians(rs8.bg, t["means3D"], t["colors_precomp"] if "colors_precomp" in t else e, t["opacities"], t["scales"],
+                                                     t["rotations"], 1.0, e, rs8.viewmatrix, rs8.projmatrix, rs8.tanfovx, rs8.tanfovy, rs8.kernel_size,
+                                                     rs8.subpixel_offset, H, W, t["shs"] if "shs" in t else e, deg, rs8.campos, False, False)[0]))
+        out["camera_sequence"]["num_rendered_per_camera"] = Rs
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.forward_only:
         # Forward-only workloads (BASELINE config 5: 10 M Gaussians @ 4K): the same two checkers, forward legs only.
@@ -492,7 +567,7 @@ def main():
             import subprocess
             try:
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_hip_bench.py"), "--gaussians", str(P), "--width", str(W),
-                                    "--height", str(H), "--colors", args.colors, "--scale-mult", str(args.scale_mult)],
+                                    "--height", str(H), "--colors", args.colors, "--scale-mult", str(args.scale_mult), "--parity-variant", "nofma"],
                                    capture_output=True, text=True, timeout=240)
                 ref = json.loads(r.stdout.strip().splitlines()[-1])
                 out["reference_on_this_gpu"] = ref

@@ -32,12 +32,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--variant", default="default")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--parity-variant", default=None, help="build of the reference the product's outputs are compared with (default: --variant); "
+                    "'nofma' = -ffp-contract=off, the arithmetic the reference's sources spell and the product's decision-exact compositing restates")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE config 5 style: time (and compare) the forward pass only")
     args = ap.parse_args()
 
     import wg_scenes as S
     from oracle.ref_hip import ref_hip
-    from tests.wg_testlib import run_hip, rel_err
+    from tests.wg_testlib import run_hip, run_hip_native, rel_err
 
     W, H, P = args.width, args.height, args.gaussians
     deg = 3 if args.colors == "sh" else None
@@ -72,6 +74,12 @@ def main():
     if args.forward_only:
         out.pop("train_ms"), out.pop("train_iters_per_s")
     if not args.no_parity:
+        pv = args.parity_variant or args.variant
+        if pv != args.variant:
+            ref_hip._lib(args.variant).refhip_release()
+            del s
+            torch.cuda.empty_cache()
+            s = ref_hip.Session(cloud, cam, sh_degree=deg if deg is not None else 0, variant=pv)
         s.forward()
         if not args.forward_only:
             s.backward(cot)
@@ -79,14 +87,19 @@ def main():
         ref_color = s.color.cpu().numpy()
         ref_radii = s.radii.cpu().numpy()
         ref_T = s.final_T.cpu().numpy().reshape(H, W)
+        ref_nc = s.n_contrib.cpu().numpy().reshape(H, W).astype(np.int64)
         ref_g = {} if args.forward_only else {k: v.cpu().numpy() for k, v in s.g.items()}
-        ref_hip._lib(args.variant).refhip_release()
+        ref_hip._lib(pv).refhip_release()
         del s
         torch.cuda.empty_cache()
         h = run_hip(cloud, cam, sh_degree=deg if deg is not None else 0, cotangent=None if args.forward_only else cot_np)
         h.setdefault("grads", {})
         err = np.abs(h["color"].astype(np.float64) - ref_color).max(axis=0)
+        nv = run_hip_native(cloud, cam, sh_degree=deg if deg is not None else 0)["views"]["image"]
         out["product_vs_reference"] = {
+            "reference_build": pv + (" (-ffp-contract=off)" if pv == "nofma" else " (compiler defaults: contraction on)"),
+            "n_contrib_mismatch": int((nv["n_contrib"].cpu().numpy().reshape(H, W).astype(np.int64) != ref_nc).sum()),
+            "final_T_bits_mismatch": int((nv["final_T"].cpu().numpy().reshape(H, W).view(np.uint32) != ref_T.astype(np.float32).view(np.uint32)).sum()),
             "color_max_abs": float(err.max()), "color_p9999_abs": float(np.quantile(err, 0.9999)),
             "pixels_over_1e-4": int((err > 1e-4).sum()), "pixels": int(err.size),
             "accumulation_max_abs": float(np.abs(h["accumulation"].reshape(H, W) - (1.0 - ref_T)).max()),

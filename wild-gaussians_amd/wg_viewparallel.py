@@ -173,9 +173,11 @@ def backend_name() -> str:
     return dist.get_backend() if dist.is_available() and dist.is_initialized() else "none"
 
 
-def timed_region(fn, steps: int, device, keep=None) -> float:
+def timed_region(fn, steps: int, device, keep=None, stamps=None) -> float:
     """bench.py's timing contract: barrier + device synchronize on both sides of exactly `steps` calls of fn, MAX over ranks.
-    keep (a one-element list) receives this rank's own time, taken before it waits for the others."""
+    keep (a one-element list) receives this rank's own time, taken before it waits for the others.  stamps (a list) receives the host
+    clock after every call (steps + 1 values with the start; ~0.1 us each): the host is in step with the GPU here, so their differences
+    locate a slow step inside the region without putting a device event into it."""
     import gc
     import time
     sync = (lambda: torch.cuda.synchronize(device)) if torch.cuda.is_available() and device is not None and torch.device(device).type == "cuda" else (lambda: None)
@@ -189,8 +191,14 @@ def timed_region(fn, steps: int, device, keep=None) -> float:
         barrier()
         sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
+        if stamps is None:
+            for _ in range(steps):
+                fn()
+        else:
+            stamps.append(t0)
+            for _ in range(steps):
+                fn()
+                stamps.append(time.perf_counter())
         sync()
         if keep is not None:
             keep[0] = time.perf_counter() - t0

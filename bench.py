@@ -271,8 +271,8 @@ def main():
 
     t_train_local = [0.0]
 
-    def timed(fn, steps, keep=None, stamps=None):   # barrier + synchronize on both sides of exactly `steps` calls, max over ranks
-        return VP.timed_region(fn, steps, device, keep, stamps)
+    def timed(fn, steps, keep=None, stamps=None, warmup=0):   # barrier + synchronize on both sides of exactly `steps` calls, max over ranks
+        return VP.timed_region(fn, steps, device, keep, stamps, warmup)
 
     if args.forward_only:
         train_step = fwd_step
@@ -282,6 +282,13 @@ def main():
     # `--steps 20 --warmup 5` the timed region WAS that ramp (round 3: mean 1.07 ms vs p50 1.00; round 4's host-clock series of the
     # region, `timed_region_host_ms`: 1.20 ms at step 3 falling monotonically to 1.07 at step 19, profiles/r4/driver_cmd_series.txt).
     # Nothing is dropped from the timed region: W untimed steps, then exactly K full steps between barrier + synchronize pairs.
+    # The interpreter's cycle collector runs ONCE, here, and stays off until the forward-only passes are through: a collection takes
+    # ~57 ms in this process (scripts/diag_idle_ramp.py), the GPU idles meanwhile, drops its clocks and needs 20 - 30 ms of load to regain
+    # them (same script: the steps after a 10 ms pause run 1.21, 1.13, 1.13, 1.11 ... 1.05 ms against 1.04 without one).  Reference
+    # counting still frees every step's tensors; no work of a step is skipped.
+    import gc
+    gc.collect()
+    gc.disable()
     stages = {}
     t_train_profiled = None
     if not args.no_profile:
@@ -292,13 +299,11 @@ def main():
         t_train_profiled = timed(train_step, args.steps)
         stages = _C.profile_read()
         _C.profile_enable(False)
-    for _ in range(args.warmup):
-        train_step()
-    torch.cuda.synchronize(device)
-    # timed region: exactly K steps, no instrumentation inside (recording a HIP event costs ~15 us on this stack, and a
-    # step would carry 16 of them)
+    # W untimed warm-up steps, then the timed region: exactly K steps, no instrumentation inside (recording a HIP event costs ~15 us on
+    # this stack, and a step would carry 16 of them).  The warm-up steps run inside timed_region, behind its collector pass and directly
+    # in front of its opening barrier + synchronize: the GPU does not sit idle between its warm-up and its timed steps.
     host_stamps = []
-    t_train = timed(train_step, args.steps, keep=t_train_local, stamps=host_stamps)
+    t_train = timed(train_step, args.steps, keep=t_train_local, stamps=host_stamps, warmup=args.warmup)
 
     # per-step distribution (median and p10/p90): one event pair per step, a third pass of the same K steps
     def step_quantiles(fn, steps):
@@ -315,9 +320,7 @@ def main():
 
     step_q = step_quantiles(train_step, args.steps)
 
-    for _ in range(max(1, args.warmup // 2)):
-        fwd_step()
-    t_fwd = timed(fwd_step, args.steps)
+    t_fwd = timed(fwd_step, args.steps, warmup=max(1, args.warmup // 2))
     fwd_q = step_quantiles(fwd_step, args.steps)
 
     # workload statistics of this rank's view (needed for the algorithmic byte counts)
@@ -359,8 +362,9 @@ def main():
                      "and covered by the device-wide synchronize that ends the timed region",
         "pass_order": ("per-stage event pass (K steps)" if not args.no_profile else "") + " -> W warm-up steps -> timed region (K steps) -> per-step quantile "
                       "pass -> forward-only passes: the GPU reaches its steady clocks before the timed region, see bench.py",
-        "host_note": "the interpreter's cycle collector runs before, not inside, each timed region (the host is in step with the GPU: "
-                     "a collector pause would be a GPU pause); every step's work is unchanged",
+        "host_note": "the interpreter's cycle collector runs once, in front of the first pass, and is off until the last timed pass is through (a "
+                     "collection is a ~57 ms GPU pause in this process, and an idle MI355X needs 20-30 ms of load to regain its clocks: "
+                     "scripts/diag_idle_ramp.py); every step's work is unchanged",
         "rccl_ranks_seen": job["rccl_ranks_seen"],
         "per_rank_ms_per_step": job["per_rank_ms_per_step"],
         "per_rank_device": job["per_rank_device"],
@@ -481,6 +485,8 @@ def main():
                                                      t["rotations"], 1.0, e, rs8.viewmatrix, rs8.projmatrix, rs8.tanfovx, rs8.tanfovy, rs8.kernel_size,
                                                      rs8.subpixel_offset, H, W, t["shs"] if "shs" in t else e, deg, rs8.campos, False, False)[0]))
         out["camera_sequence"]["num_rendered_per_camera"] = Rs
+
+    gc.enable()   # (off since the first pass: see above)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.forward_only:
         # Forward-only workloads (BASELINE config 5: 10 M Gaussians @ 4K): the same two checkers, forward legs only.

@@ -186,6 +186,43 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
                                 float* dL_drot, int debug, void* stream, const wg_sh_tone* tone);
 
 /*
+ * Beyond the reference: TWO colour sets composited in ONE call -- one projection, one binning, one forward walk and one backward walk for
+ * both.  WildGaussians rasterizes raw and toned colours over identical geometry in every training step
+ * (wildgaussians/method.py:1573-1611: 2 forward + 2 backward passes of the reference); the per-pixel decisions (alpha, transmittance,
+ * n_contrib) do not depend on the colours, so the second set only adds three sums per pixel forward and three per (tile, Gaussian)
+ * instance backward.  Precomputed colours only (shs == NULL).  The *_dual entry points take the arguments of the plain ones plus this
+ * block; both images sit on the same background.
+ *   forward : colors_precomp2 [P,3] in, out_color2 float[3*H*W] out (fully written, like out_color).
+ *   backward: dL_dpix2 float[3*H*W] in (the cotangent of out_color2; pass zeros if it took none), dL_dcolor2 [P,3] out (fully written).
+ *             dL_dmean2D / dL_dopacity / dL_dmean3D / dL_dcov3D / dL_dscale / dL_drot are the gradients of BOTH images' losses: what the
+ *             reference's two calls give after autograd adds them, up to float rounding.  Needs "grad_record" = 1 (the default) and
+ *             "deterministic_backward" = 0; WG_ERR_INVALID_ARGUMENT otherwise.
+ */
+typedef struct wg_second_colors {
+    const float* colors_precomp2;   /* forward */
+    float* out_color2;              /* forward */
+    const float* dL_dpix2;          /* backward */
+    float* dL_dcolor2;              /* backward */
+} wg_second_colors;
+
+int wg_rasterize_forward_dual(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
+                              wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                              int height, const float* means3D, const float* shs, const float* colors_precomp,
+                              const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                              const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                              float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
+                              float* out_color, int* radii, int debug, void* stream, const wg_second_colors* second);
+
+int wg_rasterize_backward_dual(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                               const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                               const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                               const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
+                               const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
+                               char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                               float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                               float* dL_drot, int debug, void* stream, const wg_second_colors* second);
+
+/*
  * Beyond the reference: a further rasterization of the SAME Gaussians through the SAME camera with other precomputed colours
  * (WildGaussians renders raw and toned colours over identical geometry in every step, wildgaussians/method.py:1573-1611; the
  * reference projects, bins and sorts twice).  parent_*: the three scratch buffers a wg_rasterize_forward call over that geometry
@@ -229,7 +266,8 @@ int wg_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
 typedef struct wg_geometry_view {
     const float* depths;          /* [P]   view-space z (forward.cu:262) */
     const int* radii;             /* [P]   internal copy */
-    const float* splats;          /* [P*12] 48-byte records: mx,my,conic.x,conic.y | conic.z,opacity*coef,0,r | g,b,0,0 */
+    const float* splats;          /* [P*12] 48-byte records: mx,my,conic.x,conic.y | conic.z,opacity*coef,r2,r | g,b,g2,b2  (r2,g2,b2: the second
+                                     colour set of a *_dual call; otherwise 0 and two internal floats) */
     const float* cov3D;           /* [P*6] */
     const unsigned char* clamped; /* [P]   bit c set <=> SH colour channel c was clamped at 0 (forward.cu:67-69) */
     const uint32_t* tiles_touched;/* [P] */

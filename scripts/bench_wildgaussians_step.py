@@ -133,8 +133,13 @@ def real_caller(args):
         shared = {k: (v.clone().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() else v)
                   for k, v in calls[0]["kwargs"].items() if k != "colors_precomp"}
         outs = []
-        for c in calls:
-            outs.append(rast(colors_precomp=c["kwargs"]["colors_precomp"].clone().requires_grad_(True), **shared)[0])
+        if args.dual and len(calls) == 2:   # both colour sets in ONE call (colors_precomp2=)
+            r = rast(colors_precomp=calls[0]["kwargs"]["colors_precomp"].clone().requires_grad_(True),
+                     colors_precomp2=calls[1]["kwargs"]["colors_precomp"].clone().requires_grad_(True), **shared)
+            outs = [r[0], r[3]]
+        else:
+            for c in calls:
+                outs.append(rast(colors_precomp=c["kwargs"]["colors_precomp"].clone().requires_grad_(True), **shared)[0])
         sum(outs).backward(cot)
     for _ in range(3):
         op_only()
@@ -155,7 +160,7 @@ def real_caller(args):
                                   f"{P} Gaussians + appearance MLP, {W}x{H}, {args.cameras} cameras, default.yml with uncertainty_mode=disabled, "
                                   "num_sky_gaussians=0, active SH degree 3",
                       "train_step_ms": round(dt * 1e3, 3), "train_steps_per_s": round(1.0 / dt, 2),
-                      "rasterizer_only_ms (2 fwd + 2 bwd, incl. input clones)": round(dop * 1e3, 3), "rasterizer_share": round(dop / dt, 3),
+                      "rasterizer_only_ms (2 fwd + 2 bwd, incl. input clones)" if not args.dual else "rasterizer_only_ms (ONE two-colour fwd + bwd, incl. input clones)": round(dop * 1e3, 3), "rasterizer_share": round(dop / dt, 3),
                       "rasterizer_calls_per_step": len(calls), "visible": int((calls[0]["out"][1] > 0).sum().item()),
                       "num_gaussians": int(len(wg.model.xyz)), "loss_first": losses[0], "loss_last": losses[-1]}))
 
@@ -186,6 +191,7 @@ def main():
                     help="SURVEY 8f N4: wg_fused_ssim.l1_ssim_loss -- the whole (1 - l) L1 + l DSSIM image loss (method.py:1948-1965) in two "
                          "launches each way instead of the L1 / mean / SSIM statement chain")
     ap.add_argument("--optins", action="store_true", help="with --real-caller: apply wg_integration.apply_optins (run-time swaps, no source edits)")
+    ap.add_argument("--dual", action="store_true", help="with --real-caller: the step's two rasterizer calls replayed as ONE two-colour call (colors_precomp2=)")
     ap.add_argument("--real-caller", action="store_true",
                     help="run the reference's OWN `WildGaussians.train_iteration` (method.py:1880-2024, staged unchanged by "
                          "tests/real_caller/stage_reference_caller.py) instead of the restated step; none of the opt-ins apply")

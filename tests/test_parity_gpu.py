@@ -1152,6 +1152,66 @@ def test_geometry_reuse_gives_what_two_separate_calls_give(record_option, scene)
         assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("scene", ["sparse", "dense_lazy", "near_far"])
+def test_two_colour_sets_in_one_call_give_what_two_calls_give(record_option, scene):
+    """`colors_precomp2=` (wg_second_colors): WildGaussians' raw and toned colours (method.py:1573-1611) composited in
+    ONE forward and ONE backward walk.  Both images, the accumulation and radii are bit-identical to two separate calls (the decisions do
+    not depend on the colours, the colour sums are the same operations in the same order); each colour set's gradient and the geometry
+    gradients -- which here are the gradients of BOTH losses, what autograd's addition of the two calls' results gives -- agree to
+    rounding (the per-pixel dL/dalpha is one sum over both sets instead of two sums added later)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    _C = record_option
+    P, W, H, sm = {"sparse": (60_000, 800, 450, 1.0), "dense_lazy": (30_000, 640, 360, 10.0), "near_far": (30_000, 640, 360, 10.0)}[scene]
+    cam = S.make_camera(W, H, yaw_deg=3.0)
+    cloud = S.make_cloud(P, W, H, sh_degree=None, seed=31, scale_mult=sm)
+    colors2 = np.random.default_rng(5).uniform(0, 1, size=(P, 3)).astype(np.float32)
+    cot1, cot2 = S.make_cotangent(W, H, seed=1), S.make_cotangent(W, H, seed=2)
+    rs = make_settings(cam, 0, bg=np.array([0.1, 0.3, 0.2], np.float32))
+
+    def step(dual, second_takes_gradient=True):
+        if scene == "near_far":
+            _C.set_option("near_split", 1)
+            _C.set_option("near_per_tile", 150)
+        t = {k: to_dev(v).requires_grad_(True) for k, v in cloud.items()}
+        c2 = to_dev(colors2).requires_grad_(True)
+        m2d = torch.zeros((P, 3), device="cuda", requires_grad=True)
+        rast = GaussianRasterizer(rs)
+        kw = dict(means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+        if dual:
+            img1, radii1, acc1, img2 = rast(colors_precomp=t["colors_precomp"], colors_precomp2=c2, **kw)
+        else:
+            img1, radii1, acc1 = rast(colors_precomp=t["colors_precomp"], **kw)
+            img2, _, _ = rast(colors_precomp=c2, **kw)
+        loss = (img1 * to_dev(cot1)).sum()
+        if second_takes_gradient:
+            loss = loss + (img2 * to_dev(cot2)).sum()
+        loss.backward()
+        out = dict(img1=img1, img2=img2, acc1=acc1, radii1=radii1, g_c2=c2.grad if c2.grad is not None else torch.zeros_like(c2), g_m2d=m2d.grad)
+        out.update({"g_" + k: v.grad for k, v in t.items()})
+        return {k: v.detach().cpu().numpy() for k, v in out.items()}
+    try:
+        for second in (True, False):
+            a, b = step(False, second), step(True, second)
+            assert not np.array_equal(a["img1"], a["img2"]) and a["img2"].any()
+            for k in ("img1", "img2", "acc1", "radii1"):
+                assert np.array_equal(a[k], b[k]), (k, second)
+            for k in a:
+                if k.startswith("g_"):
+                    scale = float(np.abs(a[k]).max())
+                    assert float(np.abs(a[k] - b[k]).max()) <= 1e-5 * scale + 1e-30, (k, second, float(np.abs(a[k] - b[k]).max()), scale)
+        _C.set_option("deterministic_backward", 1)      # ten-float slots: the two-colour walk refuses instead of dropping three sums
+        with pytest.raises(RuntimeError, match="grad_record = 1, deterministic_backward = 0"):
+            step(True)
+    finally:
+        _C.set_option("deterministic_backward", 0)
+        _C.set_option("near_split", -1)
+        _C.set_option("near_per_tile", 0)
+    with pytest.raises(Exception, match="provide colors_precomp too"):
+        GaussianRasterizer(make_settings(cam, 1))(means3D=to_dev(cloud["means3D"]), means2D=torch.zeros((P, 3), device="cuda"), opacities=to_dev(cloud["opacities"]),
+                                                  shs=torch.zeros((P, 4, 3), device="cuda"), colors_precomp2=to_dev(colors2), scales=to_dev(cloud["scales"]),
+                                                  rotations=to_dev(cloud["rotations"]))
+
+
 def test_geometry_reuse_is_not_taken_when_anything_it_depends_on_changed(record_option):
     """Identity is by tensor OBJECT and autograd version, never by address: an in-place write to a geometry tensor, another camera
     tensor, another scalar, SH colours or an intervening call of another kind all end the remembered call's reach."""
@@ -1206,9 +1266,10 @@ def test_geometry_reuse_is_not_taken_when_anything_it_depends_on_changed(record_
     assert h == 0
     # the hole that makes the option opt-in: a write through .data moves no version counter.  With the option at its default the
     # edited geometry is rendered; with it on, the caller has promised not to do this (or to call forget_geometry())
+    saved = t["means3D"].clone()
     t["means3D"].data.mul_(1.25)
     (img_moved, _, _), h = call(rast)
-    t["means3D"].data.div_(1.25)
+    t["means3D"].data.copy_(saved)
     assert h == 0 and not torch.equal(img_moved, ref_img)
     _C.set_option("geometry_reuse", 1)
     _C.forget_geometry()

@@ -312,3 +312,44 @@ def test_real_render_internal_reuses_the_geometry_of_its_first_rasterizer_call(t
     assert (ha, hb) == (0, 2)            # toned colours and depth both ride on the raw call's projection and binning
     for k in ("render", "raw_render", "accumulation", "radii", "depth"):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+@needs_staged
+def test_render_internal_with_the_two_colour_edit_gives_the_unedited_results(trained):
+    """INTEGRATION.md section 5's edit of `_render_internal` (tests/real_caller/two_colour_edit.py holds it as text replacements, applied in
+    memory to the staged method.py): raw and toned colours in ONE rasterizer call (`colors_precomp2=`).  Against the unedited method, on
+    the same trained model and camera: one rasterizer call instead of two; render, raw render, accumulation and radii bit-identical; the
+    gradients of the step's real loss shape (L1 on the toned image + a term on the raw one, method.py:1948-1960) on every parameter
+    equal to rounding."""
+    import two_colour_edit
+    from diff_gaussian_rasterization import _C
+    m, wg, _ = trained
+    m2 = two_colour_edit.import_edited_method(m)
+    assert m2.GaussianRasterizer is m.GaussianRasterizer
+    cam = wg.train_cameras[1]
+    params = [p for p in (wg.model.xyz, wg.model.scales, wg.model.rotations, wg.model.opacities, wg.model.features_dc, wg.model.features_rest,
+                          wg.model.embeddings) if p is not None and p.requires_grad]
+    params += [p for p in wg.model.appearance_mlp.parameters()]
+    torch.manual_seed(3)
+    target = torch.rand(3, int(cam.image_sizes[1]), int(cam.image_sizes[0]), device="cuda")
+
+    def run(render_internal):
+        for p in params:
+            p.grad = None
+        with harness.RasterizerTap(m) as tap:
+            out = render_internal(wg.model, cam, config=wg.config, embedding=wg.model.get_embedding(1), kernel_size=wg.config.kernel_size)
+        loss = (out["render"] - target).abs().mean() + 0.25 * ((out["raw_render"] - target) ** 2).mean()
+        loss.backward()
+        grads = [p.grad.detach().clone() for p in params] + [out["viewspace_points"].grad.detach().clone()]
+        return out, grads, len(tap.calls)
+    assert _C.get_option("geometry_reuse") == 0
+    a, ga, calls_a = run(m.GaussianModel._render_internal)
+    b, gb, calls_b = run(m2.GaussianModel._render_internal)
+    assert (calls_a, calls_b) == (2, 1)
+    for k in ("render", "raw_render", "accumulation", "radii", "visibility_filter"):
+        assert torch.equal(a[k], b[k]), k
+    assert not torch.equal(a["render"], a["raw_render"])
+    for i, (x, y) in enumerate(zip(ga, gb)):
+        scale = float(x.abs().max())
+        assert scale > 0 and float((x - y).abs().max()) <= 2e-5 * scale, (i, float((x - y).abs().max()), scale)

@@ -406,7 +406,8 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
                         const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                         float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
-                        float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, int fixed_capacity);
+                        float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, int fixed_capacity,
+                        const wg_second_colors* second = nullptr);
 
 int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
                                wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
@@ -418,6 +419,19 @@ int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, 
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
                         means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
                         tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, out_color, radii, debug, stream_, tone, 0);
+}
+
+int wg_rasterize_forward_dual(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
+                              wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                              int height, const float* means3D, const float* shs, const float* colors_precomp,
+                              const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                              const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                              float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
+                              float* out_color, int* radii, int debug, void* stream_, const wg_second_colors* second) {
+    if (second == nullptr) return WG_ERR_INVALID_ARGUMENT;
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
+                        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
+                        tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, out_color, radii, debug, stream_, nullptr, 0, second);
 }
 
 int wg_rasterize_forward_fixed(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
@@ -453,9 +467,16 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
                         const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                         float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
-                        float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, int fixed_capacity) {
+                        float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, int fixed_capacity,
+                        const wg_second_colors* second) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const wg::Options opt = options_snapshot();
+    // two colour sets over one walk (wg_second_colors): precomputed colours only, both the second set and its image required
+    float* out_color2 = nullptr;
+    if (second != nullptr && P > 0) {
+        if (!second->colors_precomp2 || !second->out_color2 || shs != nullptr || !colors_precomp) return WG_ERR_INVALID_ARGUMENT;
+        out_color2 = second->out_color2;
+    }
     const bool fixed = fixed_capacity > 0;  // no host rendezvous at all: the caller's capacity, the superset (lazy) flow, a device-side verdict
     {
         const int settled = settle_deferred();
@@ -487,6 +508,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
     wg::FwdParams fp;
     fp.P = P; fp.D = D; fp.M = M; fp.W = width; fp.H = height; fp.gx = gx; fp.gy = gy;
     fp.means3D = means3D; fp.shs = shs; fp.colors_precomp = colors_precomp; fp.opacities = opacities;
+    fp.colors_precomp2 = out_color2 ? second->colors_precomp2 : nullptr;
     fp.scales = scales; fp.scale_modifier = scale_modifier; fp.rotations = rotations; fp.cov3D_precomp = cov3D_precomp;
     fp.viewmatrix = viewmatrix; fp.projmatrix = projmatrix; fp.cam_pos = cam_pos;
     fp.tan_fovx = tan_fovx; fp.tan_fovy = tan_fovy;
@@ -560,16 +582,16 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
         if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, code_bits, opt.lazy, try_split, guard, stream), "tile_sort_lazy");
         else WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, geom, tiles, longest, guard, stream), "tile_sort");
         WG_STAGE(WG_STAGE_RENDER_FORWARD,
-                 wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, lazy, opt.exact_compositing != 0, guard, stream),
+                 wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, out_color2, lazy, opt.exact_compositing != 0, guard, stream),
                  "render_forward");
         if (lazy) {
             WG_STAGE(WG_STAGE_RENDER_FIXUP,
-                     wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, try_split, 0, opt.exact_compositing != 0, (wg::HostMailbox*)nullptr, guard, stream),
+                     wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, out_color2, opt.lazy, try_split, 0, opt.exact_compositing != 0, (wg::HostMailbox*)nullptr, guard, stream),
                      "render_fixup");
             if (far) {  // both return at once unless some tile ran out of near instances with pixels still accumulating
                 WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter_far(P, geom, img, bin, gx, tiles, code_bits, guard, stream), "tile_scatter_far");
                 WG_STAGE(WG_STAGE_RENDER_FIXUP,
-                         wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, opt.lazy, true, 1, opt.exact_compositing != 0, mbox ? mbox->dev : (wg::HostMailbox*)nullptr, guard, stream),
+                         wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, out_color2, opt.lazy, true, 1, opt.exact_compositing != 0, mbox ? mbox->dev : (wg::HostMailbox*)nullptr, guard, stream),
                          "render_fixup_far");
             }
         }
@@ -629,7 +651,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
                 if (fixed || deferred) {
                     // A frame that does not fit leaves nothing rendered: make that impossible to miss (NaN image and accumulation) and
                     // safe to differentiate (no walked instance anywhere: the backward pass returns zeros); wg_forward_status tells.
-                    WG_STAGE(WG_STAGE_RENDER_FORWARD, wg::launch_poison_unfit(img, width, height, tiles, out_color, stream), "poison_unfit");
+                    WG_STAGE(WG_STAGE_RENDER_FORWARD, wg::launch_poison_unfit(img, width, height, tiles, out_color, out_color2, stream), "poison_unfit");
                     if (deferred) {
                         t_deferred.pending = true;
                         t_deferred.seq = mbox->seq;
@@ -715,7 +737,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
         if (huge_frame) WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_ranges(num_rendered, bin, img, tiles, stream), "tile_ranges");
     }
     WG_STAGE(WG_STAGE_RENDER_FORWARD,
-             wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, false, opt.exact_compositing != 0, nullptr, stream),
+             wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, out_color2, false, opt.exact_compositing != 0, nullptr, stream),
              "render_forward");
     return num_rendered;
 }
@@ -755,6 +777,15 @@ int wg_rasterize_backward(int P, int D, int M, int R, const float* background, i
                                        dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream_, nullptr);
 }
 
+static int backward_impl(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                         const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                         const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                         const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
+                         const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
+                         char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                         float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                         float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_second_colors* second);
+
 int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
                                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
@@ -763,8 +794,40 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
                                 char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                                 float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                                 float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone) {
+    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                         viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, subpixel_offset, radii, geom_buffer, binning_buffer,
+                         image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                         debug, stream_, tone, nullptr);
+}
+
+int wg_rasterize_backward_dual(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                               const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                               const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                               const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
+                               const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
+                               char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                               float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                               float* dL_drot, int debug, void* stream_, const wg_second_colors* second) {
+    if (second == nullptr) return WG_ERR_INVALID_ARGUMENT;
+    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                         viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, subpixel_offset, radii, geom_buffer, binning_buffer,
+                         image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                         debug, stream_, nullptr, second);
+}
+
+static int backward_impl(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                         const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                         const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                         const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
+                         const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
+                         char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                         float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                         float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_second_colors* second) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const wg::Options opt = options_snapshot();
+    // two colour sets over one walk: the gradient record is where the thirteen sums go, the deterministic mode's slots hold ten
+    const bool dual = second != nullptr && P > 0;
+    if (dual && (!second->dL_dpix2 || !second->dL_dcolor2 || shs != nullptr || !opt.grad_record || opt.deterministic_backward)) return WG_ERR_INVALID_ARGUMENT;
     if (image_buffer != nullptr) {   // a deferred forward call's verdict, before anything is differentiated (found by its image buffer: the
         const void* key = reinterpret_cast<const void*>((reinterpret_cast<uintptr_t>(image_buffer) + wg::ALIGN - 1) & ~(uintptr_t)(wg::ALIGN - 1));
         const int verdict = check_ticket(key, stream);   // backward pass usually runs on torch's autograd thread, not the forward's)
@@ -830,14 +893,14 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     const bool clear_records = record && !det;
     if (clear_records && R <= 0) {
         StageScope scope_(WG_STAGE_RENDER_BACKWARD, stream);
-        hipError_t e = hipMemsetAsync(geom.grad_rec, 0, (size_t)P * wg::GRAD_REC_FLOATS * sizeof(float), stream);
+        hipError_t e = hipMemsetAsync(geom.grad_rec, 0, (size_t)P * (wg::GRAD_REC_FLOATS + (dual ? 1 : 0)) * sizeof(float), stream);
         if (e != hipSuccess) return hip_fail(e, "gradient record memset");
     }
     if (R > 0) {
         WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_order(img.tile_last, nullptr, img.order_bwd, gx * gy, clear_records ? geom.grad_rec : nullptr,
-                                                             (size_t)P * wg::GRAD_REC_FLOATS, stream), "tile_order");
+                                                             (size_t)P * (wg::GRAD_REC_FLOATS + (dual ? 1 : 0)), stream), "tile_order");
         WG_STAGE(WG_STAGE_RENDER_BACKWARD, wg::launch_render_backward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, dL_dpix,
-                                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, opt.exact_compositing != 0, det_slots, det_flags, (size_t)R, P, stream),
+                                            dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, opt.exact_compositing != 0, dual ? second->dL_dpix2 : nullptr, det_slots, det_flags, (size_t)R, P, stream),
                  "render_backward");
     }
 
@@ -850,6 +913,7 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
     bp.focal_y = height / (2.0f * tan_fovy);
     bp.focal_x = width / (2.0f * tan_fovx);
     bp.kernel_size = kernel_size; bp.radii = radii;
+    bp.dL_dcolor2 = dual ? second->dL_dcolor2 : nullptr;
     WG_STAGE(WG_STAGE_PREPROCESS_BACKWARD, wg::launch_preprocess_backward(bp, device_tone(tone), geom, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                             dL_dscale, dL_drot, record, stream),
              "preprocess_backward");

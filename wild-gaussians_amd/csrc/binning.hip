@@ -52,7 +52,7 @@ GeometryState GeometryState::fromChunk(char*& chunk, size_t P, bool lists) {
     carve(chunk, g.rects, Pa);
     carve(chunk, g.tiles_touched, Pa);
     carve(chunk, g.point_offsets, Pa);
-    carve(chunk, g.grad_rec, Pa * GRAD_REC_FLOATS);
+    carve(chunk, g.grad_rec, Pa * (GRAD_REC_FLOATS + 1));   // (+ grad_aux[P] behind the records: the two-colour walk's thirteenth sum)
     g.scan_temp_bytes = query_scan_temp_bytes(Pa);
     carve(chunk, g.scan_temp, g.scan_temp_bytes);
     lists = lists && band_lists_possible(P);

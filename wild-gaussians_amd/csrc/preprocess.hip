@@ -265,9 +265,16 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
         g.depths[idx] = vz;
         float4* rec = g.splats + 3 * (size_t)idx;
         rec[0] = make_float4(pixx, pixy, conx, cony);
-        rec[1] = make_float4(conz, opacity * coef, 0.f, cr);  // .z is reserved: the render kernels park a strip mask there
-        const float2 ext = splat_extent(conx, cony, conz, opacity * coef);  // the render kernels' strip tests (wg_alpha.h)
-        rec[2] = make_float4(cg, cb, ext.x, ext.y);
+        if (p.colors_precomp2 != nullptr) {   // wave-uniform.  Two-colour walk: the second set rides in the record's three spare floats
+            static_assert(WG_STRIP_EXACT == 1, "the box strip test keeps the splat's extent in r2.zw");
+            const float c2r = p.colors_precomp2[3 * idx], c2g = p.colors_precomp2[3 * idx + 1], c2b = p.colors_precomp2[3 * idx + 2];
+            rec[1] = make_float4(conz, opacity * coef, c2r, cr);
+            rec[2] = make_float4(cg, cb, c2g, c2b);
+        } else {
+            rec[1] = make_float4(conz, opacity * coef, 0.f, cr);  // .z: spare (the backward kernel parks the Gaussian's id there in LDS)
+            const float2 ext = splat_extent(conx, cony, conz, opacity * coef);  // the box variant of the strip tests (wg_alpha.h)
+            rec[2] = make_float4(cg, cb, ext.x, ext.y);
+        }
     }
     // always written (all-zero for a culled Gaussian): the binning kernels read the rectangle only
     g.rects[idx] = vis ? make_ushort4((unsigned short)rminx, (unsigned short)rminy, (unsigned short)rmaxx, (unsigned short)rmaxy)

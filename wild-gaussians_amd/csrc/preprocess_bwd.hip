@@ -286,6 +286,11 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
             // the reference's intermediates: only a caller that wants them passes the pointers (wg_rasterizer.h)
             if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[idx] = dconic;
             if (dL_dcolor) { dL_dcolor[3 * idx] = dcol0; dL_dcolor[3 * idx + 1] = dcol1; dL_dcolor[3 * idx + 2] = dcol2; }
+            if (p.dL_dcolor2) {   // two-colour walk (render_bwd.hip: DUAL): the record's floats 10, 11 and grad_aux; zeros for a culled Gaussian
+                const float4 r2 = grad_rec[3 * (size_t)idx + 2];
+                const float* aux = reinterpret_cast<const float*>(grad_rec) + (size_t)p.P * GRAD_REC_FLOATS;
+                p.dL_dcolor2[3 * idx] = r2.z; p.dL_dcolor2[3 * idx + 1] = r2.w; p.dL_dcolor2[3 * idx + 2] = aux[idx];
+            }
         } else if (write_dLdo) {
             dL_dopacity[idx] = dLdo_out;
         }

@@ -80,6 +80,28 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
 }
 
 
+// The same for up to sixteen values (the two-colour walk reduces thirteen): on return lane l holds the total of value index
+//     8*bit1(l) + 4*bit0(l) + 2*bit4(l) + bit5(l)
+// (bits 2 and 3 of the lane index do not matter).  Absent values are passed as 0.f: their pair adds fold away.
+__device__ __forceinline__ float butterfly13(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8, float v9,
+                                             float v10, float v11, float v12, int lane) {
+    // xor 32: w_k = v_{2k + bit5}
+    const float w0 = pair_x32(v0, v1), w1 = pair_x32(v2, v3), w2 = pair_x32(v4, v5), w3 = pair_x32(v6, v7), w4 = pair_x32(v8, v9),
+                w5 = pair_x32(v10, v11), w6 = pair_x32(v12, v12);
+    // xor 16: u_m = w_{2m + bit4}
+    const float u0 = pair_x16(w0, w1), u1 = pair_x16(w2, w3), u2 = pair_x16(w4, w5), u3 = pair_x16(w6, w6);
+    // xor 1: x_n = u_{2n + bit0}
+    const bool b0 = lane & 1;
+    const float x0 = (b0 ? u1 : u0) + dpp_f<0xB1>(b0 ? u0 : u1);
+    const float x1 = (b0 ? u3 : u2) + dpp_f<0xB1>(b0 ? u2 : u3);
+    // xor 2: y = x_{bit1}
+    const bool b1 = lane & 2;
+    float y = (b1 ? x1 : x0) + dpp_f<0x4E>(b1 ? x0 : x1);
+    y += dpp_f<0x124>(y);
+    y += dpp_f<0x128>(y);
+    return y;
+}
+
 // RECORD (default, wg_set_option("grad_record")): the ten reduced values of an instance go, unscaled, to ONE 48-byte gradient
 // record of its Gaussian (grad_rec[12 id + k], k = the value's index; wg_common.h: GRAD_REC_*) -- one L2 line per instance (two for
 // a quarter of the records) instead of partial lines of four arrays, and the per-Gaussian factors (opacity, 0.5 W,
@@ -103,7 +125,10 @@ __device__ __forceinline__ float butterfly10(float v0, float v1, float v2, float
 #else
 #define WG_BWD_OCC
 #endif
-template <bool RECORD, bool DET = false, bool EXACT = false>
+// DUAL (RECORD, !DET): two colour sets over one walk (wg_second_colors, include/wg_rasterizer.h).  The record's spare floats carry the second
+// colour; each set keeps its own dL_dalpha chain (accum_rec, background term), their sum feeds the nine geometry sums -- linear in it --
+// and the abs-gradient takes |q1| + |q2|, as two calls would accumulate it; thirteen sums are reduced per instance instead of 2 x 10.  Sums 10, 11 go to the record's two spare floats, sum 12 to grad_aux[id].
+template <bool RECORD, bool DET = false, bool EXACT = false, bool DUAL = false>
 __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
     int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
@@ -111,8 +136,10 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
     const float* __restrict__ dL_dpix, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ grad_rec,
     const ushort4* __restrict__ rects, const uint32_t* __restrict__ offsets_incl, const uint32_t* __restrict__ tiles_touched,
-    float* __restrict__ det_slots, unsigned char* __restrict__ det_flags) {
-    __shared__ float4 lds[BATCH * 3];
+    float* __restrict__ det_slots, unsigned char* __restrict__ det_flags, const float* __restrict__ dL_dpix2, float* __restrict__ grad_aux) {
+    static_assert(!DUAL || (RECORD && !DET), "the two-colour walk accumulates into the gradient record");
+    __shared__ float4 lds[BATCH * (DUAL ? 4 : 3)];
+    constexpr int RS = DUAL ? 4 : 3;   // float4 per parked record
 
     const int tile = (int)order[xcd_tile(blockIdx.x, tiles)];
     const int hi0 = (int)tile_last[tile];
@@ -125,23 +152,25 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
 
     // which of the ten reduced values this lane owns after butterfly10(), and where it accumulates it:
     //   0,1,2 -> dL_dcolor[3id + k]; 3,4,5 -> dL_dmean2D[3id + k-3]; 6,7,8 -> dL_dconic[4id + {0,1,3}]; 9 -> dL_dopacity[id]
-    const int vidx = (lane & 2) ? 8 + ((lane >> 5) & 1) : 4 * (lane & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
+    const int vidx = DUAL ? 8 * ((lane >> 1) & 1) + 4 * (lane & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1)
+                          : ((lane & 2) ? 8 + ((lane >> 5) & 1) : 4 * (lane & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1));
     const bool owner = (lane & 12) == 0;  // lanes with bits 2,3 clear: one lane per value (two spare for value 8/9 copies)
     float* abase;
     uint32_t astride;
-    if (RECORD) { abase = grad_rec + vidx; astride = GRAD_REC_FLOATS; }
+    if (DUAL && vidx >= 12) { abase = grad_aux; astride = 1; }   // (vidx 13..15 hold nothing and never issue)
+    else if (RECORD) { abase = grad_rec + vidx; astride = GRAD_REC_FLOATS; }
     else if (vidx < 3) { abase = dL_dcolor + vidx; astride = 3; }
     else if (vidx < 6) { abase = dL_dmean2D + (vidx - 3); astride = 3; }
     else if (vidx < 9) { abase = dL_dconic + (vidx == 8 ? 3 : vidx - 6); astride = 4; }
     else { abase = dL_dopacity; astride = 1; }
     // values 8 and 9 (bit1 set) are replicated over bits 0 and 4: let only the bit0 == bit4 == 0 copy issue
-    const bool issue = owner && !((lane & 2) && (lane & 17));
+    const bool issue = DUAL ? (owner && vidx <= 12) : (owner && !((lane & 2) && (lane & 17)));
     // constant factor of this lane's value (see the per-pair sums below); values 3..8 also carry the splat's opacity
     const bool oscale = vidx >= 3 && vidx <= 8;
     constexpr float INV_L = 1.0f / WG_LOG2E;  // u, v above carry a factor -log2(e)
     const float vscale = vidx == 3 ? ddelx_dx * INV_L : vidx == 4 ? ddely_dy * INV_L : vidx == 5 ? INV_L : (vidx >= 6 && vidx <= 8) ? -0.5f : 1.0f;
 
-    float pfx[4], pfy[4], T[4], tfb[4], dLr[4], dLg[4], dLb[4], recd[4];
+    float pfx[4], pfy[4], T[4], tfb[4], dLr[4], dLg[4], dLb[4], recd[4], dL2r[4], dL2g[4], dL2b[4], recd2[4], tfb2[4];
     int last[4];
     StripBounds sb;
 #pragma unroll
@@ -150,6 +179,7 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
         const bool inside = px < W && py < H;
         float2 off = make_float2(0.f, 0.f);
         T[s] = 0.f; last[s] = 0; dLr[s] = dLg[s] = dLb[s] = 0.f;
+        if (DUAL) dL2r[s] = dL2g[s] = dL2b[s] = 0.f;
         if (inside) {
             const size_t pix = (size_t)W * py + px;
             if (subpixel_offset) off = subpixel_offset[pix];
@@ -158,10 +188,16 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
             dLr[s] = dL_dpix[pix];
             dLg[s] = dL_dpix[plane + pix];
             dLb[s] = dL_dpix[2 * plane + pix];
+            if (DUAL) {
+                dL2r[s] = dL_dpix2[pix];
+                dL2g[s] = dL_dpix2[plane + pix];
+                dL2b[s] = dL_dpix2[2 * plane + pix];
+            }
         }
         pfx[s] = (float)px + off.x;
         pfy[s] = (float)py + off.y;
         tfb[s] = -T[s] * (bg0 * dLr[s] + bg1 * dLg[s] + bg2 * dLb[s]);  // -T_final * <bg, dL_dpixel>
+        if (DUAL) { tfb2[s] = -T[s] * (bg0 * dL2r[s] + bg1 * dL2g[s] + bg2 * dL2b[s]); recd2[s] = 0.f; }   // both images sit on the same background
         recd[s] = 0.f;
         const float inf = __builtin_huge_valf();
         sb.x0[s] = wave_min_uniform(inside ? pfx[s] : inf);
@@ -185,6 +221,7 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
     // the ten sums live in five register PAIRS, so that clearing them after a reduction is five v_mov_b64 instead of ten v_mov_b32
     // (backward 0.4272 -> 0.4234 ms; the names below are the pairs' halves)
     f2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, p3 = {0.f, 0.f}, p4 = {0.f, 0.f};
+    float ac2r = 0.f, ac2g = 0.f, ac2b = 0.f;   // DUAL: sum(w dL2_c)
 #define acr p0.x
 #define acg p0.y
 #define acb p1.x
@@ -207,6 +244,7 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
             float4 q1 = splats[3 * (size_t)id + 1];
             float4 q2 = splats[3 * (size_t)id + 2];
             mymask = strip_mask(q0, q1, q2, sb);
+            const float3 c2 = make_float3(q1.z, q2.z, q2.w);   // DUAL: the second colour set, in the record's spare floats
             scale_conic(q0, q1);
             q2.z = 2.0f * q0.z;  // 2 ca, 2 cc: the gradient of the exponent, up to the factor 1 / log2(e) applied after the reduction
             q2.w = 2.0f * q1.x;
@@ -217,9 +255,10 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
                 const ushort4 rc = rects[id];
                 q1.z = __uint_as_float(offsets_incl[id] - tiles_touched[id] + (uint32_t)((ty - rc.y) * (rc.z - rc.x) + (tx - rc.x)));
             }
-            lds[3 * lane] = q0;
-            lds[3 * lane + 1] = q1;
-            lds[3 * lane + 2] = q2;
+            if (DUAL) lds[RS * lane + 3] = make_float4(c2.x, c2.y, c2.z, 0.f);
+            lds[RS * lane] = q0;
+            lds[RS * lane + 1] = q1;
+            lds[RS * lane + 2] = q2;
         }
         __syncthreads();
         // the batch's strip masks as wave-uniform 64-bit words (see render_fwd.hip).  A strip none of whose pixels was still
@@ -236,13 +275,15 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
         while (todo != 0ull) {
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const float4 r1 = lds[3 * j + 1];
+            const float4 r1 = lds[RS * j + 1];
             const int pos = hi - 1 - j;  // "contributor" after the decrement at backward.cu:531
-            const float4 r0 = lds[3 * j];
+            const float4 r0 = lds[RS * j];
             const SplatCoef sc = coef_of(r0, r1);
             const float o = sc.o;
-            const float4 gb = lds[3 * j + 2];  // green, blue, 2 ca, 2 cc
+            const float4 gb = lds[RS * j + 2];  // green, blue, 2 ca, 2 cc
             const float colr = r1.w, colg = gb.x, colb = gb.y;
+            float4 col2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (DUAL) col2 = lds[RS * j + 3];
             // Per-lane partial sums over this lane's (up to four) pixels.  Constant factors of the reference's
             // expressions are applied once, after the wave reduction:
             //   q = G * dL_dalpha;   u = A dx + B dy;   v = C dy + B dx        (dG/ddelx = -G u, dG/ddely = -G v)
@@ -287,21 +328,35 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
                     const float diff = cd - recd[s];
                     recd[s] += a * diff;
                     const float dLda = diff * Tn + tfb[s] * inv;
-                    const float q = e.G * dLda;
+                    float q = e.G * dLda, qabs = fabsf(q);
+                    if (DUAL) {
+                        // the second set's own dL_dalpha: every sum below is linear in it EXCEPT the abs-gradient (backward.cu:593-595),
+                        // which two separate calls accumulate as |g1| + |g2|, not |g1 + g2|
+                        ac2r += w * dL2r[s];
+                        ac2g += w * dL2g[s];
+                        ac2b += w * dL2b[s];
+                        const float cd2 = col2.x * dL2r[s] + col2.y * dL2g[s] + col2.z * dL2b[s];
+                        const float diff2 = cd2 - recd2[s];
+                        recd2[s] += a * diff2;
+                        const float q2 = e.G * (diff2 * Tn + tfb2[s] * inv);
+                        q += q2;
+                        qabs += fabsf(q2);
+                    }
                     // -log2(e) * (A dx + B dy) and -log2(e) * (C dy + B dx): the constant goes into vscale
                     const float u = gb.z * e.dx + r0.w * e.dy;
                     const float v = gb.w * e.dy + r0.w * e.dx;
                     sq += q;
                     sx += q * u;
                     sy += q * v;
-                    sab += fabsf(q) * (ddelx_dx * fabsf(u) + ddely_dy * fabsf(v));
+                    sab += qabs * (ddelx_dx * fabsf(u) + ddely_dy * fabsf(v));
                     sxx += q * e.xx;
                     sxy += q * e.xy;
                     syy += q * e.yy;
                 }
             }
             if (__ballot(any) == 0ull) continue;
-            const float total = butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
+            const float total = DUAL ? butterfly13(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, ac2r, ac2g, ac2b, lane)
+                                     : butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
             if (DET) {
                 if (issue) {
                     const uint32_t slot = __float_as_uint(r1.z);
@@ -309,13 +364,15 @@ __global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
                     if (vidx == 0) det_flags[slot] = 1;  // only flagged slots hold sums: the slot array itself is never cleared
                 }
             } else if (RECORD) {
-                if (issue) unsafeAtomicAdd(abase + (size_t)__float_as_uint(r1.z) * GRAD_REC_FLOATS, total);  // 64-bit: shift-adds, no quarter-rate 32-bit multiply
+                if (DUAL) { if (issue) unsafeAtomicAdd(abase + (size_t)__float_as_uint(r1.z) * astride, total); }
+                else if (issue) unsafeAtomicAdd(abase + (size_t)__float_as_uint(r1.z) * GRAD_REC_FLOATS, total);  // 64-bit: shift-adds, no quarter-rate 32-bit multiply
             } else {
                 if (issue) unsafeAtomicAdd(abase + astride * __float_as_uint(r1.z), total * (oscale ? (vidx == 5 ? fabsf(o) : o) * vscale : vscale));  // 4*P < 2^32
             }
             // (hipcc scalarises "p = {0, 0}" into two v_mov_b32: spelled out)
             asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\tv_mov_b64 %4, 0"
                          : "=v"(p0), "=v"(p1), "=v"(p2), "=v"(p3), "=v"(p4));
+            if (DUAL) ac2r = ac2g = ac2b = 0.f;
         }
     }
 }
@@ -433,17 +490,20 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* 
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                   const GeometryState& g, const float* subpixel_offset, const float* background,
                                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                  float* dL_dcolor, bool record, bool exact, float* det_slots, unsigned char* det_flags, size_t slot_capacity, int P,
+                                  float* dL_dcolor, bool record, bool exact, const float* dL_dpix2, float* det_slots, unsigned char* det_flags, size_t slot_capacity, int P,
                                   hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
-#define WG_LAUNCH2(REC, DET, EX)                                                                                                            \
-    hipLaunchKernelGGL((render_backward_kernel<REC, DET, EX>), dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.order_bwd, img.ranges,     \
+#define WG_LAUNCH3(REC, DET, EX, DU)                                                                                                            \
+    hipLaunchKernelGGL((render_backward_kernel<REC, DET, EX, DU>), dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.order_bwd, img.ranges,     \
                        b.point_list, g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.final_T, img.n_contrib,    \
                        img.tile_last, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, g.grad_rec, g.rects, g.point_offsets,         \
-                       g.tiles_touched, det_slots, det_flags)
+                       g.tiles_touched, det_slots, det_flags, dL_dpix2, g.grad_rec + (size_t)P * GRAD_REC_FLOATS)
+#define WG_LAUNCH2(REC, DET, EX) WG_LAUNCH3(REC, DET, EX, false)
 #define WG_LAUNCH(REC, DET) do { if (exact) WG_LAUNCH2(REC, DET, true); else WG_LAUNCH2(REC, DET, false); } while (0)
-    if (det_slots) {
+    if (dL_dpix2) {   // (api.hip has checked: gradient record on, deterministic mode off)
+        if (exact) WG_LAUNCH3(true, false, true, true); else WG_LAUNCH3(true, false, false, true);
+    } else if (det_slots) {
         WG_LAUNCH(true, true);
         hipLaunchKernelGGL(det_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, g.point_offsets, g.tiles_touched, det_slots, det_flags,
                            g.grad_rec, slot_capacity);
@@ -451,6 +511,7 @@ hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState
     else WG_LAUNCH(false, false);
 #undef WG_LAUNCH
 #undef WG_LAUNCH2
+#undef WG_LAUNCH3
     return hipGetLastError();
 }
 

@@ -34,8 +34,13 @@ constexpr int BATCH = 64;
 // One wave owns a tile.  The walk is resumable: it composites list positions [pos_begin, pos_end) and can be continued
 // later from the state parked in the output buffers (fwd_store with complete == false / fwd_init with resume == true).
 
+// DUAL (two colour sets composited in ONE walk: wg_second_colors in include/wg_rasterizer.h; WildGaussians renders raw and toned colours over
+// identical geometry, method.py:1573-1611): the splat record's three spare floats (r1.z, r2.z, r2.w) carry the second set, the tile
+// state three more sums per pixel, out_color2 receives the second image.  Every decision (alpha, T, n_contrib) is shared.
+template <bool DUAL = false>
 __device__ void fwd_init(FwdTile& st, int W, int H, int gx, int tile, int lane, const float2* __restrict__ subpixel_offset, bool resume,
-                         const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ out_color) {
+                         const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ out_color,
+                         const float* __restrict__ out_color2 = nullptr) {
     const int tx = tile % gx, ty = tile / gx;
     st.x0 = tx * TILE_X;
     st.y0 = ty * TILE_Y;
@@ -48,6 +53,7 @@ __device__ void fwd_init(FwdTile& st, int W, int H, int gx, int tile, int lane, 
         float2 off = make_float2(0.f, 0.f);
         st.T[s] = 1.0f;
         st.Cr[s] = st.Cg[s] = st.Cb[s] = 0.f;
+        if (DUAL) st.C2r[s] = st.C2g[s] = st.C2b[s] = 0.f;
         st.last[s] = 0;
         if (inside) {
             const size_t pix = (size_t)W * py + px;
@@ -61,6 +67,11 @@ __device__ void fwd_init(FwdTile& st, int W, int H, int gx, int tile, int lane, 
                 st.Cr[s] = out_color[pix];
                 st.Cg[s] = out_color[plane + pix];
                 st.Cb[s] = out_color[2 * plane + pix];
+                if (DUAL) {
+                    st.C2r[s] = out_color2[pix];
+                    st.C2g[s] = out_color2[plane + pix];
+                    st.C2b[s] = out_color2[2 * plane + pix];
+                }
             }
         }
         st.pfx[s] = (float)px + off.x;
@@ -81,17 +92,18 @@ __device__ void fwd_init(FwdTile& st, int W, int H, int gx, int tile, int lane, 
 // EXACT (Options::exact_compositing): every value a skip / stop decision is taken on -- power, alpha, T -- is computed with the
 // reference's own float32 operations (wg_alpha.h: eval_alpha_exact), so n_contrib, final_T and the set of blended instances are the
 // reference's bit for bit; only the colour sums keep their fused multiply-adds (<= 1e-6 of a pixel).
-template <bool WGB, bool EXACT>
+template <bool WGB, bool EXACT, bool DUAL = false>
 __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, const uint32_t* __restrict__ list, const float4* __restrict__ splats,
                          int pos_begin, int pos_end) {
     const int n = pos_end - pos_begin;
     list += pos_begin;
-    float pfx[4], pfy[4], T[4], Cr[4], Cg[4], Cb[4];
+    float pfx[4], pfy[4], T[4], Cr[4], Cg[4], Cb[4], C2r[4], C2g[4], C2b[4];
     uint32_t last[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         pfx[s] = st.pfx[s]; pfy[s] = st.pfy[s]; T[s] = st.T[s]; Cr[s] = st.Cr[s]; Cg[s] = st.Cg[s]; Cb[s] = st.Cb[s];
         last[s] = st.last[s];
+        if (DUAL) { C2r[s] = st.C2r[s]; C2g[s] = st.C2g[s]; C2b[s] = st.C2b[s]; }
     }
     uint32_t alive = st.alive, strips_alive = st.strips_alive;
     const StripBounds sb = st.sb;
@@ -149,7 +161,9 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
             const ExactCoef xc = exact_coef_of(r0, r1);
             // green, blue: requested with the rest of the record (inside the blend branch it was an LDS round trip on every blending
             // strip's dependency chain: 0.288 -> 0.2815 ms)
-            const float2 gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
+            float2 gb, gb2 = make_float2(0.f, 0.f);
+            if (DUAL) { const float4 q2 = lds[3 * j + 2]; gb = make_float2(q2.x, q2.y); gb2 = make_float2(q2.z, q2.w); }  // green, blue of both sets
+            else gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
             const uint32_t pos = (uint32_t)(pos_begin + base + j + 1);
             const uint32_t alive_before = alive;
 #pragma unroll
@@ -175,6 +189,11 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
                         Cr[s] += r1.w * w;
                         Cg[s] += gb.x * w;
                         Cb[s] += gb.y * w;
+                        if (DUAL) {
+                            C2r[s] += r1.z * w;
+                            C2g[s] += gb2.x * w;
+                            C2b[s] += gb2.y * w;
+                        }
                         T[s] = test_T;
                         last[s] = pos;
                     }
@@ -195,6 +214,7 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         st.T[s] = T[s]; st.Cr[s] = Cr[s]; st.Cg[s] = Cg[s]; st.Cb[s] = Cb[s]; st.last[s] = last[s];
+        if (DUAL) { st.C2r[s] = C2r[s]; st.C2g[s] = C2g[s]; st.C2b[s] = C2b[s]; }
     }
     st.alive = alive;
     st.strips_alive = strips_alive;
@@ -202,9 +222,13 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
 
 // complete: the tile is finished (every pixel stopped, or its list is exhausted) -> final outputs.  Otherwise the state is
 // parked in the same buffers for a later fwd_init(resume): colour without background, -T for stopped pixels.
+template <bool DUAL = false>
 __device__ void fwd_store(const FwdTile& st, bool complete, int W, int H, int tile, int lane, const float* __restrict__ bg,
                           float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last,
-                          float* __restrict__ out_color, float* __restrict__ accum) {
+                          float* __restrict__ out_color, float* __restrict__ accum, float* __restrict__ out_color2 = nullptr,
+                          bool colour_only = false) {
+    // colour_only (the replay of geometry reuse): the per-pixel state belongs to the parent call, whose `accumulation` view the caller
+    // may be holding, and this pass recomputed the identical values: only the image is written
     uint32_t lmax = 0;
     const size_t plane = (size_t)W * H;
     const float bg0 = complete ? bg[0] : 0.f, bg1 = complete ? bg[1] : 0.f, bg2 = complete ? bg[2] : 0.f;
@@ -213,18 +237,25 @@ __device__ void fwd_store(const FwdTile& st, bool complete, int W, int H, int ti
         const int px = st.x0 + strip_x(lane, s), py = st.y0 + strip_y(lane, s);
         if (px < W && py < H) {
             const size_t pix = (size_t)W * py + px;
-            final_T[pix] = (complete || ((st.alive >> s) & 1u)) ? st.T[s] : -st.T[s];
-            if (complete) accum[pix] = 1.0f - st.T[s];  // accumulation (__init__.py:101-113 of the reference computes it from final_T)
-            n_contrib[pix] = st.last[s];
+            if (!colour_only) {
+                final_T[pix] = (complete || ((st.alive >> s) & 1u)) ? st.T[s] : -st.T[s];
+                if (complete) accum[pix] = 1.0f - st.T[s];  // accumulation (__init__.py:101-113 of the reference computes it from final_T)
+                n_contrib[pix] = st.last[s];
+            }
             out_color[pix] = st.Cr[s] + st.T[s] * bg0;
             out_color[plane + pix] = st.Cg[s] + st.T[s] * bg1;
             out_color[2 * plane + pix] = st.Cb[s] + st.T[s] * bg2;
+            if (DUAL) {
+                out_color2[pix] = st.C2r[s] + st.T[s] * bg0;
+                out_color2[plane + pix] = st.C2g[s] + st.T[s] * bg1;
+                out_color2[2 * plane + pix] = st.C2b[s] + st.T[s] * bg2;
+            }
             lmax = max(lmax, st.last[s]);
         }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, m));
-    if (lane == 0) tile_last[tile] = lmax;
+    if (lane == 0 && !colour_only) tile_last[tile] = lmax;
 }
 
 // seg_end == nullptr: the whole list is sorted (default).  Otherwise (lazy sort, binning.hip) only the first seg_end[tile]
@@ -241,41 +272,72 @@ __device__ void fwd_store(const FwdTile& st, bool complete, int W, int H, int ti
 #else
 #define WG_FWD_OCC
 #endif
-template <bool EXACT>
-__global__ void __launch_bounds__(64) WG_FWD_OCC render_forward_kernel(
-    int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+template <bool EXACT, bool DUAL>
+__device__ __forceinline__ void render_forward_body(
+    float4* lds, int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
-    const uint32_t* __restrict__ seg_end, uint32_t* __restrict__ tile_state,
-    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last,
-    float* __restrict__ out_color, const BinStats* __restrict__ guard, int replay, float* __restrict__ accum) {
-    __shared__ float4 lds[BATCH * 3];
+    const uint32_t* seg_end, uint32_t* __restrict__ tile_state,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* tile_last,
+    float* __restrict__ out_color, const BinStats* __restrict__ guard, int replay, float* __restrict__ accum, float* __restrict__ out_color2) {
     if (guard && guard->spec_fail) return;  // speculative forward (api.hip): the frame did not fit what was enqueued; the host re-issues
     const int tile = xcd_tile(blockIdx.x, tiles);
     const int lane = threadIdx.x;
     FwdTile st;
-    fwd_init(st, W, H, gx, tile, lane, subpixel_offset, false, final_T, n_contrib, out_color);
+    fwd_init<DUAL>(st, W, H, gx, tile, lane, subpixel_offset, false, final_T, n_contrib, out_color, out_color2);
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const int end = seg_end ? min(n, (int)seg_end[tile]) : n;
-    fwd_walk<true, EXACT>(st, lds, lane, point_list + range.x, splats, 0, end);
+    fwd_walk<true, EXACT, DUAL>(st, lds, lane, point_list + range.x, splats, 0, end);
     // replay (geometry reuse): seg_end is the tile's walked length of an earlier pass over the same geometry -- nothing behind it
     // contributes, so the tile is complete whatever is left of the list
     const bool complete = st.strips_alive == 0 || end == n || replay != 0;
-    fwd_store(st, complete, W, H, tile, lane, bg, final_T, n_contrib, tile_last, out_color, accum);
+    fwd_store<DUAL>(st, complete, W, H, tile, lane, bg, final_T, n_contrib, tile_last, out_color, accum, out_color2, replay != 0);
     if (tile_state && lane == 0) tile_state[tile] = complete ? 0xffffffffu : (uint32_t)end;
+}
+
+// (seg_end and tile_last are the same array in the replay launch: neither is __restrict__)
+template <bool EXACT>
+__global__ void __launch_bounds__(64) WG_FWD_OCC render_forward_kernel(
+    int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
+    const uint32_t* seg_end, uint32_t* __restrict__ tile_state,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* tile_last,
+    float* __restrict__ out_color, const BinStats* __restrict__ guard, int replay, float* __restrict__ accum) {
+    __shared__ float4 lds[BATCH * 3];
+    render_forward_body<EXACT, false>(lds, W, H, gx, tiles, ranges, point_list, splats, subpixel_offset, bg, seg_end, tile_state, final_T, n_contrib,
+                                      tile_last, out_color, guard, replay, accum, nullptr);
+}
+
+// the two-colour walk keeps twelve more sums per lane: its register allocation is left to the compiler (no occupancy pin)
+template <bool EXACT>
+__global__ void __launch_bounds__(64) render_forward_dual_kernel(
+    int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
+    const uint32_t* seg_end, uint32_t* __restrict__ tile_state,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* tile_last,
+    float* __restrict__ out_color, const BinStats* __restrict__ guard, float* __restrict__ accum, float* __restrict__ out_color2) {
+    __shared__ float4 lds[BATCH * 3];
+    render_forward_body<EXACT, true>(lds, W, H, gx, tiles, ranges, point_list, splats, subpixel_offset, bg, seg_end, tile_state, final_T, n_contrib,
+                                     tile_last, out_color, guard, 0, accum, out_color2);
 }
 
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                  const GeometryState& g, const float* subpixel_offset, const float* background,
-                                 float* out_color, bool lazy, bool exact, const BinStats* guard, hipStream_t stream) {
+                                 float* out_color, float* out_color2, bool lazy, bool exact, const BinStats* guard, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
 #define WG_LAUNCH(EX)                                                                                                                       \
     hipLaunchKernelGGL(render_forward_kernel<EX>, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats,   \
                        reinterpret_cast<const float2*>(subpixel_offset), background, lazy ? img.seg_end : (const uint32_t*)nullptr,        \
                        lazy ? img.tile_state : (uint32_t*)nullptr, img.final_T, img.n_contrib, img.tile_last, out_color, guard, 0, img.accum)
-    if (exact) WG_LAUNCH(true); else WG_LAUNCH(false);
+#define WG_LAUNCH_DUAL(EX)                                                                                                                  \
+    hipLaunchKernelGGL(render_forward_dual_kernel<EX>, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats, \
+                       reinterpret_cast<const float2*>(subpixel_offset), background, lazy ? img.seg_end : (const uint32_t*)nullptr,        \
+                       lazy ? img.tile_state : (uint32_t*)nullptr, img.final_T, img.n_contrib, img.tile_last, out_color, guard, img.accum, out_color2)
+    if (out_color2) { if (exact) WG_LAUNCH_DUAL(true); else WG_LAUNCH_DUAL(false); }
+    else { if (exact) WG_LAUNCH(true); else WG_LAUNCH(false); }
 #undef WG_LAUNCH
+#undef WG_LAUNCH_DUAL
     return hipGetLastError();
 }
 
@@ -294,20 +356,22 @@ hipError_t launch_render_forward_replay(int W, int H, int gx, int gy, const Imag
 }
 
 __global__ void __launch_bounds__(256) poison_unfit_kernel(const BinStats* __restrict__ stats, size_t N, int tiles, float* __restrict__ out_color,
-                                                           float* __restrict__ accum, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last) {
+                                                           float* __restrict__ accum, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last,
+                                                           float* __restrict__ out_color2) {
     if (stats->spec_fail == 0u) return;  // the usual case: one scalar load per workgroup
     const float nan = __builtin_nanf("");
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x) {
         out_color[i] = nan; out_color[N + i] = nan; out_color[2 * N + i] = nan;
+        if (out_color2) { out_color2[i] = nan; out_color2[N + i] = nan; out_color2[2 * N + i] = nan; }
         accum[i] = nan;
         n_contrib[i] = 0u;
         if (i < (size_t)tiles) tile_last[i] = 0u;
     }
 }
 
-hipError_t launch_poison_unfit(const ImageState& img, int W, int H, int tiles, float* out_color, hipStream_t stream) {
+hipError_t launch_poison_unfit(const ImageState& img, int W, int H, int tiles, float* out_color, float* out_color2, hipStream_t stream) {
     const size_t N = (size_t)W * H;   // (tiles <= N always: a tile holds at least one pixel)
-    hipLaunchKernelGGL(poison_unfit_kernel, dim3(256), dim3(256), 0, stream, img.stats, N, tiles, out_color, img.accum, img.n_contrib, img.tile_last);
+    hipLaunchKernelGGL(poison_unfit_kernel, dim3(256), dim3(256), 0, stream, img.stats, N, tiles, out_color, img.accum, img.n_contrib, img.tile_last, out_color2);
     return hipGetLastError();
 }
 
@@ -316,14 +380,14 @@ hipError_t launch_poison_unfit(const ImageState& img, int W, int H, int tiles, f
 // accumulating it loops: split the next front off the unsorted bag (or take all of it when short), sort it in place behind the
 // part already consumed, let wave 0 resume the walk over it -- until every pixel has stopped or the list is exhausted.  The
 // final list prefix is in exactly the order a full sort gives, so n_contrib / tile_last / the backward pass are unaffected.
-template <bool EXACT>
+template <bool EXACT, bool DUAL>
 __global__ void __launch_bounds__(256) render_fixup_kernel(
     int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, uint32_t* point_list, const uint32_t* __restrict__ bucket_ids,
     const float* __restrict__ depths, const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset,
     const float* __restrict__ bg, uint32_t* __restrict__ tile_state, float* final_T, uint32_t* n_contrib,
     uint32_t* __restrict__ tile_last, float* out_color, uint32_t target, uint32_t cap, uint32_t id_mask,
     const uint32_t* __restrict__ tile_near, SplitState* split, int phase, HostMailbox* mailbox, const BinStats* __restrict__ guard,
-    float* __restrict__ accum) {
+    float* __restrict__ accum, float* out_color2) {
     __shared__ float4 lds[BATCH * 3];
     __shared__ uint64_t skeys[256 * 8];
     __shared__ SelectScratch sc;
@@ -354,7 +418,7 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     const uint32_t* bag = bucket_ids + range.x + bag_lo;
     uint32_t* list = point_list + range.x;
     FwdTile st;
-    if (walker) fwd_init(st, W, H, gx, tile, tid, subpixel_offset, true, final_T, n_contrib, out_color);
+    if (walker) fwd_init<DUAL>(st, W, H, gx, tile, tid, subpixel_offset, true, final_T, n_contrib, out_color, out_color2);
     bool complete = false;
     for (;;) {
         // everything at or below the last sorted key has been taken (nothing yet when the tile had no sorted front at all)
@@ -365,7 +429,7 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
         __threadfence_block();
         __syncthreads();  // the sorted segment is visible to wave 0
         if (walker) {
-            fwd_walk<false, EXACT>(st, lds, tid, list, splats, (int)done, (int)(done + F));
+            fwd_walk<false, EXACT, DUAL>(st, lds, tid, list, splats, (int)done, (int)(done + F));
             if (tid == 0) s_complete = (st.strips_alive == 0 || done + F == n) ? 1 : 0;
         }
         done += F;
@@ -376,7 +440,7 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     }
     // complete: final outputs.  Otherwise the near bag ran out with pixels still accumulating: park the state again and ask for
     // the far instances (phase 1 continues from here).
-    if (walker) fwd_store(st, complete, W, H, tile, tid, bg, final_T, n_contrib, tile_last, out_color, accum);
+    if (walker) fwd_store<DUAL>(st, complete, W, H, tile, tid, bg, final_T, n_contrib, tile_last, out_color, accum, out_color2);
     if (tid == 0) {
         tile_state[tile] = complete ? 0xffffffffu : done;
         if (!complete) {
@@ -387,17 +451,18 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
 }
 
 hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
-                               const float* subpixel_offset, const float* background, float* out_color, const LazyConfig& g_lazy,
+                               const float* subpixel_offset, const float* background, float* out_color, float* out_color2, const LazyConfig& g_lazy,
                                bool split, int phase, bool exact, HostMailbox* mailbox_dev, const BinStats* guard, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
-#define WG_LAUNCH(EX)                                                                                                                       \
-    hipLaunchKernelGGL(render_fixup_kernel<EX>, dim3(tiles), dim3(256), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, b.bucket_ids, \
+#define WG_LAUNCH(EX, DU)                                                                                                                   \
+    hipLaunchKernelGGL((render_fixup_kernel<EX, DU>), dim3(tiles), dim3(256), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, b.bucket_ids, \
                        g.depths, g.splats, reinterpret_cast<const float2*>(subpixel_offset), background, img.tile_state, img.final_T,      \
                        img.n_contrib, img.tile_last, out_color, 1536u < g_lazy.cap ? 1536u : (g_lazy.cap * 3u) / 4u,                       \
                        g_lazy.cap < FRONT_CAP ? g_lazy.cap : FRONT_CAP, code_bits ? (1u << (32 - code_bits)) - 1u : 0xffffffffu,           \
-                       split ? img.tile_near : (const uint32_t*)nullptr, img.split, phase, mailbox_dev, guard, img.accum)
-    if (exact) WG_LAUNCH(true); else WG_LAUNCH(false);
+                       split ? img.tile_near : (const uint32_t*)nullptr, img.split, phase, mailbox_dev, guard, img.accum, out_color2)
+    if (out_color2) { if (exact) WG_LAUNCH(true, true); else WG_LAUNCH(false, true); }
+    else { if (exact) WG_LAUNCH(true, false); else WG_LAUNCH(false, false); }
 #undef WG_LAUNCH
     return hipGetLastError();
 }

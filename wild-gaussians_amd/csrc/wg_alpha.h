@@ -186,6 +186,7 @@ struct StripBounds {
 // One wave's compositing state for a tile (render_fwd.hip): 4 pixels per lane.
 struct FwdTile {
     float pfx[4], pfy[4], T[4], Cr[4], Cg[4], Cb[4];
+    float C2r[4], C2g[4], C2b[4];   // second colour set (DUAL walks only; never touched otherwise)
     uint32_t last[4];
     uint32_t alive;         // bit s: this lane's pixel of strip s is still accumulating
     uint32_t strips_alive;  // wave-uniform: strips with at least one such pixel

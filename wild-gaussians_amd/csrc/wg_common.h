@@ -31,7 +31,8 @@ struct GeometryState {
     uint32_t* point_offsets;
     uint16_t* band_list;  // large P only (g_band_list_min_p): [BIN_CHUNKS][8][chunk size] chunk-local indices of the Gaussians touching
     uint32_t* band_cnt;   // each XCD band of tiles, and their counts [BIN_CHUNKS][8]; the candidates of both scatter kernels
-    float* grad_rec;      // backward only: one 48-byte gradient record per Gaussian (GRAD_REC_*), cleared at the start of every backward
+    float* grad_rec;      // backward only: one 48-byte gradient record per Gaussian (GRAD_REC_*), cleared at the start of every backward;
+                          // grad_rec + 12 P: P more floats, the two-colour walk's thirteenth sum (render_bwd.hip: DUAL)
     char* scan_temp;
     size_t scan_temp_bytes;
     // band_lists: whether the two band-list arrays exist.  They are carved LAST, so that everything the backward pass and the
@@ -43,7 +44,8 @@ struct GeometryState {
 // Gradient record of the per-tile backward pass (render_bwd.hip, RECORD): 12 floats = 48 bytes per Gaussian (three float4; a
 // record lies within one 128-byte L2 line in 6 of 8 cases, in two otherwise), holding the raw wave-reduced sums
 //   [0..2] sum(w dL_c)  [3] sum(q u)  [4] sum(q v)  [5] sum(|q| (0.5W|u| + 0.5H|v|))  [6..8] sum(q dx dx), sum(q dx dy), sum(q dy dy)
-//   [9] sum(q)  [10..11] unused.   preprocess_bwd.hip turns them into the reference's four arrays.
+//   [9] sum(q)  [10..11] unused -- two-colour walk (DUAL): sum(w dL2_r), sum(w dL2_g); sum(w dL2_b) goes to grad_aux[id].
+//   preprocess_bwd.hip turns them into the reference's four arrays (+ dL_dcolor2).
 constexpr int GRAD_REC_FLOATS = 12;
 
 struct BinStats {  // read back by the host once per forward (the reference's num_rendered sync point)
@@ -164,6 +166,7 @@ struct FwdParams {
     const float* means3D;
     const float* shs;
     const float* colors_precomp;
+    const float* colors_precomp2;   // second colour set (two-colour walk) or null: written to the record's spare floats r1.z, r2.z, r2.w
     const float* opacities;
     const float* scales;
     float scale_modifier;
@@ -242,25 +245,25 @@ hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, c
                                  const LazyConfig& lazy, bool split, const BinStats* guard, hipStream_t stream);
 // phase 0: the near bag (all of the bucket without a split); phase 1: the far bag of the tiles that asked for it
 hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, const ImageState& img, const BinningState& b, const GeometryState& g,
-                               const float* subpixel_offset, const float* background, float* out_color, const LazyConfig& lazy,
+                               const float* subpixel_offset, const float* background, float* out_color, float* out_color2, const LazyConfig& lazy,
                                bool split, int phase, bool exact, HostMailbox* mailbox_dev, const BinStats* guard, hipStream_t stream);
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
                             const BinStats* guard, hipStream_t stream);
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                  const GeometryState& g, const float* subpixel_offset, const float* background,
-                                 float* out_color, bool lazy, bool exact, const BinStats* guard, hipStream_t stream);
+                                 float* out_color, float* out_color2, bool lazy, bool exact, const BinStats* guard, hipStream_t stream);
 // the compositing of a frame whose binning and per-pixel stops are known (img.tile_last, img.n_contrib of an earlier pass over the
 // same geometry): each tile walks exactly its list's first tile_last entries and stores final outputs
 // capturable forward (api.hip: wg_rasterize_forward_fixed): when the frame did not fit (BinStats::spec_fail) the image and the
 // accumulation become NaN and tile_last / n_contrib zero
-hipError_t launch_poison_unfit(const ImageState& img, int W, int H, int tiles, float* out_color, hipStream_t stream);
+hipError_t launch_poison_unfit(const ImageState& img, int W, int H, int tiles, float* out_color, float* out_color2, hipStream_t stream);
 hipError_t launch_render_forward_replay(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                         const GeometryState& g, const float* subpixel_offset, const float* background,
                                         float* out_color, bool exact, hipStream_t stream);
 hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                   const GeometryState& g, const float* subpixel_offset, const float* background,
                                   const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                  float* dL_dcolor, bool record, bool exact, float* det_slots, unsigned char* det_flags, size_t slot_capacity, int P,
+                                  float* dL_dcolor, bool record, bool exact, const float* dL_dpix2, float* det_slots, unsigned char* det_flags, size_t slot_capacity, int P,
                                   hipStream_t stream);  // det_slots != nullptr: deterministic mode (det_flags: one byte per slot, cleared)
 
 struct BwdParams {
@@ -276,6 +279,7 @@ struct BwdParams {
     const float* campos;
     float tan_fovx, tan_fovy, focal_x, focal_y, kernel_size;
     const int* radii;
+    float* dL_dcolor2 = nullptr;    // two-colour walk: [P,3], written from the record's floats 10, 11 and grad_aux
 };
 // record: the four arrays are OUTPUTS computed from g.grad_rec (see GRAD_REC_*); otherwise inputs accumulated by the per-tile pass
 hipError_t launch_preprocess_backward(const BwdParams& p, const ShTone& tone, const GeometryState& g, float* dL_dmean2D,

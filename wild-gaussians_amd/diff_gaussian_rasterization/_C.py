@@ -51,6 +51,16 @@ _lib.wg_rasterize_forward_toned.restype = _i
 _lib.wg_rasterize_forward_toned.argtypes = _lib.wg_rasterize_forward.argtypes + [C.POINTER(_ShTone)]
 _lib.wg_rasterize_backward_toned.restype = _i
 _lib.wg_rasterize_backward_toned.argtypes = _lib.wg_rasterize_backward.argtypes + [C.POINTER(_ShTone)]
+
+
+class _SecondColors(C.Structure):  # include/wg_rasterizer.h: wg_second_colors
+    _fields_ = [("colors_precomp2", _vp), ("out_color2", _vp), ("dL_dpix2", _vp), ("dL_dcolor2", _vp)]
+
+
+_lib.wg_rasterize_forward_dual.restype = _i
+_lib.wg_rasterize_forward_dual.argtypes = _lib.wg_rasterize_forward.argtypes + [C.POINTER(_SecondColors)]
+_lib.wg_rasterize_backward_dual.restype = _i
+_lib.wg_rasterize_backward_dual.argtypes = _lib.wg_rasterize_backward.argtypes + [C.POINTER(_SecondColors)]
 _lib.wg_rasterize_forward_fixed.restype = _i
 _lib.wg_rasterize_forward_fixed.argtypes = _lib.wg_rasterize_forward.argtypes[:-2] + [_vp, C.POINTER(_ShTone), _i]   # no debug flag; + tone, capacity
 _lib.wg_forward_status.restype = _i
@@ -268,8 +278,10 @@ def forget_geometry():
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width, sh, degree,
-                        campos, prefiltered, debug, sh_tone=None, binning_capacity=None):
-    """binning_capacity (beyond the reference): an int makes the call wg_rasterize_forward_fixed -- no host rendezvous, capturable in
+                        campos, prefiltered, debug, sh_tone=None, binning_capacity=None, colors2=None):
+    """colors2 (beyond the reference: wg_second_colors, include/wg_rasterizer.h): a second [P,3] set of precomputed colours composited in
+    the same walk; the tuple then ends with a seventh element, the second image.
+    binning_capacity (beyond the reference): an int makes the call wg_rasterize_forward_fixed -- no host rendezvous, capturable in
     a hipGraph; the returned `rendered` is then the capacity, and forward_status(imgBuffer, H, W) tells the real count and whether
     the frame fit (include/wg_rasterizer.h)."""
     if means3D.dim() != 2 or means3D.size(1) != 3:
@@ -280,7 +292,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     P, H, W = means3D.size(0), int(image_height), int(image_width)
 
     # precomputed colours over remembered geometry: no projection, no binning
-    reusable = (P != 0 and sh_tone is None and not debug and colors.numel() == 3 * P and sh.numel() == 0
+    if colors2 is not None:
+        if sh_tone is not None or binning_capacity is not None or sh.numel() != 0 or colors.numel() != 3 * P or colors2.numel() != 3 * P:
+            raise RuntimeError("colors2 needs precomputed colours of P x 3 in both sets (no SH, no sh_tone, no binning_capacity)")
+    reusable = (P != 0 and sh_tone is None and not debug and colors.numel() == 3 * P and sh.numel() == 0 and colors2 is None
                 and _lib.wg_get_option(b"geometry_reuse") == 1)
     if binning_capacity is not None and debug:
         raise RuntimeError("binning_capacity (wg_rasterize_forward_fixed) has no debug mode")
@@ -311,7 +326,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     geom, binning, img = _Scratch(device), _Scratch(device), _Scratch(device)
     if P == 0:  # rasterize_points.cu:83: nothing is launched, the image stays zero
         return (0, torch.zeros((3, H, W), dtype=torch.float32, device=device), torch.zeros((0,), dtype=torch.int32, device=device),
-                geom.take(), binning.take(), img.take())
+                geom.take(), binning.take(), img.take()) + (() if colors2 is None else (torch.zeros((3, H, W), dtype=torch.float32, device=device),))
     # both outputs are fully written by the kernels (every pixel, every Gaussian): no need for the reference's zero fill
     out_color = torch.empty((3, H, W), dtype=torch.float32, device=device)
     radii = torch.empty((P,), dtype=torch.int32, device=device)
@@ -326,9 +341,20 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     M = sh.size(1) if sh.numel() != 0 else 0  # rasterize_points.cu:85-89
 
     tone, _keep = (None, None) if sh_tone is None else _tone_block(sh_tone, device, P)
+    out_color2 = None
     try:
         with torch.cuda.device(device):
-            if binning_capacity is None:
+            if colors2 is not None:
+                colors2 = _f32(colors2, device)
+                out_color2 = torch.empty((3, H, W), dtype=torch.float32, device=device)
+                second = _SecondColors(colors2.data_ptr(), out_color2.data_ptr(), None, None)
+                rendered = _lib.wg_rasterize_forward_dual(
+                    geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
+                    _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
+                    _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                    float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
+                    int(bool(debug)), _stream(device), C.byref(second))
+            elif binning_capacity is None:
                 rendered = _lib.wg_rasterize_forward_toned(
                     geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
                     _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
@@ -351,13 +377,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     if key is not None and rendered >= 0 and binning_capacity is None and _lib.wg_get_option(b"speculative_forward") != 2:
         _reuse.last = dict(tensors=key[0], scalars=key[1], R=rendered, radii=radii, geom=buffers[0], binning=buffers[1], img=buffers[2],
                            epoch=_reuse_epoch)
-    return (rendered, out_color, radii) + buffers
+    return (rendered, out_color, radii) + buffers + (() if out_color2 is None else (out_color2,))
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, dL_dout_color, sh,
-                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, sh_tone=None):
-    """With sh_tone (see rasterize_gaussians) two more tensors are appended to the result: dL_dsh_mul, dL_dsh_offset (None where the
+                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, sh_tone=None, dL_dout_color2=None):
+    """dL_dout_color2 (a frame rasterized with colors2): the second image's cotangent; the result ends with dL_dcolors2 [P,3].
+    With sh_tone (see rasterize_gaussians) two more tensors are appended to the result: dL_dsh_mul, dL_dsh_offset (None where the
     input was None), and dL_dsh is the gradient w.r.t. the raw coefficients."""
     global _reuse_epoch
     _reuse_epoch += 1   # what the forward calls remembered ends here (see "Geometry reuse" above) ...
@@ -393,6 +420,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dsh = alloc((P, M, 3), dtype=torch.float32, device=device)
     dL_dscales = (alloc if have_scales else torch.zeros)((P, 3), dtype=torch.float32, device=device)
     dL_drotations = (alloc if have_scales else torch.zeros)((P, 4), dtype=torch.float32, device=device)
+    dual = dL_dout_color2 is not None
+    if dual and (sh_tone is not None or not record or _lib.wg_get_option(b"deterministic_backward") == 1):
+        raise RuntimeError("the two-colour backward pass needs grad_record = 1, deterministic_backward = 0 and no sh_tone")
+    dL_dcolors2 = alloc((P, 3), dtype=torch.float32, device=device) if dual else None
     tone_grads = None
     if sh_tone is not None:
         tone_grads = tuple(None if v is None else alloc((P, 3), dtype=torch.float32, device=device) for v in sh_tone[:2])
@@ -407,17 +438,24 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         subpixel_offset, dL_dout_color = _f32(subpixel_offset, device), _f32(dL_dout_color, device)
         radii = radii if radii.is_contiguous() else radii.contiguous()
         tone, _keep = (None, None) if sh_tone is None else _tone_block(sh_tone, device, P, tone_grads)
+        common = (P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
+                  float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
+                  float(tan_fovx), float(tan_fovy), float(kernel_size), _ptr(subpixel_offset), _ptr(radii),
+                  geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL_dout_color),
+                  dL_dmeans2D.data_ptr(), None if dL_dconic is None else dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                  dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(), dL_drotations.data_ptr(),
+                  int(bool(debug)), _stream(device))
         with torch.cuda.device(device):
-            status = _lib.wg_rasterize_backward_toned(
-                P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
-                float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
-                float(tan_fovx), float(tan_fovy), float(kernel_size), _ptr(subpixel_offset), _ptr(radii),
-                geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL_dout_color),
-                dL_dmeans2D.data_ptr(), None if dL_dconic is None else dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
-                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(), dL_drotations.data_ptr(),
-                int(bool(debug)), _stream(device), None if tone is None else C.byref(tone))
+            if dual:
+                dL2 = _f32(dL_dout_color2, device)
+                second = _SecondColors(None, None, dL2.data_ptr(), dL_dcolors2.data_ptr())
+                status = _lib.wg_rasterize_backward_dual(*common, C.byref(second))
+            else:
+                status = _lib.wg_rasterize_backward_toned(*common, None if tone is None else C.byref(tone))
         _check(status, "wg_rasterize_backward")
     out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    if dual:
+        return out + (dL_dcolors2,)
     return out if sh_tone is None else out + tone_grads
 
 

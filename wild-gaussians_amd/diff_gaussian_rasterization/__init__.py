@@ -74,7 +74,7 @@ def _accumulation_from_image_state(img_buffer: torch.Tensor, height: int, width:
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None):
+                sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None, colors_precomp2=None):
         rs = raster_settings
         native_args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset,
@@ -89,8 +89,17 @@ class _RasterizeGaussians(torch.autograd.Function):
             native_args = native_args + (ctx.sh_tone,)
         if binning_capacity is not None:   # beyond the reference: no host rendezvous (wg_rasterize_forward_fixed), capturable in a hipGraph
             native_args = native_args + ((None,) if ctx.sh_tone is None else ()) + (int(binning_capacity),)
-        num_rendered, color, radii, geom_buf, binning_buf, img_buf = _call_native(
-            _C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
+        # beyond the reference: a second set of precomputed colours composited in the same walk (wg_second_colors)
+        ctx.dual = colors_precomp2 is not None
+        color2 = None
+        if ctx.dual:
+            if ctx.sh_tone is not None or binning_capacity is not None:
+                raise Exception("colors_precomp2 cannot be combined with sh_mul / sh_offset / binning_capacity")
+            num_rendered, color, radii, geom_buf, binning_buf, img_buf, color2 = _call_native(
+                lambda *a: _C.rasterize_gaussians(*a, colors2=colors_precomp2), native_args, rs.debug, "snapshot_fw.dump", "forward")
+        else:
+            num_rendered, color, radii, geom_buf, binning_buf, img_buf = _call_native(
+                _C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
 
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
@@ -105,10 +114,12 @@ class _RasterizeGaussians(torch.autograd.Function):
                 accumulation = torch.zeros((rs.image_height, rs.image_width), dtype=torch.float32, device=color.device)
             else:
                 accumulation = _accumulation_from_image_state(img_buf, rs.image_height, rs.image_width)
+        if ctx.dual:
+            return color, radii, accumulation, color2
         return color, radii, accumulation
 
     @staticmethod
-    def backward(ctx, grad_out_color, _grad_radii, _grad_accumulation):
+    def backward(ctx, grad_out_color, _grad_radii, _grad_accumulation, grad_out_color2=None):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf = ctx.saved_tensors
         if grad_out_color is None:  # the image itself took no gradient (only radii / accumulation were used downstream)
@@ -116,8 +127,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         native_args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                        rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset, grad_out_color, sh,
                        rs.sh_degree, rs.campos, geom_buf, ctx.num_rendered, binning_buf, img_buf, rs.debug)
-        g_mul = g_offset = None
-        if ctx.sh_tone is None:
+        g_mul = g_offset = g_colors2 = None
+        if ctx.dual:
+            if grad_out_color2 is None:   # the second image took no gradient
+                grad_out_color2 = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
+            (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations, g_colors2) = _call_native(
+                lambda *a: _C.rasterize_gaussians_backward(*a, dL_dout_color2=grad_out_color2), native_args, rs.debug, "snapshot_bw.dump", "backward")
+        elif ctx.sh_tone is None:
             (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations) = _call_native(
                 _C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
         else:
@@ -127,13 +143,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_mul = None if mul is None else g_mul.view(mul.shape)
             g_offset = None if offset is None else g_offset.view(offset.shape)
         # order of forward()'s inputs; None for raster_settings and the two clamp constants
-        return g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3Ds, None, g_mul, g_offset, None, None, None
+        return g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3Ds, None, g_mul, g_offset, None, None, None, g_colors2
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                        sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None):
+                        sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None, colors_precomp2=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity)
+                                     raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity, colors_precomp2)
 
 
 class GaussianRasterizer(nn.Module):
@@ -152,8 +168,13 @@ class GaussianRasterizer(nn.Module):
                 rotations: Optional[torch.Tensor] = None, cov3D_precomp: Optional[torch.Tensor] = None, *,
                 sh_mul: Optional[torch.Tensor] = None, sh_offset: Optional[torch.Tensor] = None,
                 sh_pre_clamp_max: Optional[float] = None, sh_post_clamp_max: Optional[float] = None,
-                binning_capacity: Optional[int] = None):
-        """`binning_capacity=` (keyword-only, beyond the reference): the forward pass without any host rendezvous
+                binning_capacity: Optional[int] = None, colors_precomp2: Optional[torch.Tensor] = None):
+        """`colors_precomp2=` (keyword-only, beyond the reference; with `colors_precomp`): a second [P,3] colour set composited in the SAME
+        call -- one projection, one binning, one forward and one backward walk for both (WildGaussians' raw and toned colours,
+        method.py:1573-1611).  Returns `(color, radii, accumulation, color2)`; gradients flow to both colour
+        tensors, the geometry gradients are those of both images' losses together.
+
+        `binning_capacity=` (keyword-only, beyond the reference): the forward pass without any host rendezvous
         (wg_rasterize_forward_fixed: the caller supplies the number of (tile, Gaussian) instances the binning buffer holds), for steps
         captured in a hipGraph; a frame that does not fit comes back as NaN, `_C.forward_status` tells.  Otherwise:
 
@@ -164,6 +185,8 @@ class GaussianRasterizer(nn.Module):
         gradients for `shs` (raw), `sh_mul` and `sh_offset` ([P, 3] each)."""
         if (shs is None) == (colors_precomp is None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if colors_precomp2 is not None and colors_precomp is None:
+            raise Exception('colors_precomp2 is a second set of precomputed colours: provide colors_precomp too')
         has_scale_rot = scales is not None or rotations is not None
         complete_scale_rot = scales is not None and rotations is not None
         if (cov3D_precomp is None and not complete_scale_rot) or (cov3D_precomp is not None and has_scale_rot):
@@ -177,4 +200,4 @@ class GaussianRasterizer(nn.Module):
             _absent() if scales is None else scales,
             _absent() if rotations is None else rotations,
             _absent() if cov3D_precomp is None else cov3D_precomp,
-            self.raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity)
+            self.raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity, colors_precomp2)

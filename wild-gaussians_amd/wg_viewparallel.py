@@ -173,21 +173,30 @@ def backend_name() -> str:
     return dist.get_backend() if dist.is_available() and dist.is_initialized() else "none"
 
 
-def timed_region(fn, steps: int, device, keep=None, stamps=None) -> float:
+def timed_region(fn, steps: int, device, keep=None, stamps=None, warmup: int = 0) -> float:
     """bench.py's timing contract: barrier + device synchronize on both sides of exactly `steps` calls of fn, MAX over ranks.
     keep (a one-element list) receives this rank's own time, taken before it waits for the others.  stamps (a list) receives the host
     clock after every call (steps + 1 values with the start; ~0.1 us each): the host is in step with the GPU here, so their differences
-    locate a slow step inside the region without putting a device event into it."""
+    locate a slow step inside the region without putting a device event into it.  warmup: that many untimed calls of fn run HERE, after
+    the collector pass and directly in front of the region's opening barrier + synchronize, so that the GPU is not left idle between its
+    warm-up and its timed steps (a cycle collection over a large heap takes tens of milliseconds; an idle MI355X drops its clocks and needs
+    ~20 ms of load to regain them: the opening steps of a region measured right after one ran 10 - 15 % slow)."""
     import gc
     import time
     sync = (lambda: torch.cuda.synchronize(device)) if torch.cuda.is_available() and device is not None and torch.device(device).type == "cuda" else (lambda: None)
     # The host is in step with the GPU here (a forward call returns the frame's exact instance count, i.e. waits for its scan), so a
     # pause of the interpreter's cycle collector is a pause of the GPU, and with N ranks the slowest rank's pauses are everybody's:
     # collect before the region, keep the collector off inside it (no work of a step is skipped; reference counting still frees).
+    # A caller that has switched the collector off already (bench.py: once, in front of all its passes) has collected too: a cycle
+    # collection takes tens of milliseconds in a process holding a scene, the GPU idles meanwhile, an idle MI355X drops its clocks and
+    # needs ~20-30 ms of load to regain them (scripts/diag_idle_ramp.py) -- the opening steps of the region would measure that ramp.
     gc_was_on = gc.isenabled()
-    gc.collect()
-    gc.disable()
+    if gc_was_on:
+        gc.collect()
+        gc.disable()
     try:
+        for _ in range(warmup):
+            fn()
         barrier()
         sync()
         t0 = time.perf_counter()

@@ -1,0 +1,11 @@
+#!/bin/bash
+O=gpurun_out/r4c7; mkdir -p $O
+python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc $?" | tee $O/summary.txt; tail -8 $O/pytest_gpu.log
+for rep in 1 2; do
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/driver_cmd.$rep.json 2> $O/driver_cmd.$rep.err
+python - $O/driver_cmd.$rep.json <<'PY' | tee -a $O/summary.txt
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("driver cmd: value", d["value"], "ms_per_step", d["ms_per_step"], "quantiles", d.get("step_ms_quantiles"), "host", d.get("timed_region_host_ms"), "camera_sequence", d.get("camera_sequence"))
+PY
+done

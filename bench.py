@@ -69,7 +69,7 @@ def design_bytes(stage: str, P: int, V: int, R: int, N: int, tiles: int, M: int,
     return float(table[stage])
 
 
-OPERATOR_SOURCES = ("api.hip", "binning.hip", "preprocess.hip", "preprocess_bwd.hip", "render_fwd.hip", "render_bwd.hip",
+OPERATOR_SOURCES = ("api.hip", "binning.hip", "preprocess.hip", "preprocess_bwd.hip", "render_fwd.hip", "render_bwd.hip", "wg_act.h",
                     "wg_common.h", "wg_alpha.h", "wg_sort.h")
 
 

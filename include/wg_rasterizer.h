@@ -186,6 +186,40 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
                                 float* dL_drot, int debug, void* stream, const wg_sh_tone* tone);
 
 /*
+ * Beyond the reference ("fuse the step before the operator"): the caller's `get_gaussians()` -- rotation
+ * normalisation, exp / sigmoid activations and the 3-D filter on scales and opacities (wildgaussians/method.py:1060-1086) -- evaluated
+ * INSIDE the preprocess kernels instead of by a chain of P-sized elementwise passes in front of the operator (and their backward passes
+ * behind it).  The *_raw entry points take the arguments of the *_toned ones (tone may be NULL) plus this block; then
+ *   forward : `opacities` [P], `scales` [P,3], `rotations` [P,4] are the RAW parameters (logit, log-scale, unnormalised quaternion);
+ *             the kernels use  q = r / max(|r|, 1e-12),  s = sqrt(exp(ls)^2 + f^2),  o = sigmoid(lo) sqrt(prod exp(ls)^2 / prod s^2).
+ *   backward: `scales`, `rotations` raw as in the forward call, raw_opacities the forward call's `opacities`; dL_dopacity, dL_dscale,
+ *             dL_drot receive the gradients of the RAW parameters.  Needs the gradient record ("grad_record" = 1, the default).
+ * Scale / rotation pairs only (cov3D_precomp == NULL).  Same device functions as wg_activations_forward / _backward
+ * (include/wg_activations.h), compiled with the same flags: the frame equals the one of activations + plain call, bit for bit.
+ */
+typedef struct wg_raw_gaussians {
+    const float* filter_3D;       /* [P] */
+    const float* raw_opacities;   /* [P], backward only */
+} wg_raw_gaussians;
+
+int wg_rasterize_forward_raw(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
+                             wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                             int height, const float* means3D, const float* shs, const float* colors_precomp,
+                             const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                             const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                             float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
+                             float* out_color, int* radii, int debug, void* stream, const wg_sh_tone* tone, const wg_raw_gaussians* raw);
+
+int wg_rasterize_backward_raw(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                              const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                              const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                              const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
+                              const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
+                              char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                              float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                              float* dL_drot, int debug, void* stream, const wg_sh_tone* tone, const wg_raw_gaussians* raw);
+
+/*
  * Beyond the reference: TWO colour sets composited in ONE call -- one projection, one binning, one forward walk and one backward walk for
  * both.  WildGaussians rasterizes raw and toned colours over identical geometry in every training step
  * (wildgaussians/method.py:1573-1611: 2 forward + 2 backward passes of the reference); the per-pixel decisions (alpha, transmittance,

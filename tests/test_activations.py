@@ -83,3 +83,64 @@ def test_c_abi_exports_the_activation_entry_points():
     lib.wg_activations_forward.argtypes = [C.c_int] + [C.c_void_p] * 8
     assert lib.wg_activations_forward(-1, *([None] * 8)) == -1
     assert lib.wg_activations_forward(0, *([None] * 8)) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("colors", ["precomp", "sh_toned"])
+def test_raw_parameter_mode_of_the_operator_equals_activations_then_plain_call(colors):
+    """`filter_3D=` (wg_raw_gaussians; SURVEY 8f N3 as worded: the activations and the 3-D filter INSIDE the preprocess kernels): the
+    operator takes the raw opacities / scales / rotations and runs get_gaussians() (method.py:1060-1086) itself, forward and backward.
+    Against fused activations (wg_fused_gaussians.activate: the same device functions, the same compiler flags) followed by the plain
+    call: image, radii and accumulation bit-identical; every gradient -- those of the raw parameters included -- equal to rounding; and
+    against the PyTorch restatement of get_gaussians within float32 tolerance.  With `shs` + `sh_mul` / `sh_offset` on top, the whole
+    step in front of the operator (activations, filter, toning, SH evaluation) is in-kernel."""
+    import numpy as np
+    import wg_scenes as S
+    import wg_fused_gaussians as FG
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from tests.wg_testlib import make_settings, to_dev
+    P, W, H = 80_000, 640, 400
+    sh = colors == "sh_toned"
+    cloud = S.make_cloud(P, W, H, sh_degree=3 if sh else None, seed=9, scale_mult=2.0)
+    cam = S.make_camera(W, H, yaw_deg=2.0)
+    rs = make_settings(cam, 3 if sh else 0)
+    g = torch.Generator().manual_seed(4)
+    filt = (0.3 * torch.rand(P, 1, generator=g) * torch.from_numpy(cloud["scales"]).mean(dim=1, keepdim=True)).cuda()
+    # raw parameters whose activations reproduce the recipe's cloud (before the filter)
+    raw = dict(opacities=torch.special.logit(torch.from_numpy(cloud["opacities"]).clamp(1e-4, 1 - 1e-4)).cuda(),
+               scales=torch.log(torch.from_numpy(cloud["scales"])).cuda(),
+               rotations=(torch.from_numpy(cloud["rotations"]) * (0.5 + torch.rand(P, 1, generator=g))).cuda())
+    cot = to_dev(S.make_cotangent(W, H, seed=6))
+    tone = {}
+    if sh:
+        tone = dict(sh_mul=(0.8 + 0.4 * torch.rand(P, 3, generator=g)).cuda(), sh_offset=(0.2 * torch.rand(P, 3, generator=g)).cuda(),
+                    sh_pre_clamp_max=1.0, sh_post_clamp_max=1.0)
+
+    def run(mode):
+        t = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+        m3 = to_dev(cloud["means3D"]).requires_grad_(True)
+        col = to_dev(cloud["shs"] if sh else cloud["colors_precomp"]).requires_grad_(True)
+        m2d = torch.zeros((P, 3), device="cuda", requires_grad=True)
+        tn = {k: (v.clone().requires_grad_(True) if torch.is_tensor(v) else v) for k, v in tone.items()}
+        kw = dict(shs=col, **tn) if sh else dict(colors_precomp=col)
+        rast = GaussianRasterizer(rs)
+        if mode == "raw":
+            img, radii, acc = rast(means3D=m3, means2D=m2d, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], filter_3D=filt, **kw)
+        else:
+            act = FG.activate if mode == "fused" else ref_get_gaussians
+            o, s_, r = act(t["opacities"], t["scales"], t["rotations"], filt)
+            img, radii, acc = rast(means3D=m3, means2D=m2d, opacities=o, scales=s_, rotations=r, **kw)
+        (img * cot).sum().backward()
+        out = dict(img=img, radii=radii, acc=acc, g_m3=m3.grad, g_col=col.grad, g_m2d=m2d.grad, **{"g_" + k: v.grad for k, v in t.items()})
+        out.update({"g_" + k: v.grad for k, v in tn.items() if torch.is_tensor(v)})
+        return {k: v.detach().cpu().numpy() for k, v in out.items()}
+    a, b, c = run("raw"), run("fused"), run("torch")
+    for k in ("img", "radii", "acc"):
+        assert np.array_equal(a[k], b[k]), k
+    assert int((a["radii"] > 0).sum()) > P // 2 and a["img"].any()
+    for k in a:
+        if k.startswith("g_"):
+            scale = float(np.abs(b[k]).max())
+            assert scale > 0 and float(np.abs(a[k] - b[k]).max()) <= 1e-5 * scale, (k, float(np.abs(a[k] - b[k]).max()), scale)
+            assert float(np.abs(a[k] - c[k]).max()) <= 2e-3 * float(np.abs(c[k]).max()), (k, "vs torch restatement")
+    assert (a["radii"] != c["radii"]).sum() <= max(2, P // 50_000) and float(np.quantile(np.abs(a["img"] - c["img"]), 0.9999)) <= 1e-5

@@ -39,12 +39,13 @@ SOURCES = {
     "api.hip": [],
     "knn.hip": ["-ffp-contract=off"],  # simple_knn.distCUDA2 replacement (include/wg_knn.h)
     "ssim.hip": [],                    # fused SSIM map fwd/bwd (include/wg_ssim.h)
-    "activations.hip": [],             # fused activations + 3-D filter fwd/bwd (include/wg_activations.h)
+    "activations.hip": ["-ffp-contract=off"],   # fused activations + 3-D filter fwd/bwd (include/wg_activations.h); same flags as
+                                               # preprocess.hip, whose raw-parameter mode runs the same device functions (wg_act.h): same bits
     "densify.hip": [],                 # fused densification statistics (include/wg_densify.h)
     "sh_eval.hip": [],                 # fused eval_sh fwd/bwd (include/wg_sh_eval.h)
     "adam.hip": ["-ffp-contract=off"],   # fused Adam step (include/wg_adam.h); no FMA contraction: torch's update, op for op
 }
-HEADERS = ["wg_common.h", "wg_alpha.h", "wg_sort.h", os.path.join(INCLUDE, "wg_rasterizer.h"), os.path.join(INCLUDE, "wg_knn.h"),
+HEADERS = ["wg_common.h", "wg_alpha.h", "wg_sort.h", "wg_act.h", os.path.join(INCLUDE, "wg_rasterizer.h"), os.path.join(INCLUDE, "wg_knn.h"),
            os.path.join(INCLUDE, "wg_ssim.h"), os.path.join(INCLUDE, "wg_activations.h"), os.path.join(INCLUDE, "wg_densify.h"), os.path.join(INCLUDE, "wg_adam.h"), os.path.join(INCLUDE, "wg_sh_eval.h")]
 
 

@@ -407,7 +407,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                         float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
                         float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, int fixed_capacity,
-                        const wg_second_colors* second = nullptr);
+                        const wg_second_colors* second = nullptr, const wg_raw_gaussians* raw = nullptr);
 
 int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
                                wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
@@ -432,6 +432,19 @@ int wg_rasterize_forward_dual(wg_alloc_fn geometry_alloc, void* geometry_user, w
     return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
                         means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
                         tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, out_color, radii, debug, stream_, nullptr, 0, second);
+}
+
+int wg_rasterize_forward_raw(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
+                             wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                             int height, const float* means3D, const float* shs, const float* colors_precomp,
+                             const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                             const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                             float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
+                             float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, const wg_raw_gaussians* raw) {
+    if (raw == nullptr) return WG_ERR_INVALID_ARGUMENT;
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
+                        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
+                        tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, out_color, radii, debug, stream_, tone, 0, nullptr, raw);
 }
 
 int wg_rasterize_forward_fixed(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
@@ -468,7 +481,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                         float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
                         float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, int fixed_capacity,
-                        const wg_second_colors* second) {
+                        const wg_second_colors* second, const wg_raw_gaussians* raw) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const wg::Options opt = options_snapshot();
     // two colour sets over one walk (wg_second_colors): precomputed colours only, both the second set and its image required
@@ -509,6 +522,10 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
     fp.P = P; fp.D = D; fp.M = M; fp.W = width; fp.H = height; fp.gx = gx; fp.gy = gy;
     fp.means3D = means3D; fp.shs = shs; fp.colors_precomp = colors_precomp; fp.opacities = opacities;
     fp.colors_precomp2 = out_color2 ? second->colors_precomp2 : nullptr;
+    if (raw != nullptr && P > 0) {   // get_gaussians() inside the preprocess kernel: needs the scale / rotation pair it acts on
+        if (!raw->filter_3D || !scales || !rotations || cov3D_precomp) return WG_ERR_INVALID_ARGUMENT;
+        fp.filter_3D = raw->filter_3D;
+    }
     fp.scales = scales; fp.scale_modifier = scale_modifier; fp.rotations = rotations; fp.cov3D_precomp = cov3D_precomp;
     fp.viewmatrix = viewmatrix; fp.projmatrix = projmatrix; fp.cam_pos = cam_pos;
     fp.tan_fovx = tan_fovx; fp.tan_fovy = tan_fovy;
@@ -784,7 +801,8 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                          const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
                          char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                          float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                         float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_second_colors* second);
+                         float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_second_colors* second,
+                         const wg_raw_gaussians* raw = nullptr);
 
 int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
                                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
@@ -798,6 +816,21 @@ int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* backgro
                          viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, subpixel_offset, radii, geom_buffer, binning_buffer,
                          image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
                          debug, stream_, tone, nullptr);
+}
+
+int wg_rasterize_backward_raw(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                              const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                              const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                              const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
+                              const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
+                              char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                              float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                              float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_raw_gaussians* raw) {
+    if (raw == nullptr) return WG_ERR_INVALID_ARGUMENT;
+    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                         viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, subpixel_offset, radii, geom_buffer, binning_buffer,
+                         image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                         debug, stream_, tone, nullptr, raw);
 }
 
 int wg_rasterize_backward_dual(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
@@ -822,11 +855,16 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                          const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
                          char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                          float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                         float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_second_colors* second) {
+                         float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_second_colors* second,
+                         const wg_raw_gaussians* raw) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const wg::Options opt = options_snapshot();
     // two colour sets over one walk: the gradient record is where the thirteen sums go, the deterministic mode's slots hold ten
     const bool dual = second != nullptr && P > 0;
+    // raw-parameter mode: the per-Gaussian kernel turns the gradients of the activated values into those of the raw parameters where it
+    // WRITES them, i.e. with the gradient record
+    if (raw != nullptr && P > 0 && (!raw->filter_3D || !raw->raw_opacities || !scales || !rotations || cov3D_precomp ||
+                                    !(opt.grad_record || opt.deterministic_backward))) return WG_ERR_INVALID_ARGUMENT;
     if (dual && (!second->dL_dpix2 || !second->dL_dcolor2 || shs != nullptr || !opt.grad_record || opt.deterministic_backward)) return WG_ERR_INVALID_ARGUMENT;
     if (image_buffer != nullptr) {   // a deferred forward call's verdict, before anything is differentiated (found by its image buffer: the
         const void* key = reinterpret_cast<const void*>((reinterpret_cast<uintptr_t>(image_buffer) + wg::ALIGN - 1) & ~(uintptr_t)(wg::ALIGN - 1));
@@ -914,6 +952,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     bp.focal_x = width / (2.0f * tan_fovx);
     bp.kernel_size = kernel_size; bp.radii = radii;
     bp.dL_dcolor2 = dual ? second->dL_dcolor2 : nullptr;
+    if (raw != nullptr) { bp.filter_3D = raw->filter_3D; bp.raw_opacities = raw->raw_opacities; }
     WG_STAGE(WG_STAGE_PREPROCESS_BACKWARD, wg::launch_preprocess_backward(bp, device_tone(tone), geom, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                             dL_dscale, dL_drot, record, stream),
              "preprocess_backward");

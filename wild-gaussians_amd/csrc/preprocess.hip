@@ -11,6 +11,7 @@
 // per-Gaussian outputs packed into one 48-byte record that the render kernels gather in one go.
 #include "wg_common.h"
 #include "wg_alpha.h"
+#include "wg_act.h"
 
 #pragma clang fp contract(off)
 
@@ -73,7 +74,10 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
     // Geometry inputs first, SH block second: the memory counter retires loads in issue order, so whatever the geometry
     // waits for has to be issued ahead of the twelve SH loads for those to stay in flight behind it.
     float px = p.means3D[3 * ld], py = p.means3D[3 * ld + 1], pz = p.means3D[3 * ld + 2];
-    const float opacity = p.opacities[ld];
+    float opacity = p.opacities[ld];
+    // raw-parameter mode: the 3-D filter's value, loaded with the rest (through a pointer that is always valid: a branch around a
+    // load here would be a join the compiler waits at for every load in flight)
+    float filt = (p.filter_3D ? p.filter_3D : p.opacities)[ld];
     float sc0 = 0.f, sc1 = 0.f, sc2 = 0.f;
     float4 quat = make_float4(0.f, 0.f, 0.f, 0.f);
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f;
@@ -96,7 +100,13 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
 #undef WG_SH_LOAD
     }
     // pin the order: nothing of the geometry below may be scheduled ahead of the SH loads, nor the LDS staging ahead of it
-    asm volatile("" : "+v"(px), "+v"(py), "+v"(pz) : : "memory");
+    asm volatile("" : "+v"(px), "+v"(py), "+v"(pz), "+v"(filt) : : "memory");
+    if (!PRECOMP && p.filter_3D != nullptr) {   // wave-uniform: get_gaussians() (method.py:1060-1086) on the raw parameters
+        const ActFwd a = act_forward(quat, sc0, sc1, sc2, opacity, filt);
+        quat = a.q;
+        sc0 = a.sc[0]; sc1 = a.sc[1]; sc2 = a.sc[2];
+        opacity = a.o * a.coef;
+    }
 
     // forward.cu:200-201
     int radius_i = 0;

@@ -18,6 +18,7 @@
 //  - dL_dmean3D is OVERWRITTEN by the covariance path then accumulated (backward.cu:309,423,138);
 //  - the quaternion gradient is w.r.t. the un-normalised quaternion (backward.cu:376).
 #include "wg_common.h"
+#include "wg_act.h"
 
 namespace wg {
 
@@ -106,9 +107,12 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     int cl = clamped[ld];
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     float sc0 = 0.f, sc1 = 0.f, sc2 = 0.f;
+    float raw_op = 0.f, filt = 0.f;   // raw-parameter mode (wg_raw_gaussians): loaded with the rest, through pointers that are always valid
     if (HAS_SCALES) {
         q = reinterpret_cast<const float4*>(p.rotations)[ld];
         sc0 = p.scales[3 * ld]; sc1 = p.scales[3 * ld + 1]; sc2 = p.scales[3 * ld + 2];
+        raw_op = (p.raw_opacities ? p.raw_opacities : p.scales)[ld];
+        filt = (p.filter_3D ? p.filter_3D : p.scales)[ld];
     }
     __builtin_amdgcn_sched_barrier(0);  // the machine scheduler would otherwise slip some of the loads above behind the SH ones
     float4 sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7, sr8, sr9, sr10, sr11;
@@ -125,9 +129,18 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     asm volatile(""
                  : "+v"(mx), "+v"(my), "+v"(mz), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(dconic.x), "+v"(dconic.y),
                    "+v"(dconic.w), "+v"(combined_opacity), "+v"(dLdo_in), "+v"(g2x), "+v"(g2y), "+v"(g2abs), "+v"(cl), "+v"(dcol0), "+v"(dcol1),
-                   "+v"(dcol2), "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w), "+v"(sc0), "+v"(sc1), "+v"(sc2), "+v"(radius)
+                   "+v"(dcol2), "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w), "+v"(sc0), "+v"(sc1), "+v"(sc2), "+v"(radius), "+v"(raw_op), "+v"(filt)
                  :
                  : "memory");
+    // raw-parameter mode: what the forward kernel made of the raw parameters, recomputed (nothing was saved); the gradients of the
+    // activated values are turned into those of the raw ones where they are written, below
+    const bool raw_mode = HAS_SCALES && p.filter_3D != nullptr;   // wave-uniform
+    ActFwd act{};
+    if (raw_mode) {
+        act = act_forward(q, sc0, sc1, sc2, raw_op, filt);
+        q = act.q;
+        sc0 = act.sc[0]; sc1 = act.sc[1]; sc2 = act.sc[2];
+    }
     const bool vis = in && radius > 0;
     if (RECORD) {
         // the factors the per-tile pass leaves out (render_bwd.hip): mean2D.x = o * 0.5W / log2e * sum(q u'), .y likewise with 0.5H,
@@ -274,6 +287,15 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
             dq.w = 2 * r * (D(0, 1) - D(1, 0)) + 2 * x * (D(2, 0) + D(0, 2)) + 2 * y * (D(1, 2) + D(2, 1)) - 4 * z * (D(1, 1) + D(0, 0));
 #undef D
         }
+    }
+
+    if (raw_mode) {   // (RECORD only: api.hip refuses the combination otherwise)
+        float gs[3], go;
+        float4 gr;
+        act_backward(act, dq, dsc, write_dLdo ? dLdo_out : dLdo_in, gr, gs, go);
+        dq = gr;
+        dsc[0] = gs[0]; dsc[1] = gs[1]; dsc[2] = gs[2];
+        dLdo_out = dLdo_in = go;
     }
 
     // ---- the outputs that do not depend on the SH block ----

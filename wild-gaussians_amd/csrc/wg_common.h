@@ -177,6 +177,8 @@ struct FwdParams {
     const float* cam_pos;
     float tan_fovx, tan_fovy, focal_x, focal_y, kernel_size;
     int prefiltered;
+    const float* filter_3D = nullptr;   // raw-parameter mode (wg_raw_gaussians): opacities / scales / rotations above are the caller's RAW
+                                        // parameters and get_gaussians() (method.py:1060-1086) runs inside the kernel (wg_act.h)
 };
 
 // kernels / stages (each launches on `stream`, returns hipGetLastError())
@@ -280,6 +282,8 @@ struct BwdParams {
     float tan_fovx, tan_fovy, focal_x, focal_y, kernel_size;
     const int* radii;
     float* dL_dcolor2 = nullptr;    // two-colour walk: [P,3], written from the record's floats 10, 11 and grad_aux
+    const float* filter_3D = nullptr;      // raw-parameter mode: scales / rotations above are RAW, raw_opacities the raw opacities; dL_dscale /
+    const float* raw_opacities = nullptr;  // dL_drot / dL_dopacity come out as the gradients of the RAW parameters
 };
 // record: the four arrays are OUTPUTS computed from g.grad_rec (see GRAD_REC_*); otherwise inputs accumulated by the per-tile pass
 hipError_t launch_preprocess_backward(const BwdParams& p, const ShTone& tone, const GeometryState& g, float* dL_dmean2D,

@@ -57,6 +57,14 @@ class _SecondColors(C.Structure):  # include/wg_rasterizer.h: wg_second_colors
     _fields_ = [("colors_precomp2", _vp), ("out_color2", _vp), ("dL_dpix2", _vp), ("dL_dcolor2", _vp)]
 
 
+class _RawGaussians(C.Structure):  # include/wg_rasterizer.h: wg_raw_gaussians
+    _fields_ = [("filter_3D", _vp), ("raw_opacities", _vp)]
+
+
+_lib.wg_rasterize_forward_raw.restype = _i
+_lib.wg_rasterize_forward_raw.argtypes = _lib.wg_rasterize_forward.argtypes + [C.POINTER(_ShTone), C.POINTER(_RawGaussians)]
+_lib.wg_rasterize_backward_raw.restype = _i
+_lib.wg_rasterize_backward_raw.argtypes = _lib.wg_rasterize_backward.argtypes + [C.POINTER(_ShTone), C.POINTER(_RawGaussians)]
 _lib.wg_rasterize_forward_dual.restype = _i
 _lib.wg_rasterize_forward_dual.argtypes = _lib.wg_rasterize_forward.argtypes + [C.POINTER(_SecondColors)]
 _lib.wg_rasterize_backward_dual.restype = _i
@@ -278,8 +286,10 @@ def forget_geometry():
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width, sh, degree,
-                        campos, prefiltered, debug, sh_tone=None, binning_capacity=None, colors2=None):
-    """colors2 (beyond the reference: wg_second_colors, include/wg_rasterizer.h): a second [P,3] set of precomputed colours composited in
+                        campos, prefiltered, debug, sh_tone=None, binning_capacity=None, colors2=None, filter_3D=None):
+    """filter_3D (beyond the reference: wg_raw_gaussians): opacity / scales / rotations are the caller's RAW parameters and
+    get_gaussians() (method.py:1060-1086) runs inside the preprocess kernel.
+    colors2 (beyond the reference: wg_second_colors, include/wg_rasterizer.h): a second [P,3] set of precomputed colours composited in
     the same walk; the tuple then ends with a seventh element, the second image.
     binning_capacity (beyond the reference): an int makes the call wg_rasterize_forward_fixed -- no host rendezvous, capturable in
     a hipGraph; the returned `rendered` is then the capacity, and forward_status(imgBuffer, H, W) tells the real count and whether
@@ -292,11 +302,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     P, H, W = means3D.size(0), int(image_height), int(image_width)
 
     # precomputed colours over remembered geometry: no projection, no binning
+    if filter_3D is not None and (colors2 is not None or binning_capacity is not None or scales.numel() == 0 or filter_3D.numel() != P):
+        raise RuntimeError("filter_3D (raw-parameter mode) needs scales and rotations, P filter values, and neither colors2 nor binning_capacity")
     if colors2 is not None:
         if sh_tone is not None or binning_capacity is not None or sh.numel() != 0 or colors.numel() != 3 * P or colors2.numel() != 3 * P:
             raise RuntimeError("colors2 needs precomputed colours of P x 3 in both sets (no SH, no sh_tone, no binning_capacity)")
     reusable = (P != 0 and sh_tone is None and not debug and colors.numel() == 3 * P and sh.numel() == 0 and colors2 is None
-                and _lib.wg_get_option(b"geometry_reuse") == 1)
+                and filter_3D is None and _lib.wg_get_option(b"geometry_reuse") == 1)
     if binning_capacity is not None and debug:
         raise RuntimeError("binning_capacity (wg_rasterize_forward_fixed) has no debug mode")
     key = None
@@ -354,6 +366,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                     _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
                     float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
                     int(bool(debug)), _stream(device), C.byref(second))
+            elif filter_3D is not None:
+                filter_3D = _f32(filter_3D, device)
+                rawg = _RawGaussians(filter_3D.data_ptr(), None)
+                rendered = _lib.wg_rasterize_forward_raw(
+                    geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
+                    _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
+                    _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                    float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
+                    int(bool(debug)), _stream(device), None if tone is None else C.byref(tone), C.byref(rawg))
             elif binning_capacity is None:
                 rendered = _lib.wg_rasterize_forward_toned(
                     geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
@@ -382,8 +403,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, dL_dout_color, sh,
-                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, sh_tone=None, dL_dout_color2=None):
-    """dL_dout_color2 (a frame rasterized with colors2): the second image's cotangent; the result ends with dL_dcolors2 [P,3].
+                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, sh_tone=None, dL_dout_color2=None, raw=None):
+    """raw = (filter_3D, raw_opacities) of a raw-parameter forward call: dL_dopacity / dL_dscales / dL_drotations are then the gradients
+    of the RAW parameters.
+    dL_dout_color2 (a frame rasterized with colors2): the second image's cotangent; the result ends with dL_dcolors2 [P,3].
     With sh_tone (see rasterize_gaussians) two more tensors are appended to the result: dL_dsh_mul, dL_dsh_offset (None where the
     input was None), and dL_dsh is the gradient w.r.t. the raw coefficients."""
     global _reuse_epoch
@@ -420,6 +443,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dsh = alloc((P, M, 3), dtype=torch.float32, device=device)
     dL_dscales = (alloc if have_scales else torch.zeros)((P, 3), dtype=torch.float32, device=device)
     dL_drotations = (alloc if have_scales else torch.zeros)((P, 4), dtype=torch.float32, device=device)
+    if raw is not None and (not record or dL_dout_color2 is not None):
+        raise RuntimeError("the raw-parameter backward pass needs grad_record = 1 and cannot be combined with the two-colour call")
     dual = dL_dout_color2 is not None
     if dual and (sh_tone is not None or not record or _lib.wg_get_option(b"deterministic_backward") == 1):
         raise RuntimeError("the two-colour backward pass needs grad_record = 1, deterministic_backward = 0 and no sh_tone")
@@ -450,13 +475,17 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 dL2 = _f32(dL_dout_color2, device)
                 second = _SecondColors(None, None, dL2.data_ptr(), dL_dcolors2.data_ptr())
                 status = _lib.wg_rasterize_backward_dual(*common, C.byref(second))
+            elif raw is not None:
+                f3d, rop = _f32(raw[0], device), _f32(raw[1], device)
+                rawg = _RawGaussians(f3d.data_ptr(), rop.data_ptr())
+                status = _lib.wg_rasterize_backward_raw(*common, None if tone is None else C.byref(tone), C.byref(rawg))
             else:
                 status = _lib.wg_rasterize_backward_toned(*common, None if tone is None else C.byref(tone))
         _check(status, "wg_rasterize_backward")
     out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     if dual:
         return out + (dL_dcolors2,)
-    return out if sh_tone is None else out + tone_grads
+    return out if sh_tone is None else out + tone_grads   # (raw-parameter mode: same tuple, slots 2, 6, 7 are gradients of the raw parameters)
 
 
 def forward_status(imageBuffer, H, W):

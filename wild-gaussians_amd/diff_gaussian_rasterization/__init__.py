@@ -74,7 +74,8 @@ def _accumulation_from_image_state(img_buffer: torch.Tensor, height: int, width:
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None, colors_precomp2=None):
+                sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None, colors_precomp2=None,
+                filter_3D=None):
         rs = raster_settings
         native_args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset,
@@ -92,11 +93,19 @@ class _RasterizeGaussians(torch.autograd.Function):
         # beyond the reference: a second set of precomputed colours composited in the same walk (wg_second_colors)
         ctx.dual = colors_precomp2 is not None
         color2 = None
+        # beyond the reference: opacities / scales / rotations are the RAW parameters, get_gaussians() runs in-kernel (wg_raw_gaussians)
+        ctx.raw = filter_3D is not None
+        if ctx.raw and (ctx.dual or binning_capacity is not None):
+            raise Exception("filter_3D (raw-parameter mode) cannot be combined with colors_precomp2 / binning_capacity")
         if ctx.dual:
             if ctx.sh_tone is not None or binning_capacity is not None:
                 raise Exception("colors_precomp2 cannot be combined with sh_mul / sh_offset / binning_capacity")
             num_rendered, color, radii, geom_buf, binning_buf, img_buf, color2 = _call_native(
                 lambda *a: _C.rasterize_gaussians(*a, colors2=colors_precomp2), native_args, rs.debug, "snapshot_fw.dump", "forward")
+        elif ctx.raw:
+            tone_arg = ctx.sh_tone
+            num_rendered, color, radii, geom_buf, binning_buf, img_buf = _call_native(
+                lambda *a: _C.rasterize_gaussians(*a[:21], sh_tone=tone_arg, filter_3D=filter_3D), native_args, rs.debug, "snapshot_fw.dump", "forward")
         else:
             num_rendered, color, radii, geom_buf, binning_buf, img_buf = _call_native(
                 _C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
@@ -106,7 +115,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         # radii and accumulation take no gradient (reference backward signature (ctx, grad_out_color, _, _), :117): do not let
         # autograd materialise P- and H*W-sized zero tensors for them on every backward pass
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf)
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf,
+                              *((filter_3D, opacities) if ctx.raw else ()))
 
         accumulation = None
         if rs.return_accumulation:
@@ -121,7 +131,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii, _grad_accumulation, grad_out_color2=None):
         rs = ctx.raster_settings
-        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf = ctx.saved_tensors
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf = ctx.saved_tensors[:10]
         if grad_out_color is None:  # the image itself took no gradient (only radii / accumulation were used downstream)
             grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
         native_args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
@@ -133,6 +143,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                 grad_out_color2 = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
             (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations, g_colors2) = _call_native(
                 lambda *a: _C.rasterize_gaussians_backward(*a, dL_dout_color2=grad_out_color2), native_args, rs.debug, "snapshot_bw.dump", "backward")
+        elif ctx.raw:
+            raw = tuple(ctx.saved_tensors[10:12])
+            res = _call_native(lambda *a: _C.rasterize_gaussians_backward(*a[:23], sh_tone=ctx.sh_tone, raw=raw), native_args, rs.debug,
+                               "snapshot_bw.dump", "backward")
+            (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations) = res[:8]
+            if ctx.sh_tone is not None:
+                mul, offset = ctx.sh_tone[:2]
+                g_mul = None if mul is None else res[8].view(mul.shape)
+                g_offset = None if offset is None else res[9].view(offset.shape)
         elif ctx.sh_tone is None:
             (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations) = _call_native(
                 _C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
@@ -143,13 +162,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_mul = None if mul is None else g_mul.view(mul.shape)
             g_offset = None if offset is None else g_offset.view(offset.shape)
         # order of forward()'s inputs; None for raster_settings and the two clamp constants
-        return g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3Ds, None, g_mul, g_offset, None, None, None, g_colors2
+        return g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3Ds, None, g_mul, g_offset, None, None, None, g_colors2, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
-                        sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None, colors_precomp2=None):
+                        sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None, colors_precomp2=None,
+                        filter_3D=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity, colors_precomp2)
+                                     raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity, colors_precomp2,
+                                     filter_3D)
 
 
 class GaussianRasterizer(nn.Module):
@@ -168,8 +189,14 @@ class GaussianRasterizer(nn.Module):
                 rotations: Optional[torch.Tensor] = None, cov3D_precomp: Optional[torch.Tensor] = None, *,
                 sh_mul: Optional[torch.Tensor] = None, sh_offset: Optional[torch.Tensor] = None,
                 sh_pre_clamp_max: Optional[float] = None, sh_post_clamp_max: Optional[float] = None,
-                binning_capacity: Optional[int] = None, colors_precomp2: Optional[torch.Tensor] = None):
-        """`colors_precomp2=` (keyword-only, beyond the reference; with `colors_precomp`): a second [P,3] colour set composited in the SAME
+                binning_capacity: Optional[int] = None, colors_precomp2: Optional[torch.Tensor] = None,
+                filter_3D: Optional[torch.Tensor] = None):
+        """`filter_3D=` (keyword-only, beyond the reference): `opacities`, `scales`, `rotations` are then the caller's RAW
+        parameters (logit, log-scale, unnormalised quaternion) and `get_gaussians()` (method.py:1060-1086: normalise, exp, sigmoid, 3-D
+        filter with this [P,1] tensor) runs inside the preprocess kernels, forward and backward: the gradients returned for those three
+        inputs are the raw parameters'.  Composes with `shs` + `sh_mul` / `sh_offset` (the whole step before the operator in-kernel).
+
+        `colors_precomp2=` (keyword-only, beyond the reference; with `colors_precomp`): a second [P,3] colour set composited in the SAME
         call -- one projection, one binning, one forward and one backward walk for both (WildGaussians' raw and toned colours,
         method.py:1573-1611).  Returns `(color, radii, accumulation, color2)`; gradients flow to both colour
         tensors, the geometry gradients are those of both images' losses together.
@@ -200,4 +227,4 @@ class GaussianRasterizer(nn.Module):
             _absent() if scales is None else scales,
             _absent() if rotations is None else rotations,
             _absent() if cov3D_precomp is None else cov3D_precomp,
-            self.raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity, colors_precomp2)
+            self.raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity, colors_precomp2, filter_3D)

@@ -135,8 +135,12 @@ def governing_roofline(dom: str, d: dict, pmc_row, launch_ms: float, survey_byte
     if valu_frac is not None and valu_frac >= hbm_frac:
         r = {"bound": "valu_issue", "kernel": dom, "achieved": round(valu_frac * VALU_ISSUE_PEAK_G, 1), "peak": round(VALU_ISSUE_PEAK_G, 1),
              "unit": "G wave-instr/s", "frac": valu_frac, "wave_instructions_per_launch": pmc_row["SQ_INSTS_VALU"],
-             "note": "SQ_INSTS_VALU (PMC pass, stamped to these kernel sources) / this run's HIP-event time; a few instruction kinds "
-                     "(readlane, DPP moves) take fewer than 4 cycles, so a kernel at the ceiling can read above 1"}
+             "valu_busy": pmc_row.get("valu_busy"),   # measured: 4 * SQ_ACTIVE_INST_VALU / (SIMDs * kernel cycles), scripts/pmc_traffic.py
+             "note": "frac = SQ_INSTS_VALU (PMC pass, stamped to these kernel sources) / this run's HIP-event time / the ceiling of one wave64 "
+                     "VALU instruction per SIMD per 4 cycles (MI355X_MICROARCH.md lists v_fma_f32 at 2 cycles on a 32-wide SIMD; this part's "
+                     "counters and scripts/pk_probe.hip -> profiles/r4/pk_probe.txt say 4: plain FMA peaks at ~half of the packed rate); "
+                     "valu_busy is the counters' own busy fraction, with no constant in it.  The >= 0.60 HBM target is judged on "
+                     "hbm.by_survey_8d_bytes.frac"}
     else:
         basis = "by_survey_8d_bytes" if hbm["by_survey_8d_bytes"]["frac"] is not None else ("by_pmc_traffic" if by_traffic else "by_design_bytes")
         r = {"bound": "hbm", "kernel": dom, "achieved": hbm[basis]["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

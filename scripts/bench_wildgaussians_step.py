@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--in-kernel-sh", action="store_true",
                     help="SURVEY 8f N3 (caller side): hand the SH features to the operator (shs=) instead of evaluating them in torch")
     ap.add_argument("--fused-activations", action="store_true", help="SURVEY 8f N3: wg_fused_gaussians.activate instead of the torch ops")
+    ap.add_argument("--in-kernel-activations", action="store_true",
+                    help="SURVEY 8f N3: activations + 3-D filter inside the operator's preprocess kernels (filter_3D=): no activation kernels at all")
     ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the foreach implementation")
     ap.add_argument("--wg-adam", action="store_true", help="SURVEY 8f N4: wg_fused_gaussians.FusedAdam (one launch over all parameters)")
     ap.add_argument("--densification-stats", choices=["off", "torch", "fused"], default="off",
@@ -248,7 +250,11 @@ def main():
 
     def step():
         means2D = torch.zeros_like(prm["xyz"], requires_grad=True)
-        if args.fused_activations:
+        raw_kw = {}
+        if args.in_kernel_activations:   # SURVEY 8f N3 as worded: get_gaussians() inside the preprocess kernels (filter_3D=)
+            opac, scales, rot = prm["opacities"], prm["scales"], prm["rotations"]
+            raw_kw = dict(filter_3D=filter_3d)
+        elif args.fused_activations:
             from wg_fused_gaussians import activate
             opac, scales, rot = activate(prm["opacities"], prm["scales"], prm["rotations"], filter_3d)
         else:
@@ -258,7 +264,7 @@ def main():
             s2f = s2 + filter_3d * filter_3d
             scales = s2f.sqrt()
             opac = torch.sigmoid(prm["opacities"]) * torch.sqrt(s2.prod(1) / s2f.prod(1))[:, None]
-        kw = dict(means3D=prm["xyz"], means2D=means2D, opacities=opac, scales=scales, rotations=rot)
+        kw = dict(means3D=prm["xyz"], means2D=means2D, opacities=opac, scales=scales, rotations=rot, **raw_kw)
         if args.in_kernel_tone:
             shs = prm["features"].view(P, 16, 3)
             raw, radii, acc = rast_sh(shs=shs, sh_pre_clamp_max=1.0, **kw)

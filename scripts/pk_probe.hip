@@ -1,5 +1,8 @@
 // Probe: is v_pk_fma_f32 issued at the same rate as v_fma_f32 on gfx950?  (scripts/, not part of the library)
-// build: hipcc --offload-arch=gfx950 -O3 scripts/pk_probe.hip -o gpurun_out/pk_probe ; run on the GPU box
+// build: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize scripts/pk_probe.hip -o gpurun_out/pk_probe ; run on the GPU box
+// (-fno-slp-vectorize is essential: at plain -O3 the SLP vectoriser packs k_scalar's sixteen independent FMAs into eight v_pk_fma_f32 and
+//  the probe compares packed with packed -- check with llvm-objdump that k_scalar holds v_fma_f32.  The first repetition runs on cold
+//  clocks; read the later ones.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -40,7 +43,7 @@ int main() {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int iters = 4096;
-    for (int rep = 0; rep < 2; rep++) {
+    for (int rep = 0; rep < 5; rep++) {
         float ms;
         hipEventRecord(e0);
         hipLaunchKernelGGL(k_scalar, dim3(2048), dim3(256), 0, 0, out, 0.999f, 0.001f, iters);

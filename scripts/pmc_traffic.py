@@ -22,7 +22,8 @@ STAGE_OF = {"preprocess_kernel": "preprocess", "tile_count_kernel": "scan", "chu
             "render_backward_kernel": "render_backward", "preprocess_backward_kernel": "preprocess_backward"}
 vals = {}
 for line in open(sys.argv[1]):
-    m = re.match(r"(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU|SQ_INSTS_SALU|SQ_INSTS_LDS)\s+dispatches=\s*\d+\s+per_dispatch=\s*(\d+)", line)
+    m = re.match(r"(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU|SQ_INSTS_SALU|SQ_INSTS_LDS|SQ_ACTIVE_INST_VALU|GRBM_GUI_ACTIVE|SQ_LDS_BANK_CONFLICT|"
+                 r"SQ_INSTS_VALU_TRANS_F32)\s+dispatches=\s*\d+\s+per_dispatch=\s*(\d+)", line)
     if not m:
         continue
     name = re.sub(r"^void ", "", m.group(1)).split("(")[0].replace("wg::", "").split("<")[0]
@@ -38,4 +39,13 @@ except Exception:  # noqa: BLE001
     src_sha = None
 out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "kernel_source_sha": src_sha, "collected": time.strftime("%Y-%m-%d"), "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving; WRITE_SIZE as reported)",
        "stages": {k: dict(v, hbm_bytes=(2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024) for k, v in vals.items()}}
+# How busy the vector ALUs were, from counters alone: SQ_ACTIVE_INST_VALU counts, summed over all SIMDs, the cycles a
+# SIMD's VALU was executing an instruction, in units of 4 cycles; GRBM_GUI_ACTIVE the kernel's cycles, summed over the 8 XCDs.
+#   valu_busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
+# (the two come from different passes of the same command, so a few percent of run-to-run spread are in it; multi-pass instructions --
+# transcendentals, DPP -- can push it past 1 by this accounting).  A stage of several kernels sums both counters over them.
+for st in out["stages"].values():
+    if st.get("SQ_ACTIVE_INST_VALU") and st.get("GRBM_GUI_ACTIVE"):
+        st["valu_busy"] = round(4.0 * st["SQ_ACTIVE_INST_VALU"] / (1024.0 * st["GRBM_GUI_ACTIVE"] / 8.0), 3)
+out["valu_busy_note"] = "4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs): fraction of SIMD cycles with the vector ALU executing"
 print(json.dumps(out, indent=1))

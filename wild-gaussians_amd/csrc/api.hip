@@ -55,6 +55,7 @@ struct DeferredTicket {
     uint32_t seq;
     uint32_t reported_seq;  // the frame whose failure a backward call has already returned (the owning thread's settle then stays quiet)
     bool reported;
+    hipStream_t stream;     // the stream the deferred forward call was queued on (what a waiting backward-side check synchronises)
 };
 std::mutex g_ticket_mu;
 std::vector<DeferredTicket> g_tickets;
@@ -286,21 +287,29 @@ int settle_deferred() {
     t_spec.push(t_deferred.P, t_deferred.W, t_deferred.H, st.num_rendered, st.max_tile_count);
     t_last_instances_per_tile = st.num_rendered / (uint32_t)std::max(1, ((t_deferred.W + wg::TILE_X - 1) / wg::TILE_X) * ((t_deferred.H + wg::TILE_Y - 1) / wg::TILE_Y));
     t_wait.spec_frames += 1;
-    if (st.spec_fail != 0u) {
-        t_wait.spec_misses += 1;
+    // The owning thread has the verdict now: the frame's ticket gives its address up (a frame that is never differentiated -- evaluation,
+    // no_grad -- would otherwise leave it there for whatever frame the caller's allocator hands the same address to next).
+    bool reported_already = false;
+    {
         std::lock_guard<std::mutex> l(g_ticket_mu);
         for (auto& k : g_tickets)
-            if (k.host == mb.host && k.reported && k.reported_seq == t_deferred.seq) return WG_OK;  // its backward call has said so already
-        return WG_ERR_SPECULATION;
+            if (k.host == mb.host) {
+                if (k.reported && k.reported_seq == t_deferred.seq) reported_already = true;   // its backward call has said so already
+                if (k.seq == t_deferred.seq) k.image_buffer = nullptr;
+            }
+    }
+    if (st.spec_fail != 0u) {
+        t_wait.spec_misses += 1;
+        return reported_already ? WG_OK : WG_ERR_SPECULATION;
     }
     return WG_OK;
 }
 
-void post_ticket(const void* image_buffer, const wg::HostMailbox* host, uint32_t seq) {
+void post_ticket(const void* image_buffer, const wg::HostMailbox* host, uint32_t seq, hipStream_t stream) {
     std::lock_guard<std::mutex> l(g_ticket_mu);
     for (auto& t : g_tickets)
-        if (t.host == host) { t.image_buffer = image_buffer; t.seq = seq; return; }
-    g_tickets.push_back({image_buffer, host, seq, 0u, false});
+        if (t.host == host) { t.image_buffer = image_buffer; t.seq = seq; t.stream = stream; return; }
+    g_tickets.push_back({image_buffer, host, seq, 0u, false, stream});
 }
 
 // Backward side: was `image_buffer` produced by a deferred forward call whose verdict nobody has looked at yet, and did it fit?
@@ -339,7 +348,7 @@ int check_ticket(const void* image_buffer, hipStream_t stream) {
         // a later frame of the owning thread is in the mailbox: that thread's call has settled (and reported) this one already
         if ((int32_t)(sa - t.seq) > 0 || (int32_t)(sb - t.seq) > 0) { consume(false); return WG_OK; }
         if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-            hipError_t e = hipStreamSynchronize(stream);   // the frame's scan has not run yet: wait for the stream once, then look again
+            hipError_t e = hipStreamSynchronize(t.stream ? t.stream : stream);   // the frame's scan has not run yet: wait for the stream the forward call was queued on, then look again
             if (e != hipSuccess) return hip_fail(e, "deferred forward (backward-side check)");
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(6)) return hip_fail(hipErrorUnknown, "deferred forward: the instance count never arrived");
         }
@@ -674,13 +683,17 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
                         t_deferred.seq = mbox->seq;
                         t_deferred.P = P; t_deferred.W = width; t_deferred.H = height;
                         t_deferred.stream = stream;
-                        post_ticket(img.final_T, mbox->host, mbox->seq);   // (the state's first array: image_alloc's pointer, aligned)
+                        post_ticket(img.final_T, mbox->host, mbox->seq, stream);   // (the state's first array: image_alloc's pointer, aligned)
                     }
                     return (int)spec.capacity;
                 }
             }
         } else {
             huge_frame = true;  // tile histogram does not fit LDS: count through the per-Gaussian prefix sum instead
+            {   // tile_scan, which fills the frame's BinStats, does not run on this path: wg_forward_status must not read a fresh buffer's bytes
+                hipError_t e0 = hipMemsetAsync(img.stats, 0, sizeof(wg::BinStats), stream);
+                if (e0 != hipSuccess) return hip_fail(e0, "stats memset");
+            }
             WG_STAGE(WG_STAGE_SCAN, wg::run_scan(geom, P, stream), "inclusive_scan");
             WG_STAGE(WG_STAGE_SCAN, wg::launch_scan_overflow_check(geom, P, &img.stats->max_tile_count, stream), "scan_overflow_check");
         }
@@ -725,6 +738,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
         }
     } else {
         hipError_t e = hipMemsetAsync(img.ranges, 0, (size_t)tiles * sizeof(uint2), stream);
+        if (e == hipSuccess) e = hipMemsetAsync(img.stats, 0, sizeof(wg::BinStats), stream);   // (no Gaussians: nothing rendered, fits)
         if (e != hipSuccess) return hip_fail(e, "ranges memset");
     }
     if (rendered) return num_rendered;

@@ -128,8 +128,15 @@ __device__ __forceinline__ float butterfly13(float v0, float v1, float v2, float
 // DUAL (RECORD, !DET): two colour sets over one walk (wg_second_colors, include/wg_rasterizer.h).  The record's spare floats carry the second
 // colour; each set keeps its own dL_dalpha chain (accum_rec, background term), their sum feeds the nine geometry sums -- linear in it --
 // and the abs-gradient takes |q1| + |q2|, as two calls would accumulate it; thirteen sums are reduced per instance instead of 2 x 10.  Sums 10, 11 go to the record's two spare floats, sum 12 to grad_aux[id].
+#ifndef WG_BWD_DUAL_WAVES
+#define WG_BWD_DUAL_WAVES 0
+#endif
 template <bool RECORD, bool DET = false, bool EXACT = false, bool DUAL = false>
-__global__ void __launch_bounds__(64) WG_BWD_OCC render_backward_kernel(
+__global__ void __launch_bounds__(64) WG_BWD_OCC
+#if WG_BWD_DUAL_WAVES
+__attribute__((amdgpu_waves_per_eu(DUAL ? WG_BWD_DUAL_WAVES : 1, DUAL ? WG_BWD_DUAL_WAVES : 8)))
+#endif
+render_backward_kernel(
     int W, int H, int gx, int tiles, const uint32_t* __restrict__ order, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ tile_last,

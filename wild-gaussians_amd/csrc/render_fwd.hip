@@ -309,8 +309,16 @@ __global__ void __launch_bounds__(64) WG_FWD_OCC render_forward_kernel(
 }
 
 // the two-colour walk keeps twelve more sums per lane: its register allocation is left to the compiler (no occupancy pin)
+#ifndef WG_FWD_DUAL_WAVES
+#define WG_FWD_DUAL_WAVES 6   // 80 VGPRs (two spilled outside the loop): 1.737 / 1.711 ms against 1.743 / 1.751 unpinned (3 M real-caller replay, profiles/r4/ab_two_colour_occupancy.txt)
+#endif
+#if WG_FWD_DUAL_WAVES
+#define WG_FWD_DUAL_OCC __attribute__((amdgpu_waves_per_eu(WG_FWD_DUAL_WAVES, WG_FWD_DUAL_WAVES)))
+#else
+#define WG_FWD_DUAL_OCC
+#endif
 template <bool EXACT>
-__global__ void __launch_bounds__(64) render_forward_dual_kernel(
+__global__ void __launch_bounds__(64) WG_FWD_DUAL_OCC render_forward_dual_kernel(
     int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     const uint32_t* seg_end, uint32_t* __restrict__ tile_state,

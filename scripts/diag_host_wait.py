@@ -72,4 +72,18 @@ _C.set_option("speculative_forward", 1)
 call(8 * 1024 * 1024)
 n, _ = _C.last_forward_status()
 out["flows"].append(measure("fixed capacity (no rendezvous)", capacity=int(1.25 * n) + 4096))
+# the compiled torch binding (csrc/torch_binding.cpp, WG_BINDING=torch) against the ctypes one, same flows: what the marshalling costs
+try:
+    _C.use_binding("torch")
+    _C.set_option("speculative_forward", 1)
+    out["flows"].append(measure("speculative, compiled torch binding"))
+    _C.set_option("speculative_forward", 2)
+    _C.set_option("spec_margin_pct", 50)
+    out["flows"].append(measure("deferred speculation, compiled torch binding"))
+    _C.set_option("spec_margin_pct", 25)
+    _C.set_option("speculative_forward", 1)
+except ImportError as ex:
+    out["compiled_binding"] = f"not built: {ex}"
+finally:
+    _C.use_binding("ctypes")
 print(json.dumps(out))

@@ -135,6 +135,58 @@ def test_round3_entry_points_reject_invalid_arguments_before_any_device_work(lib
     assert not called
 
 
+def test_round4_entry_points_reject_invalid_arguments_before_any_device_work(lib):
+    """wg_rasterize_{forward,backward}_dual (two colour sets in one call) and _raw (get_gaussians() inside the preprocess kernels): no
+    allocator callback and no HIP call before the arguments have been checked (this test runs on a box without a GPU)."""
+    ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    called = []
+    cb = ALLOC(lambda n, u: called.append(n) or 0)
+    one = C.c_void_p(16)
+
+    class Second(C.Structure):
+        _fields_ = [("colors_precomp2", vp), ("out_color2", vp), ("dL_dpix2", vp), ("dL_dcolor2", vp)]
+
+    class Raw(C.Structure):
+        _fields_ = [("filter_3D", vp), ("raw_opacities", vp)]
+    fwd_args = [ALLOC, vp, ALLOC, vp, ALLOC, vp, i, i, i, vp, i, i, vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, f, vp, i, vp, vp, i, vp]
+    lib.wg_rasterize_forward_dual.restype, lib.wg_rasterize_forward_dual.argtypes = i, fwd_args + [C.POINTER(Second)]
+    lib.wg_rasterize_forward_raw.restype, lib.wg_rasterize_forward_raw.argtypes = i, fwd_args + [vp, C.POINTER(Raw)]
+
+    def fwd(fn, extra, shs=None, colors=one, scales=one, cov=None):
+        return fn(cb, None, cb, None, cb, None, 10, 0, 0, one, 64, 64, one, shs, colors, one, scales, 1.0, one, cov, one, one, one, 1.0, 1.0, 0.1,
+                  None, 0, one, None, 0, None, *extra)
+    dual = lib.wg_rasterize_forward_dual
+    assert fwd(dual, (None,)) == -1                                                     # the block itself is required
+    assert fwd(dual, (C.byref(Second(None, 16, None, None)),)) == -1                    # no second colour set
+    assert fwd(dual, (C.byref(Second(16, None, None, None)),)) == -1                    # no second image
+    assert fwd(dual, (C.byref(Second(16, 16, None, None)),), shs=one, colors=None) == -1   # SH colours: precomputed only
+    raw = lib.wg_rasterize_forward_raw
+    assert fwd(raw, (None, None)) == -1
+    assert fwd(raw, (None, C.byref(Raw(None, None)))) == -1                              # no filter
+    assert fwd(raw, (None, C.byref(Raw(16, None))), scales=None, cov=one) == -1          # acts on scale / rotation pairs
+    assert not called
+
+    bwd_args = [i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, f, vp, vp, vp, vp, vp, vp] + [vp] * 9 + [i, vp]
+    lib.wg_rasterize_backward_dual.restype, lib.wg_rasterize_backward_dual.argtypes = i, bwd_args + [C.POINTER(Second)]
+    lib.wg_rasterize_backward_raw.restype, lib.wg_rasterize_backward_raw.argtypes = i, bwd_args + [vp, C.POINTER(Raw)]
+
+    def bwd(fn, extra, shs=None, scales=one):
+        return fn(10, 0, 0, 5, one, 64, 64, one, shs, one, scales, 1.0, one, None, one, one, one, 1.0, 1.0, 0.1, None, None, one, one, None,
+                  one, one, None, one, one, one, one, None, one, one, 0, None, *extra)
+    # (image_buffer NULL throughout: a deferred-ticket lookup is skipped and the NULL check comes after the block's own checks)
+    assert bwd(lib.wg_rasterize_backward_dual, (None,)) == -1
+    assert bwd(lib.wg_rasterize_backward_dual, (C.byref(Second(None, None, None, 16)),)) == -1   # no second cotangent
+    assert bwd(lib.wg_rasterize_backward_dual, (C.byref(Second(None, None, 16, None)),)) == -1   # no place for the second colour gradient
+    assert bwd(lib.wg_rasterize_backward_raw, (None, None)) == -1
+    assert bwd(lib.wg_rasterize_backward_raw, (None, C.byref(Raw(16, None)))) == -1              # raw opacities are needed again
+    lib.wg_set_option.restype, lib.wg_set_option.argtypes = i, [C.c_char_p, i]
+    lib.wg_get_option.restype, lib.wg_get_option.argtypes = i, [C.c_char_p]
+    assert lib.wg_get_option(b"exact_compositing") == 1 and lib.wg_get_option(b"geometry_reuse") == 0   # round-4 defaults
+    assert lib.wg_set_option(b"exact_compositing", 0) == 0 and lib.wg_get_option(b"exact_compositing") == 0
+    assert lib.wg_set_option(b"exact_compositing", 1) == 0
+
+
 def test_python_surface_matches_the_reference_operator():
     import diff_gaussian_rasterization as dgr
     assert dgr.GaussianRasterizationSettings._fields == (

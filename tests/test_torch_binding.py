@@ -1,0 +1,80 @@
+"""The compiled torch binding of the C-ABI (wild-gaussians_amd/csrc/torch_binding.cpp -> diff_gaussian_rasterization/_C_torch*.so; INTEGRATION.md
+section 2 as a file that builds): the reference's pybind11 surface (ext.cpp:15-19, rasterize_points.h:18-71) on top of libwg_rasterizer.so.
+Held to the ctypes binding, which is the default and carries the opt-ins beyond that surface."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "wild-gaussians_amd"))
+import wg_scenes as S  # noqa: E402
+
+built = bool(glob.glob(os.path.join(ROOT, "wild-gaussians_amd", "diff_gaussian_rasterization", "_C_torch*.so")))
+needs_binding = pytest.mark.skipif(not built, reason="compiled binding not built (python wild-gaussians_amd/build.py --torch-binding)")
+
+
+@pytest.fixture()
+def binding():
+    from diff_gaussian_rasterization import _C
+    yield _C
+    _C.use_binding("ctypes")
+
+
+@needs_binding
+def test_compiled_binding_has_the_reference_modules_surface_and_errors(binding):
+    _C = binding
+    from diff_gaussian_rasterization import _C_torch as m
+    assert {"rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"} <= set(dir(m))
+    e = torch.Tensor([])
+    args = lambda m3: (torch.zeros(3), m3, e, torch.zeros(5, 1), e, e, 1.0, e, torch.eye(4), torch.eye(4), 1.0, 1.0, 0.1, e, 8, 8, e, 0, torch.zeros(3), False, False)
+    with pytest.raises(RuntimeError, match="num_points, 3"):      # rasterize_points.cu:59-61
+        m.rasterize_gaussians(*args(torch.zeros(5, 2)))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.rasterize_gaussians(*args(torch.zeros(5, 3)))
+    assert _C.binding_name() == "ctypes" and _C.use_binding("torch") == "ctypes" and _C.binding_name() == "torch"
+    with pytest.raises(ValueError):
+        _C.use_binding("pybind")
+
+
+@pytest.mark.gpu
+@needs_binding
+@pytest.mark.parametrize("colors", ["sh", "precomp"])
+def test_compiled_binding_gives_the_ctypes_bindings_results(binding, colors):
+    """Same library underneath: images, radii, accumulation and the image state bit-identical; gradients to the atomics' run-to-run
+    rounding; markVisible equal; through the native functions and through the autograd operator."""
+    _C = binding
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from tests.wg_testlib import make_settings, run_hip, run_hip_native, to_dev
+    P, W, H = 120_000, 800, 450
+    deg = 2 if colors == "sh" else None
+    cloud = S.make_cloud(P, W, H, sh_degree=deg, seed=21, scale_mult=2.0)
+    cam = S.make_camera(W, H, yaw_deg=-4.0)
+    cot = S.make_cotangent(W, H, seed=8)
+    d = deg if deg is not None else 0
+    out = {}
+    for name in ("ctypes", "torch"):
+        _C.use_binding(name)
+        assert _C.binding_name() == name
+        h = run_hip(cloud, cam, sh_degree=d, cotangent=cot)
+        n = run_hip_native(cloud, cam, sh_degree=d)
+        vis = _C.mark_visible(to_dev(cloud["means3D"]), to_dev(cam["viewmatrix"]), to_dev(cam["projmatrix"]))
+        out[name] = dict(h=h, n_contrib=n["views"]["image"]["n_contrib"].cpu().numpy(), final_T=n["views"]["image"]["final_T"].cpu().numpy(),
+                         R=int(n["num_rendered"]), vis=vis.cpu().numpy())
+    a, b = out["ctypes"], out["torch"]
+    assert a["R"] == b["R"] > 0 and np.array_equal(a["vis"], b["vis"]) and a["vis"].dtype == np.bool_
+    for k in ("color", "radii", "accumulation"):
+        assert np.array_equal(a["h"][k], b["h"][k]), k
+    assert np.array_equal(a["n_contrib"], b["n_contrib"]) and np.array_equal(a["final_T"], b["final_T"])
+    assert set(a["h"]["grads"]) == set(b["h"]["grads"])
+    for k, g in a["h"]["grads"].items():
+        assert float(np.abs(g - b["h"]["grads"][k]).max()) <= 4e-6 * float(np.abs(g).max()) + 1e-30, k
+    # no Gaussians: zero image, empty radii, nothing launched (rasterize_points.cu:83)
+    _C.use_binding("torch")
+    rs = make_settings(cam, 0)
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    img, radii, acc = GaussianRasterizer(rs)(means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1), colors_precomp=z(0, 3), scales=z(0, 3), rotations=z(0, 4))
+    assert img.shape == (3, H, W) and not img.any() and radii.numel() == 0 and acc.shape == (H, W)

@@ -99,7 +99,34 @@ def build_driver(force: bool = False) -> str:
     return out
 
 
+def build_torch_binding(force: bool = False) -> str:
+    """csrc/torch_binding.cpp -> diff_gaussian_rasterization/_C_torch.so: the compiled torch binding of the C-ABI (INTEGRATION.md section 2 as
+    a file; the ctypes binding stays the default).  Host C++ only: g++ against torch's headers, linked to libwg_rasterizer.so next to it
+    (rpath $ORIGIN)."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    lib = build(force)
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    out = os.path.join(os.path.dirname(lib), "_C_torch" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    if not (force or _newer(out, [src, lib, os.path.join(INCLUDE, "wg_rasterizer.h"), os.path.abspath(__file__)])):
+        return out
+    tlib = ce.library_paths()[0]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_C_torch",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations",
+           "-I" + INCLUDE, "-I/opt/rocm/include", "-I" + sysconfig.get_paths()["include"]] + ["-I" + p for p in ce.include_paths()] + \
+          [src, "-o", out, "-L" + tlib, "-L" + os.path.dirname(lib), "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
+           "-lwg_rasterizer", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr[-4000:])
+    return out
+
+
 if __name__ == "__main__":
+    if "--torch-binding" in sys.argv:
+        print(build_torch_binding(force="--force" in sys.argv))
+        sys.exit(0)
     if "--driver" in sys.argv:
         print(build_driver(force="--force" in sys.argv))
         sys.exit(0)

@@ -499,6 +499,8 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
         if (!second->colors_precomp2 || !second->out_color2 || shs != nullptr || !colors_precomp) return WG_ERR_INVALID_ARGUMENT;
         out_color2 = second->out_color2;
     }
+    // get_gaussians() inside the preprocess kernel (wg_raw_gaussians): needs the scale / rotation pair it acts on
+    if (raw != nullptr && P > 0 && (!raw->filter_3D || !scales || !rotations || cov3D_precomp)) return WG_ERR_INVALID_ARGUMENT;
     const bool fixed = fixed_capacity > 0;  // no host rendezvous at all: the caller's capacity, the superset (lazy) flow, a device-side verdict
     {
         const int settled = settle_deferred();
@@ -531,10 +533,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
     fp.P = P; fp.D = D; fp.M = M; fp.W = width; fp.H = height; fp.gx = gx; fp.gy = gy;
     fp.means3D = means3D; fp.shs = shs; fp.colors_precomp = colors_precomp; fp.opacities = opacities;
     fp.colors_precomp2 = out_color2 ? second->colors_precomp2 : nullptr;
-    if (raw != nullptr && P > 0) {   // get_gaussians() inside the preprocess kernel: needs the scale / rotation pair it acts on
-        if (!raw->filter_3D || !scales || !rotations || cov3D_precomp) return WG_ERR_INVALID_ARGUMENT;
-        fp.filter_3D = raw->filter_3D;
-    }
+    if (raw != nullptr && P > 0) fp.filter_3D = raw->filter_3D;
     fp.scales = scales; fp.scale_modifier = scale_modifier; fp.rotations = rotations; fp.cov3D_precomp = cov3D_precomp;
     fp.viewmatrix = viewmatrix; fp.projmatrix = projmatrix; fp.cam_pos = cam_pos;
     fp.tan_fovx = tan_fovx; fp.tan_fovy = tan_fovy;

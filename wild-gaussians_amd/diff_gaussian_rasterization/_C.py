@@ -32,6 +32,32 @@ if not os.path.exists(_LIB_PATH):
 
 _lib = C.CDLL(_LIB_PATH)
 
+# The compiled torch binding of the same C-ABI (csrc/torch_binding.cpp -> _C_torch*.so, built by build.py --torch-binding; INTEGRATION.md
+# section 2): the reference's three functions with the reference's signatures, nothing beyond them.  WG_BINDING=torch (or use_binding("torch"))
+# routes the plain calls through it; every opt-in beyond the reference's surface stays with the ctypes code below, which is the default.
+_torch_ext = None
+
+
+def use_binding(name: str) -> str:
+    """"ctypes" (default) or "torch": which binding serves the reference-surface calls.  Returns the previous name."""
+    global _torch_ext
+    prev = "ctypes" if _torch_ext is None else "torch"
+    if name == "torch":
+        if _LIB_PATH != os.path.join(_HERE, "libwg_rasterizer.so"):
+            raise ImportError("the compiled binding links the in-tree libwg_rasterizer.so; WG_RASTERIZER_LIB points elsewhere")
+        from . import _C_torch  # noqa: F401  (ImportError when it has not been built: python wild-gaussians_amd/build.py --torch-binding)
+        _torch_ext = _C_torch
+    elif name == "ctypes":
+        _torch_ext = None
+    else:
+        raise ValueError(name)
+    return prev
+
+
+def binding_name() -> str:
+    return "ctypes" if _torch_ext is None else "torch"
+
+
 _ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
@@ -294,6 +320,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     binning_capacity (beyond the reference): an int makes the call wg_rasterize_forward_fixed -- no host rendezvous, capturable in
     a hipGraph; the returned `rendered` is then the capacity, and forward_status(imgBuffer, H, W) tells the real count and whether
     the frame fit (include/wg_rasterizer.h)."""
+    if (_torch_ext is not None and sh_tone is None and binning_capacity is None and colors2 is None and filter_3D is None
+            and subpixel_offset is not None and _lib.wg_get_option(b"geometry_reuse") == 0):
+        _reuse.last = None
+        return _torch_ext.rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp,
+                                              viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), float(kernel_size), subpixel_offset,
+                                              int(image_height), int(image_width), sh, int(degree), campos, bool(prefiltered), bool(debug))
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:59-61
     if not means3D.is_cuda:
@@ -410,6 +442,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     With sh_tone (see rasterize_gaussians) two more tensors are appended to the result: dL_dsh_mul, dL_dsh_offset (None where the
     input was None), and dL_dsh is the gradient w.r.t. the raw coefficients."""
     global _reuse_epoch
+    if _torch_ext is not None and sh_tone is None and dL_dout_color2 is None and raw is None and subpixel_offset is not None:
+        _reuse_epoch += 1
+        return _torch_ext.rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, float(scale_modifier), cov3D_precomp,
+                                                       viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), float(kernel_size), subpixel_offset,
+                                                       dL_dout_color, sh, int(degree), campos, geomBuffer, int(R), binningBuffer, imageBuffer,
+                                                       bool(debug))
     _reuse_epoch += 1   # what the forward calls remembered ends here (see "Geometry reuse" above) ...
     for st in list(_PerThread._states.values()):   # ... and so do the references that kept those frames' scratch alive (any thread's)
         st.last = None
@@ -503,6 +541,8 @@ def last_forward_status():
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):
+    if _torch_ext is not None:
+        return _torch_ext.mark_visible(means3D, viewmatrix, projmatrix)
     device = means3D.device
     P = means3D.size(0)
     present = torch.zeros((P,), dtype=torch.bool, device=device)
@@ -622,3 +662,7 @@ def profile_read() -> dict:
 for _kv in filter(None, os.environ.get("WG_OPTIONS", "").split(",")):
     _k, _, _v = _kv.partition("=")
     set_option(_k.strip(), int(_v or "1"))
+
+
+if os.environ.get("WG_BINDING", "ctypes") != "ctypes":
+    use_binding(os.environ["WG_BINDING"])

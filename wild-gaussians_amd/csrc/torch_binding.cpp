@@ -6,8 +6,8 @@
 // The reference's surface only -- the opt-ins beyond it (sh_tone, binning_capacity, colors2, filter_3D, geometry reuse) stay with the
 // ctypes binding (_C.py), which also remains the default; WG_BINDING=torch selects this module for the plain calls.
 #include <torch/extension.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>   // torch on ROCm calls its device type "cuda": the stream getter of that name
+#include <c10/core/DeviceGuard.h>
 
 #include <tuple>
 
@@ -48,7 +48,7 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
     if (means3D.ndimension() != 2 || means3D.size(1) != 3) AT_ERROR("means3D must have dimensions (num_points, 3)");   // :59-61
     if (!means3D.is_cuda()) throw std::runtime_error("means3D must live on a HIP device: this rasterizer has no CPU path");
     const auto dev = means3D.device();
-    const c10::hip::HIPGuard guard(dev);
+    const c10::DeviceGuard guard(dev);
     const int P = static_cast<int>(means3D.size(0)), H = image_height, W = image_width;
     const auto bytes = torch::TensorOptions().dtype(torch::kUInt8).device(dev);
     torch::Tensor geomBuffer = torch::empty({0}, bytes), binningBuffer = torch::empty({0}, bytes), imgBuffer = torch::empty({0}, bytes);
@@ -65,7 +65,7 @@ std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torc
     const int rendered = wg_rasterize_forward(
         resize_cb, &geomBuffer, resize_cb, &binningBuffer, resize_cb, &imgBuffer, P, degree, M, ptr(bg), W, H, ptr(m3), ptr(shs), ptr(col),
         ptr(op), ptr(sc), scale_modifier, ptr(rot), ptr(cov), ptr(vm), ptr(pm), ptr(cam), tan_fovx, tan_fovy, kernel_size, ptr(so),
-        prefiltered ? 1 : 0, out_color.data_ptr<float>(), radii.data_ptr<int>(), debug ? 1 : 0, c10::hip::getCurrentHIPStream(dev.index()).stream());
+        prefiltered ? 1 : 0, out_color.data_ptr<float>(), radii.data_ptr<int>(), debug ? 1 : 0, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream());
     check(rendered, "wg_rasterize_forward");
     return std::make_tuple(rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer);
 }
@@ -80,7 +80,7 @@ RasterizeGaussiansBackwardHIP(const torch::Tensor& background, const torch::Tens
                               const torch::Tensor& geomBuffer, const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
                               const bool debug) {
     const auto dev = means3D.device();
-    const c10::hip::HIPGuard guard(dev);
+    const c10::DeviceGuard guard(dev);
     const int P = static_cast<int>(means3D.size(0));
     const int H = static_cast<int>(dL_dout_color.size(1)), W = static_cast<int>(dL_dout_color.size(2));
     const auto shs = f32(sh, dev);
@@ -110,7 +110,7 @@ RasterizeGaussiansBackwardHIP(const torch::Tensor& background, const torch::Tens
             reinterpret_cast<char*>(imageBuffer.data_ptr()), ptr(dL), dL_dmeans2D.data_ptr<float>(),
             dL_dconic.defined() ? dL_dconic.data_ptr<float>() : nullptr, dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(),
             dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(), M ? dL_dsh.data_ptr<float>() : nullptr, dL_dscales.data_ptr<float>(),
-            dL_drotations.data_ptr<float>(), debug ? 1 : 0, c10::hip::getCurrentHIPStream(dev.index()).stream());
+            dL_drotations.data_ptr<float>(), debug ? 1 : 0, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream());
         check(status, "wg_rasterize_backward");
     }
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);   // :201
@@ -122,10 +122,10 @@ torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, tor
     const int P = static_cast<int>(means3D.size(0));
     torch::Tensor present = torch::zeros({P}, means3D.options().dtype(torch::kBool));
     if (P != 0) {
-        const c10::hip::HIPGuard guard(dev);
+        const c10::DeviceGuard guard(dev);
         const auto m3 = f32(means3D, dev), vm = f32(viewmatrix, dev), pm = f32(projmatrix, dev);
         check(wg_mark_visible(P, ptr(m3), ptr(vm), ptr(pm), reinterpret_cast<unsigned char*>(present.data_ptr()),
-                              c10::hip::getCurrentHIPStream(dev.index()).stream()), "wg_mark_visible");
+                              c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream()), "wg_mark_visible");
     }
     return present;
 }

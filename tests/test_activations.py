@@ -141,6 +141,6 @@ def test_raw_parameter_mode_of_the_operator_equals_activations_then_plain_call(c
     for k in a:
         if k.startswith("g_"):
             scale = float(np.abs(b[k]).max())
-            assert scale > 0 and float(np.abs(a[k] - b[k]).max()) <= 1e-5 * scale, (k, float(np.abs(a[k] - b[k]).max()), scale)
+            assert scale > 0 and float(np.abs(a[k] - b[k]).max()) <= 1e-4 * scale, (k, float(np.abs(a[k] - b[k]).max()), scale)
             assert float(np.abs(a[k] - c[k]).max()) <= 2e-3 * float(np.abs(c[k]).max()), (k, "vs torch restatement")
     assert (a["radii"] != c["radii"]).sum() <= max(2, P // 50_000) and float(np.quantile(np.abs(a["img"] - c["img"]), 0.9999)) <= 1e-5

@@ -3,6 +3,7 @@
 //   * scripts/asan_pass.sh builds it and the library with -fsanitize=address (host side) and runs it on the GPU: the sanitizer
 //     pass SURVEY.md section 5 asks for, without a Python interpreter between ASan and the HIP runtime;
 //   * evidence that the boundary really is "plain pointers and sizes, no torch types" (tests/test_native_driver.py).
+// Since round 4 it also drives wg_rasterize_{forward,backward}_dual and _raw and checks their images, bit for bit, against plain calls.
 // Prints one line "ok num_rendered=... checksum=..." and exits 0, or a diagnostic and a non-zero code.
 // With a fourth argument (a path) it also DUMPS its inputs and every output of the three calls there, raw little-endian:
 //   int32 {P, W, H, D, M, R}, float32 {tanx, tany}, then float32 arrays means[3P] scales[3P] rots[4P] opac[P] shs[3MP] view[16] proj[16]
@@ -16,6 +17,7 @@
 #include <utility>
 #include <vector>
 #include "wg_rasterizer.h"
+#include "wg_activations.h"
 
 #define CHECK_HIP(x)                                                                  \
     do {                                                                              \
@@ -151,6 +153,85 @@ int main(int argc, char** argv) {
         for (float v : c2) { if (!std::isfinite(v)) { std::fprintf(stderr, "non-finite recoloured image\n"); return 12; } s2 += v; }
         if (!(s2 > 0)) { std::fprintf(stderr, "empty recoloured image\n"); return 12; }
         (void)hipFree(d_cols); (void)hipFree(d_color2); (void)hipFree(geom2.p);
+    }
+    // round 4: two colour sets in ONE call, and get_gaussians() inside the preprocess kernels.  Self-consistency, bit for bit: each image of
+    // the two-colour call equals the plain call's with that colour set; the raw-parameter call equals activations + plain call.
+    {
+        std::vector<float> c1(3 * (size_t)P), c2(3 * (size_t)P), filt(P), lsc(3 * (size_t)P), lop(P), rrot(4 * (size_t)P);
+        for (auto& v : c1) v = uni(seed);
+        for (auto& v : c2) v = uni(seed);
+        for (int i = 0; i < P; i++) {
+            filt[i] = 0.3f * scales[3 * i] * uni(seed);
+            for (int k = 0; k < 3; k++) lsc[3 * i + k] = std::log(scales[3 * i + k]);
+            lop[i] = std::log(opac[i] / (1.0f - opac[i]));
+            const float m = 0.5f + uni(seed);
+            for (int k = 0; k < 4; k++) rrot[4 * i + k] = m * rots[4 * i + k];
+        }
+        float *d_c1, *d_c2, *d_filt, *d_lsc, *d_lop, *d_rrot, *d_asc, *d_aop, *d_arot, *imgA, *imgB, *imgC, *imgD, *d_gc2;
+        if (upload(c1, &d_c1) || upload(c2, &d_c2) || upload(filt, &d_filt) || upload(lsc, &d_lsc) || upload(lop, &d_lop) || upload(rrot, &d_rrot)) return 2;
+        const size_t ibytes = (size_t)3 * W * H * sizeof(float);
+        for (float** q : {&imgA, &imgB, &imgC, &imgD}) CHECK_HIP(hipMalloc(reinterpret_cast<void**>(q), ibytes));
+        CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d_asc), (size_t)P * 12));
+        CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d_aop), (size_t)P * 4));
+        CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d_arot), (size_t)P * 16));
+        CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d_gc2), (size_t)P * 12));
+        Grow g2, b2, i2;
+        auto plain = [&](const float* cols, const float* op, const float* sc, const float* rt, float* out) {
+            return wg_rasterize_forward(Grow::alloc, &g2, Grow::alloc, &b2, Grow::alloc, &i2, P, 0, 0, d_bg, W, H, d_means, nullptr, cols, op, sc, 1.0f, rt,
+                                        nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, out, nullptr, 0, stream);
+        };
+        auto same = [&](const float* a, const float* b, const char* what) {
+            std::vector<float> ha((size_t)3 * W * H), hb(ha.size());
+            if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(ha.data(), a, ibytes, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(hb.data(), b, ibytes, hipMemcpyDeviceToHost) != hipSuccess) return false;
+            double sum = 0;
+            for (size_t k = 0; k < ha.size(); k++) {
+                if (ha[k] != hb[k]) { std::fprintf(stderr, "%s: images differ at %zu (%g vs %g)\n", what, k, ha[k], hb[k]); return false; }
+                sum += ha[k];
+            }
+            if (!(sum > 0)) { std::fprintf(stderr, "%s: empty image\n", what); return false; }
+            return true;
+        };
+        if (plain(d_c1, d_opac, d_scales, d_rots, imgA) <= 0 || plain(d_c2, d_opac, d_scales, d_rots, imgB) <= 0) return 13;
+        wg_second_colors sec = {d_c2, imgD, nullptr, nullptr};
+        const int Rd = wg_rasterize_forward_dual(Grow::alloc, &g2, Grow::alloc, &b2, Grow::alloc, &i2, P, 0, 0, d_bg, W, H, d_means, nullptr, d_c1, d_opac, d_scales,
+                                                 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, imgC, d_radii, 0, stream, &sec);
+        if (Rd != R) { std::fprintf(stderr, "two-colour forward: %d (%s)\n", Rd, wg_last_hip_error()); return 13; }
+        if (!same(imgA, imgC, "two-colour call, first set") || !same(imgB, imgD, "two-colour call, second set")) return 13;
+        sec.dL_dpix2 = d_cot; sec.dL_dcolor2 = d_gc2;
+        if (wg_rasterize_backward_dual(P, 0, 0, Rd, d_bg, W, H, d_means, nullptr, d_c1, d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany,
+                                       0.1f, nullptr, d_radii, g2.p, b2.p, i2.p, d_cot, g2d, nullptr, gop, gcol, g3d, gcov, nullptr, gsc, grot, 0, stream, &sec) != WG_OK) {
+            std::fprintf(stderr, "two-colour backward: %s\n", wg_last_hip_error());
+            return 14;
+        }
+        {
+            std::vector<float> h(3 * (size_t)P);
+            CHECK_HIP(hipStreamSynchronize(stream));
+            CHECK_HIP(hipMemcpy(h.data(), d_gc2, h.size() * 4, hipMemcpyDeviceToHost));
+            double l1 = 0;
+            for (float v : h) { if (!std::isfinite(v)) { std::fprintf(stderr, "non-finite dL_dcolor2\n"); return 14; } l1 += std::fabs(v); }
+            if (!(l1 > 0)) { std::fprintf(stderr, "dL_dcolor2 is zero\n"); return 14; }
+        }
+        // raw parameters: activations + 3-D filter by the stand-alone kernel, then the plain call -- against the raw-parameter call
+        if (wg_activations_forward(P, d_rrot, d_lsc, d_lop, d_filt, d_arot, d_asc, d_aop, stream) != WG_OK) return 15;
+        if (plain(d_c1, d_aop, d_asc, d_arot, imgA) <= 0) return 15;
+        wg_raw_gaussians rawg = {d_filt, d_lop};
+        const int Rr = wg_rasterize_forward_raw(Grow::alloc, &g2, Grow::alloc, &b2, Grow::alloc, &i2, P, 0, 0, d_bg, W, H, d_means, nullptr, d_c1, d_lop, d_lsc, 1.0f,
+                                                d_rrot, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, imgC, d_radii, 0, stream, nullptr, &rawg);
+        if (Rr <= 0) { std::fprintf(stderr, "raw-parameter forward: %d (%s)\n", Rr, wg_last_hip_error()); return 15; }
+        if (!same(imgA, imgC, "raw-parameter call")) return 15;
+        if (wg_rasterize_backward_raw(P, 0, 0, Rr, d_bg, W, H, d_means, nullptr, d_c1, d_lsc, 1.0f, d_rrot, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f,
+                                      nullptr, d_radii, g2.p, b2.p, i2.p, d_cot, g2d, nullptr, gop, gcol, g3d, gcov, nullptr, gsc, grot, 0, stream, nullptr, &rawg) != WG_OK) {
+            std::fprintf(stderr, "raw-parameter backward: %s\n", wg_last_hip_error());
+            return 16;
+        }
+        // (d_radii was overwritten by these calls: restore the SH frame's for the dump below)
+        if (wg_rasterize_forward(Grow::alloc, &geom, Grow::alloc, &bin, Grow::alloc, &img, P, D, M, d_bg, W, H, d_means, d_shs, nullptr, d_opac, d_scales, 1.0f,
+                                 d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, d_color, d_radii, 0, stream) != R) return 4;
+        CHECK_HIP(hipStreamSynchronize(stream));
+        for (void* q : {(void*)d_c1, (void*)d_c2, (void*)d_filt, (void*)d_lsc, (void*)d_lop, (void*)d_rrot, (void*)d_asc, (void*)d_aop, (void*)d_arot, (void*)imgA,
+                        (void*)imgB, (void*)imgC, (void*)imgD, (void*)d_gc2, (void*)g2.p, (void*)b2.p, (void*)i2.p})
+            (void)hipFree(q);
     }
     // (the backward pass after the recolouring overwrote the gradient buffers: run the SH call's backward again for the dump below)
     if (wg_rasterize_backward(P, D, M, R, d_bg, W, H, d_means, d_shs, nullptr, d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f,

@@ -52,7 +52,8 @@ GeometryState GeometryState::fromChunk(char*& chunk, size_t P, bool lists) {
     carve(chunk, g.rects, Pa);
     carve(chunk, g.tiles_touched, Pa);
     carve(chunk, g.point_offsets, Pa);
-    carve(chunk, g.grad_rec, Pa * (GRAD_REC_FLOATS + 1));   // (+ grad_aux[P] behind the records: the two-colour walk's thirteenth sum)
+    carve(chunk, g.grad_rec, (Pa * (GRAD_REC_FLOATS + 1) + 3) & ~(size_t)3);   // (+ grad_aux[P] behind the records: the two-colour walk's thirteenth
+                                                                               //  sum; a whole number of float4: the clear below writes float4)
     g.scan_temp_bytes = query_scan_temp_bytes(Pa);
     carve(chunk, g.scan_temp, g.scan_temp_bytes);
     lists = lists && band_lists_possible(P);
@@ -1134,8 +1135,8 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __rest
 hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_or_null, uint32_t* order, int tiles, float* clear, size_t clear_floats,
                              hipStream_t stream) {
     if (tiles <= 0) return hipSuccess;
-    // clear: 16-byte aligned, a multiple of 4 floats (the gradient records: 12 floats per Gaussian in a 256-byte aligned array)
-    const size_t vec4 = clear ? clear_floats / 4 : 0;
+    // clear: 16-byte aligned (the gradient records: 12 floats per Gaussian, + P floats in a two-colour call, in a 256-byte aligned array)
+    const size_t vec4 = clear ? (clear_floats + 3) / 4 : 0;   // (rounded UP: 13 floats per Gaussian in a two-colour call; the array is carved to a whole float4)
     const unsigned clear_blocks = vec4 ? (unsigned)std::min<size_t>(2048, (vec4 + 4095) / 4096) : 0u;
     hipLaunchKernelGGL(tile_order_kernel, dim3(8 + clear_blocks), dim3(1024), 0, stream, cost_or_null, ranges_or_null, order, tiles,
                        reinterpret_cast<float4*>(clear), vec4);

@@ -449,8 +449,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                                        dL_dout_color, sh, int(degree), campos, geomBuffer, int(R), binningBuffer, imageBuffer,
                                                        bool(debug))
     _reuse_epoch += 1   # what the forward calls remembered ends here (see "Geometry reuse" above) ...
-    for st in list(_PerThread._states.values()):   # ... and so do the references that kept those frames' scratch alive (any thread's)
+    alive = {t.ident for t in threading.enumerate()}
+    for ident, st in list(_PerThread._states.items()):   # ... and so do the references that kept those frames' scratch alive (any thread's)
         st.last = None
+        if ident not in alive:                           # (a thread that has ended: its state goes with it)
+            _PerThread._states.pop(ident, None)
     device = means3D.device
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)

@@ -229,8 +229,8 @@ int wg_rasterize_backward_raw(int P, int D, int M, int R, const float* backgroun
  *   forward : colors_precomp2 [P,3] in, out_color2 float[3*H*W] out (fully written, like out_color).
  *   backward: dL_dpix2 float[3*H*W] in (the cotangent of out_color2; pass zeros if it took none), dL_dcolor2 [P,3] out (fully written).
  *             dL_dmean2D / dL_dopacity / dL_dmean3D / dL_dcov3D / dL_dscale / dL_drot are the gradients of BOTH images' losses: what the
- *             reference's two calls give after autograd adds them, up to float rounding.  Needs "grad_record" = 1 (the default) and
- *             "deterministic_backward" = 0; WG_ERR_INVALID_ARGUMENT otherwise.
+ *             reference's two calls give after autograd adds them, up to float rounding.  Needs the gradient record ("grad_record" = 1,
+ *             the default, or "deterministic_backward" = 1: bit-reproducible, fourteen-float slots); WG_ERR_INVALID_ARGUMENT otherwise.
  */
 typedef struct wg_second_colors {
     const float* colors_precomp2;   /* forward */

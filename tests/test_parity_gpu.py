@@ -1192,8 +1192,10 @@ def test_two_colour_sets_in_one_call_give_what_two_calls_give(record_option, sce
         out.update({"g_" + k: v.grad for k, v in t.items()})
         return {k: v.detach().cpu().numpy() for k, v in out.items()}
     try:
-        for second in (True, False):
+        step_ref = None
+        for second in (False, True):
             a, b = step(False, second), step(True, second)
+            step_ref = b
             assert not np.array_equal(a["img1"], a["img2"]) and a["img2"].any()
             for k in ("img1", "img2", "acc1", "radii1"):
                 assert np.array_equal(a[k], b[k]), (k, second)
@@ -1201,11 +1203,23 @@ def test_two_colour_sets_in_one_call_give_what_two_calls_give(record_option, sce
                 if k.startswith("g_"):
                     scale = float(np.abs(a[k]).max())
                     assert float(np.abs(a[k] - b[k]).max()) <= 1e-5 * scale + 1e-30, (k, second, float(np.abs(a[k] - b[k]).max()), scale)
-        _C.set_option("deterministic_backward", 1)      # ten-float slots: the two-colour walk refuses instead of dropping three sums
-        with pytest.raises(RuntimeError, match="grad_record = 1, deterministic_backward = 0"):
+        _C.set_option("deterministic_backward", 1)      # fourteen-float slots + the ordered per-Gaussian sum: bit-reproducible
+        d1, d2 = step(True), step(True)
+        for k in d1:
+            assert np.array_equal(d1[k], d2[k]), ("deterministic two-colour backward, two runs", k)
+        for k in ("img1", "img2", "acc1", "radii1"):
+            assert np.array_equal(a[k], d1[k]), k
+        for k in a:
+            if k.startswith("g_"):
+                scale = float(np.abs(a[k]).max())
+                assert float(np.abs(step_ref[k] - d1[k]).max()) <= 1e-5 * scale + 1e-30, ("deterministic vs atomic two-colour backward", k)
+        _C.set_option("deterministic_backward", 0)
+        _C.set_option("grad_record", 0)                  # accumulation into the four arrays: thirteen sums have nowhere to go
+        with pytest.raises(RuntimeError, match="needs the gradient record"):
             step(True)
     finally:
         _C.set_option("deterministic_backward", 0)
+        _C.set_option("grad_record", 1)
         _C.set_option("near_split", -1)
         _C.set_option("near_per_tile", 0)
     with pytest.raises(Exception, match="provide colors_precomp too"):

@@ -872,13 +872,13 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                          const wg_raw_gaussians* raw) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const wg::Options opt = options_snapshot();
-    // two colour sets over one walk: the gradient record is where the thirteen sums go, the deterministic mode's slots hold ten
+    // two colour sets over one walk: the thirteen sums go to the gradient record (or, deterministic mode, to fourteen-float slots)
     const bool dual = second != nullptr && P > 0;
     // raw-parameter mode: the per-Gaussian kernel turns the gradients of the activated values into those of the raw parameters where it
     // WRITES them, i.e. with the gradient record
     if (raw != nullptr && P > 0 && (!raw->filter_3D || !raw->raw_opacities || !scales || !rotations || cov3D_precomp ||
                                     !(opt.grad_record || opt.deterministic_backward))) return WG_ERR_INVALID_ARGUMENT;
-    if (dual && (!second->dL_dpix2 || !second->dL_dcolor2 || shs != nullptr || !opt.grad_record || opt.deterministic_backward)) return WG_ERR_INVALID_ARGUMENT;
+    if (dual && (!second->dL_dpix2 || !second->dL_dcolor2 || shs != nullptr || !(opt.grad_record || opt.deterministic_backward))) return WG_ERR_INVALID_ARGUMENT;
     if (image_buffer != nullptr) {   // a deferred forward call's verdict, before anything is differentiated (found by its image buffer: the
         const void* key = reinterpret_cast<const void*>((reinterpret_cast<uintptr_t>(image_buffer) + wg::ALIGN - 1) & ~(uintptr_t)(wg::ALIGN - 1));
         const int verdict = check_ticket(key, stream);   // backward pass usually runs on torch's autograd thread, not the forward's)
@@ -930,7 +930,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     unsigned char* det_flags = nullptr;
     if (det) {  // slots: 40 B per tile instance, never cleared; flags: 1 B per instance behind them, cleared
         StageScope scope_(WG_STAGE_RENDER_BACKWARD, stream);
-        const size_t slot_bytes = (((size_t)R * 10 * sizeof(float)) + 255) & ~(size_t)255;
+        const size_t slot_bytes = (((size_t)R * (dual ? 14 : 10) * sizeof(float)) + 255) & ~(size_t)255;   // (the two-colour walk: thirteen sums, padded to fourteen)
         hipError_t e = wg::run_scan(geom, P, stream);
         if (e == hipSuccess) e = hipMallocAsync(reinterpret_cast<void**>(&det_slots), slot_bytes + (size_t)R + 4, stream);  // (+4: the flags are read as 32-bit words)
         if (e == hipSuccess) {

@@ -125,7 +125,7 @@ __device__ __forceinline__ float butterfly13(float v0, float v1, float v2, float
 #else
 #define WG_BWD_OCC
 #endif
-// DUAL (RECORD, !DET): two colour sets over one walk (wg_second_colors, include/wg_rasterizer.h).  The record's spare floats carry the second
+// DUAL (RECORD): two colour sets over one walk (wg_second_colors, include/wg_rasterizer.h).  The record's spare floats carry the second
 // colour; each set keeps its own dL_dalpha chain (accum_rec, background term), their sum feeds the nine geometry sums -- linear in it --
 // and the abs-gradient takes |q1| + |q2|, as two calls would accumulate it; thirteen sums are reduced per instance instead of 2 x 10.  Sums 10, 11 go to the record's two spare floats, sum 12 to grad_aux[id].
 #ifndef WG_BWD_DUAL_WAVES
@@ -144,7 +144,8 @@ render_backward_kernel(
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ grad_rec,
     const ushort4* __restrict__ rects, const uint32_t* __restrict__ offsets_incl, const uint32_t* __restrict__ tiles_touched,
     float* __restrict__ det_slots, unsigned char* __restrict__ det_flags, const float* __restrict__ dL_dpix2, float* __restrict__ grad_aux) {
-    static_assert(!DUAL || (RECORD && !DET), "the two-colour walk accumulates into the gradient record");
+    static_assert(!DUAL || RECORD, "the two-colour walk accumulates into the gradient record (or, DET, into fourteen-float slots)");
+    constexpr int SLOT_FLOATS = DUAL ? 14 : 10;   // deterministic mode: floats per (tile, Gaussian) slot (thirteen sums, padded to 8-byte multiples)
     __shared__ float4 lds[BATCH * (DUAL ? 4 : 3)];
     constexpr int RS = DUAL ? 4 : 3;   // float4 per parked record
 
@@ -367,7 +368,7 @@ render_backward_kernel(
             if (DET) {
                 if (issue) {
                     const uint32_t slot = __float_as_uint(r1.z);
-                    det_slots[(size_t)slot * 10 + vidx] = total;
+                    det_slots[(size_t)slot * SLOT_FLOATS + vidx] = total;
                     if (vidx == 0) det_flags[slot] = 1;  // only flagged slots hold sums: the slot array itself is never cleared
                 }
             } else if (RECORD) {
@@ -407,6 +408,9 @@ render_backward_kernel(
 // (Round 2: every slot cleared and read, ten dependent strided loads per slot.  Earlier round-3 versions: sixteen threads per
 // Gaussian, one per value, 237 us; one thread per Gaussian reading its flags itself, two round trips per eight slots, 153 us.)
 constexpr uint32_t DET_FLAG_CHUNK = 4096;
+// NF2 = float2 per slot: 5 (ten sums) or 7 (the two-colour walk's thirteen, padded to fourteen: sums 10, 11 go to the record's two spare
+// floats, sum 12 to grad_aux[g] = grad_rec[12 P + g])
+template <int NF2>
 __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* __restrict__ offsets_incl, const uint32_t* __restrict__ tiles_touched,
                                                          const float* __restrict__ det_slots, const unsigned char* __restrict__ det_flags,
                                                          float* __restrict__ grad_rec, size_t slot_capacity) {
@@ -423,9 +427,9 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* 
     const int last_lane = min(63, P - 1 - g0);
     const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
     const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)end, last_lane);
-    float acc[10];
+    float acc[2 * NF2];
 #pragma unroll
-    for (int v = 0; v < 10; v++) acc[v] = 0.f;
+    for (int v = 0; v < 2 * NF2; v++) acc[v] = 0.f;
     unsigned char* sf = sflags[wave];
     constexpr int U = 8;
     for (uint32_t clo = wlo; clo < whi; clo += DET_FLAG_CHUNK) {  // wave-uniform trip count; one trip unless the wave owns > 4096 slots
@@ -460,18 +464,18 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* 
         uint32_t pend[U];
         int np = 0;
         auto flush = [&]() {
-            float2 x[U][5];
+            float2 x[U][NF2];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const float2* sl = reinterpret_cast<const float2*>(det_slots + (size_t)pend[u < np ? u : 0] * 10);  // 40-byte slots: 8-byte aligned
+                const float2* sl = reinterpret_cast<const float2*>(det_slots + (size_t)pend[u < np ? u : 0] * (2 * NF2));  // 40- / 56-byte slots: 8-byte aligned
 #pragma unroll
-                for (int h = 0; h < 5; h++) x[u][h] = u < np ? sl[h] : make_float2(0.f, 0.f);
+                for (int h = 0; h < NF2; h++) x[u][h] = u < np ? sl[h] : make_float2(0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < U; u++)
                 if (u < np) {
 #pragma unroll
-                    for (int h = 0; h < 5; h++) { acc[2 * h] += x[u][h].x; acc[2 * h + 1] += x[u][h].y; }
+                    for (int h = 0; h < NF2; h++) { acc[2 * h] += x[u][h].x; acc[2 * h + 1] += x[u][h].y; }
                 }
             np = 0;
         };
@@ -490,7 +494,11 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* 
         float4* out = reinterpret_cast<float4*>(grad_rec + (size_t)g * GRAD_REC_FLOATS);
         out[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         out[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        out[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
+        if (NF2 == 5) out[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
+        else {
+            out[2] = make_float4(acc[8], acc[9], acc[NF2 == 5 ? 0 : 10], acc[NF2 == 5 ? 0 : 11]);
+            grad_rec[(size_t)P * GRAD_REC_FLOATS + g] = acc[NF2 == 5 ? 0 : 12];
+        }
     }
 }
 
@@ -508,11 +516,15 @@ hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState
                        g.tiles_touched, det_slots, det_flags, dL_dpix2, g.grad_rec + (size_t)P * GRAD_REC_FLOATS)
 #define WG_LAUNCH2(REC, DET, EX) WG_LAUNCH3(REC, DET, EX, false)
 #define WG_LAUNCH(REC, DET) do { if (exact) WG_LAUNCH2(REC, DET, true); else WG_LAUNCH2(REC, DET, false); } while (0)
-    if (dL_dpix2) {   // (api.hip has checked: gradient record on, deterministic mode off)
+    if (dL_dpix2 && det_slots) {   // two colour sets, deterministic: fourteen-float slots
+        if (exact) WG_LAUNCH3(true, true, true, true); else WG_LAUNCH3(true, true, false, true);
+        hipLaunchKernelGGL(det_reduce_kernel<7>, dim3((P + 255) / 256), dim3(256), 0, stream, P, g.point_offsets, g.tiles_touched, det_slots, det_flags,
+                           g.grad_rec, slot_capacity);
+    } else if (dL_dpix2) {   // (api.hip has checked: gradient record on)
         if (exact) WG_LAUNCH3(true, false, true, true); else WG_LAUNCH3(true, false, false, true);
     } else if (det_slots) {
         WG_LAUNCH(true, true);
-        hipLaunchKernelGGL(det_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, g.point_offsets, g.tiles_touched, det_slots, det_flags,
+        hipLaunchKernelGGL(det_reduce_kernel<5>, dim3((P + 255) / 256), dim3(256), 0, stream, P, g.point_offsets, g.tiles_touched, det_slots, det_flags,
                            g.grad_rec, slot_capacity);
     } else if (record) WG_LAUNCH(true, false);
     else WG_LAUNCH(false, false);

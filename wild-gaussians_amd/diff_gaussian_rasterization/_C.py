@@ -487,8 +487,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if raw is not None and (not record or dL_dout_color2 is not None):
         raise RuntimeError("the raw-parameter backward pass needs grad_record = 1 and cannot be combined with the two-colour call")
     dual = dL_dout_color2 is not None
-    if dual and (sh_tone is not None or not record or _lib.wg_get_option(b"deterministic_backward") == 1):
-        raise RuntimeError("the two-colour backward pass needs grad_record = 1, deterministic_backward = 0 and no sh_tone")
+    if dual and (sh_tone is not None or not record):
+        raise RuntimeError("the two-colour backward pass needs the gradient record (grad_record = 1 or deterministic_backward = 1) and no sh_tone")
     dL_dcolors2 = alloc((P, 3), dtype=torch.float32, device=device) if dual else None
     tone_grads = None
     if sh_tone is not None:

@@ -481,6 +481,30 @@ def main():
                        "spec_frames": warm["spec_frames"] - cold["spec_frames"], "spec_misses": warm["spec_misses"] - cold["spec_misses"]},
             "steady_without_speculation": {"ms_per_step": round(1e3 * t_seq_classic / args.steps, 4)},
         }
+        # ... and what ONE miss costs: the history taught on the smallest of the eight frames (camera 7, R 3.46 M), then the largest
+        # (camera 0, R 7.44 M: more than the 25 % margin above it) -- the guarded kernels return at once and the host re-issues the tail
+        # with the real sizes -- against the same frame once the history has learnt it.  Single steps between device synchronises.
+        def one_step_ms(i):
+            torch.cuda.synchronize(device)
+            t0_ = time.perf_counter()
+            seq_step(i)
+            torch.cuda.synchronize(device)
+            return 1e3 * (time.perf_counter() - t0_)
+        miss_ms, hit_ms, misses = [], [], 0
+        for _ in range(5):
+            _C.set_option("speculative_forward", spec_mode)
+            for _k in range(3):
+                seq_step(7)
+            m0 = _C.get_option("spec_misses")
+            miss_ms.append(one_step_ms(0))
+            misses += _C.get_option("spec_misses") - m0
+            for _k in range(3):
+                seq_step(0)
+            hit_ms.append(one_step_ms(0))
+        out["camera_sequence"]["one_miss"] = {
+            "what": "frame history taught on camera 7 (smallest R), then camera 0 (largest): a frame that does not fit its predicted buffer; "
+                    "single synchronised steps, median of 5", "misses_seen": misses,
+            "step_with_miss_ms": round(sorted(miss_ms)[2], 4), "same_frame_predicted_ms": round(sorted(hit_ms)[2], 4)}
         with torch.no_grad():
             Rs = []
             for r8 in rasts:

@@ -495,8 +495,8 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
     const wg::Options opt = options_snapshot();
     // two colour sets over one walk (wg_second_colors): precomputed colours only, both the second set and its image required
     float* out_color2 = nullptr;
-    if (second != nullptr && P > 0) {
-        if (!second->colors_precomp2 || !second->out_color2 || shs != nullptr || !colors_precomp) return WG_ERR_INVALID_ARGUMENT;
+    if (second != nullptr) {   // (the second image is written whatever P is: the background alone when there is nothing to composite)
+        if (!second->out_color2 || (P > 0 && (!second->colors_precomp2 || shs != nullptr || !colors_precomp))) return WG_ERR_INVALID_ARGUMENT;
         out_color2 = second->out_color2;
     }
     // get_gaussians() inside the preprocess kernel (wg_raw_gaussians): needs the scale / rotation pair it acts on
@@ -532,7 +532,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
     wg::FwdParams fp;
     fp.P = P; fp.D = D; fp.M = M; fp.W = width; fp.H = height; fp.gx = gx; fp.gy = gy;
     fp.means3D = means3D; fp.shs = shs; fp.colors_precomp = colors_precomp; fp.opacities = opacities;
-    fp.colors_precomp2 = out_color2 ? second->colors_precomp2 : nullptr;
+    fp.colors_precomp2 = (out_color2 && P > 0) ? second->colors_precomp2 : nullptr;
     if (raw != nullptr && P > 0) fp.filter_3D = raw->filter_3D;
     fp.scales = scales; fp.scale_modifier = scale_modifier; fp.rotations = rotations; fp.cov3D_precomp = cov3D_precomp;
     fp.viewmatrix = viewmatrix; fp.projmatrix = projmatrix; fp.cam_pos = cam_pos;

@@ -163,6 +163,7 @@ def host_step_summary(stamps) -> dict:
     srt = sorted(d)
     out = {"p50": round(srt[len(srt) // 2], 4), "min": round(srt[0], 4), "max": round(srt[-1], 4), "argmax": int(d.index(srt[-1])),
            "mean": round(sum(d) / len(d), 4), "steps_over_1.25x_p50": int(sum(1 for x in d if x > 1.25 * srt[len(srt) // 2]))}
+    out["slow_steps"] = [[i, round(x, 3)] for i, x in enumerate(d) if x > 1.15 * srt[len(srt) // 2]][:16]   # [index in the region, ms]
     if len(d) <= 64:
         out["series"] = [round(x, 3) for x in d]
     else:

@@ -564,3 +564,26 @@ def test_experiment_patches_still_apply():
                         open(os.path.join(tmp, f), "wb").write(blob.stdout)
                 r = subprocess.run(["git", "apply", "--check", p], cwd=tmp, capture_output=True, text=True)
                 assert r.returncode == 0, f"{os.path.relpath(p, ROOT)} does not apply to {sha}:\n{r.stderr}"
+
+
+def test_timed_region_runs_its_warmup_inside_and_stamps_every_step():
+    """bench.py's timing contract (wg_viewparallel.timed_region): W untimed warm-up calls run inside the function, behind the collector pass
+    and directly in front of the opening barrier + synchronize (an idle GPU drops its clocks: EXPERIMENTS.md R4.4); exactly K timed calls;
+    the host clock after every one of them; the cycle collector is left as the caller had it."""
+    import gc
+    import wg_viewparallel as VP
+    sys.path.insert(0, ROOT)
+    import bench
+    calls, stamps, keep = [], [], [0.0]
+    was = gc.isenabled()
+    t = VP.timed_region(lambda: calls.append(1), 7, None, keep, stamps, warmup=3)
+    assert len(calls) == 10 and len(stamps) == 8 and stamps == sorted(stamps) and 0.0 <= keep[0] <= t and gc.isenabled() == was
+    gc.disable()
+    try:   # a caller that has collected and switched the collector off itself (bench.py) is left alone
+        VP.timed_region(lambda: None, 2, None)
+        assert not gc.isenabled()
+    finally:
+        gc.enable() if was else gc.disable()
+    s = bench.host_step_summary([0.0, 0.001, 0.002, 0.0031, 0.0041, 0.0091])
+    assert s["argmax"] == 4 and s["slow_steps"] == [[4, 5.0]] and s["steps_over_1.25x_p50"] == 1 and len(s["series"]) == 5
+    assert bench.host_step_summary([]) == {} and bench.host_step_summary([1.0]) == {}

@@ -104,9 +104,16 @@ def real_caller(args):
     P, W, H = args.gaussians, args.width, args.height
     m, wg = harness.make_method(P, W, H, n_cams=args.cameras, cloud_shapes="bench", gt="random")
     wg.model.active_sh_degree.fill_(3)   # the state a trained model is in (oneupSHdegree every 1000 iterations, method.py:1896)
+    if args.two_colour_edit:   # INTEGRATION.md section 5's three-replacement edit of _render_internal, applied in memory to the staged method.py
+        import two_colour_edit
+        m2 = two_colour_edit.import_edited_method(m)
+        m.GaussianModel._render_internal = m2.GaussianModel._render_internal
     if args.optins:   # the run-time opt-ins that need no source edit (wg_integration.apply_optins): fused SSIM, FusedAdam, fused densification
         import wg_integration   # statistics, fused activations, fused eval_sh
         wg_integration.apply_optins(m, model=wg.model)
+        if args.two_colour_edit:   # the edited _render_internal looks its module-level names (eval_sh) up in ITS module
+            wg_integration.apply_optins(sys.modules["wildgaussians.method_two_colour"], adam=False, densification_stats=False, activations=False,
+                                        geometry_reuse=False)
     if args.tall_linear and wg.model.appearance_mlp is not None:   # measurement scaffolding for the caller's MLP (see _TallLinear)
         for lin in wg.model.appearance_mlp.mlp:
             if isinstance(lin, torch.nn.Linear):
@@ -133,7 +140,12 @@ def real_caller(args):
         shared = {k: (v.clone().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() else v)
                   for k, v in calls[0]["kwargs"].items() if k != "colors_precomp"}
         outs = []
-        if args.dual and len(calls) == 2:   # both colour sets in ONE call (colors_precomp2=)
+        if len(calls) == 1 and "colors_precomp2" in calls[0]["kwargs"]:   # the edited step made ONE two-colour call: replay it as it is
+            kw1 = calls[0]["kwargs"]
+            r = rast(colors_precomp=kw1["colors_precomp"].clone().requires_grad_(True), colors_precomp2=kw1["colors_precomp2"].clone().requires_grad_(True),
+                     **{k: v for k, v in shared.items() if k != "colors_precomp2"})
+            outs = [r[0], r[3]]
+        elif args.dual and len(calls) == 2:   # both colour sets in ONE call (colors_precomp2=)
             r = rast(colors_precomp=calls[0]["kwargs"]["colors_precomp"].clone().requires_grad_(True),
                      colors_precomp2=calls[1]["kwargs"]["colors_precomp"].clone().requires_grad_(True), **shared)
             outs = [r[0], r[3]]
@@ -154,13 +166,13 @@ def real_caller(args):
                  "geometry_reuse_hits": _C.geometry_reuse_hits(), "spec_frames": _C.get_option("spec_frames"), "spec_misses": _C.get_option("spec_misses"),
                  "forward_polls": _C.get_option("forward_polls"), "forward_polls_that_waited": _C.get_option("forward_polls_waited"),
                  "forward_wait_us_total": _C.get_option("forward_wait_us_total")}
-    print(json.dumps({"library": lib_state, "workload": f"REAL caller: wildgaussians/method.py WildGaussians.train_iteration unchanged (staged copy, sha256-verified)"
+    print(json.dumps({"library": lib_state, "workload": f"REAL caller: wildgaussians/method.py WildGaussians.train_iteration " + ("with the two-colour edit of _render_internal (INTEGRATION.md section 5; three replacements applied in memory)" if args.two_colour_edit else "unchanged") + " (staged copy, sha256-verified)"
                                   + (" + wg_integration.apply_optins (run-time swaps: fused SSIM, FusedAdam, fused densification statistics, fused activations, fused eval_sh), "
                                      if args.optins else ", ") + ("tall_linear for the appearance MLP's layers (this script), " if args.tall_linear else "") +
                                   f"{P} Gaussians + appearance MLP, {W}x{H}, {args.cameras} cameras, default.yml with uncertainty_mode=disabled, "
                                   "num_sky_gaussians=0, active SH degree 3",
                       "train_step_ms": round(dt * 1e3, 3), "train_steps_per_s": round(1.0 / dt, 2),
-                      "rasterizer_only_ms (2 fwd + 2 bwd, incl. input clones)" if not args.dual else "rasterizer_only_ms (ONE two-colour fwd + bwd, incl. input clones)": round(dop * 1e3, 3), "rasterizer_share": round(dop / dt, 3),
+                      "rasterizer_only_ms (2 fwd + 2 bwd, incl. input clones)" if not (args.dual or len(calls) == 1) else "rasterizer_only_ms (ONE two-colour fwd + bwd, incl. input clones)": round(dop * 1e3, 3), "rasterizer_share": round(dop / dt, 3),
                       "rasterizer_calls_per_step": len(calls), "visible": int((calls[0]["out"][1] > 0).sum().item()),
                       "num_gaussians": int(len(wg.model.xyz)), "loss_first": losses[0], "loss_last": losses[-1]}))
 
@@ -193,6 +205,8 @@ def main():
                     help="SURVEY 8f N4: wg_fused_ssim.l1_ssim_loss -- the whole (1 - l) L1 + l DSSIM image loss (method.py:1948-1965) in two "
                          "launches each way instead of the L1 / mean / SSIM statement chain")
     ap.add_argument("--optins", action="store_true", help="with --real-caller: apply wg_integration.apply_optins (run-time swaps, no source edits)")
+    ap.add_argument("--two-colour-edit", action="store_true",
+                    help="with --real-caller: run the REAL step with INTEGRATION.md section 5's edit of _render_internal (raw + toned colours in one rasterizer call)")
     ap.add_argument("--dual", action="store_true", help="with --real-caller: the step's two rasterizer calls replayed as ONE two-colour call (colors_precomp2=)")
     ap.add_argument("--real-caller", action="store_true",
                     help="run the reference's OWN `WildGaussians.train_iteration` (method.py:1880-2024, staged unchanged by "

@@ -257,6 +257,37 @@ int wg_rasterize_backward_dual(int P, int D, int M, int R, const float* backgrou
                                float* dL_drot, int debug, void* stream, const wg_second_colors* second);
 
 /*
+ * Beyond the reference: the two colour sets of one call, BOTH evaluated from the same SH coefficients -- WildGaussians' training step
+ * whole (wildgaussians/method.py:1573-1611 with the appearance toning in the operator): `out_color` is the coefficients through `tone`,
+ * `out_color2` the same coefficients through `tone2` (either may be NULL: no affine, no clamp), one projection, one binning, one
+ * forward walk, one backward walk, one read of the coefficients per pass.  SH colours only (shs != NULL, colors_precomp == NULL); `raw`
+ * (may be NULL) as in the *_raw entry points.  The frame equals the one two wg_rasterize_forward_toned (_raw) calls give, bit for bit.
+ *   backward: dL_dpix2 = the cotangent of out_color2 (zeros if it took none); dL_dsh is the gradient of BOTH images' losses w.r.t. the raw
+ *             coefficients, tone->dL_dmul / dL_doffset and tone2->dL_dmul / dL_doffset those of each tone's inputs; dL_dcolor and
+ *             dL_dcolor2 (the gradients of the two evaluated RGB sets) are intermediates and may be NULL; the geometry gradients are
+ *             those of both losses.  Needs the gradient record ("grad_record" = 1, the default, or "deterministic_backward" = 1).
+ * Bits 3-5 of the per-Gaussian colour-clamp byte of the geometry buffer hold the second set's flags.
+ */
+int wg_rasterize_forward_two_tone(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
+                                  wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                                  int height, const float* means3D, const float* shs, const float* colors_precomp,
+                                  const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                  float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
+                                  float* out_color, int* radii, int debug, void* stream, const wg_sh_tone* tone, const wg_sh_tone* tone2,
+                                  const wg_raw_gaussians* raw, float* out_color2);
+
+int wg_rasterize_backward_two_tone(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                                   const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                                   const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                   const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
+                                   const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
+                                   char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                   float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                                   float* dL_drot, int debug, void* stream, const wg_sh_tone* tone, const wg_sh_tone* tone2,
+                                   const wg_raw_gaussians* raw, const float* dL_dpix2, float* dL_dcolor2);
+
+/*
  * Beyond the reference: a further rasterization of the SAME Gaussians through the SAME camera with other precomputed colours
  * (WildGaussians renders raw and toned colours over identical geometry in every step, wildgaussians/method.py:1573-1611; the
  * reference projects, bins and sorts twice).  parent_*: the three scratch buffers a wg_rasterize_forward call over that geometry

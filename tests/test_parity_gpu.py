@@ -1228,6 +1228,93 @@ def test_two_colour_sets_in_one_call_give_what_two_calls_give(record_option, sce
                                                   rotations=to_dev(cloud["rotations"]))
 
 
+@pytest.mark.parametrize("layout", ["sh3_fast", "sh2_generic", "sh3_raw_parameters", "first_set_plain"])
+def test_two_tones_of_one_sh_block_in_one_call_give_what_two_toned_calls_give(record_option, layout):
+    """`sh_second=True` (wg_rasterize_*_two_tone): WildGaussians' whole step before the loss -- the raw colours (SH block, clamped) and the
+    toned colours (the same block through the appearance MLP's affine) -- in ONE call: the preprocess kernel evaluates the polynomial
+    twice from one read of the coefficients, the walk composites both sets, the per-Gaussian backward kernel sends both sets' dL/dRGB
+    through their tones into one dL_dsh.  Images, accumulation, radii bit-identical to two `sh_mul=` calls; gradients to rounding."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    _C = record_option
+    deg = 2 if layout == "sh2_generic" else 3
+    P, W, H = 40_003, 640, 360
+    cam = S.make_camera(W, H, yaw_deg=-4.0)
+    cloud = S.make_cloud(P, W, H, sh_degree=deg, seed=77, scale_mult=2.0)
+    rng = np.random.default_rng(9)
+    cloud["shs"] = (cloud["shs"] * 3.0).astype(np.float32)      # the clamps and the colour clamp at zero both bite
+    mul = rng.uniform(0.5, 1.5, size=(P, 3)).astype(np.float32)
+    offset = rng.normal(0.0, 0.3, size=(P, 3)).astype(np.float32)
+    mul2 = rng.uniform(0.8, 1.2, size=(P, 3)).astype(np.float32)
+    filt = rng.uniform(0.0005, 0.01, size=(P, 1)).astype(np.float32)
+    cot1, cot2 = S.make_cotangent(W, H, seed=1), S.make_cotangent(W, H, seed=2)
+    rs = make_settings(cam, deg, bg=np.array([0.2, 0.1, 0.3], np.float32))
+    rawp = layout == "sh3_raw_parameters"
+    if rawp:   # opacities / scales / rotations are then the raw parameters (logit, log-scale, unnormalised quaternion)
+        o = cloud["opacities"].astype(np.float64)
+        cloud["opacities"] = np.log(o / (1 - o)).astype(np.float32)
+        cloud["scales"] = np.log(cloud["scales"]).astype(np.float32)
+        cloud["rotations"] = (cloud["rotations"] * rng.uniform(0.5, 2.0, size=(P, 1))).astype(np.float32)
+    # first set: the toned one (WildGaussians' order of outputs is up to the caller) -- or no tone at all; second: pre-clamp only, or a tone of its own
+    first = {} if layout == "first_set_plain" else dict(sh_mul="mul", sh_offset="offset", sh_pre_clamp_max=1.0, sh_post_clamp_max=1.0)
+    second = dict(sh_mul="mul2", sh_pre_clamp_max=0.8) if layout == "first_set_plain" else dict(sh_pre_clamp_max=1.0)
+
+    def step(one_call, second_takes_gradient=True):
+        t = {k: to_dev(v).requires_grad_(True) for k, v in cloud.items()}
+        tn = dict(mul=to_dev(mul).requires_grad_(True), offset=to_dev(offset).requires_grad_(True), mul2=to_dev(mul2).requires_grad_(True))
+        m2d = torch.zeros((P, 3), device="cuda", requires_grad=True)
+        rast = GaussianRasterizer(rs)
+        kw = dict(means3D=t["means3D"], means2D=m2d, opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"], shs=t["shs"])
+        if rawp:
+            kw["filter_3D"] = to_dev(filt)
+        res = lambda d: {k: (tn[v] if isinstance(v, str) else v) for k, v in d.items()}
+        if one_call:
+            img1, radii1, acc1, img2 = rast(**kw, **res(first), sh_second=True, **{k + "2": v for k, v in res(second).items()})
+        else:
+            img1, radii1, acc1 = rast(**kw, **res(first))
+            img2, _, _ = rast(**kw, **res(second))
+        loss = (img1 * to_dev(cot1)).sum()
+        if second_takes_gradient:
+            loss = loss + (img2 * to_dev(cot2)).sum()
+        loss.backward()
+        out = dict(img1=img1, img2=img2, acc1=acc1, radii1=radii1, g_m2d=m2d.grad)
+        out.update({"g_" + k: v.grad for k, v in t.items()})
+        out.update({"g_" + k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in tn.items()})
+        return {k: v.detach().cpu().numpy() for k, v in out.items()}
+    try:
+        for second_takes in (True, False):
+            a, b = step(False, second_takes), step(True, second_takes)
+            assert not np.array_equal(a["img1"], a["img2"]) and a["img2"].any()
+            for k in ("img1", "img2", "acc1", "radii1"):
+                assert np.array_equal(a[k], b[k]), (k, second_takes)
+            for k in a:
+                if k.startswith("g_"):
+                    scale = float(np.abs(a[k]).max())
+                    assert float(np.abs(a[k] - b[k]).max()) <= 1e-5 * scale + 1e-30, (k, second_takes, float(np.abs(a[k] - b[k]).max()), scale)
+            used = ("g_mul", "g_offset") if layout != "first_set_plain" else ("g_mul2",)
+            for k in used if second_takes or layout != "first_set_plain" else ():
+                assert np.abs(a[k]).max() > 0, k
+        _C.set_option("deterministic_backward", 1)
+        d1, d2 = step(True), step(True)
+        for k in d1:
+            assert np.array_equal(d1[k], d2[k]), ("deterministic two-tone backward, two runs", k)
+        ref = step(False)
+        for k in ref:
+            if k.startswith("g_"):
+                scale = float(np.abs(ref[k]).max())
+                assert float(np.abs(ref[k] - d1[k]).max()) <= 1e-5 * scale + 1e-30, ("deterministic two-tone vs two calls", k)
+        _C.set_option("deterministic_backward", 0)
+        _C.set_option("grad_record", 0)
+        with pytest.raises(RuntimeError, match="needs (the gradient record|grad_record = 1)"):
+            step(True)
+    finally:
+        _C.set_option("deterministic_backward", 0)
+        _C.set_option("grad_record", 1)
+    with pytest.raises(Exception, match="provide shs"):
+        GaussianRasterizer(make_settings(cam, 0))(means3D=to_dev(cloud["means3D"]), means2D=torch.zeros((P, 3), device="cuda"), opacities=to_dev(cloud["opacities"]),
+                                                  colors_precomp=torch.zeros((P, 3), device="cuda"), sh_second=True, scales=to_dev(cloud["scales"]),
+                                                  rotations=to_dev(cloud["rotations"]))
+
+
 def test_geometry_reuse_is_not_taken_when_anything_it_depends_on_changed(record_option):
     """Identity is by tensor OBJECT and autograd version, never by address: an in-place write to a geometry tensor, another camera
     tensor, another scalar, SH colours or an intervening call of another kind all end the remembered call's reach."""

@@ -3,6 +3,7 @@
 #include "wg_common.h"
 
 #include <dlfcn.h>
+#include <limits>
 
 #include <algorithm>
 #include <atomic>
@@ -385,13 +386,28 @@ size_t wg_binning_buffer_size(int R) {  // upper bound over both binning paths
     return required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)(R > 0 ? R : 0), true); });
 }
 
-static wg::ShTone device_tone(const wg_sh_tone* t) {
+// sh_second (wg_rasterize_*_two_tone): the tone kernels run even when a set has no tone of its own (NULL = identity: no affine, clamps at
+// +infinity -- min(x, inf) = x, x * 1 + 0 = x)
+static wg::ShTone device_tone(const wg_sh_tone* t, const wg_sh_tone* t2 = nullptr, bool sh_second = false) {
     wg::ShTone d;
+    const float inf = std::numeric_limits<float>::infinity();
     if (t != nullptr) {
         d.enabled = 1;
         d.mul = t->mul; d.offset = t->offset;
         d.pre_clamp = t->pre_clamp_max; d.post_clamp = t->post_clamp_max;
         d.dL_dmul = t->dL_dmul; d.dL_doffset = t->dL_doffset;
+    } else if (sh_second) {
+        d.enabled = 1;
+        d.pre_clamp = d.post_clamp = inf;
+    }
+    if (sh_second) {
+        d.second = 1;
+        d.pre_clamp2 = d.post_clamp2 = inf;
+        if (t2 != nullptr) {
+            d.mul2 = t2->mul; d.offset2 = t2->offset;
+            d.pre_clamp2 = t2->pre_clamp_max; d.post_clamp2 = t2->post_clamp_max;
+            d.dL_dmul2 = t2->dL_dmul; d.dL_doffset2 = t2->dL_doffset;
+        }
     }
     return d;
 }
@@ -416,7 +432,8 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                         float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
                         float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, int fixed_capacity,
-                        const wg_second_colors* second = nullptr, const wg_raw_gaussians* raw = nullptr);
+                        const wg_second_colors* second = nullptr, const wg_raw_gaussians* raw = nullptr, const wg_sh_tone* tone2 = nullptr,
+                        bool sh_second = false);
 
 int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
                                wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
@@ -456,6 +473,21 @@ int wg_rasterize_forward_raw(wg_alloc_fn geometry_alloc, void* geometry_user, wg
                         tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, out_color, radii, debug, stream_, tone, 0, nullptr, raw);
 }
 
+int wg_rasterize_forward_two_tone(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
+                                  wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                                  int height, const float* means3D, const float* shs, const float* colors_precomp,
+                                  const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                  float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
+                                  float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, const wg_sh_tone* tone2,
+                                  const wg_raw_gaussians* raw, float* out_color2) {
+    wg_second_colors second{nullptr, out_color2, nullptr, nullptr};
+    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
+                        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
+                        tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, out_color, radii, debug, stream_, tone, 0, &second, raw,
+                        tone2, true);
+}
+
 int wg_rasterize_forward_fixed(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
                                wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
                                int height, const float* means3D, const float* shs, const float* colors_precomp,
@@ -490,14 +522,19 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                         float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
                         float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, int fixed_capacity,
-                        const wg_second_colors* second, const wg_raw_gaussians* raw) {
+                        const wg_second_colors* second, const wg_raw_gaussians* raw, const wg_sh_tone* tone2, bool sh_second) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const wg::Options opt = options_snapshot();
-    // two colour sets over one walk (wg_second_colors): precomputed colours only, both the second set and its image required
+    // two colour sets over one walk: a second set of precomputed colours (wg_second_colors), or the SAME SH coefficients through a
+    // second tone (sh_second; wg_rasterize_forward_two_tone).  The second image is required either way.
     float* out_color2 = nullptr;
     if (second != nullptr) {   // (the second image is written whatever P is: the background alone when there is nothing to composite)
-        if (!second->out_color2 || (P > 0 && (!second->colors_precomp2 || shs != nullptr || !colors_precomp))) return WG_ERR_INVALID_ARGUMENT;
+        if (!second->out_color2) return WG_ERR_INVALID_ARGUMENT;
+        if (P > 0 && !sh_second && (!second->colors_precomp2 || shs != nullptr || !colors_precomp)) return WG_ERR_INVALID_ARGUMENT;
+        if (P > 0 && sh_second && (second->colors_precomp2 || shs == nullptr || colors_precomp)) return WG_ERR_INVALID_ARGUMENT;
         out_color2 = second->out_color2;
+    } else if (sh_second) {
+        return WG_ERR_INVALID_ARGUMENT;
     }
     // get_gaussians() inside the preprocess kernel (wg_raw_gaussians): needs the scale / rotation pair it acts on
     if (raw != nullptr && P > 0 && (!raw->filter_3D || !scales || !rotations || cov3D_precomp)) return WG_ERR_INVALID_ARGUMENT;
@@ -532,7 +569,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
     wg::FwdParams fp;
     fp.P = P; fp.D = D; fp.M = M; fp.W = width; fp.H = height; fp.gx = gx; fp.gy = gy;
     fp.means3D = means3D; fp.shs = shs; fp.colors_precomp = colors_precomp; fp.opacities = opacities;
-    fp.colors_precomp2 = (out_color2 && P > 0) ? second->colors_precomp2 : nullptr;
+    fp.colors_precomp2 = (out_color2 && P > 0 && !sh_second) ? second->colors_precomp2 : nullptr;
     if (raw != nullptr && P > 0) fp.filter_3D = raw->filter_3D;
     fp.scales = scales; fp.scale_modifier = scale_modifier; fp.rotations = rotations; fp.cov3D_precomp = cov3D_precomp;
     fp.viewmatrix = viewmatrix; fp.projmatrix = projmatrix; fp.cam_pos = cam_pos;
@@ -625,7 +662,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
 
     bool rendered = false;  // the render kernels of this frame are already in the stream (a speculation that held)
     if (P > 0) {
-        WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, device_tone(tone), geom, radii, stream), "preprocess");
+        WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, device_tone(tone, tone2, sh_second), geom, radii, stream), "preprocess");
         wg::SpecLimits spec;   // all zero: the classic flow
         char* spec_chunk = nullptr;
         bool spec_lazy = false;
@@ -815,7 +852,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                          char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                          float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                          float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_second_colors* second,
-                         const wg_raw_gaussians* raw = nullptr);
+                         const wg_raw_gaussians* raw = nullptr, const wg_sh_tone* tone2 = nullptr, bool sh_second = false);
 
 int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
                                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
@@ -861,6 +898,22 @@ int wg_rasterize_backward_dual(int P, int D, int M, int R, const float* backgrou
                          debug, stream_, nullptr, second);
 }
 
+int wg_rasterize_backward_two_tone(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                                   const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                                   const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                   const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
+                                   const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
+                                   char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                   float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                                   float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_sh_tone* tone2,
+                                   const wg_raw_gaussians* raw, const float* dL_dpix2, float* dL_dcolor2) {
+    wg_second_colors second{nullptr, nullptr, dL_dpix2, dL_dcolor2};
+    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
+                         viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, subpixel_offset, radii, geom_buffer, binning_buffer,
+                         image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                         debug, stream_, tone, &second, raw, tone2, true);
+}
+
 static int backward_impl(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
                          const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                          const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
@@ -869,7 +922,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
                          char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                          float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                          float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_second_colors* second,
-                         const wg_raw_gaussians* raw) {
+                         const wg_raw_gaussians* raw, const wg_sh_tone* tone2, bool sh_second) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const wg::Options opt = options_snapshot();
     // two colour sets over one walk: the thirteen sums go to the gradient record (or, deterministic mode, to fourteen-float slots)
@@ -878,7 +931,13 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     // WRITES them, i.e. with the gradient record
     if (raw != nullptr && P > 0 && (!raw->filter_3D || !raw->raw_opacities || !scales || !rotations || cov3D_precomp ||
                                     !(opt.grad_record || opt.deterministic_backward))) return WG_ERR_INVALID_ARGUMENT;
-    if (dual && (!second->dL_dpix2 || !second->dL_dcolor2 || shs != nullptr || !(opt.grad_record || opt.deterministic_backward))) return WG_ERR_INVALID_ARGUMENT;
+    if (sh_second && second == nullptr) return WG_ERR_INVALID_ARGUMENT;
+    if (dual && (!second->dL_dpix2 || !(opt.grad_record || opt.deterministic_backward))) return WG_ERR_INVALID_ARGUMENT;
+    if (dual && !sh_second && (!second->dL_dcolor2 || shs != nullptr)) return WG_ERR_INVALID_ARGUMENT;
+    if (dual && sh_second) {   // the second set's dL/dRGB is an intermediate here (dL_dcolor2 optional, like dL_dcolor with SH colours)
+        if (shs == nullptr) return WG_ERR_INVALID_ARGUMENT;
+        if (tone2 != nullptr && ((tone2->mul != nullptr && tone2->dL_dmul == nullptr) || (tone2->offset != nullptr && tone2->dL_doffset == nullptr))) return WG_ERR_INVALID_ARGUMENT;
+    }
     if (image_buffer != nullptr) {   // a deferred forward call's verdict, before anything is differentiated (found by its image buffer: the
         const void* key = reinterpret_cast<const void*>((reinterpret_cast<uintptr_t>(image_buffer) + wg::ALIGN - 1) & ~(uintptr_t)(wg::ALIGN - 1));
         const int verdict = check_ticket(key, stream);   // backward pass usually runs on torch's autograd thread, not the forward's)
@@ -966,7 +1025,7 @@ static int backward_impl(int P, int D, int M, int R, const float* background, in
     bp.kernel_size = kernel_size; bp.radii = radii;
     bp.dL_dcolor2 = dual ? second->dL_dcolor2 : nullptr;
     if (raw != nullptr) { bp.filter_3D = raw->filter_3D; bp.raw_opacities = raw->raw_opacities; }
-    WG_STAGE(WG_STAGE_PREPROCESS_BACKWARD, wg::launch_preprocess_backward(bp, device_tone(tone), geom, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
+    WG_STAGE(WG_STAGE_PREPROCESS_BACKWARD, wg::launch_preprocess_backward(bp, device_tone(tone, tone2, sh_second && dual), geom, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                             dL_dscale, dL_drot, record, stream),
              "preprocess_backward");
     {

@@ -223,6 +223,9 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
 
     if (vis) {
         float cr, cg, cb;
+        float c2r = 0.f, c2g = 0.f, c2b = 0.f;   // second colour set (two-colour walk): precomputed, or the same SH block through a second tone
+        bool two = false;                        // wave-uniform
+        if constexpr (TONE) two = tone.second != 0;
         if (p.colors_precomp == nullptr) {
             // computeColorFromSH, forward.cu:20-71
             float dx = px - camx, dy = py - camy, dz = pz - camz;
@@ -248,6 +251,26 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
                 cr = sh_channel(p.D, sh + 0, dx, dy, dz);
                 cg = sh_channel(p.D, sh + 1, dx, dy, dz);
                 cb = sh_channel(p.D, sh + 2, dx, dy, dz);
+                if constexpr (TONE) {
+                    if (tone.second) {   // kernel argument: the same coefficients (still staged in LDS) through the second tone
+                        float m[3], o[3], xin, t;
+#pragma unroll
+                        for (int q = 0; q < 12; q++) {
+                            const float4 v = stage[lane * SH_PITCH4 + q];
+                            sh[4 * q] = v.x; sh[4 * q + 1] = v.y; sh[4 * q + 2] = v.z; sh[4 * q + 3] = v.w;
+                        }
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            m[ch] = tone.mul2 ? tone.mul2[3 * idx + ch] : 1.0f;
+                            o[ch] = tone.offset2 ? tone.offset2[3 * idx + ch] : 0.0f;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 48; e++) sh[e] = tone_value(sh[e], m[e % 3], e < 3 ? o[e] : 0.0f, tone.pre_clamp2, tone.post_clamp2, xin, t);
+                        c2r = sh_channel(p.D, sh + 0, dx, dy, dz);
+                        c2g = sh_channel(p.D, sh + 1, dx, dy, dz);
+                        c2b = sh_channel(p.D, sh + 2, dx, dy, dz);
+                    }
+                }
             } else if constexpr (TONE) {  // generic layout (M != 16 or unaligned): the (D+1)^2 <= 16 coefficients the evaluation reads
                 const float* src = p.shs + (size_t)idx * p.M * 3;
                 float sh[48], xin, t;
@@ -261,23 +284,40 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
                 cr = sh_channel(p.D, sh + 0, dx, dy, dz);
                 cg = sh_channel(p.D, sh + 1, dx, dy, dz);
                 cb = sh_channel(p.D, sh + 2, dx, dy, dz);
+                if (tone.second) {
+                    for (int e = 0; e < 48; e++) {
+                        const int ch = e % 3;
+                        const float m = tone.mul2 ? tone.mul2[3 * idx + ch] : 1.0f;
+                        const float o = (e < 3 && tone.offset2) ? tone.offset2[3 * idx + ch] : 0.0f;
+                        sh[e] = e < used ? tone_value(src[e], m, o, tone.pre_clamp2, tone.post_clamp2, xin, t) : 0.0f;
+                    }
+                    c2r = sh_channel(p.D, sh + 0, dx, dy, dz);
+                    c2g = sh_channel(p.D, sh + 1, dx, dy, dz);
+                    c2b = sh_channel(p.D, sh + 2, dx, dy, dz);
+                }
             } else {
                 const float* sh = p.shs + (size_t)idx * p.M * 3;
                 cr = sh_channel(p.D, sh + 0, dx, dy, dz);
                 cg = sh_channel(p.D, sh + 1, dx, dy, dz);
                 cb = sh_channel(p.D, sh + 2, dx, dy, dz);
             }
-            g.clamped[idx] = (unsigned char)((cr < 0 ? 1 : 0) | (cg < 0 ? 2 : 0) | (cb < 0 ? 4 : 0));
+            int flags = (cr < 0 ? 1 : 0) | (cg < 0 ? 2 : 0) | (cb < 0 ? 4 : 0);
+            if (two) flags |= (c2r < 0 ? 8 : 0) | (c2g < 0 ? 16 : 0) | (c2b < 0 ? 32 : 0);   // (only the TONE instantiations can get here with two set)
+            g.clamped[idx] = (unsigned char)flags;
             cr = fmaxf(cr, 0.0f); cg = fmaxf(cg, 0.0f); cb = fmaxf(cb, 0.0f);
+            c2r = fmaxf(c2r, 0.0f); c2g = fmaxf(c2g, 0.0f); c2b = fmaxf(c2b, 0.0f);
         } else {
             cr = p.colors_precomp[3 * idx]; cg = p.colors_precomp[3 * idx + 1]; cb = p.colors_precomp[3 * idx + 2];
+            if (p.colors_precomp2 != nullptr) {
+                two = true;
+                c2r = p.colors_precomp2[3 * idx]; c2g = p.colors_precomp2[3 * idx + 1]; c2b = p.colors_precomp2[3 * idx + 2];
+            }
         }
         g.depths[idx] = vz;
         float4* rec = g.splats + 3 * (size_t)idx;
         rec[0] = make_float4(pixx, pixy, conx, cony);
-        if (p.colors_precomp2 != nullptr) {   // wave-uniform.  Two-colour walk: the second set rides in the record's three spare floats
+        if (two) {   // Two-colour walk: the second set rides in the record's three spare floats
             static_assert(WG_STRIP_EXACT == 1, "the box strip test keeps the splat's extent in r2.zw");
-            const float c2r = p.colors_precomp2[3 * idx], c2g = p.colors_precomp2[3 * idx + 1], c2b = p.colors_precomp2[3 * idx + 2];
             rec[1] = make_float4(conz, opacity * coef, c2r, cr);
             rec[2] = make_float4(cg, cb, c2g, c2b);
         } else {

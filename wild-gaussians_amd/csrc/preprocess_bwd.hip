@@ -340,6 +340,7 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
 
     // ------------------------------------------------------------------ SH backward, backward.cu:20-139
     float tdm[3] = {0.f, 0.f, 0.f}, tdo[3] = {0.f, 0.f, 0.f};  // TONE: dL/dmul, dL/doffset of this Gaussian
+    float tdm2[3] = {0.f, 0.f, 0.f}, tdo2[3] = {0.f, 0.f, 0.f};  // ... of the second tone (ShTone::second)
     float dsh[FAST_SH ? 48 : 1];
     if (FAST_SH) {
 #pragma unroll
@@ -353,6 +354,23 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
         sh_basis(p.D, ox * ilen, oy * ilen, oz * ilen, B, Dx, Dy, Dz);
         const float dRGB[3] = {(cl & 1) ? 0.f : dcol0, (cl & 2) ? 0.f : dcol1, (cl & 4) ? 0.f : dcol2};
         float ddx = 0.f, ddy = 0.f, ddz = 0.f;  // dL_ddir
+        // TONE with a second set (ShTone::second): the same coefficients fed a second colour through tone 2; its dL/dRGB are the record's
+        // floats 10, 11 and grad_aux (render_bwd.hip: DUAL), its clamp flags bits 3-5.  Both chains add into dL_dsh and dL_ddir.
+        float dRGB2[3] = {0.f, 0.f, 0.f}, tm2[3] = {1.f, 1.f, 1.f}, to2[3] = {0.f, 0.f, 0.f};
+        bool second = false;
+        if constexpr (TONE && RECORD) {
+            if (tone.second) {
+                second = true;
+                const float4 r2 = grad_rec[3 * (size_t)ld + 2];
+                const float* aux = reinterpret_cast<const float*>(grad_rec) + (size_t)p.P * GRAD_REC_FLOATS;
+                dRGB2[0] = (cl & 8) ? 0.f : r2.z; dRGB2[1] = (cl & 16) ? 0.f : r2.w; dRGB2[2] = (cl & 32) ? 0.f : aux[ld];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    if (tone.mul2) tm2[ch] = tone.mul2[3 * idx + ch];
+                    if (tone.offset2) to2[ch] = tone.offset2[3 * idx + ch];
+                }
+            }
+        }
         // TONE (wg_common.h: ShTone): the evaluation saw min(min(raw, pre) * mul + offset[k == 0], post); chain rule back to the raw
         // coefficients, the multiplier and the offset (clamp_max passes the gradient where x <= max, as torch does)
         float tm[3] = {1.f, 1.f, 1.f}, to[3] = {0.f, 0.f, 0.f};
@@ -390,6 +408,27 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
                     ddy += Dy[k] * w;
                     ddz += Dz[k] * w;
                 }
+            if constexpr (TONE) {
+                if (second) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            float g = B[k] * dRGB2[ch], xin, t;
+                            const float raw = sh[3 * k + ch];
+                            const float val = tone_value(raw, tm2[ch], k == 0 ? to2[ch] : 0.0f, tone.pre_clamp2, tone.post_clamp2, xin, t);
+                            g = (t <= tone.post_clamp2) ? g : 0.0f;
+                            tdm2[ch] += g * xin;
+                            if (k == 0) tdo2[ch] = g;
+                            g = (raw <= tone.pre_clamp2) ? g * tm2[ch] : 0.0f;
+                            dsh[3 * k + ch] += g;
+                            const float w = val * dRGB2[ch];
+                            ddx += Dx[k] * w;
+                            ddy += Dy[k] * w;
+                            ddz += Dz[k] * w;
+                        }
+                }
+            }
         } else {
             const float* sh = p.shs + (size_t)idx * p.M * 3;
             float* d = dL_dsh + (size_t)idx * p.M * 3;
@@ -408,8 +447,20 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
                         if (k == 0) tdo[ch] = g;
                         g = (raw <= tone.pre_clamp) ? g * tm[ch] : 0.0f;
                     }
+                    float w = val * dRGB[ch];
+                    if constexpr (TONE) {
+                        if (second) {
+                            float g2 = bk * dRGB2[ch], xin, t;
+                            const float raw = sh[3 * k + ch];
+                            const float val2 = tone_value(raw, tm2[ch], k == 0 ? to2[ch] : 0.0f, tone.pre_clamp2, tone.post_clamp2, xin, t);
+                            g2 = (t <= tone.post_clamp2) ? g2 : 0.0f;
+                            tdm2[ch] += g2 * xin;
+                            if (k == 0) tdo2[ch] = g2;
+                            g += (raw <= tone.pre_clamp2) ? g2 * tm2[ch] : 0.0f;
+                            w += val2 * dRGB2[ch];
+                        }
+                    }
                     d[3 * k + ch] = g;
-                    const float w = val * dRGB[ch];
                     ddx += dxk * w;
                     ddy += dyk * w;
                     ddz += dzk * w;
@@ -436,6 +487,8 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
             for (int ch = 0; ch < 3; ch++) {
                 if (tone.dL_dmul) tone.dL_dmul[3 * idx + ch] = tdm[ch];
                 if (tone.dL_doffset) tone.dL_doffset[3 * idx + ch] = tdo[ch];
+                if (tone.dL_dmul2) tone.dL_dmul2[3 * idx + ch] = tdm2[ch];
+                if (tone.dL_doffset2) tone.dL_doffset2[3 * idx + ch] = tdo2[ch];
             }
         }
     }

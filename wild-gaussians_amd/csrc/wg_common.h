@@ -147,6 +147,14 @@ struct ShTone {
     float pre_clamp = 0.f, post_clamp = 0.f;
     float* dL_dmul = nullptr;       // backward: [P,3] each, written for every Gaussian (zeros when culled)
     float* dL_doffset = nullptr;
+    // second != 0 (wg_rasterize_*_two_tone): a SECOND colour set from the same coefficients through a tone of its own, composited in
+    // the same walk (render_fwd.hip / render_bwd.hip: DUAL); its colour-clamp flags take bits 3-5 of GeometryState::clamped
+    int second = 0;
+    const float* mul2 = nullptr;
+    const float* offset2 = nullptr;
+    float pre_clamp2 = 0.f, post_clamp2 = 0.f;
+    float* dL_dmul2 = nullptr;
+    float* dL_doffset2 = nullptr;
 };
 
 // the used value and, for the backward pass, what it was made of

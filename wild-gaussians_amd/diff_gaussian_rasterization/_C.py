@@ -92,6 +92,10 @@ _lib.wg_rasterize_forward_raw.argtypes = _lib.wg_rasterize_forward.argtypes + [C
 _lib.wg_rasterize_backward_raw.restype = _i
 _lib.wg_rasterize_backward_raw.argtypes = _lib.wg_rasterize_backward.argtypes + [C.POINTER(_ShTone), C.POINTER(_RawGaussians)]
 _lib.wg_rasterize_forward_dual.restype = _i
+_lib.wg_rasterize_forward_two_tone.argtypes = _lib.wg_rasterize_forward.argtypes + [C.POINTER(_ShTone), C.POINTER(_ShTone), C.POINTER(_RawGaussians), _vp]
+_lib.wg_rasterize_forward_two_tone.restype = _i
+_lib.wg_rasterize_backward_two_tone.argtypes = _lib.wg_rasterize_backward.argtypes + [C.POINTER(_ShTone), C.POINTER(_ShTone), C.POINTER(_RawGaussians), _vp, _vp]
+_lib.wg_rasterize_backward_two_tone.restype = _i
 _lib.wg_rasterize_forward_dual.argtypes = _lib.wg_rasterize_forward.argtypes + [C.POINTER(_SecondColors)]
 _lib.wg_rasterize_backward_dual.restype = _i
 _lib.wg_rasterize_backward_dual.argtypes = _lib.wg_rasterize_backward.argtypes + [C.POINTER(_SecondColors)]
@@ -312,15 +316,18 @@ def forget_geometry():
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width, sh, degree,
-                        campos, prefiltered, debug, sh_tone=None, binning_capacity=None, colors2=None, filter_3D=None):
-    """filter_3D (beyond the reference: wg_raw_gaussians): opacity / scales / rotations are the caller's RAW parameters and
+                        campos, prefiltered, debug, sh_tone=None, binning_capacity=None, colors2=None, filter_3D=None, sh_second=None):
+    """sh_second (beyond the reference: wg_rasterize_forward_two_tone): a 4-tuple like sh_tone (all four may be None: the plain
+    coefficients) -- a SECOND colour set evaluated from the same SH coefficients through this tone and composited in the same walk; the
+    tuple then ends with a seventh element, the second image.  Composes with sh_tone (the first set's) and filter_3D.
+    filter_3D (beyond the reference: wg_raw_gaussians): opacity / scales / rotations are the caller's RAW parameters and
     get_gaussians() (method.py:1060-1086) runs inside the preprocess kernel.
     colors2 (beyond the reference: wg_second_colors, include/wg_rasterizer.h): a second [P,3] set of precomputed colours composited in
     the same walk; the tuple then ends with a seventh element, the second image.
     binning_capacity (beyond the reference): an int makes the call wg_rasterize_forward_fixed -- no host rendezvous, capturable in
     a hipGraph; the returned `rendered` is then the capacity, and forward_status(imgBuffer, H, W) tells the real count and whether
     the frame fit (include/wg_rasterizer.h)."""
-    if (_torch_ext is not None and sh_tone is None and binning_capacity is None and colors2 is None and filter_3D is None
+    if (_torch_ext is not None and sh_tone is None and binning_capacity is None and colors2 is None and filter_3D is None and sh_second is None
             and subpixel_offset is not None and _lib.wg_get_option(b"geometry_reuse") == 0):
         _reuse.last = None
         return _torch_ext.rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp,
@@ -336,11 +343,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     # precomputed colours over remembered geometry: no projection, no binning
     if filter_3D is not None and (colors2 is not None or binning_capacity is not None or scales.numel() == 0 or filter_3D.numel() != P):
         raise RuntimeError("filter_3D (raw-parameter mode) needs scales and rotations, P filter values, and neither colors2 nor binning_capacity")
+    if sh_second is not None and (colors2 is not None or binning_capacity is not None or sh.numel() == 0 or colors.numel() != 0):
+        raise RuntimeError("sh_second (two tones of one SH block) needs SH colours and neither colors2 nor binning_capacity")
     if colors2 is not None:
         if sh_tone is not None or binning_capacity is not None or sh.numel() != 0 or colors.numel() != 3 * P or colors2.numel() != 3 * P:
             raise RuntimeError("colors2 needs precomputed colours of P x 3 in both sets (no SH, no sh_tone, no binning_capacity)")
     reusable = (P != 0 and sh_tone is None and not debug and colors.numel() == 3 * P and sh.numel() == 0 and colors2 is None
-                and filter_3D is None and _lib.wg_get_option(b"geometry_reuse") == 1)
+                and filter_3D is None and sh_second is None and _lib.wg_get_option(b"geometry_reuse") == 1)
     if binning_capacity is not None and debug:
         raise RuntimeError("binning_capacity (wg_rasterize_forward_fixed) has no debug mode")
     key = None
@@ -370,7 +379,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     geom, binning, img = _Scratch(device), _Scratch(device), _Scratch(device)
     if P == 0:  # rasterize_points.cu:83: nothing is launched, the image stays zero
         return (0, torch.zeros((3, H, W), dtype=torch.float32, device=device), torch.zeros((0,), dtype=torch.int32, device=device),
-                geom.take(), binning.take(), img.take()) + (() if colors2 is None else (torch.zeros((3, H, W), dtype=torch.float32, device=device),))
+                geom.take(), binning.take(), img.take()) + (() if colors2 is None and sh_second is None else (torch.zeros((3, H, W), dtype=torch.float32, device=device),))
     # both outputs are fully written by the kernels (every pixel, every Gaussian): no need for the reference's zero fill
     out_color = torch.empty((3, H, W), dtype=torch.float32, device=device)
     radii = torch.empty((P,), dtype=torch.int32, device=device)
@@ -388,7 +397,21 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     out_color2 = None
     try:
         with torch.cuda.device(device):
-            if colors2 is not None:
+            if sh_second is not None:
+                tone2, _keep2 = _tone_block(sh_second, device, P)
+                out_color2 = torch.empty((3, H, W), dtype=torch.float32, device=device)
+                rawg = None
+                if filter_3D is not None:
+                    filter_3D = _f32(filter_3D, device)
+                    rawg = _RawGaussians(filter_3D.data_ptr(), None)
+                rendered = _lib.wg_rasterize_forward_two_tone(
+                    geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
+                    _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
+                    _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                    float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
+                    int(bool(debug)), _stream(device), None if tone is None else C.byref(tone), C.byref(tone2),
+                    None if rawg is None else C.byref(rawg), out_color2.data_ptr())
+            elif colors2 is not None:
                 colors2 = _f32(colors2, device)
                 out_color2 = torch.empty((3, H, W), dtype=torch.float32, device=device)
                 second = _SecondColors(colors2.data_ptr(), out_color2.data_ptr(), None, None)
@@ -435,14 +458,17 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, dL_dout_color, sh,
-                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, sh_tone=None, dL_dout_color2=None, raw=None):
-    """raw = (filter_3D, raw_opacities) of a raw-parameter forward call: dL_dopacity / dL_dscales / dL_drotations are then the gradients
+                                 degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, sh_tone=None, dL_dout_color2=None, raw=None,
+                                 sh_second=None):
+    """sh_second (a frame rasterized with sh_second; needs dL_dout_color2): the result is the eight tensors + (dL_dsh_mul, dL_dsh_offset,
+    dL_dsh_mul2, dL_dsh_offset2), None where the input was None; dL_dsh is the gradient of both images' losses.
+    raw = (filter_3D, raw_opacities) of a raw-parameter forward call: dL_dopacity / dL_dscales / dL_drotations are then the gradients
     of the RAW parameters.
     dL_dout_color2 (a frame rasterized with colors2): the second image's cotangent; the result ends with dL_dcolors2 [P,3].
     With sh_tone (see rasterize_gaussians) two more tensors are appended to the result: dL_dsh_mul, dL_dsh_offset (None where the
     input was None), and dL_dsh is the gradient w.r.t. the raw coefficients."""
     global _reuse_epoch
-    if _torch_ext is not None and sh_tone is None and dL_dout_color2 is None and raw is None and subpixel_offset is not None:
+    if _torch_ext is not None and sh_tone is None and dL_dout_color2 is None and raw is None and sh_second is None and subpixel_offset is not None:
         _reuse_epoch += 1
         return _torch_ext.rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, float(scale_modifier), cov3D_precomp,
                                                        viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), float(kernel_size), subpixel_offset,
@@ -484,15 +510,20 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dsh = alloc((P, M, 3), dtype=torch.float32, device=device)
     dL_dscales = (alloc if have_scales else torch.zeros)((P, 3), dtype=torch.float32, device=device)
     dL_drotations = (alloc if have_scales else torch.zeros)((P, 4), dtype=torch.float32, device=device)
-    if raw is not None and (not record or dL_dout_color2 is not None):
+    if raw is not None and (not record or (dL_dout_color2 is not None and sh_second is None)):
         raise RuntimeError("the raw-parameter backward pass needs grad_record = 1 and cannot be combined with the two-colour call")
-    dual = dL_dout_color2 is not None
-    if dual and (sh_tone is not None or not record):
+    if sh_second is not None and dL_dout_color2 is None:
+        raise RuntimeError("sh_second needs the second image's cotangent (dL_dout_color2)")
+    dual = dL_dout_color2 is not None and sh_second is None
+    if (dual or sh_second is not None) and ((dual and sh_tone is not None) or (not record and P != 0)):
         raise RuntimeError("the two-colour backward pass needs the gradient record (grad_record = 1 or deterministic_backward = 1) and no sh_tone")
     dL_dcolors2 = alloc((P, 3), dtype=torch.float32, device=device) if dual else None
     tone_grads = None
     if sh_tone is not None:
         tone_grads = tuple(None if v is None else alloc((P, 3), dtype=torch.float32, device=device) for v in sh_tone[:2])
+    tone2_grads = None
+    if sh_second is not None:
+        tone2_grads = tuple(None if v is None else alloc((P, 3), dtype=torch.float32, device=device) for v in sh_second[:2])
 
     if P != 0:
         means3D = _f32(means3D, device)
@@ -512,7 +543,16 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                   dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(), dL_drotations.data_ptr(),
                   int(bool(debug)), _stream(device))
         with torch.cuda.device(device):
-            if dual:
+            if sh_second is not None:
+                dL2 = _f32(dL_dout_color2, device)
+                tone2, _keep2 = _tone_block(sh_second, device, P, tone2_grads)
+                rawg = None
+                if raw is not None:
+                    f3d, rop = _f32(raw[0], device), _f32(raw[1], device)
+                    rawg = _RawGaussians(f3d.data_ptr(), rop.data_ptr())
+                status = _lib.wg_rasterize_backward_two_tone(*common, None if tone is None else C.byref(tone), C.byref(tone2),
+                                                             None if rawg is None else C.byref(rawg), dL2.data_ptr(), None)
+            elif dual:
                 dL2 = _f32(dL_dout_color2, device)
                 second = _SecondColors(None, None, dL2.data_ptr(), dL_dcolors2.data_ptr())
                 status = _lib.wg_rasterize_backward_dual(*common, C.byref(second))
@@ -524,6 +564,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 status = _lib.wg_rasterize_backward_toned(*common, None if tone is None else C.byref(tone))
         _check(status, "wg_rasterize_backward")
     out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    if sh_second is not None:
+        return out + (tone_grads or (None, None)) + tone2_grads
     if dual:
         return out + (dL_dcolors2,)
     return out if sh_tone is None else out + tone_grads   # (raw-parameter mode: same tuple, slots 2, 6, 7 are gradients of the raw parameters)

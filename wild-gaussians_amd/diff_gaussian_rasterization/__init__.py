@@ -75,7 +75,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                 sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None, colors_precomp2=None,
-                filter_3D=None):
+                filter_3D=None, sh_second=False, sh_mul2=None, sh_offset2=None, sh_pre_clamp_max2=None, sh_post_clamp_max2=None):
         rs = raster_settings
         native_args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset,
@@ -97,7 +97,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raw = filter_3D is not None
         if ctx.raw and (ctx.dual or binning_capacity is not None):
             raise Exception("filter_3D (raw-parameter mode) cannot be combined with colors_precomp2 / binning_capacity")
-        if ctx.dual:
+        # beyond the reference: both colour sets from the same SH block, each through its own tone (wg_rasterize_forward_two_tone)
+        ctx.sh_second = None
+        if sh_second:
+            if sh.numel() == 0 or ctx.dual or binning_capacity is not None:
+                raise Exception("sh_second renders a second tone of the SH coefficients: provide shs, and neither colors_precomp2 nor binning_capacity")
+            ctx.sh_second = (None if sh_mul2 is None else sh_mul2.detach(), None if sh_offset2 is None else sh_offset2.detach(),
+                             sh_pre_clamp_max2, sh_post_clamp_max2)
+            tone_arg, second_arg = ctx.sh_tone, ctx.sh_second
+            num_rendered, color, radii, geom_buf, binning_buf, img_buf, color2 = _call_native(
+                lambda *a: _C.rasterize_gaussians(*a[:21], sh_tone=tone_arg, filter_3D=filter_3D, sh_second=second_arg), native_args, rs.debug,
+                "snapshot_fw.dump", "forward")
+        elif ctx.dual:
             if ctx.sh_tone is not None or binning_capacity is not None:
                 raise Exception("colors_precomp2 cannot be combined with sh_mul / sh_offset / binning_capacity")
             num_rendered, color, radii, geom_buf, binning_buf, img_buf, color2 = _call_native(
@@ -124,7 +135,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 accumulation = torch.zeros((rs.image_height, rs.image_width), dtype=torch.float32, device=color.device)
             else:
                 accumulation = _accumulation_from_image_state(img_buf, rs.image_height, rs.image_width)
-        if ctx.dual:
+        if ctx.dual or ctx.sh_second is not None:
             return color, radii, accumulation, color2
         return color, radii, accumulation
 
@@ -137,8 +148,20 @@ class _RasterizeGaussians(torch.autograd.Function):
         native_args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                        rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset, grad_out_color, sh,
                        rs.sh_degree, rs.campos, geom_buf, ctx.num_rendered, binning_buf, img_buf, rs.debug)
-        g_mul = g_offset = g_colors2 = None
-        if ctx.dual:
+        g_mul = g_offset = g_colors2 = g_mul2 = g_offset2 = None
+        if ctx.sh_second is not None:
+            if grad_out_color2 is None:   # the second image took no gradient
+                grad_out_color2 = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
+            raw = tuple(ctx.saved_tensors[10:12]) if ctx.raw else None
+            res = _call_native(lambda *a: _C.rasterize_gaussians_backward(*a[:23], sh_tone=ctx.sh_tone, raw=raw, dL_dout_color2=grad_out_color2,
+                                                                           sh_second=ctx.sh_second), native_args, rs.debug, "snapshot_bw.dump", "backward")
+            (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations, g_mul, g_offset, g_mul2, g_offset2) = res
+            if ctx.sh_tone is not None:
+                g_mul = None if g_mul is None else g_mul.view(ctx.sh_tone[0].shape)
+                g_offset = None if g_offset is None else g_offset.view(ctx.sh_tone[1].shape)
+            g_mul2 = None if g_mul2 is None else g_mul2.view(ctx.sh_second[0].shape)
+            g_offset2 = None if g_offset2 is None else g_offset2.view(ctx.sh_second[1].shape)
+        elif ctx.dual:
             if grad_out_color2 is None:   # the second image took no gradient
                 grad_out_color2 = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
             (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations, g_colors2) = _call_native(
@@ -162,15 +185,16 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_mul = None if mul is None else g_mul.view(mul.shape)
             g_offset = None if offset is None else g_offset.view(offset.shape)
         # order of forward()'s inputs; None for raster_settings and the two clamp constants
-        return g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3Ds, None, g_mul, g_offset, None, None, None, g_colors2, None
+        return (g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3Ds, None, g_mul, g_offset, None, None, None, g_colors2, None,
+                None, g_mul2, g_offset2, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                         sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None, colors_precomp2=None,
-                        filter_3D=None):
+                        filter_3D=None, sh_second=False, sh_mul2=None, sh_offset2=None, sh_pre_clamp_max2=None, sh_post_clamp_max2=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                      raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity, colors_precomp2,
-                                     filter_3D)
+                                     filter_3D, sh_second, sh_mul2, sh_offset2, sh_pre_clamp_max2, sh_post_clamp_max2)
 
 
 class GaussianRasterizer(nn.Module):
@@ -190,8 +214,17 @@ class GaussianRasterizer(nn.Module):
                 sh_mul: Optional[torch.Tensor] = None, sh_offset: Optional[torch.Tensor] = None,
                 sh_pre_clamp_max: Optional[float] = None, sh_post_clamp_max: Optional[float] = None,
                 binning_capacity: Optional[int] = None, colors_precomp2: Optional[torch.Tensor] = None,
-                filter_3D: Optional[torch.Tensor] = None):
-        """`filter_3D=` (keyword-only, beyond the reference): `opacities`, `scales`, `rotations` are then the caller's RAW
+                filter_3D: Optional[torch.Tensor] = None, sh_second: bool = False, sh_mul2: Optional[torch.Tensor] = None,
+                sh_offset2: Optional[torch.Tensor] = None, sh_pre_clamp_max2: Optional[float] = None,
+                sh_post_clamp_max2: Optional[float] = None):
+        """`sh_second=True` (keyword-only, beyond the reference; with `shs`): a SECOND image from the same SH coefficients through a tone
+        of its own (`sh_mul2` / `sh_offset2` / `sh_*_clamp_max2`, each optional), composited in the SAME call as the first -- WildGaussians'
+        step (method.py:1573-1611) renders the raw and the toned colours of one SH block: `rast(shs=f, sh_mul=mul, sh_offset=offset / C0,
+        sh_pre_clamp_max=1, sh_post_clamp_max=1, sh_second=True, sh_pre_clamp_max2=1)` returns `(toned, radii, accumulation, raw)` from one
+        projection, one binning, one forward and one backward walk.  Gradients flow to `shs` (both images' losses), and to each tone's
+        `mul` / `offset`.  Composes with `filter_3D`.
+
+        `filter_3D=` (keyword-only, beyond the reference): `opacities`, `scales`, `rotations` are then the caller's RAW
         parameters (logit, log-scale, unnormalised quaternion) and `get_gaussians()` (method.py:1060-1086: normalise, exp, sigmoid, 3-D
         filter with this [P,1] tensor) runs inside the preprocess kernels, forward and backward: the gradients returned for those three
         inputs are the raw parameters'.  Composes with `shs` + `sh_mul` / `sh_offset` (the whole step before the operator in-kernel).
@@ -227,4 +260,5 @@ class GaussianRasterizer(nn.Module):
             _absent() if scales is None else scales,
             _absent() if rotations is None else rotations,
             _absent() if cov3D_precomp is None else cov3D_precomp,
-            self.raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity, colors_precomp2, filter_3D)
+            self.raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity, colors_precomp2, filter_3D,
+            sh_second, sh_mul2, sh_offset2, sh_pre_clamp_max2, sh_post_clamp_max2)

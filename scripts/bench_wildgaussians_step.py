@@ -104,15 +104,21 @@ def real_caller(args):
     P, W, H = args.gaussians, args.width, args.height
     m, wg = harness.make_method(P, W, H, n_cams=args.cameras, cloud_shapes="bench", gt="random")
     wg.model.active_sh_degree.fill_(3)   # the state a trained model is in (oneupSHdegree every 1000 iterations, method.py:1896)
-    if args.two_colour_edit:   # INTEGRATION.md section 5's three-replacement edit of _render_internal, applied in memory to the staged method.py
+    edited = None
+    if args.two_colour_edit or args.two_tone_edit:   # INTEGRATION.md section 5's edits of _render_internal, applied in memory to the staged method.py
         import two_colour_edit
-        m2 = two_colour_edit.import_edited_method(m)
+        if args.two_tone_edit:
+            edited = "wildgaussians.method_two_tone"
+            m2 = two_colour_edit.import_edited_method(m, two_colour_edit.EDITS_TWO_TONE, edited)
+        else:
+            edited = "wildgaussians.method_two_colour"
+            m2 = two_colour_edit.import_edited_method(m)
         m.GaussianModel._render_internal = m2.GaussianModel._render_internal
     if args.optins:   # the run-time opt-ins that need no source edit (wg_integration.apply_optins): fused SSIM, FusedAdam, fused densification
         import wg_integration   # statistics, fused activations, fused eval_sh
         wg_integration.apply_optins(m, model=wg.model)
-        if args.two_colour_edit:   # the edited _render_internal looks its module-level names (eval_sh) up in ITS module
-            wg_integration.apply_optins(sys.modules["wildgaussians.method_two_colour"], adam=False, densification_stats=False, activations=False,
+        if edited:   # the edited _render_internal looks its module-level names (eval_sh) up in ITS module
+            wg_integration.apply_optins(sys.modules[edited], adam=False, densification_stats=False, activations=False,
                                         geometry_reuse=False)
     if args.tall_linear and wg.model.appearance_mlp is not None:   # measurement scaffolding for the caller's MLP (see _TallLinear)
         for lin in wg.model.appearance_mlp.mlp:
@@ -140,7 +146,10 @@ def real_caller(args):
         shared = {k: (v.clone().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() else v)
                   for k, v in calls[0]["kwargs"].items() if k != "colors_precomp"}
         outs = []
-        if len(calls) == 1 and "colors_precomp2" in calls[0]["kwargs"]:   # the edited step made ONE two-colour call: replay it as it is
+        if len(calls) == 1 and calls[0]["kwargs"].get("sh_second"):   # the two-tone edit: ONE call with SH features + the MLP's affine
+            r = rast(**{k: (v.clone().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in calls[0]["kwargs"].items()})
+            outs = [r[0], r[3]]
+        elif len(calls) == 1 and "colors_precomp2" in calls[0]["kwargs"]:   # the edited step made ONE two-colour call: replay it as it is
             kw1 = calls[0]["kwargs"]
             r = rast(colors_precomp=kw1["colors_precomp"].clone().requires_grad_(True), colors_precomp2=kw1["colors_precomp2"].clone().requires_grad_(True),
                      **{k: v for k, v in shared.items() if k != "colors_precomp2"})
@@ -166,7 +175,7 @@ def real_caller(args):
                  "geometry_reuse_hits": _C.geometry_reuse_hits(), "spec_frames": _C.get_option("spec_frames"), "spec_misses": _C.get_option("spec_misses"),
                  "forward_polls": _C.get_option("forward_polls"), "forward_polls_that_waited": _C.get_option("forward_polls_waited"),
                  "forward_wait_us_total": _C.get_option("forward_wait_us_total")}
-    print(json.dumps({"library": lib_state, "workload": f"REAL caller: wildgaussians/method.py WildGaussians.train_iteration " + ("with the two-colour edit of _render_internal (INTEGRATION.md section 5; three replacements applied in memory)" if args.two_colour_edit else "unchanged") + " (staged copy, sha256-verified)"
+    print(json.dumps({"library": lib_state, "workload": f"REAL caller: wildgaussians/method.py WildGaussians.train_iteration " + ("with the two-tone edit of _render_internal (INTEGRATION.md section 5; SH features + the MLP's affine to ONE rasterizer call, applied in memory)" if args.two_tone_edit else "with the two-colour edit of _render_internal (INTEGRATION.md section 5; three replacements applied in memory)" if args.two_colour_edit else "unchanged") + " (staged copy, sha256-verified)"
                                   + (" + wg_integration.apply_optins (run-time swaps: fused SSIM, FusedAdam, fused densification statistics, fused activations, fused eval_sh), "
                                      if args.optins else ", ") + ("tall_linear for the appearance MLP's layers (this script), " if args.tall_linear else "") +
                                   f"{P} Gaussians + appearance MLP, {W}x{H}, {args.cameras} cameras, default.yml with uncertainty_mode=disabled, "
@@ -197,6 +206,8 @@ def main():
     ap.add_argument("--in-kernel-tone", action="store_true",
                     help="SURVEY 8f N3: the appearance toning (clamp, * mul, + offset / C0, clamp; method.py:890-900, 1590-1595) inside the "
                          "preprocess kernels (sh_mul / sh_offset / sh_*_clamp_max) instead of P x 48 torch tensors; implies --in-kernel-sh")
+    ap.add_argument("--two-tone-call", action="store_true",
+                    help="with --in-kernel-tone: the step's raw and toned renders as ONE rasterizer call (sh_second=; wg_rasterize_*_two_tone)")
     ap.add_argument("--tall-linear", action="store_true",
                     help="tall_linear (defined in this script) for the appearance MLP's three layers (weight gradients as a batched product over "
                          "row chunks: plain PyTorch, a BLAS kernel-selection workaround for 3 M-row reductions)")
@@ -207,6 +218,8 @@ def main():
     ap.add_argument("--optins", action="store_true", help="with --real-caller: apply wg_integration.apply_optins (run-time swaps, no source edits)")
     ap.add_argument("--two-colour-edit", action="store_true",
                     help="with --real-caller: run the REAL step with INTEGRATION.md section 5's edit of _render_internal (raw + toned colours in one rasterizer call)")
+    ap.add_argument("--two-tone-edit", action="store_true",
+                    help="with --real-caller: run the REAL step with INTEGRATION.md section 5's two-tone edit of _render_internal (shs= + sh_mul= / sh_offset= + sh_second=: one call, no eval_sh, no P x 48 toned tensor)")
     ap.add_argument("--dual", action="store_true", help="with --real-caller: the step's two rasterizer calls replayed as ONE two-colour call (colors_precomp2=)")
     ap.add_argument("--real-caller", action="store_true",
                     help="run the reference's OWN `WildGaussians.train_iteration` (method.py:1880-2024, staged unchanged by "
@@ -279,6 +292,13 @@ def main():
             scales = s2f.sqrt()
             opac = torch.sigmoid(prm["opacities"]) * torch.sqrt(s2.prod(1) / s2f.prod(1))[:, None]
         kw = dict(means3D=prm["xyz"], means2D=means2D, opacities=opac, scales=scales, rotations=rot, **raw_kw)
+        if args.two_tone_call:   # both renders of the step in ONE rasterizer call (sh_second=: wg_rasterize_*_two_tone)
+            shs = prm["features"].view(P, 16, 3)
+            inp = torch.cat((prm["features"][:, :3].clamp_max(1.0), prm["embeddings"], prm["image_embedding"][None].expand(P, -1)), dim=-1)
+            offset, mul = torch.split(mlp_fn(inp) * 0.01, [3, 3], dim=-1)
+            img, radii, acc, raw = rast_sh(shs=shs, sh_mul=mul, sh_offset=offset / C0, sh_pre_clamp_max=1.0, sh_post_clamp_max=1.0,
+                                           sh_second=True, sh_pre_clamp_max2=1.0, **kw)
+            return finish(img, raw, radii, means2D)
         if args.in_kernel_tone:
             shs = prm["features"].view(P, 16, 3)
             raw, radii, acc = rast_sh(shs=shs, sh_pre_clamp_max=1.0, **kw)
@@ -363,7 +383,7 @@ def main():
     torch.cuda.synchronize()
     dop = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"workload": f"WildGaussians-style train step: {P} Gaussians + appearance MLP, {W}x{H}, 2 fwd + 2 bwd raster calls, "
-                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)" + (", SH evaluated in the operator" if args.in_kernel_sh or args.in_kernel_tone else "") + (", appearance toning in the operator" if args.in_kernel_tone else "") + (", fused L1+DSSIM loss" if args.fused_loss else ", fused SSIM" if args.fused_ssim else "") + (", fused activations" if args.fused_activations else "") + (", wg FusedAdam" if args.wg_adam else ", torch fused Adam" if args.fused_adam else "") + ("" if args.densification_stats == "off" else f", densification statistics ({args.densification_stats})"),
+                                  "L1 + DSSIM, Adam (caller restated; uncertainty disabled)" + (", SH evaluated in the operator" if args.in_kernel_sh or args.in_kernel_tone else "") + (", appearance toning in the operator" if args.in_kernel_tone else "") + (", raw + toned renders in ONE rasterizer call" if args.two_tone_call else "") + (", fused L1+DSSIM loss" if args.fused_loss else ", fused SSIM" if args.fused_ssim else "") + (", fused activations" if args.fused_activations else "") + (", wg FusedAdam" if args.wg_adam else ", torch fused Adam" if args.fused_adam else "") + ("" if args.densification_stats == "off" else f", densification statistics ({args.densification_stats})"),
                       "train_step_ms": round(dt * 1e3, 3), "train_steps_per_s": round(1.0 / dt, 2),
                       "rasterizer_only_ms (2 fwd + 2 bwd)": round(dop * 1e3, 3), "rasterizer_share": round(dop / dt, 3),
                       "visible": int((vis[0] > 0).sum().item()), "loss": float(step().item())}))

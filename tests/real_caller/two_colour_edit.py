@@ -31,19 +31,52 @@ EDITS = [
 ]
 
 
-def edited_source(path: str) -> str:
+# The further-reaching edit ("two tones of one SH block"): the toned call takes the SH features themselves
+# (`shs=`), the MLP's affine as `sh_mul=` / `sh_offset=`, and asks for the untoned render of the same coefficients as its second image
+# (`sh_second=True`).  Neither eval_sh nor the P x 48 toned tensor is evaluated in torch; one rasterizer call per step.  Applies to the
+# default appearance model (appearance_model_sh = False: a 3-wide affine) with SH features.
+EDITS_TWO_TONE = [
+    # 1. torch's eval_sh of the raw colours is only needed without the two-tone call
+    ("        dir_pp_normalized = F.normalize(means3D - camera_center.repeat(features.shape[0], 1), dim=1)\n"
+     "        if features.shape[-1] == 3:\n",
+     "        dir_pp_normalized = F.normalize(means3D - camera_center.repeat(features.shape[0], 1), dim=1)\n"
+     "        two_tone = self.config.appearance_enabled and not self.config.appearance_model_sh and features.shape[-1] != 3\n"
+     "        if two_tone:\n"
+     "            colors = None\n"
+     "        elif features.shape[-1] == 3:\n"),
+    # 2. no raw call of its own
+    ("        if not self.config.appearance_enabled or (self.config.appearance_separate_tuned_color and return_raw):\n",
+     "        if not two_tone and (not self.config.appearance_enabled or (self.config.appearance_separate_tuned_color and return_raw)):\n"),
+    # 3. the one call: toned image first, the untoned render of the same coefficients second
+    ("        if self.config.appearance_enabled:\n"
+     "            assert self.appearance_mlp is not None\n",
+     "        if two_tone:\n"
+     "            shdim = (self.config.sh_degree + 1) ** 2\n"
+     "            inp = torch.cat((features[..., :3], self.embeddings, embedding_expanded), dim=-1)\n"
+     "            offset, mul = torch.split(self.appearance_mlp.mlp(inp) * 0.01, [3, 3], dim=-1)\n"
+     "            rendered_image, radii, accumulation, raw_rendered_image = rasterizer(\n"
+     "                means3D=means3D, means2D=means2D, shs=gaussians[\"features\"].view(-1, shdim, 3), colors_precomp=None,\n"
+     "                opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None,\n"
+     "                sh_mul=mul, sh_offset=offset / C0, sh_pre_clamp_max=1.0, sh_post_clamp_max=1.0, sh_second=True, sh_pre_clamp_max2=1.0)\n"
+     "            raw_rendered_image = raw_rendered_image if self.config.appearance_separate_tuned_color else rendered_image\n"
+     "        elif self.config.appearance_enabled:\n"
+     "            assert self.appearance_mlp is not None\n"),
+]
+
+
+def edited_source(path: str, edits=None) -> str:
     src = open(path).read()
-    for old, new in EDITS:
+    for old, new in (EDITS if edits is None else edits):
         if src.count(old) != 1:
             raise RuntimeError(f"the documented edit no longer applies to {path}: {old.strip().splitlines()[0]!r} found {src.count(old)} times")
         src = src.replace(old, new)
     return src
 
 
-def import_edited_method(method_module):
+def import_edited_method(method_module, edits=None, name="wildgaussians.method_two_colour"):
     """A second module object, `wildgaussians.method_two_colour`, compiled from the staged method.py with EDITS applied (same package:
-    its relative imports resolve to the same staged modules; the operator packages are the ones `method_module` bound)."""
-    name = "wildgaussians.method_two_colour"
+    its relative imports resolve to the same staged modules; the operator packages are the ones `method_module` bound).
+    edits=EDITS_TWO_TONE, name="wildgaussians.method_two_tone": the two-tone edit."""
     if name in sys.modules:
         return sys.modules[name]
     path = method_module.__file__
@@ -52,5 +85,5 @@ def import_edited_method(method_module):
     mod.__file__ = path
     mod.__package__ = "wildgaussians"
     sys.modules[name] = mod
-    exec(compile(edited_source(path), os.path.join(os.path.dirname(path), "method_two_colour.py"), "exec"), mod.__dict__)
+    exec(compile(edited_source(path, edits), os.path.join(os.path.dirname(path), name.rsplit(".", 1)[1] + ".py"), "exec"), mod.__dict__)
     return mod

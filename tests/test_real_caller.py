@@ -356,3 +356,51 @@ def test_render_internal_with_the_two_colour_edit_gives_the_unedited_results(tra
         #  normalised -- and of magnitude 1e-7: the float atomics' order alone moves them by ~2e-5 of it between two runs)
         assert float((x - y).abs().max()) <= 2e-4 * scale, (i, float((x - y).abs().max()), scale)
     assert sum(float(x.abs().max()) > 0 for x in ga) >= 6
+
+
+@pytest.mark.gpu
+@needs_staged
+def test_render_internal_with_the_two_tone_edit_gives_the_unedited_results(trained):
+    """INTEGRATION.md section 5's further edit of `_render_internal` (two_colour_edit.EDITS_TWO_TONE): the SH features themselves, the
+    appearance MLP's affine and `sh_second=True` go to ONE rasterizer call -- no eval_sh, no P x 48 toned tensor in torch.  Against the
+    unedited method, same trained model and camera: one call instead of two; accumulation, radii bit-identical (the geometry path does
+    not see colours); both renders to 2e-6 (the polynomial is evaluated by the kernel instead of torch's eval_sh: rounding); the real
+    loss shape's gradients on every parameter to 2e-4 of a tensor's largest magnitude."""
+    import two_colour_edit
+    m, wg, _ = trained
+    m2 = two_colour_edit.import_edited_method(m, two_colour_edit.EDITS_TWO_TONE, "wildgaussians.method_two_tone")
+    cam = wg.train_cameras[1]
+    params = [p for p in (wg.model.xyz, wg.model.scales, wg.model.rotations, wg.model.opacities, wg.model.features_dc, wg.model.features_rest,
+                          wg.model.embeddings) if p is not None and p.requires_grad]
+    params += [p for p in wg.model.appearance_mlp.parameters()]
+    torch.manual_seed(3)
+    target = torch.rand(3, int(cam.image_sizes[1]), int(cam.image_sizes[0]), device="cuda")
+
+    def run(render_internal):
+        for p in params:
+            p.grad = None
+        with harness.RasterizerTap(m) as tap:
+            out = render_internal(wg.model, cam, config=wg.config, embedding=wg.model.get_embedding(1), kernel_size=wg.config.kernel_size)
+        loss = (out["render"] - target).abs().mean() + 0.25 * ((out["raw_render"] - target) ** 2).mean()
+        loss.backward()
+        grads = [p.grad.detach().clone() for p in params] + [out["viewspace_points"].grad.detach().clone()]
+        return out, grads, tap.calls
+    degree_was = int(wg.model.active_sh_degree.item())
+    try:
+        for degree in (degree_was, 3):   # as trained (45 steps: band 0 only), and the state a trained model is in (all bands evaluated)
+            wg.model.active_sh_degree.fill_(degree)
+            a, ga, calls_a = run(m.GaussianModel._render_internal)
+            b, gb, calls_b = run(m2.GaussianModel._render_internal)
+            assert (len(calls_a), len(calls_b)) == (2, 1)
+            assert calls_b[0]["kwargs"]["sh_second"] is True and calls_b[0]["kwargs"]["colors_precomp"] is None
+            for k in ("accumulation", "radii", "visibility_filter"):
+                assert torch.equal(a[k], b[k]), (k, degree)
+            assert not torch.equal(a["render"], a["raw_render"])
+            for k in ("render", "raw_render"):
+                assert float((a[k] - b[k]).abs().max()) <= 2e-6, (k, degree, float((a[k] - b[k]).abs().max()))
+            for i, (x, y) in enumerate(zip(ga, gb)):
+                scale = float(x.abs().max())
+                assert float((x - y).abs().max()) <= 2e-4 * scale, (i, degree, float((x - y).abs().max()), scale)
+            assert sum(float(x.abs().max()) > 0 for x in ga) >= (7 if degree == 3 else 6)
+    finally:
+        wg.model.active_sh_degree.fill_(degree_was)

@@ -3,7 +3,8 @@
 //   * scripts/asan_pass.sh builds it and the library with -fsanitize=address (host side) and runs it on the GPU: the sanitizer
 //     pass SURVEY.md section 5 asks for, without a Python interpreter between ASan and the HIP runtime;
 //   * evidence that the boundary really is "plain pointers and sizes, no torch types" (tests/test_native_driver.py).
-// Since round 4 it also drives wg_rasterize_{forward,backward}_dual and _raw and checks their images, bit for bit, against plain calls.
+// Since round 4 it also drives wg_rasterize_{forward,backward}_dual, _raw and _two_tone and checks their images, bit for bit, against plain
+// (toned) calls.
 // Prints one line "ok num_rendered=... checksum=..." and exits 0, or a diagnostic and a non-zero code.
 // With a fourth argument (a path) it also DUMPS its inputs and every output of the three calls there, raw little-endian:
 //   int32 {P, W, H, D, M, R}, float32 {tanx, tany}, then float32 arrays means[3P] scales[3P] rots[4P] opac[P] shs[3MP] view[16] proj[16]
@@ -224,6 +225,41 @@ int main(int argc, char** argv) {
                                       nullptr, d_radii, g2.p, b2.p, i2.p, d_cot, g2d, nullptr, gop, gcol, g3d, gcov, nullptr, gsc, grot, 0, stream, nullptr, &rawg) != WG_OK) {
             std::fprintf(stderr, "raw-parameter backward: %s\n", wg_last_hip_error());
             return 16;
+        }
+        // two tones of one SH block in ONE call: each image equals the toned call's with that tone, bit for bit
+        {
+            std::vector<float> mul(3 * (size_t)P), off(3 * (size_t)P);
+            for (auto& v : mul) v = 0.5f + uni(seed);
+            for (auto& v : off) v = 0.4f * (uni(seed) - 0.5f);
+            float *d_mul, *d_off, *d_gmul, *d_goff;
+            if (upload(mul, &d_mul) || upload(off, &d_off)) return 2;
+            CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d_gmul), (size_t)P * 12));
+            CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d_goff), (size_t)P * 12));
+            wg_sh_tone t1 = {d_mul, d_off, 1.0f, 1.0f, d_gmul, d_goff};
+            wg_sh_tone t2 = {nullptr, nullptr, 0.2f, INFINITY, nullptr, nullptr};
+            auto toned = [&](const wg_sh_tone* t, float* out) {
+                return wg_rasterize_forward_toned(Grow::alloc, &g2, Grow::alloc, &b2, Grow::alloc, &i2, P, D, M, d_bg, W, H, d_means, d_shs, nullptr, d_opac, d_scales,
+                                                  1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, out, nullptr, 0, stream, t);
+            };
+            if (toned(&t1, imgA) != R || toned(&t2, imgB) != R) return 17;
+            const int Rt = wg_rasterize_forward_two_tone(Grow::alloc, &g2, Grow::alloc, &b2, Grow::alloc, &i2, P, D, M, d_bg, W, H, d_means, d_shs, nullptr, d_opac,
+                                                         d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, imgC, d_radii, 0,
+                                                         stream, &t1, &t2, nullptr, imgD);
+            if (Rt != R) { std::fprintf(stderr, "two-tone forward: %d (%s)\n", Rt, wg_last_hip_error()); return 17; }
+            if (!same(imgA, imgC, "two-tone call, first tone") || !same(imgB, imgD, "two-tone call, second tone")) return 17;
+            if (wg_rasterize_backward_two_tone(P, D, M, Rt, d_bg, W, H, d_means, d_shs, nullptr, d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany,
+                                               0.1f, nullptr, d_radii, g2.p, b2.p, i2.p, d_cot, g2d, nullptr, gop, nullptr, g3d, gcov, gsh, gsc, grot, 0, stream, &t1,
+                                               &t2, nullptr, d_cot, nullptr) != WG_OK) {
+                std::fprintf(stderr, "two-tone backward: %s\n", wg_last_hip_error());
+                return 18;
+            }
+            std::vector<float> h(3 * (size_t)P);
+            CHECK_HIP(hipStreamSynchronize(stream));
+            CHECK_HIP(hipMemcpy(h.data(), d_gmul, h.size() * 4, hipMemcpyDeviceToHost));
+            double l1 = 0;
+            for (float v : h) { if (!std::isfinite(v)) { std::fprintf(stderr, "non-finite dL_dmul\n"); return 18; } l1 += std::fabs(v); }
+            if (!(l1 > 0)) { std::fprintf(stderr, "dL_dmul is zero\n"); return 18; }
+            for (void* q : {(void*)d_mul, (void*)d_off, (void*)d_gmul, (void*)d_goff}) (void)hipFree(q);
         }
         // (d_radii was overwritten by these calls: restore the SH frame's for the dump below)
         if (wg_rasterize_forward(Grow::alloc, &geom, Grow::alloc, &bin, Grow::alloc, &img, P, D, M, d_bg, W, H, d_means, d_shs, nullptr, d_opac, d_scales, 1.0f,

@@ -165,6 +165,14 @@ def test_round4_entry_points_reject_invalid_arguments_before_any_device_work(lib
     assert fwd(raw, (None, None)) == -1
     assert fwd(raw, (None, C.byref(Raw(None, None)))) == -1                              # no filter
     assert fwd(raw, (None, C.byref(Raw(16, None))), scales=None, cov=one) == -1          # acts on scale / rotation pairs
+    # two tones of one SH block in one call: SH colours only, the second image required
+    class Tone(C.Structure):
+        _fields_ = [("mul", vp), ("offset", vp), ("pre_clamp_max", f), ("post_clamp_max", f), ("dL_dmul", vp), ("dL_doffset", vp)]
+    two = lib.wg_rasterize_forward_two_tone
+    two.restype, two.argtypes = i, fwd_args + [C.POINTER(Tone), C.POINTER(Tone), C.POINTER(Raw), vp]
+    assert fwd(two, (None, None, None, None), shs=one, colors=None) == -1               # no second image
+    assert fwd(two, (None, None, None, one)) == -1                                      # precomputed colours: the tones act on SH coefficients
+    assert fwd(two, (None, None, C.byref(Raw(None, None)), one), shs=one, colors=None) == -1   # raw block without a filter
     assert not called
 
     bwd_args = [i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, f, vp, vp, vp, vp, vp, vp] + [vp] * 9 + [i, vp]
@@ -180,6 +188,11 @@ def test_round4_entry_points_reject_invalid_arguments_before_any_device_work(lib
     assert bwd(lib.wg_rasterize_backward_dual, (C.byref(Second(None, None, 16, None)),)) == -1   # no place for the second colour gradient
     assert bwd(lib.wg_rasterize_backward_raw, (None, None)) == -1
     assert bwd(lib.wg_rasterize_backward_raw, (None, C.byref(Raw(16, None)))) == -1              # raw opacities are needed again
+    two_b = lib.wg_rasterize_backward_two_tone
+    two_b.restype, two_b.argtypes = i, bwd_args + [C.POINTER(Tone), C.POINTER(Tone), C.POINTER(Raw), vp, vp]
+    assert bwd(two_b, (None, None, None, None, None), shs=one) == -1                                  # no second cotangent
+    assert bwd(two_b, (None, None, None, one, None)) == -1                                            # no SH coefficients
+    assert bwd(two_b, (None, C.byref(Tone(16, None, 1.0, 1.0, None, None)), None, one, None), shs=one) == -1   # a multiplier without a place for its gradient
     lib.wg_set_option.restype, lib.wg_set_option.argtypes = i, [C.c_char_p, i]
     lib.wg_get_option.restype, lib.wg_get_option.argtypes = i, [C.c_char_p]
     assert lib.wg_get_option(b"exact_compositing") == 1 and lib.wg_get_option(b"geometry_reuse") == 0   # round-4 defaults

@@ -15,7 +15,7 @@ export WG_RASTERIZER_LIB=$PWD/wild-gaussians_amd/build/asan/libwg_rasterizer.so
   # 1. no interpreter in between: the torch-free driver (tests/native/c_abi_driver.cpp), itself built with ASan, runs a forward +
   #    backward + markVisible through the instrumented library on the GPU (nothing to run without one)
   if [ -e /dev/kfd ]; then
-    echo "== C-ABI driver under ASan (forward + backward + markVisible + recolor + two-colour + raw-parameter calls, 20000 Gaussians @ 320x200, then 200000 @ 1280x720)"
+    echo "== C-ABI driver under ASan (forward + backward + markVisible + recolor + two-colour + raw-parameter + two-tone calls, 20000 Gaussians @ 320x200, then 200000 @ 1280x720)"
     env -u LD_PRELOAD wild-gaussians_amd/build/asan/c_abi_driver 2>&1 | tail -20; echo "rc=${PIPESTATUS[0]}"
     env -u LD_PRELOAD wild-gaussians_amd/build/asan/c_abi_driver 200000 1280 720 2>&1 | tail -20; echo "rc=${PIPESTATUS[0]}"
   fi
@@ -24,7 +24,7 @@ export WG_RASTERIZER_LIB=$PWD/wild-gaussians_amd/build/asan/libwg_rasterizer.so
   echo "rc=${PIPESTATUS[0]}"
   if python -c "import torch,sys; sys.exit(0 if torch.cuda.is_available() else 1)" 2>/dev/null; then
     echo "== GPU slice under ASan"
-    python -m pytest tests/test_parity_gpu.py -q -k "operator_surface or all_culled or c_abi_backward or gradient_record or (sweep_against and (3 or 7 or 11))" 2>&1 | tail -15
+    python -m pytest tests/test_parity_gpu.py -q -k "operator_surface or all_culled or c_abi_backward or gradient_record or two_tones or (sweep_against and (3 or 7 or 11))" 2>&1 | tail -15
     echo "rc=${PIPESTATUS[0]}"
     python -m pytest tests/test_knn.py tests/test_ssim.py tests/test_densify.py tests/test_activations.py -q -m gpu 2>&1 | tail -5
     echo "rc=${PIPESTATUS[0]}"

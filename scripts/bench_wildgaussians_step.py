@@ -104,22 +104,13 @@ def real_caller(args):
     P, W, H = args.gaussians, args.width, args.height
     m, wg = harness.make_method(P, W, H, n_cams=args.cameras, cloud_shapes="bench", gt="random")
     wg.model.active_sh_degree.fill_(3)   # the state a trained model is in (oneupSHdegree every 1000 iterations, method.py:1896)
-    edited = None
-    if args.two_colour_edit or args.two_tone_edit:   # INTEGRATION.md section 5's edits of _render_internal, applied in memory to the staged method.py
-        import two_colour_edit
-        if args.two_tone_edit:
-            edited = "wildgaussians.method_two_tone"
-            m2 = two_colour_edit.import_edited_method(m, two_colour_edit.EDITS_TWO_TONE, edited)
-        else:
-            edited = "wildgaussians.method_two_colour"
-            m2 = two_colour_edit.import_edited_method(m)
-        m.GaussianModel._render_internal = m2.GaussianModel._render_internal
+    which = "two_tone" if args.two_tone_edit else "two_colour" if args.two_colour_edit else None
     if args.optins:   # the run-time opt-ins that need no source edit (wg_integration.apply_optins): fused SSIM, FusedAdam, fused densification
-        import wg_integration   # statistics, fused activations, fused eval_sh
-        wg_integration.apply_optins(m, model=wg.model)
-        if edited:   # the edited _render_internal looks its module-level names (eval_sh) up in ITS module
-            wg_integration.apply_optins(sys.modules[edited], adam=False, densification_stats=False, activations=False,
-                                        geometry_reuse=False)
+        import wg_integration   # statistics, fused activations, fused eval_sh; render_edit: INTEGRATION.md section 5's edit of _render_internal, in memory
+        wg_integration.apply_optins(m, model=wg.model, render_edit=which)
+    elif which:   # the edit alone
+        import wg_render_edits
+        m.GaussianModel._render_internal = wg_render_edits.import_edited_method(m, which=which).GaussianModel._render_internal
     if args.tall_linear and wg.model.appearance_mlp is not None:   # measurement scaffolding for the caller's MLP (see _TallLinear)
         for lin in wg.model.appearance_mlp.mlp:
             if isinstance(lin, torch.nn.Linear):

@@ -45,6 +45,22 @@ def test_omegaconf_stand_in_builds_the_config_the_caller_expects():
 
 
 @needs_staged
+def test_documented_render_edits_apply_to_the_caller_as_it_is_and_compile():
+    """wg_render_edits: every replacement's anchor is found exactly once in the staged, byte-identical method.py,
+    the edited source compiles, and an anchor that has gone raises instead of silently leaving the function as it was.  (CPU: text only.)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "wild-gaussians_amd"))
+    import wg_render_edits as E
+    path = os.path.join(stage.DST, "method.py")
+    for which, edits in E.EDIT_SETS.items():
+        src = E.edited_source(path, edits)
+        compile(src, which, "exec")
+        assert src != open(path).read()
+        assert ("sh_second=True" in src) == (which == "two_tone") and ("colors_precomp2" in src) == (which == "two_colour")
+    with pytest.raises(RuntimeError, match="no longer applies"):
+        E.edited_source(path, [("this line is not in the caller\n", "")])
+
+
+@needs_staged
 def test_synthetic_dataset_has_the_reference_types():
     harness.import_method()
     from wildgaussians.types import Cameras
@@ -146,11 +162,13 @@ def test_real_optimize_embedding_runs_the_rasterizer_with_gradients_to_the_colou
 
 @pytest.mark.gpu
 @needs_staged
-def test_runtime_optins_leave_the_real_step_where_it_was():
+@pytest.mark.parametrize("render_edit", [None, "two_tone"])
+def test_runtime_optins_leave_the_real_step_where_it_was(render_edit):
     """wg_integration.apply_optins swaps four names of the reference's module at run time (fused SSIM, FusedAdam, fused densification
     statistics, fused activations) and touches no source.  The same seeded model takes the same first steps either way: the
     losses agree to the fused pieces' own tolerances, the per-Gaussian statistics the densification reads agree, and the loop
-    then runs on through densification, pruning and the opacity reset."""
+    then runs on through densification, pruning and the opacity reset.  render_edit="two_tone": also `_render_internal` replaced by the
+    caller's own function with INTEGRATION.md section 5's two-tone edit applied in memory (one rasterizer call per step)."""
     import random
     import wg_integration
     ov = {"densify_from_iter": 10, "densification_interval": 15, "opacity_reset_interval": 40, "densify_until_iter": 55,
@@ -159,18 +177,21 @@ def test_runtime_optins_leave_the_real_step_where_it_was():
     def run(optins, steps):
         random.seed(7), np.random.seed(7), torch.manual_seed(7)
         m, wg = harness.make_method(30_000, 480, 320, n_cams=3, overrides=ov)
-        undo = wg_integration.apply_optins(m, model=wg.model) if optins else (lambda: None)
+        undo = wg_integration.apply_optins(m, model=wg.model, render_edit=render_edit) if optins else (lambda: None)
         try:
             random.seed(11)
-            out = [wg.train_iteration(i) for i in range(steps)]
-            kinds = (type(wg.model.optimizer), m.ssim.__module__)
+            with harness.RasterizerTap(m) as tap:
+                out = [wg.train_iteration(i) for i in range(steps)]
+            kinds = (type(wg.model.optimizer), m.ssim.__module__, len(tap.calls) // steps, m.GaussianModel._render_internal.__module__)
         finally:
             undo()
         return m, wg, out, kinds
     m, wg_a, a, kinds_a = run(False, 6)
     m, wg_b, b, kinds_b = run(True, 70)
     from wg_fused_gaussians import FusedAdam
-    assert kinds_b == (FusedAdam, "wg_fused_ssim") and kinds_a[0] is torch.optim.Adam and "wg_fused" not in kinds_a[1]
+    assert kinds_b[:2] == (FusedAdam, "wg_fused_ssim") and kinds_a[0] is torch.optim.Adam and "wg_fused" not in kinds_a[1]
+    assert (kinds_a[2], kinds_b[2]) == (2, 1 if render_edit else 2)   # rasterizer calls per step
+    assert kinds_b[3].endswith("_two_tone") == (render_edit is not None) and not m.GaussianModel._render_internal.__module__.endswith("_two_tone")
     assert type(wg_b.model.optimizer) is torch.optim.Adam   # undo() hands the adopted optimizer back too
     assert "wg_fused" not in m.ssim.__module__ and "apply_optins" not in m.GaussianModel.get_gaussians.__qualname__   # undone
     for i in range(6):   # the first steps, before the atomics' rounding noise has been through many Adam steps
@@ -317,15 +338,15 @@ def test_real_render_internal_reuses_the_geometry_of_its_first_rasterizer_call(t
 @pytest.mark.gpu
 @needs_staged
 def test_render_internal_with_the_two_colour_edit_gives_the_unedited_results(trained):
-    """INTEGRATION.md section 5's edit of `_render_internal` (tests/real_caller/two_colour_edit.py holds it as text replacements, applied in
+    """INTEGRATION.md section 5's edit of `_render_internal` (wild-gaussians_amd/wg_render_edits.py holds it as text replacements, applied in
     memory to the staged method.py): raw and toned colours in ONE rasterizer call (`colors_precomp2=`).  Against the unedited method, on
     the same trained model and camera: one rasterizer call instead of two; render, raw render, accumulation and radii bit-identical; the
     gradients of the step's real loss shape (L1 on the toned image + a term on the raw one, method.py:1948-1960) on every parameter
     equal to rounding (2e-4 of a tensor's largest magnitude; observed <= 2.2e-5)."""
-    import two_colour_edit
+    import wg_render_edits
     from diff_gaussian_rasterization import _C
     m, wg, _ = trained
-    m2 = two_colour_edit.import_edited_method(m)
+    m2 = wg_render_edits.import_edited_method(m, which="two_colour")
     assert m2.GaussianRasterizer is m.GaussianRasterizer
     cam = wg.train_cameras[1]
     params = [p for p in (wg.model.xyz, wg.model.scales, wg.model.rotations, wg.model.opacities, wg.model.features_dc, wg.model.features_rest,
@@ -361,14 +382,14 @@ def test_render_internal_with_the_two_colour_edit_gives_the_unedited_results(tra
 @pytest.mark.gpu
 @needs_staged
 def test_render_internal_with_the_two_tone_edit_gives_the_unedited_results(trained):
-    """INTEGRATION.md section 5's further edit of `_render_internal` (two_colour_edit.EDITS_TWO_TONE): the SH features themselves, the
+    """INTEGRATION.md section 5's further edit of `_render_internal` (wg_render_edits.EDITS_TWO_TONE): the SH features themselves, the
     appearance MLP's affine and `sh_second=True` go to ONE rasterizer call -- no eval_sh, no P x 48 toned tensor in torch.  Against the
     unedited method, same trained model and camera: one call instead of two; accumulation, radii bit-identical (the geometry path does
     not see colours); both renders to 2e-6 (the polynomial is evaluated by the kernel instead of torch's eval_sh: rounding); the real
     loss shape's gradients on every parameter to 2e-4 of a tensor's largest magnitude."""
-    import two_colour_edit
+    import wg_render_edits
     m, wg, _ = trained
-    m2 = two_colour_edit.import_edited_method(m, two_colour_edit.EDITS_TWO_TONE, "wildgaussians.method_two_tone")
+    m2 = wg_render_edits.import_edited_method(m, which="two_tone")
     cam = wg.train_cameras[1]
     params = [p for p in (wg.model.xyz, wg.model.scales, wg.model.rotations, wg.model.opacities, wg.model.features_dc, wg.model.features_rest,
                           wg.model.embeddings) if p is not None and p.requires_grad]

@@ -1,8 +1,15 @@
-"""The caller edit INTEGRATION.md section 5 documents for the two-colour call, as text replacements applied IN MEMORY to the staged
-(byte-identical) `wildgaussians/method.py`: `_render_internal` (method.py:1573-1611) rasterizes raw and toned colours over identical
-geometry with two calls; with the edit the first call is skipped when both are wanted and the second hands the raw colours over as
-`colors_precomp2=`.  TEST INFRASTRUCTURE: nothing is written to disk; a replacement whose original text is not found exactly once raises
-(the edit documented in INTEGRATION.md stays one that applies to the reference as it is)."""
+"""The two caller edits INTEGRATION.md section 5 documents for `_render_internal` (wildgaussians/method.py:1479-1632), as text replacements
+applied IN MEMORY to the caller's own `method.py` -- nothing is written to disk; a replacement whose original text is not found exactly once
+raises (an edit stays one that applies to the reference as it is):
+
+  EDITS           "two_colour": `_render_internal` rasterizes raw and toned colours over identical geometry with two calls
+                  (method.py:1573-1611); with the edit the first call is skipped when both are wanted and the second hands the raw colours
+                  over as `colors_precomp2=`.
+  EDITS_TWO_TONE  "two_tone": the one call takes the SH features themselves and the appearance MLP's affine (`shs=`, `sh_mul=`,
+                  `sh_offset=`, `sh_second=True`): no eval_sh, no P x 48 toned tensor in torch.
+
+`wg_integration.apply_optins(method, render_edit="two_tone")` applies one at run time; tests/test_real_caller.py holds both to the unedited
+function's results.  The `old` halves are the reference's own lines, quoted as anchors -- the only way to say where an edit goes."""
 from __future__ import annotations
 
 import importlib.util
@@ -73,17 +80,30 @@ def edited_source(path: str, edits=None) -> str:
     return src
 
 
-def import_edited_method(method_module, edits=None, name="wildgaussians.method_two_colour"):
-    """A second module object, `wildgaussians.method_two_colour`, compiled from the staged method.py with EDITS applied (same package:
-    its relative imports resolve to the same staged modules; the operator packages are the ones `method_module` bound).
-    edits=EDITS_TWO_TONE, name="wildgaussians.method_two_tone": the two-tone edit."""
+EDIT_SETS = {"two_colour": EDITS, "two_tone": EDITS_TWO_TONE}
+
+
+def import_edited_method(method_module, edits=None, name=None, which=None):
+    """A second module object compiled from `method_module`'s own source file with one edit set applied, in the same package (its
+    relative imports resolve to the same modules; the operator packages are the ones `method_module` bound).  which = "two_colour" /
+    "two_tone" (default name `<module>_<which>`), or an explicit list of (old, new) replacements and a module name."""
+    if which is not None:
+        edits = EDIT_SETS[which]
+    elif edits is None:
+        which, edits = "two_colour", EDITS
+    if name is None:
+        name = f"{method_module.__name__}_{which or 'edited'}"
     if name in sys.modules:
         return sys.modules[name]
     path = method_module.__file__
     spec = importlib.util.spec_from_loader(name, loader=None, origin=path)
     mod = importlib.util.module_from_spec(spec)
     mod.__file__ = path
-    mod.__package__ = "wildgaussians"
+    mod.__package__ = method_module.__package__
     sys.modules[name] = mod
-    exec(compile(edited_source(path, edits), os.path.join(os.path.dirname(path), name.rsplit(".", 1)[1] + ".py"), "exec"), mod.__dict__)
+    try:
+        exec(compile(edited_source(path, edits), os.path.join(os.path.dirname(path), name.rsplit(".", 1)[-1] + ".py"), "exec"), mod.__dict__)
+    except BaseException:
+        sys.modules.pop(name, None)
+        raise
     return mod

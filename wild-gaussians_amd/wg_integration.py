@@ -88,7 +88,7 @@ def apply_optins(method_module, model=None, ssim: bool = True, adam: bool = True
         import wg_render_edits
         edited = wg_render_edits.import_edited_method(method_module, which=render_edit)
         for name in ("ssim", "eval_sh"):   # the edited function looks module-level names up in ITS module: hand it the swapped ones
-            setattr(edited, name, getattr(method_module, name))
+            swap(edited, name, getattr(method_module, name))   # (undo() puts its own back: the module object is cached in sys.modules)
         swap(GM, "_render_internal", edited.GaussianModel._render_internal)
 
     reuse_before = None

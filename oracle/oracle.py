@@ -88,6 +88,8 @@ class OracleContext:
         "ranges": (np.uint32, lambda s: (s.tiles, 2)),
         "frag_alpha": ("real", lambda s: (s.H, s.W)),
         "frag_T": ("real", lambda s: (s.H, s.W)),
+        "n_evaluated": (np.uint32, lambda s: (s.H, s.W)),
+        "n_blended": (np.uint32, lambda s: (s.H, s.W)),
     }
 
     def __init__(self, lib, handle, precision, P, W, H):

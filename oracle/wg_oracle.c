@@ -171,6 +171,9 @@ typedef struct wgo_ctx {
     /* test aid (not in the reference): per-pixel distance to the nearest threshold decision */
     real* frag_alpha; /* min over evaluated pairs of |alpha*255 - 1| */
     real* frag_T;     /* min over blended-or-terminating pairs of |test_T*1e4 - 1| */
+    /* measurement aid (SURVEY 8d's secondary ceiling: flops per evaluated / contributing pair): per-pixel pair counts of K8 */
+    uint32_t* n_evaluated; /* list entries the pixel's thread evaluated (forward.cu:340-366: up to and including the one that stopped it) */
+    uint32_t* n_blended;   /* of those, the ones blended (forward.cu:374-381) = the pairs the backward pass differentiates */
 } wgo_ctx;
 
 /* forward.cu:20-71 */
@@ -316,6 +319,7 @@ WGO_API void wgo_free(wgo_ctx* c) {
     free(c->conic_opacity); free(c->rgb); free(c->tiles_touched); free(c->point_offsets);
     free(c->keys_unsorted); free(c->vals_unsorted); free(c->keys); free(c->point_list);
     free(c->final_T); free(c->n_contrib); free(c->ranges); free(c->frag_alpha); free(c->frag_T);
+    free(c->n_evaluated); free(c->n_blended);
     free(c);
 }
 
@@ -357,6 +361,8 @@ WGO_API wgo_ctx* wgo_forward(int P, int D, int M, const real* background, int wi
     c->ranges = (uint32_t*)calloc((Tn ? Tn : 1) * 2, sizeof(uint32_t));
     c->frag_alpha = (real*)calloc(N ? N : 1, sizeof(real));
     c->frag_T = (real*)calloc(N ? N : 1, sizeof(real));
+    c->n_evaluated = (uint32_t*)calloc(N ? N : 1, sizeof(uint32_t));
+    c->n_blended = (uint32_t*)calloc(N ? N : 1, sizeof(uint32_t));
 
     /* K1: preprocessCUDA, forward.cu:167-268 */
 #pragma omp parallel for schedule(static)
@@ -486,7 +492,7 @@ WGO_API wgo_ctx* wgo_forward(int P, int D, int M, const real* background, int wi
                 pixf_x += subpixel_offset[2 * pix_id];
                 pixf_y += subpixel_offset[2 * pix_id + 1];
                 real T = (real)1.0;
-                uint32_t contributor = 0, last_contributor = 0;
+                uint32_t contributor = 0, last_contributor = 0, blended = 0;
                 real C[NUM_CHANNELS] = {0, 0, 0};
                 real fr_a = (real)1e30, fr_t = (real)1e30;
                 for (uint32_t k = r0; k < r1; k++) {
@@ -506,7 +512,10 @@ WGO_API wgo_ctx* wgo_forward(int P, int D, int M, const real* background, int wi
                     for (int ch = 0; ch < NUM_CHANNELS; ch++) C[ch] += features[(size_t)g * NUM_CHANNELS + ch] * alpha * T;
                     T = test_T;
                     last_contributor = contributor;
+                    blended++;
                 }
+                c->n_evaluated[pix_id] = contributor;
+                c->n_blended[pix_id] = blended;
                 c->final_T[pix_id] = T;
                 c->frag_alpha[pix_id] = fr_a;
                 c->frag_T[pix_id] = fr_t;
@@ -919,3 +928,5 @@ GETTER(n_contrib, uint32_t, n_contrib, (size_t)c->W * c->H)
 GETTER(ranges, uint32_t, ranges, 2 * (size_t)c->gx * c->gy)
 GETTER(frag_alpha, real, frag_alpha, (size_t)c->W * c->H)
 GETTER(frag_T, real, frag_T, (size_t)c->W * c->H)
+GETTER(n_evaluated, uint32_t, n_evaluated, (size_t)c->W * c->H)
+GETTER(n_blended, uint32_t, n_blended, (size_t)c->W * c->H)

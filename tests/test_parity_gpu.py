@@ -30,6 +30,24 @@ def _gpu():
     _need_gpu()
 
 
+def arbitrate_with_the_reference_build(cloud, cam, deg, hip_color, **kw):
+    """The same frame through oracle/_ref (the reference's CUDA sources built for gfx950 with -ffp-contract=off) and through the product's
+    native module: num_rendered, radii, n_contrib equal, final_T equal bit for bit, NO pixel of the image over 1e-4 (all within 2e-6).
+    A box with a HIP device and without oracle/_ref fails (tests/ref_mode_checks.need_ref)."""
+    from ref_mode_checks import IMG_ATOL, need_ref
+    ref_hip = need_ref("nofma")
+    H, W = cam["height"], cam["width"]
+    r = ref_hip.run_scene(cloud, cam, sh_degree=deg, variant="nofma", **kw)
+    n = run_hip_native(cloud, cam, sh_degree=deg, **{k: v for k, v in kw.items() if k in ("kernel_size", "bg", "subpixel_offset")})
+    assert int(n["num_rendered"]) == int(r["num_rendered"])
+    np.testing.assert_array_equal(n["radii"].cpu().numpy(), r["radii"])
+    im = n["views"]["image"]
+    np.testing.assert_array_equal(im["n_contrib"].cpu().numpy().reshape(H, W).astype(np.int64), r["n_contrib"].astype(np.int64))
+    np.testing.assert_array_equal(im["final_T"].cpu().numpy().reshape(H, W).view(np.uint32), r["final_T"].astype(np.float32).view(np.uint32))
+    err = np.abs(np.asarray(hip_color, np.float64) - r["color"]).max(axis=0)
+    assert int((err > 1e-4).sum()) == 0 and float(err.max()) <= IMG_ATOL, (int((err > 1e-4).sum()), float(err.max()))
+
+
 CASES = {
     # name: (P, W, H, sh_degree or None for precomputed colours, scale_mult)
     "config1_sh0_256": (10000, 256, 256, 0, 1.0),
@@ -111,8 +129,10 @@ def test_forward_rgb_parity(oracle, name):
     c = compare_forward(h["color"], o)
     assert c["max_err_solid"] <= 1e-4, c
     assert c["n_fragile"] <= 0.01 * c["n_pixels"], c           # the margin thresholds leave >= 99% of pixels strict
-    assert c["n_over_in_fragile"] <= max(3, 1e-5 * c["n_pixels"]), c  # and only a handful of those actually flip (observed: ~2 ppm)
-    assert c["max_err_all"] <= 5e-3, c                                # a flipped decision moves a pixel by at most ~4e-3
+    # The fragile pixels are where the CPU oracle's libm expf and the GPU's float32 exp expansion may land on different sides of a
+    # threshold: the oracle cannot arbitrate them, the reference's own kernels on this GPU can -- and there no pixel may differ at all
+    # (decision-exact compositing: n_contrib and final_T bit for bit, the image within the colour sums' fused multiply-adds).
+    arbitrate_with_the_reference_build(cloud, cam, deg, h["color"], bg=bg, subpixel_offset=so)
     # accumulation = 1 - final_T
     acc_ref = 1.0 - o["ctx"].get("final_T")
     ok = np.abs(h["accumulation"] - acc_ref) <= 1e-4
@@ -186,8 +206,7 @@ def test_config2_500k_1080p_sh3_fwd_bwd(oracle):
     np.testing.assert_array_equal(h["radii"], o["radii"])
     c = compare_forward(h["color"], o)
     assert c["max_err_solid"] <= 1e-4, c
-    assert c["n_over_in_fragile"] <= max(3, 1e-5 * c["n_pixels"]), c
-    assert c["max_err_all"] <= 5e-3, c
+    arbitrate_with_the_reference_build(cloud, cam, 3, h["color"])   # the fragile pixels: no flip budget, the reference's kernels decide
     errs = compare_grads(h["grads"], o["grads"])
     for k, e in errs.items():
         assert e <= 1e-3, (k, e, errs)
@@ -680,35 +699,7 @@ def test_staged_scatter_fills_the_same_buckets(oracle, lazy_options, cap, lists)
 
 
 # ---- seeded sweep over the operator's arguments ------------------------------------------------------------------------------
-def _sweep_case(i):
-    """Case i of a deterministic sweep: odd frame sizes, fields of view, rotated / translated cameras, every SH degree and
-    precomputed colours, mip-filter sizes, non-zero background, sub-pixel offsets, scale_modifier, precomputed covariances."""
-    rng = np.random.default_rng(1000 + i)
-    W = int(rng.integers(17, 230))
-    H = int(rng.integers(17, 170))
-    fov = float(rng.uniform(35.0, 95.0))
-    yaw = float(rng.uniform(-12.0, 12.0))
-    cam = S.make_camera(W, H, fov_x_deg=fov, yaw_deg=yaw)
-    deg = [None, 0, 1, 2, 3][i % 5]
-    P = int(rng.integers(50, 2500))
-    cloud = S.make_cloud(P, W, H, sh_degree=deg, seed=2000 + i, fov_x_deg=fov, scale_mult=float(rng.uniform(0.5, 9.0)))
-    if i % 7 == 3:   # some Gaussians behind / too close to the camera, some far outside the frame
-        cloud["means3D"][: P // 5, 2] = rng.uniform(-1.0, 0.25, size=P // 5).astype(np.float32)
-        cloud["means3D"][P // 5: P // 4, 0] *= 6.0
-    kw = dict(kernel_size=float(rng.choice([0.0, 0.1, 0.3, 1.0])),
-              bg=rng.uniform(0, 1, size=3).astype(np.float32) if i % 2 else None,
-              subpixel_offset=rng.uniform(-0.5, 0.5, size=(H, W, 2)).astype(np.float32) if i % 3 == 0 else None,
-              scale_modifier=float(rng.choice([1.0, 0.6, 1.7])))
-    if i % 6 == 5:   # covariances instead of scales + rotations (the operator accepts exactly one of the two)
-        s, q = cloud.pop("scales").astype(np.float64), cloud.pop("rotations").astype(np.float64)
-        r, x, y, z = q.T
-        Rm = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
-                       2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
-                       2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], axis=1).reshape(-1, 3, 3)
-        M = Rm * (s * kw["scale_modifier"])[:, None, :]
-        Sg = M @ M.transpose(0, 2, 1)
-        cloud["cov3D_precomp"] = np.stack([Sg[:, 0, 0], Sg[:, 0, 1], Sg[:, 0, 2], Sg[:, 1, 1], Sg[:, 1, 2], Sg[:, 2, 2]], 1).astype(np.float32)
-    return cloud, cam, (deg if deg is not None else 0), kw, W, H
+from wg_testlib import sweep_case as _sweep_case  # noqa: E402  (shared with tests/ref_mode_checks.py and tests/tools/)
 
 
 @pytest.mark.parametrize("i", range(30))

@@ -12,7 +12,17 @@ sys.path.insert(0, os.path.join(HERE, "real_caller"))
 import harness  # noqa: E402
 import stage_reference_caller as stage  # noqa: E402
 
-needs_staged = pytest.mark.skipif(not stage.staged_ok(), reason="real caller not staged (run tests/real_caller/stage_reference_caller.py)")
+# The staged copy of the reference's caller travels with the tree like oracle/_ref (git-ignored, not gpurun-ignored).  Without it the
+# CPU-side tests skip; on a box with a HIP device its absence FAILS the GPU tests (a green suite must mean the real caller ran).
+needs_staged = pytest.mark.skipif(not stage.staged_ok() and not torch.cuda.is_available(),
+                                  reason="real caller not staged (run tests/real_caller/stage_reference_caller.py)")
+
+
+@pytest.fixture(autouse=True)
+def _staged_or_fail(request):
+    if request.node.get_closest_marker("skipif") is not None and not stage.staged_ok():
+        pytest.fail("tests/real_caller/_staged is missing on a box with a HIP device: stage it where /root/reference exists "
+                    "(python __graft_entry__.py) -- it travels with the tree")
 
 
 def test_staged_caller_is_byte_identical_to_the_reference():
@@ -98,9 +108,8 @@ def test_real_train_iteration_runs_and_the_loss_falls(trained):
 def test_real_render_internal_matches_the_reference_build(trained):
     """One `_render_internal` (method.py:1479-1632) of the trained state; each of its rasterizer calls replayed through
     oracle/_ref (the reference's CUDA sources built for gfx950, no-contraction build): radii bit-exact, image <= 1e-4."""
-    from oracle.ref_hip import ref_hip
-    if not ref_hip.available("nofma"):
-        pytest.skip("oracle/_ref not built")
+    from ref_mode_checks import need_ref   # a GPU box without oracle/_ref FAILS (tests/ref_mode_checks.py)
+    ref_hip = need_ref("nofma")
     m, wg, _ = trained
     cam = wg.train_cameras[1]
     with harness.RasterizerTap(m) as tap, torch.no_grad():
@@ -112,9 +121,10 @@ def test_real_render_internal_matches_the_reference_build(trained):
         assert torch.equal(radii, ref["radii"])
         err = (color - ref["color"]).abs()
         flipped = int((err > 1e-4).any(dim=0).sum())   # PIXELS on the other side of a threshold (a flip moves up to three channels)
-        # observed 1..2 of 307 200; the trained state itself differs from run to run (atomics in the 45 training steps), hence the margin
-        assert flipped <= 6 and float(err.max()) <= 5e-3, (flipped, float(err.max()))
-        assert float((acc - ref["accumulation"]).abs().max()) <= 5e-3
+        # decision-exact compositing: the same inputs through both give the same decisions -- no flip budget; what is left of the image
+        # difference are the colour sums' fused multiply-adds, and the accumulation (1 - final_T) is the reference's bits
+        assert flipped == 0 and float(err.max()) <= 2e-6, (flipped, float(err.max()))
+        assert torch.equal(acc, ref["accumulation"])
     assert torch.equal(out["render"], tap.calls[1]["out"][0]) and torch.equal(out["raw_render"], tap.calls[0]["out"][0])
 
 
@@ -209,9 +219,8 @@ def test_real_step_backward_replayed_through_the_reference_build(trained):
     """VERDICT r2 missing item 3, first half: one REAL `train_iteration` (method.py:1880-2024) with every rasterizer call recorded --
     inputs, settings and the dL/d(image) autograd hands it -- and each call's backward pass replayed, on those very tensors, through
     this repo's operator and through oracle/_ref (the reference's own kernels, no-contraction build): every gradient <= 1e-3."""
-    from oracle.ref_hip import ref_hip
-    if not ref_hip.available("nofma"):
-        pytest.skip("oracle/_ref not built")
+    from ref_mode_checks import need_ref   # a GPU box without oracle/_ref FAILS (tests/ref_mode_checks.py)
+    ref_hip = need_ref("nofma")
     import ref_backed
     from diff_gaussian_rasterization import GaussianRasterizer
     m, wg, _ = trained
@@ -276,9 +285,8 @@ def test_training_trajectory_on_the_product_and_on_the_reference_kernels():
         (the larger of the two implementations' own run-to-run differences, x 1.5, with floors that cover the spreads seen over five
         GPU runs of this test: counts +-3 %, PSNR +-0.5 dB, loss +-1.5 %): a sanity statement about a chaotic process, not a tight one."""
     import json
-    from oracle.ref_hip import ref_hip
-    if not ref_hip.available("nofma"):
-        pytest.skip("oracle/_ref not built")
+    from ref_mode_checks import need_ref   # a GPU box without oracle/_ref FAILS (tests/ref_mode_checks.py)
+    ref_hip = need_ref("nofma")
     ov = {"densify_from_iter": 30, "densification_interval": 40, "opacity_reset_interval": 120, "densify_until_iter": 260,
           "densify_grad_threshold": 0.00002}
     a1, a2 = _trajectory("product", 300, ov), _trajectory("product", 300, ov)

@@ -94,3 +94,39 @@ def compare_grads(hip_grads, oracle_grads):
         if k in hip_grads and k in oracle_grads and oracle_grads[k].size:
             res[k] = rel_err(hip_grads[k].reshape(oracle_grads[k].shape), oracle_grads[k])
     return res
+
+
+def _S():
+    import wg_scenes
+    return wg_scenes
+
+
+def sweep_case(i):
+    """Case i of a deterministic sweep: odd frame sizes, fields of view, rotated / translated cameras, every SH degree and
+    precomputed colours, mip-filter sizes, non-zero background, sub-pixel offsets, scale_modifier, precomputed covariances."""
+    rng = np.random.default_rng(1000 + i)
+    W = int(rng.integers(17, 230))
+    H = int(rng.integers(17, 170))
+    fov = float(rng.uniform(35.0, 95.0))
+    yaw = float(rng.uniform(-12.0, 12.0))
+    cam = _S().make_camera(W, H, fov_x_deg=fov, yaw_deg=yaw)
+    deg = [None, 0, 1, 2, 3][i % 5]
+    P = int(rng.integers(50, 2500))
+    cloud = _S().make_cloud(P, W, H, sh_degree=deg, seed=2000 + i, fov_x_deg=fov, scale_mult=float(rng.uniform(0.5, 9.0)))
+    if i % 7 == 3:   # some Gaussians behind / too close to the camera, some far outside the frame
+        cloud["means3D"][: P // 5, 2] = rng.uniform(-1.0, 0.25, size=P // 5).astype(np.float32)
+        cloud["means3D"][P // 5: P // 4, 0] *= 6.0
+    kw = dict(kernel_size=float(rng.choice([0.0, 0.1, 0.3, 1.0])),
+              bg=rng.uniform(0, 1, size=3).astype(np.float32) if i % 2 else None,
+              subpixel_offset=rng.uniform(-0.5, 0.5, size=(H, W, 2)).astype(np.float32) if i % 3 == 0 else None,
+              scale_modifier=float(rng.choice([1.0, 0.6, 1.7])))
+    if i % 6 == 5:   # covariances instead of scales + rotations (the operator accepts exactly one of the two)
+        s, q = cloud.pop("scales").astype(np.float64), cloud.pop("rotations").astype(np.float64)
+        r, x, y, z = q.T
+        Rm = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                       2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                       2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], axis=1).reshape(-1, 3, 3)
+        M = Rm * (s * kw["scale_modifier"])[:, None, :]
+        Sg = M @ M.transpose(0, 2, 1)
+        cloud["cov3D_precomp"] = np.stack([Sg[:, 0, 0], Sg[:, 0, 1], Sg[:, 0, 2], Sg[:, 1, 1], Sg[:, 1, 2], Sg[:, 2, 2]], 1).astype(np.float32)
+    return cloud, cam, (deg if deg is not None else 0), kw, W, H

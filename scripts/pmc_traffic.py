@@ -23,7 +23,8 @@ STAGE_OF = {"preprocess_kernel": "preprocess", "tile_count_kernel": "scan", "chu
 vals = {}
 for line in open(sys.argv[1]):
     m = re.match(r"(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE|SQ_INSTS_VALU|SQ_INSTS_SALU|SQ_INSTS_LDS|SQ_ACTIVE_INST_VALU|GRBM_GUI_ACTIVE|SQ_LDS_BANK_CONFLICT|"
-                 r"SQ_INSTS_VALU_TRANS_F32)\s+dispatches=\s*\d+\s+per_dispatch=\s*(\d+)", line)
+                 r"SQ_INSTS_VALU_TRANS_F32|SQ_THREAD_CYCLES_VALU|SQ_INSTS_VALU_ADD_F32|SQ_INSTS_VALU_MUL_F32|SQ_INSTS_VALU_FMA_F32|SQ_INST_CYCLES_VALU|"
+                 r"SQ_INSTS_VALU_INT32)\s+dispatches=\s*\d+\s+per_dispatch=\s*(\d+)", line)
     if not m:
         continue
     name = re.sub(r"^void ", "", m.group(1)).split("(")[0].replace("wg::", "").split("<")[0]
@@ -39,13 +40,19 @@ except Exception:  # noqa: BLE001
     src_sha = None
 out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "kernel_source_sha": src_sha, "collected": time.strftime("%Y-%m-%d"), "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving; WRITE_SIZE as reported)",
        "stages": {k: dict(v, hbm_bytes=(2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024) for k, v in vals.items()}}
-# How busy the vector ALUs were, from counters alone: SQ_ACTIVE_INST_VALU counts, summed over all SIMDs, the cycles a
-# SIMD's VALU was executing an instruction, in units of 4 cycles; GRBM_GUI_ACTIVE the kernel's cycles, summed over the 8 XCDs.
-#   valu_busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
-# (the two come from different passes of the same command, so a few percent of run-to-run spread are in it; multi-pass instructions --
-# transcendentals, DPP -- can push it past 1 by this accounting).  A stage of several kernels sums both counters over them.
+# Lane utilisation of the vector ALU from counters alone (rocprofiler's VALUUtilization): SQ_THREAD_CYCLES_VALU counts thread-cycles of VALU
+# execution, SQ_ACTIVE_INST_VALU the (quad-)cycles waves spent executing VALU instructions:
+#   thread_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)            (<= 1: the mean fraction of a wave's 64 lanes that were active)
+# (the two come from different passes of the same command: a few percent of run-to-run spread are in it).  Round 4 also derived a "busy
+# fraction" 4 * SQ_ACTIVE_INST_VALU / (SIMDs * GRBM_GUI_ACTIVE / 8), which read 1.1 - 1.4 for the render kernels: SQ_ACTIVE_INST_VALU is summed
+# over WAVES, and the execution windows of different waves' instructions on one SIMD overlap (a transcendental or a DPP instruction is still in
+# the pipe when the next wave's instruction issues), so that sum is not bounded by the SIMD's cycles.  It is kept as
+# `valu_wave_cycles_per_simd_cycle` -- an occupancy-like figure, NOT a fraction of anything.
 for st in out["stages"].values():
     if st.get("SQ_ACTIVE_INST_VALU") and st.get("GRBM_GUI_ACTIVE"):
-        st["valu_busy"] = round(4.0 * st["SQ_ACTIVE_INST_VALU"] / (1024.0 * st["GRBM_GUI_ACTIVE"] / 8.0), 3)
-out["valu_busy_note"] = "4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs): fraction of SIMD cycles with the vector ALU executing"
+        st["valu_wave_cycles_per_simd_cycle"] = round(4.0 * st["SQ_ACTIVE_INST_VALU"] / (1024.0 * st["GRBM_GUI_ACTIVE"] / 8.0), 3)
+    if st.get("SQ_ACTIVE_INST_VALU") and st.get("SQ_THREAD_CYCLES_VALU"):
+        st["thread_utilisation"] = round(st["SQ_THREAD_CYCLES_VALU"] / (64.0 * st["SQ_ACTIVE_INST_VALU"]), 4)
+out["valu_note"] = ("thread_utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU): mean active lanes per executed vector instruction; "
+                    "valu_wave_cycles_per_simd_cycle = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs): summed over waves, may exceed 1")
 print(json.dumps(out, indent=1))

@@ -270,6 +270,27 @@ def test_view_partition():
     assert len(cams) == 3 and not np.allclose(cams[0]["viewmatrix"], cams[1]["viewmatrix"])
 
 
+def test_config4_fixed_batch_of_eight_views_over_1_2_4_8_ranks():
+    """BASELINE config 4 as it is worded -- a FIXED batch of eight views, 1/2/4/8 GPUs (`bench.py --gpus N --views 8`): rank r
+    renders views r, r + N, ... of the batch every step, every view is rendered exactly once per step whatever N, and the job's value counts the
+    batch's eight iterations per step (strong scaling).  With the per-view costs of the eight cameras (R falls from 7.44 M to 3.46 M) the dealing
+    leaves rank 0 the heaviest share: the imbalance the line reports per rank instead of hiding it behind 'one view per rank'."""
+    import wg_viewparallel as VP
+    R = [7437959, 7057510, 6346333, 5694514, 5098037, 4532755, 3992739, 3456334]   # tests/golden/ref_hip_fullsize_sha256.json: num_rendered of the eight cameras
+    for world in (1, 2, 4, 8):
+        shares = [VP.views_for_rank(8, r, world) for r in range(world)]
+        assert sorted(sum(shares, [])) == list(range(8)) and all(len(sh) == 8 // world for sh in shares)
+        assert shares[0][0] == 0 and all(sh == list(range(r, 8, world)) for r, sh in enumerate(shares))
+        rows = [[float(r), float(r), 1.0 + 0.1 * r, float(sum(R[v] for v in sh)), float(len(sh))] for r, sh in enumerate(shares)]
+        job = VP.job_fields(world, 10, 0.02, rows, views_total=8)
+        assert job["value"] == round(8 * 10 / 0.02, 3) and job["n_gpus"] == world          # eight iterations per step whatever N
+        inst = [job["per_rank_num_rendered"][str(r)]["instances"] for r in range(world)]
+        assert sum(inst) == sum(R) and inst[0] == max(inst)
+        if world == 8:
+            assert inst[0] / inst[7] > 2.1                                                    # the N = 8 point is bounded by camera 0's rank
+    assert VP.job_fields(2, 10, 0.02, [[0.0, 0.0, 1.0], [1.0, 1.0, 1.0]])["value"] == round(2 * 10 / 0.02, 3)   # default: one view per rank (weak)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -344,7 +365,7 @@ def _job8_worker(rank, world, port, q):
     cam = VP.view_cameras(w, 64, 48)[r]          # bench.py: one camera per rank, rank 0 = the base camera
     own = [0.0]
     t = VP.timed_region(lambda: time.sleep(0.002 * (1 + (r == 5))), 5, None, own)   # rank 5 is the slow one
-    seen = VP.gather_over_ranks([float(r), float(lr), 1000.0 * own[0] / 5], None)
+    seen = VP.gather_over_ranks([float(r), float(lr), 1000.0 * own[0] / 5, 1000.0 * (r + 1), 1.0], None)
     job = VP.job_fields(w, 5, t, seen, baseline_iters_per_s=400.0)
     ls = VP.LossStream()
     ls.submit(torch.full((3, 2, 2), float(r)), torch.ones(12))
@@ -378,6 +399,7 @@ def test_bench_job_flow_with_eight_ranks_gloo():
         eff = job["scaling_efficiency"]
         assert abs(eff["efficiency"] - job["value"] / (8 * 400.0)) < 1e-3
         assert abs(loss - 12.0 * sum(range(8))) < 1e-4                         # SUM all-reduce of <image, cotangent> over the 8 ranks
+        assert job["per_rank_num_rendered"][str(r)] == {"instances": 1000 * (r + 1), "views": 1}   # every rank's own instance count is in the line
         if len(before) >= 8:                                                    # every rank on its own slice of the allowed cores
             per = len(before) // 8
             assert after == before[r * per:(r + 1) * per], (r, before, after)
@@ -443,18 +465,32 @@ def test_bench_byte_model():
     csrc = os.path.join(ROOT, "wild-gaussians_amd", "csrc")
     files = {f for f in os.listdir(csrc) if f.endswith((".hip", ".h"))}
     assert files == set(bench.OPERATOR_SOURCES) | set(bench.OPT_IN_SOURCES), files ^ (set(bench.OPERATOR_SOURCES) | set(bench.OPT_IN_SOURCES))
-    # the roofline label follows the ceiling the kernel is closest to: VALU issue for the render kernels when a PMC pass says so,
-    # HBM by SURVEY 8(d) bytes otherwise (never "hbm, 0.0955" for a kernel at 1.00 of the VALU ceiling)
+    # the roofline object is SURVEY 8(d)'s: HBM, algorithmic bytes / launch time / 8 TB/s -- whatever else is known about the kernel
+    # (`frac` is the number the >= 0.60 target is judged on, 0.19 for K9, never a builder-defined VALU "ceiling")
     row = {"ms": 0.42, "design_GBps": 346.0, "reference_scheme_equiv_GBps": 1614.0, "frac_of_peak_by_design_bytes": 0.0433,
-           "hbm_traffic_GBps": 758.0, "frac_of_peak_by_traffic": 0.0948, "frac_of_valu_issue_peak": 1.002}
-    r = bench.governing_roofline("render_backward", row, {"hbm_bytes": 318361600, "SQ_INSTS_VALU": 258500000}, 0.42, 677980720.0, 145484664.0)
-    assert r["bound"] == "valu_issue" and r["frac"] == 1.002 and r["unit"] == "G wave-instr/s" and abs(r["peak"] - 614.4) < 1e-9
-    assert r["hbm"]["by_survey_8d_bytes"]["frac"] == round(1614.0 / 8000.0, 4) and r["hbm"]["by_pmc_traffic"]["frac"] == 0.0948 and r["traffic"] == 318361600
+           "hbm_traffic_GBps": 758.0, "frac_of_peak_by_traffic": 0.0948, "valu_G_wave_instr_per_s": 615.5}
+    pmc_row = {"hbm_bytes": 318361600, "SQ_INSTS_VALU": 258500000, "SQ_ACTIVE_INST_VALU": 70_000_000, "SQ_THREAD_CYCLES_VALU": 2_800_000_000}
+    r = bench.governing_roofline("render_backward", row, pmc_row, 0.42, 677980720.0, 145484664.0)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["achieved"] == 1614.0 and r["frac"] == round(1614.0 / 8000.0, 4)
+    assert r["frac_basis"] == "by_survey_8d_bytes" and r["traffic"] == 318361600 and r["traffic_over_algorithmic_bytes"] == round(318361600 / 677980720.0, 3)
+    assert r["other_byte_counts"]["by_pmc_traffic"]["frac"] == 0.0948
     row2 = {k: v for k, v in row.items() if "traffic" not in k and "valu" not in k}
     r2 = bench.governing_roofline("render_backward", row2, None, 0.42, 677980720.0, 145484664.0)
-    assert r2["bound"] == "hbm" and r2["frac_basis"] == "by_survey_8d_bytes" and r2["frac"] == round(1614.0 / 8000.0, 4) and r2["traffic"] is None
+    assert r2["bound"] == "hbm" and r2["frac"] == round(1614.0 / 8000.0, 4) and r2["traffic"] is None
     row3 = dict(row2, reference_scheme_equiv_GBps=14000.0)   # a binning stage: the reference-scheme bytes exceed the peak -> not a fraction
-    assert bench.governing_roofline("sort", row3, None, 0.07, 1.0, 1.0)["frac_basis"] == "by_design_bytes"
+    r3 = bench.governing_roofline("sort", row3, None, 0.07, 1.0, 1.0)
+    assert r3["frac_basis"] == "by_design_bytes" and r3["frac"] == 0.0433 and r3["survey_8d_equivalent_GBps"] == 14000.0
+    # the compute view: useful flops from COUNTED pairs against the fp32 peaks; every ratio at most 1; the VALU figure is a rate, not a fraction
+    ref_pairs = {"pairs_evaluated": 530_336_190, "pairs_blended": 145_466_768, "source": "test"}
+    kpairs = {"file": "pair_counts.json", "render_backward": {"strip_evaluations": 4_000_000, "pairs_evaluated": 256_000_000, "pairs_contributing": 145_000_000}}
+    c = bench.compute_view("render_backward", 0.42, pmc_row, kpairs, ref_pairs)
+    assert c["algorithmic_pairs_per_launch"] == 145_466_768 and c["flops_per_pair"] == 70
+    assert abs(c["useful_TFLOPs"] - 145_466_768 * 70 / 0.42e-3 / 1e12) < 0.01 and 0 < c["frac_of_fp32_packed_peak"] < c["frac_of_fp32_plain_peak"] < 1
+    assert abs(c["peaks_TFLOPs"]["fp32_plain"] - 78.6) < 0.1 and abs(c["peaks_TFLOPs"]["fp32_packed"] - 157.3) < 0.1
+    assert c["valu"]["thread_utilisation"] == round(2_800_000_000 / (64.0 * 70_000_000), 4) <= 1 and "frac" not in " ".join(c["valu"])
+    assert 0 < c["this_kernel"]["lane_pairs_useful_over_evaluated"] <= 1
+    cf = bench.compute_view("render_forward", 0.3, None, None, ref_pairs)
+    assert cf["algorithmic_pairs_per_launch"] == 530_336_190 and cf["flops_per_pair"] == 21 and "valu" not in cf
     stages, note = bench.load_pmc("no such workload")
     assert stages == {} and ("another workload" in note or "no profiles" in note)
 

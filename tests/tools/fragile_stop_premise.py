@@ -4,14 +4,14 @@ T (1 - alpha) < 1e-4 (forward.cu:367-372) is within rounding distance of its thr
 frag_T = min over its chain of |test_T * 1e4 - 1|: the relative distance of the nearest stop test from 1e-4): how many pixels, and how many
 16x16 tiles holding at least one, lie inside a band delta -- for the range of deltas a provable bound could take.  Also the pair counts
 SURVEY 8(d)'s secondary ceiling is stated in (evaluated and blended (pixel, entry) pairs of the reference's K8 walk).
-usage: python scripts/fragile_stop_premise.py [--gaussians P --width W --height H --colors sh|precomp --scale-mult S]   (CPU; ~1 min at 1 M / 1080p)"""
+usage: python tests/tools/fragile_stop_premise.py [--gaussians P --width W --height H --colors sh|precomp --scale-mult S]   (CPU; ~1 min at 1 M / 1080p)"""
 import argparse
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "wild-gaussians_amd"))
 import numpy as np  # noqa: E402

@@ -99,6 +99,19 @@ def build_driver(force: bool = False) -> str:
     return out
 
 
+def build_exp_probe(force: bool = False) -> str:
+    """tests/native/exp_probe.hip -> tests/native/libexp_probe.so: the device unit test of wg_alpha.h's restated `exp` expansion against the
+    compiler's own `exp(float)`.  Test infrastructure; -ffp-contract=off like the reference's no-contraction checker build."""
+    src = os.path.join(os.path.dirname(HERE), "tests", "native", "exp_probe.hip")
+    out = os.path.join(os.path.dirname(HERE), "tests", "native", "libexp_probe.so")
+    if force or _newer(out, [src, os.path.join(CSRC, "wg_alpha.h"), os.path.abspath(__file__)]):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I" + CSRC, src, "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return out
+
+
 def build_torch_binding(force: bool = False) -> str:
     """csrc/torch_binding.cpp -> diff_gaussian_rasterization/_C_torch.so: the compiled torch binding of the C-ABI (INTEGRATION.md section 2 as
     a file; the ctypes binding stays the default).  Host C++ only: g++ against torch's headers, linked to libwg_rasterizer.so next to it

@@ -25,6 +25,19 @@ namespace wg {
 
 constexpr int BATCH = 64;
 
+// WG_COUNT_PAIRS (a VARIANT build only, see render_fwd.hip): [0] instances visited, [1] strip evaluations (one = 64 (pixel, entry) pairs),
+// [2] of those pairs, the ones at or before their pixel's last contributor, [3] contributing pairs (what backward.cu:536-600
+// differentiates), [4] instances reduced and added to their Gaussian's record.
+#ifndef WG_COUNT_PAIRS
+#define WG_COUNT_PAIRS 0
+#endif
+#if WG_COUNT_PAIRS
+__device__ unsigned long long g_bwd_counters[8];
+#define WG_CNT(i, v) wgc[i] += (unsigned long long)(v)
+#else
+#define WG_CNT(i, v)
+#endif
+
 // Measured and rejected variants of this kernel (packed f32 per-pair math, scalar any-mask, two instances per butterfly, the reduction
 // on the matrix pipe, forced occupancy) are NOT in this file: experiments/r3_render_bwd_variants.patch adds them back as compile-time
 // knobs for scripts/ab_variants.sh; their numbers are in EXPERIMENTS.md (R3.1).
@@ -241,6 +254,9 @@ render_backward_kernel(
 #define syy p4.x
 #define sq p4.y
 
+#if WG_COUNT_PAIRS
+    unsigned long long wgc[5] = {0, 0, 0, 0, 0};
+#endif
     for (int hi = hi0; hi > 0; hi -= BATCH) {
         // lane l stages the instance at list position hi-1-l (back to front, backward.cu:517)
         const int posl = hi - 1 - lane;
@@ -300,9 +316,12 @@ render_backward_kernel(
             //   dL_dmean2D.z =  o * sum(|q| (0.5W |u| + 0.5H |v|))   dL_dconic.yy = -0.5 o * sum(q dy dy)
             //   dL_dopacity  = sum(q)
             bool any = false;
+            WG_CNT(0, 1);
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 if (((reach[s] >> j) & 1ull) == 0ull) continue;  // wave-uniform
+                WG_CNT(1, 1);
+                WG_CNT(2, __popcll(__ballot(pos < last[s])));
                 PairEval e;
                 bool pass;
                 if (EXACT) {
@@ -320,6 +339,7 @@ render_backward_kernel(
                 } else {
                     pass = eval_alpha(sc, pfx[s], pfy[s], e);
                 }
+                WG_CNT(3, __popcll(__ballot(pos < last[s] && pass)));
                 if (pos < last[s] && pass) {
                     any = true;
                     const float a = e.alpha;
@@ -363,6 +383,7 @@ render_backward_kernel(
                 }
             }
             if (__ballot(any) == 0ull) continue;
+            WG_CNT(4, 1);
             const float total = DUAL ? butterfly13(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, ac2r, ac2g, ac2b, lane)
                                      : butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
             if (DET) {
@@ -383,6 +404,10 @@ render_backward_kernel(
             if (DUAL) ac2r = ac2g = ac2b = 0.f;
         }
     }
+#if WG_COUNT_PAIRS
+    if (lane == 0)
+        for (int i = 0; i < 5; i++) atomicAdd(&g_bwd_counters[i], wgc[i]);
+#endif
 }
 
 #undef acr
@@ -396,99 +421,81 @@ render_backward_kernel(
 #undef syy
 #undef sq
 
-// Ordered per-Gaussian sum of the deterministic mode.  One thread per Gaussian adds its tiles_touched slots in slot order -- only the
-// slots the per-tile pass flagged as written: the slot array (40 B per tile instance) is never cleared, only the flags (1 B per
-// instance) are -- and WRITES the whole 48-byte record, zeros for a Gaussian nothing was added to, so the record needs no clearing
-// either.  The kernel is a latency problem, not a bandwidth one (7 MB of flags, ~70 MB of flagged slots, 48 MB of records at the
-// headline scene), so it is built around the number of dependent memory round trips per wave, three whatever the lists' lengths:
-//   1. every lane's slot range (tiles_touched, prefix);
-//   2. the 64 Gaussians of a wave own ONE contiguous range of slots: its flag bytes are fetched by the whole wave, 64 consecutive
-//      bytes per load, into LDS (chunks of 4 KB for the rare wave that owns more); each lane then scans its own range there;
-//   3. the flagged slots' ten floats (five 8-byte loads each), up to eight slots of a lane in flight together, added in slot order.
-// (Round 2: every slot cleared and read, ten dependent strided loads per slot.  Earlier round-3 versions: sixteen threads per
-// Gaussian, one per value, 237 us; one thread per Gaussian reading its flags itself, two round trips per eight slots, 153 us.)
-constexpr uint32_t DET_FLAG_CHUNK = 4096;
+// Per-Gaussian sum of the deterministic mode, in a FIXED order.  The 64 Gaussians of a wave own ONE contiguous range of slots
+// [prefix(first) .. prefix(last) + tiles_touched(last)) -- slot = exclusive prefix of tiles_touched + the tile's index inside the
+// Gaussian's rectangle --, so the wave walks that range 64 slots at a time with EVERY lane busy: lane l takes slot clo + l (its flag: 64
+// consecutive bytes per wave; if flagged, its ten floats: consecutive 40-byte slots, i.e. coalesced), a segmented inclusive scan over the
+// lanes (segment heads = the Gaussians' first slots) adds each Gaussian's slots of the chunk in a fixed tree, and the Gaussian's own lane
+// picks its segment's total from the segment's last lane and adds it to its accumulator -- chunk after chunk, in slot order.  The shape of
+// the tree depends only on tiles_touched, never on timing: bit-identical gradients run to run.  Only flagged slots are read (the slot array
+// is never cleared, only the 1-byte flags are); the kernel WRITES the whole 48-byte record, zeros for a Gaussian nothing was added to.
+// (Rounds 3-4: one thread per Gaussian scanning its own flags and gathering its flagged slots, three dependent round trips with one lane
+// in ~4 doing anything: 121 us at the headline scene, a latency problem.  This form streams: see profiles/r5/ab_deterministic_backward*.)
 // NF2 = float2 per slot: 5 (ten sums) or 7 (the two-colour walk's thirteen, padded to fourteen: sums 10, 11 go to the record's two spare
 // floats, sum 12 to grad_aux[g] = grad_rec[12 P + g])
 template <int NF2>
 __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* __restrict__ offsets_incl, const uint32_t* __restrict__ tiles_touched,
                                                          const float* __restrict__ det_slots, const unsigned char* __restrict__ det_flags,
                                                          float* __restrict__ grad_rec, size_t slot_capacity) {
-    __shared__ __attribute__((aligned(16))) unsigned char sflags[4][DET_FLAG_CHUNK + 16];   // (+ the word-alignment shift)
+    __shared__ unsigned char sheads[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = g < P;
     const uint32_t n = valid ? tiles_touched[g] : 0u;
     const uint32_t end = valid ? offsets_incl[g] : 0u;
     const uint32_t base = end - n;
-    // the wave's slot range: from its first valid lane's base to its last valid lane's end (prefix sums are monotone)
     const int g0 = blockIdx.x * blockDim.x + wave * 64;
     if (g0 >= P) return;  // wave-uniform
     const int last_lane = min(63, P - 1 - g0);
     const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
     const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)end, last_lane);
-    float acc[2 * NF2];
+    constexpr int NV = 2 * NF2;
+    float acc[NV];
 #pragma unroll
-    for (int v = 0; v < 2 * NF2; v++) acc[v] = 0.f;
-    unsigned char* sf = sflags[wave];
-    constexpr int U = 8;
-    for (uint32_t clo = wlo; clo < whi; clo += DET_FLAG_CHUNK) {  // wave-uniform trip count; one trip unless the wave owns > 4096 slots
-        const uint32_t clen = min(DET_FLAG_CHUNK, whi - clo);
-        __builtin_amdgcn_wave_barrier();  // the previous chunk's flags have been read by every lane
-        // the chunk's flag bytes as aligned 32-bit words, four loads per lane in flight before the first is stored (a plain byte loop
-        // was one memory round trip per 64 bytes: nine in a row for an average wave)
+    for (int v = 0; v < NV; v++) acc[v] = 0.f;
+    unsigned char* heads = sheads[wave];
+    for (uint32_t clo = wlo; clo < whi; clo += 64u) {  // wave-uniform trip count
+        const uint32_t k = clo + (uint32_t)lane;
+        const bool flagged = k < whi && (size_t)k < slot_capacity && det_flags[k] != 0;
+        float x[NV];
         {
-            const uint32_t a0 = clo & ~3u, shift = clo - a0;                   // word-aligned start; sf[] is indexed from a0
-            const uint32_t words = (shift + clen + 3u) >> 2;
-            const uint32_t cap_words = (uint32_t)std::min<size_t>((slot_capacity + 3) >> 2, 0xffffffffu);   // (the allocation is padded to 256 B)
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(det_flags) + (a0 >> 2);
-            uint32_t* dst = reinterpret_cast<uint32_t*>(sf);
-            for (uint32_t i0 = 0; i0 < words; i0 += 256) {   // wave-uniform
-                uint32_t v[4];
+            const float2* sl = reinterpret_cast<const float2*>(det_slots + (size_t)(flagged ? k : clo) * NV);  // 40- / 56-byte slots: 8-byte aligned
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + 64u * u + lane;
-                    v[u] = (i < words && (a0 >> 2) + i < cap_words) ? src[i] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + 64u * u + lane;
-                    if (i < words) dst[i] = v[u];
-                }
+            for (int h = 0; h < NF2; h++) {
+                const float2 t = flagged ? sl[h] : make_float2(0.f, 0.f);
+                x[2 * h] = t.x;
+                x[2 * h + 1] = t.y;
             }
         }
+        // segment heads of this chunk: a Gaussian with slots of its own starts one at its first slot (two Gaussians never share one)
         __builtin_amdgcn_wave_barrier();
-        // this lane's slots inside the chunk, in order; flagged ones gathered U at a time
-        const uint32_t sbase = clo & ~3u;   // sf[k - sbase] is slot k's flag
-        const uint32_t mylo = max(base, clo), myhi = min(end, clo + clen);
-        uint32_t pend[U];
-        int np = 0;
-        auto flush = [&]() {
-            float2 x[U][NF2];
+        heads[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (n != 0u && base >= clo && base < clo + 64u) heads[base - clo] = 1;
+        __builtin_amdgcn_wave_barrier();
+        int head = (lane == 0 || heads[lane] != 0) ? 1 : 0;
+        // segmented inclusive scan over the 64 lanes (Hillis-Steele; a lane stops taking once a head lies in its window)
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const float2* sl = reinterpret_cast<const float2*>(det_slots + (size_t)pend[u < np ? u : 0] * (2 * NF2));  // 40- / 56-byte slots: 8-byte aligned
+        for (int d = 1; d < 64; d <<= 1) {
+            const int hup = __shfl_up(head, d);
+            float up[NV];
 #pragma unroll
-                for (int h = 0; h < NF2; h++) x[u][h] = u < np ? sl[h] : make_float2(0.f, 0.f);
-            }
+            for (int v = 0; v < NV; v++) up[v] = __shfl_up(x[v], d);
+            if (lane >= d && head == 0) {
 #pragma unroll
-            for (int u = 0; u < U; u++)
-                if (u < np) {
-#pragma unroll
-                    for (int h = 0; h < NF2; h++) { acc[2 * h] += x[u][h].x; acc[2 * h + 1] += x[u][h].y; }
-                }
-            np = 0;
-        };
-        for (uint32_t k = mylo; k < myhi; k++) {
-            if (sf[k - sbase]) {
-#pragma unroll
-                for (int u = 0; u < U; u++)
-                    if (u == np) pend[u] = k;   // (register array: written through a static index)
-                np++;
-                if (np == U) flush();
+                for (int v = 0; v < NV; v++) x[v] += up[v];
+                head = hup;
             }
         }
-        if (np > 0) flush();
+        // the Gaussian's own lane takes the total of its segment's part in this chunk from that part's last lane
+        const uint32_t lo = max(base, clo), hi = min(end, clo + 64u);
+        const bool mine = n != 0u && lo < hi;
+        const int src = mine ? (int)(hi - 1u - clo) : 0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const float t = __shfl(x[v], src);
+            if (mine) acc[v] += t;
+        }
     }
     if (valid) {
         float4* out = reinterpret_cast<float4*>(grad_rec + (size_t)g * GRAD_REC_FLOATS);
@@ -535,3 +542,15 @@ hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState
 }
 
 }  // namespace wg
+
+#if WG_COUNT_PAIRS
+extern "C" int wg_debug_bwd_counters(unsigned long long* out8, int reset) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && out8) e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(wg::g_bwd_counters), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[8] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(wg::g_bwd_counters), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : -3;
+}
+#endif

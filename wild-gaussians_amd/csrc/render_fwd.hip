@@ -30,6 +30,21 @@ namespace wg {
 
 constexpr int BATCH = 64;
 
+// WG_COUNT_PAIRS (a VARIANT build only: scripts/count_pairs.py; never the product library): what the walk does, counted -- the inputs of
+// SURVEY 8(d)'s secondary (compute) ceiling.  [0] instances visited, [1] strip evaluations (one = 64 (pixel, entry) pairs), [2] of those
+// pairs, the ones whose pixel is still accumulating, [3] pairs that pass both skips, [4] pixels stopped by the T < 1e-4 test (a pair that
+// passes is either blended or stops its pixel: blended = [3] - [4]).  (The counters live in lane 0's registers: they are only touched
+// where every lane is active.)
+#ifndef WG_COUNT_PAIRS
+#define WG_COUNT_PAIRS 0
+#endif
+#if WG_COUNT_PAIRS
+__device__ unsigned long long g_fwd_counters[8];
+#define WG_CNT(i, v) wgc[i] += (unsigned long long)(v)
+#else
+#define WG_CNT(i, v)
+#endif
+
 // ---- the per-tile walk, as device functions shared by render_forward_kernel and the lazy-sort fix-up kernel (binning.hip) ----
 // One wave owns a tile.  The walk is resumable: it composites list positions [pos_begin, pos_end) and can be continued
 // later from the state parked in the output buffers (fwd_store with complete == false / fwd_init with resume == true).
@@ -114,6 +129,9 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
     // and "kept", and hipcc resolved that merge with copies placed right behind the loads -- i.e. an s_waitcnt that stalled the wave
     // on the "prefetch" it had just issued.
     if (n <= 0 || strips_alive == 0) return;  // nothing to do: st is unchanged
+#if WG_COUNT_PAIRS
+    unsigned long long wgc[5] = {0, 0, 0, 0, 0};
+#endif
     const int nl = n - 1;
     float4 a0, a1, a2;
     {
@@ -166,9 +184,12 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
             else gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
             const uint32_t pos = (uint32_t)(pos_begin + base + j + 1);
             const uint32_t alive_before = alive;
+            WG_CNT(0, 1);
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 if (((reach[s] >> j) & 1ull) == 0ull) continue;  // wave-uniform
+                WG_CNT(1, 1);
+                WG_CNT(2, __popcll(__ballot((alive >> s) & 1u)));
                 bool pass;
                 float alpha;
                 if (EXACT) {
@@ -179,6 +200,7 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
                     pass = eval_alpha(sc, pfx[s], pfy[s], e);
                     alpha = e.alpha;
                 }
+                WG_CNT(3, __popcll(__ballot(((alive >> s) & 1u) && pass)));
                 if (((alive >> s) & 1u) && pass) {
                     const float w = alpha * T[s];
                     // T (1 - alpha), forward.cu:367: as spelled there (EXACT), or one rounding step apart
@@ -211,6 +233,12 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
             }
         }
     }
+#if WG_COUNT_PAIRS
+#pragma unroll
+    for (int s = 0; s < 4; s++) WG_CNT(4, __popcll(__ballot((st.alive >> s) & 1u)) - __popcll(__ballot((alive >> s) & 1u)));
+    if (lane == 0)
+        for (int i = 0; i < 5; i++) atomicAdd(&g_fwd_counters[i], wgc[i]);
+#endif
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         st.T[s] = T[s]; st.Cr[s] = Cr[s]; st.Cg[s] = Cg[s]; st.Cb[s] = Cb[s]; st.last[s] = last[s];
@@ -476,3 +504,15 @@ hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, cons
 }
 
 }  // namespace wg
+
+#if WG_COUNT_PAIRS
+extern "C" int wg_debug_fwd_counters(unsigned long long* out8, int reset) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && out8) e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(wg::g_fwd_counters), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[8] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(wg::g_fwd_counters), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : -3;
+}
+#endif

@@ -16,7 +16,12 @@ struct ActFwd {
     float o, coef, det1, det2;
 };
 
+// No fused multiply-adds in either function, whatever the flags of the file that includes them (the pragma binds to the function body):
+// the preprocess kernel (built -ffp-contract=off), the stand-alone activation kernels (likewise) and the preprocess-BACKWARD kernel
+// (built with the compiler's default contraction) all recompute act_forward() and must get the same bits -- the backward pass chains
+// through the very q / scales / coef the forward frame was made of.
 __device__ __forceinline__ ActFwd act_forward(float4 r, float s0, float s1, float s2, float ol, float f) {
+#pragma clang fp contract(off)
     ActFwd a;
     const float n = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
     a.clamped = n < 1e-12f;
@@ -40,6 +45,7 @@ __device__ __forceinline__ ActFwd act_forward(float4 r, float s0, float s1, floa
 // gradients w.r.t. the raw parameters from those w.r.t. the activated ones (dq: rotation, dsc: filtered scales, dop: filtered opacity)
 __device__ __forceinline__ void act_backward(const ActFwd& a, float4 dq, const float dsc[3], float dop, float4& g_rot, float g_scale[3],
                                              float& g_opac) {
+#pragma clang fp contract(off)
     // rotation: q = v / max(|v|, eps)
     if (a.clamped) {
         g_rot = make_float4(dq.x * a.inv_n, dq.y * a.inv_n, dq.z * a.inv_n, dq.w * a.inv_n);

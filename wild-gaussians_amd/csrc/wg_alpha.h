@@ -80,6 +80,16 @@ __device__ __forceinline__ ExactCoef exact_coef_of(const float4 r0, const float4
 }
 // exp(x) for x <= 0 as the reference build computes it.  The expansion's two range selects are dropped: x > 88.7 cannot occur, and
 // below -103 (where it returns 0) the clamp keeps ldexp's result a denormal: either way alpha < 1/255 and the pair is skipped.
+// (The clamp is not optional: for |x| >~ 2^23 the split's low part pl is the rounding error of x * log2e, as large as ulp(ph) / 2, and
+//  v_exp_f32 of it would overflow.)
+// ONE documented exception to "the reference's decisions bit for bit" (ADVICE r4): a NaN power.  The reference keeps it -- `power > 0` is
+// false, min(0.99f, NaN) = 0.99f, the pair is blended at alpha 0.99 --; here v_max_f32 returns the other operand, the power becomes -104
+// and the pair is skipped.  A NaN power needs a NaN mean or conic in the splat record, and such a Gaussian never gets one: its radius
+// (ceil of a NaN, converted to int: 0) or its tile rectangle (built from NaN pixel coordinates: empty) removes it in K1, as in the reference
+// (forward.cu:241-250).  A NaN OPACITY does reach the walk and behaves as in the reference (alpha = min(0.99f, NaN) = 0.99f in both).
+// Guarding the clamp (x != x ? x : ...) would cost two VALU instructions per strip evaluation for an input no caller can produce.
+// tests/test_exp_expansion.py holds this function to the compiler's own `expf` (built -ffp-contract=off) over a dense range of arguments:
+// a toolchain whose exp lowering changes fails that test directly, not only the parity tests downstream.
 __device__ __forceinline__ float ref_expf_nonpos(float x) {
 #pragma clang fp contract(off)
     x = fmaxf(x, -104.0f);

@@ -218,14 +218,18 @@ def timed_region(fn, steps: int, device, keep=None, stamps=None, warmup: int = 0
             gc.enable()
 
 
-def job_fields(world: int, steps: int, t_region: float, ranks_seen, baseline_iters_per_s: float | None = None) -> dict:
-    """The whole-job part of bench.py's JSON line from the timed region and the all-gathered (rank, device, own ms/step) rows.
-    `value` = iterations of ALL ranks per second of the slowest rank's region (weak scaling: one view per GPU).  With the 1-GPU
-    rate supplied the line also states efficiency = T(N) / (N T(1)) -- the driver computes its own from the per-N lines."""
+def job_fields(world: int, steps: int, t_region: float, ranks_seen, baseline_iters_per_s: float | None = None, views_total: int | None = None) -> dict:
+    """The whole-job part of bench.py's JSON line from the timed region and the all-gathered (rank, device, own ms/step[, instances of the
+    rank's views, number of views]) rows.  `value` = iterations (one view forward + backward each) of ALL ranks per second of the slowest
+    rank's region: `views_total` views per step over the job (default one per rank: weak scaling; a fixed batch, e.g. BASELINE config 4's
+    eight views, is strong scaling).  With the 1-GPU rate supplied the line also states efficiency = T(N) / (N T(1)) -- the driver computes
+    its own from the per-N lines."""
     rows = sorted(ranks_seen, key=lambda r: r[0])
-    out = {"value": round(world * steps / t_region, 3), "n_gpus": world, "ms_per_step": round(1000.0 * t_region / steps, 4),
+    views = world if views_total is None else int(views_total)
+    out = {"value": round(views * steps / t_region, 3), "n_gpus": world, "ms_per_step": round(1000.0 * t_region / steps, 4),
            "rccl_ranks_seen": [int(r[0]) for r in rows], "per_rank_ms_per_step": {str(int(r[0])): round(r[2], 4) for r in rows},
-           "per_rank_device": {str(int(r[0])): int(r[1]) for r in rows}}
+           "per_rank_device": {str(int(r[0])): int(r[1]) for r in rows},
+           "per_rank_num_rendered": {str(int(r[0])): {"instances": int(r[3]), "views": int(r[4])} for r in rows if len(r) >= 5}}
     if len(rows) != world or out["rccl_ranks_seen"] != list(range(world)):
         raise RuntimeError(f"expected ranks 0..{world - 1}, saw {out['rccl_ranks_seen']}")
     if baseline_iters_per_s:

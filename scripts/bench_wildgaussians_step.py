@@ -198,7 +198,7 @@ def main():
                     help="SURVEY 8f N3: the appearance toning (clamp, * mul, + offset / C0, clamp; method.py:890-900, 1590-1595) inside the "
                          "preprocess kernels (sh_mul / sh_offset / sh_*_clamp_max) instead of P x 48 torch tensors; implies --in-kernel-sh")
     ap.add_argument("--two-tone-call", action="store_true",
-                    help="with --in-kernel-tone: the step's raw and toned renders as ONE rasterizer call (sh_second=; wg_rasterize_*_two_tone)")
+                    help="with --in-kernel-tone: the step's raw and toned renders as ONE rasterizer call (sh_second=; wg_forward_args::sh_second)")
     ap.add_argument("--tall-linear", action="store_true",
                     help="tall_linear (defined in this script) for the appearance MLP's three layers (weight gradients as a batched product over "
                          "row chunks: plain PyTorch, a BLAS kernel-selection workaround for 3 M-row reductions)")
@@ -283,7 +283,7 @@ def main():
             scales = s2f.sqrt()
             opac = torch.sigmoid(prm["opacities"]) * torch.sqrt(s2.prod(1) / s2f.prod(1))[:, None]
         kw = dict(means3D=prm["xyz"], means2D=means2D, opacities=opac, scales=scales, rotations=rot, **raw_kw)
-        if args.two_tone_call:   # both renders of the step in ONE rasterizer call (sh_second=: wg_rasterize_*_two_tone)
+        if args.two_tone_call:   # both renders of the step in ONE rasterizer call (sh_second=: wg_forward_args::sh_second)
             shs = prm["features"].view(P, 16, 3)
             inp = torch.cat((prm["features"][:, :3].clamp_max(1.0), prm["embeddings"], prm["image_embedding"][None].expand(P, -1)), dim=-1)
             offset, mul = torch.split(mlp_fn(inp) * 0.01, [3, 3], dim=-1)

@@ -3,7 +3,8 @@
 //   * scripts/asan_pass.sh builds it and the library with -fsanitize=address (host side) and runs it on the GPU: the sanitizer
 //     pass SURVEY.md section 5 asks for, without a Python interpreter between ASan and the HIP runtime;
 //   * evidence that the boundary really is "plain pointers and sizes, no torch types" (tests/test_native_driver.py).
-// Since round 4 it also drives wg_rasterize_{forward,backward}_dual, _raw and _two_tone and checks their images, bit for bit, against plain
+// Since round 5 everything beyond the reference goes through wg_rasterize_{forward,backward}_ex (one struct, optional blocks, per-call
+// options): the two-colour, raw-parameter, toned, two-tone and recolouring calls are driven through it and their images checked, bit for bit, against plain
 // (toned) calls.
 // Prints one line "ok num_rendered=... checksum=..." and exits 0, or a diagnostic and a non-zero code.
 // With a fourth argument (a path) it also DUMPS its inputs and every output of the three calls there, raw little-endian:
@@ -133,6 +134,48 @@ int main(int argc, char** argv) {
                                          tany, 0.1f, nullptr, d_radii, geom.p, bin.p, img.p, d_cot, g2d, gcon, gop, gcol, g3d, gcov, gsh, gsc, grot, 0,
                                          stream);
     if (st != WG_OK) { std::fprintf(stderr, "backward: %s (%s)\n", wg_status_string(st), wg_last_hip_error()); return 5; }
+    // ---- the struct entry points (wg_rasterize_forward_ex / _backward_ex): the reference-shaped arguments once, blocks added per call ----
+    auto fwd_args = [&](Grow* g, Grow* b, Grow* i, int deg, int m, const float* shs_, const float* cols, const float* op, const float* sc, const float* rt,
+                        float* out, int* rad) {
+        wg_forward_args a{};
+        a.struct_size = sizeof(a);
+        a.geometry_alloc = Grow::alloc; a.geometry_user = g; a.binning_alloc = Grow::alloc; a.binning_user = b; a.image_alloc = Grow::alloc; a.image_user = i;
+        a.P = P; a.D = deg; a.M = m; a.width = W; a.height = H;
+        a.scale_modifier = 1.0f; a.tan_fovx = tanx; a.tan_fovy = tany; a.kernel_size = 0.1f;
+        a.background = d_bg; a.means3D = d_means; a.shs = shs_; a.colors_precomp = cols; a.opacities = op; a.scales = sc; a.rotations = rt;
+        a.viewmatrix = d_view; a.projmatrix = d_proj; a.cam_pos = d_campos;
+        a.out_color = out; a.radii = rad; a.stream = stream;
+        return a;
+    };
+    auto bwd_args = [&](int deg, int m, int R_, const float* shs_, const float* cols, const float* sc, const float* rt, char* g, char* b, char* i, float* dconic,
+                        float* dcol, float* dsh) {
+        wg_backward_args a{};
+        a.struct_size = sizeof(a);
+        a.P = P; a.D = deg; a.M = m; a.R = R_; a.width = W; a.height = H;
+        a.scale_modifier = 1.0f; a.tan_fovx = tanx; a.tan_fovy = tany; a.kernel_size = 0.1f;
+        a.background = d_bg; a.means3D = d_means; a.shs = shs_; a.colors_precomp = cols; a.scales = sc; a.rotations = rt;
+        a.viewmatrix = d_view; a.projmatrix = d_proj; a.campos = d_campos; a.radii = d_radii;
+        a.geom_buffer = g; a.binning_buffer = b; a.image_buffer = i; a.dL_dpix = d_cot;
+        a.dL_dmean2D = g2d; a.dL_dconic = dconic; a.dL_dopacity = gop; a.dL_dcolor = dcol; a.dL_dmean3D = g3d; a.dL_dcov3D = gcov; a.dL_dsh = dsh;
+        a.dL_dscale = gsc; a.dL_drot = grot; a.stream = stream;
+        return a;
+    };
+    {   // a struct of another size (an older / newer header) is refused, and so is a per-call option that contradicts the frame's forward call
+        wg_forward_args bad = fwd_args(&geom, &bin, &img, D, M, d_shs, nullptr, d_opac, d_scales, d_rots, d_color, d_radii);
+        bad.struct_size = sizeof(bad) - 8;
+        if (wg_rasterize_forward_ex(&bad) != WG_ERR_INVALID_ARGUMENT || wg_rasterize_forward_ex(nullptr) != WG_ERR_INVALID_ARGUMENT) {
+            std::fprintf(stderr, "struct_size check missing\n");
+            return 9;
+        }
+        const wg_call_options fast = {0, 0, 1};
+        wg_backward_args mism = bwd_args(D, M, R, d_shs, nullptr, d_scales, d_rots, geom.p, bin.p, img.p, gcon, gcol, gsh);
+        mism.options = &fast;   // the frame above was composited with exact_compositing = 1
+        if (wg_rasterize_backward_ex(&mism) != WG_ERR_INVALID_ARGUMENT) { std::fprintf(stderr, "forward / backward option mismatch not detected\n"); return 9; }
+        if (wg_set_option("exact_compositing", 0) == WG_OK || wg_get_option("deterministic_backward") != -1) {
+            std::fprintf(stderr, "a result-affecting switch is still process-wide\n");
+            return 9;
+        }
+    }
     // geometry reuse: the same Gaussians and camera with other (precomputed) colours ride on the first call's projection and binning
     {
         std::vector<float> cols(3 * (size_t)P);
@@ -141,7 +184,10 @@ int main(int argc, char** argv) {
         if (upload(cols, &d_cols)) return 2;
         CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&d_color2), (size_t)3 * W * H * sizeof(float)));
         Grow geom2;
-        const int R2 = wg_rasterize_forward_recolor(Grow::alloc, &geom2, geom.p, bin.p, img.p, P, R, d_bg, W, H, d_cols, nullptr, d_color2, nullptr, stream);
+        wg_forward_args ra = fwd_args(&geom2, nullptr, nullptr, 0, 0, nullptr, d_cols, nullptr, nullptr, nullptr, d_color2, nullptr);
+        const wg_recolor_parent parent = {geom.p, bin.p, img.p, R};
+        ra.recolor = &parent;
+        const int R2 = wg_rasterize_forward_ex(&ra);
         if (R2 != R) { std::fprintf(stderr, "recolor: %s (%s)\n", wg_status_string(R2), wg_last_hip_error()); return 10; }
         const int st2 = wg_rasterize_backward(P, 0, 0, R, d_bg, W, H, d_means, nullptr, d_cols, d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx,
                                               tany, 0.1f, nullptr, d_radii, geom2.p, bin.p, img.p, d_cot, g2d, gcon, gop, gcol, g3d, gcov, nullptr, gsc, grot,
@@ -194,14 +240,16 @@ int main(int argc, char** argv) {
             return true;
         };
         if (plain(d_c1, d_opac, d_scales, d_rots, imgA) <= 0 || plain(d_c2, d_opac, d_scales, d_rots, imgB) <= 0) return 13;
-        wg_second_colors sec = {d_c2, imgD, nullptr, nullptr};
-        const int Rd = wg_rasterize_forward_dual(Grow::alloc, &g2, Grow::alloc, &b2, Grow::alloc, &i2, P, 0, 0, d_bg, W, H, d_means, nullptr, d_c1, d_opac, d_scales,
-                                                 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, imgC, d_radii, 0, stream, &sec);
+        wg_second_image sec = {d_c2, imgD, nullptr, nullptr};
+        wg_forward_args da = fwd_args(&g2, &b2, &i2, 0, 0, nullptr, d_c1, d_opac, d_scales, d_rots, imgC, d_radii);
+        da.second = &sec;
+        const int Rd = wg_rasterize_forward_ex(&da);
         if (Rd != R) { std::fprintf(stderr, "two-colour forward: %d (%s)\n", Rd, wg_last_hip_error()); return 13; }
         if (!same(imgA, imgC, "two-colour call, first set") || !same(imgB, imgD, "two-colour call, second set")) return 13;
         sec.dL_dpix2 = d_cot; sec.dL_dcolor2 = d_gc2;
-        if (wg_rasterize_backward_dual(P, 0, 0, Rd, d_bg, W, H, d_means, nullptr, d_c1, d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany,
-                                       0.1f, nullptr, d_radii, g2.p, b2.p, i2.p, d_cot, g2d, nullptr, gop, gcol, g3d, gcov, nullptr, gsc, grot, 0, stream, &sec) != WG_OK) {
+        wg_backward_args db = bwd_args(0, 0, Rd, nullptr, d_c1, d_scales, d_rots, g2.p, b2.p, i2.p, nullptr, gcol, nullptr);
+        db.second = &sec;
+        if (wg_rasterize_backward_ex(&db) != WG_OK) {
             std::fprintf(stderr, "two-colour backward: %s\n", wg_last_hip_error());
             return 14;
         }
@@ -217,12 +265,14 @@ int main(int argc, char** argv) {
         if (wg_activations_forward(P, d_rrot, d_lsc, d_lop, d_filt, d_arot, d_asc, d_aop, stream) != WG_OK) return 15;
         if (plain(d_c1, d_aop, d_asc, d_arot, imgA) <= 0) return 15;
         wg_raw_gaussians rawg = {d_filt, d_lop};
-        const int Rr = wg_rasterize_forward_raw(Grow::alloc, &g2, Grow::alloc, &b2, Grow::alloc, &i2, P, 0, 0, d_bg, W, H, d_means, nullptr, d_c1, d_lop, d_lsc, 1.0f,
-                                                d_rrot, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, imgC, d_radii, 0, stream, nullptr, &rawg);
+        wg_forward_args rfa = fwd_args(&g2, &b2, &i2, 0, 0, nullptr, d_c1, d_lop, d_lsc, d_rrot, imgC, d_radii);
+        rfa.raw = &rawg;
+        const int Rr = wg_rasterize_forward_ex(&rfa);
         if (Rr <= 0) { std::fprintf(stderr, "raw-parameter forward: %d (%s)\n", Rr, wg_last_hip_error()); return 15; }
         if (!same(imgA, imgC, "raw-parameter call")) return 15;
-        if (wg_rasterize_backward_raw(P, 0, 0, Rr, d_bg, W, H, d_means, nullptr, d_c1, d_lsc, 1.0f, d_rrot, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f,
-                                      nullptr, d_radii, g2.p, b2.p, i2.p, d_cot, g2d, nullptr, gop, gcol, g3d, gcov, nullptr, gsc, grot, 0, stream, nullptr, &rawg) != WG_OK) {
+        wg_backward_args rba = bwd_args(0, 0, Rr, nullptr, d_c1, d_lsc, d_rrot, g2.p, b2.p, i2.p, nullptr, gcol, nullptr);
+        rba.raw = &rawg;
+        if (wg_rasterize_backward_ex(&rba) != WG_OK) {
             std::fprintf(stderr, "raw-parameter backward: %s\n", wg_last_hip_error());
             return 16;
         }
@@ -238,18 +288,20 @@ int main(int argc, char** argv) {
             wg_sh_tone t1 = {d_mul, d_off, 1.0f, 1.0f, d_gmul, d_goff};
             wg_sh_tone t2 = {nullptr, nullptr, 0.2f, INFINITY, nullptr, nullptr};
             auto toned = [&](const wg_sh_tone* t, float* out) {
-                return wg_rasterize_forward_toned(Grow::alloc, &g2, Grow::alloc, &b2, Grow::alloc, &i2, P, D, M, d_bg, W, H, d_means, d_shs, nullptr, d_opac, d_scales,
-                                                  1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, out, nullptr, 0, stream, t);
+                wg_forward_args ta = fwd_args(&g2, &b2, &i2, D, M, d_shs, nullptr, d_opac, d_scales, d_rots, out, nullptr);
+                ta.tone = t;
+                return wg_rasterize_forward_ex(&ta);
             };
             if (toned(&t1, imgA) != R || toned(&t2, imgB) != R) return 17;
-            const int Rt = wg_rasterize_forward_two_tone(Grow::alloc, &g2, Grow::alloc, &b2, Grow::alloc, &i2, P, D, M, d_bg, W, H, d_means, d_shs, nullptr, d_opac,
-                                                         d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0.1f, nullptr, 0, imgC, d_radii, 0,
-                                                         stream, &t1, &t2, nullptr, imgD);
+            wg_second_image sec2 = {nullptr, imgD, d_cot, nullptr};
+            wg_forward_args tta = fwd_args(&g2, &b2, &i2, D, M, d_shs, nullptr, d_opac, d_scales, d_rots, imgC, d_radii);
+            tta.tone = &t1; tta.tone2 = &t2; tta.sh_second = 1; tta.second = &sec2;
+            const int Rt = wg_rasterize_forward_ex(&tta);
             if (Rt != R) { std::fprintf(stderr, "two-tone forward: %d (%s)\n", Rt, wg_last_hip_error()); return 17; }
             if (!same(imgA, imgC, "two-tone call, first tone") || !same(imgB, imgD, "two-tone call, second tone")) return 17;
-            if (wg_rasterize_backward_two_tone(P, D, M, Rt, d_bg, W, H, d_means, d_shs, nullptr, d_scales, 1.0f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany,
-                                               0.1f, nullptr, d_radii, g2.p, b2.p, i2.p, d_cot, g2d, nullptr, gop, nullptr, g3d, gcov, gsh, gsc, grot, 0, stream, &t1,
-                                               &t2, nullptr, d_cot, nullptr) != WG_OK) {
+            wg_backward_args ttb = bwd_args(D, M, Rt, d_shs, nullptr, d_scales, d_rots, g2.p, b2.p, i2.p, nullptr, nullptr, gsh);
+            ttb.tone = &t1; ttb.tone2 = &t2; ttb.sh_second = 1; ttb.second = &sec2;
+            if (wg_rasterize_backward_ex(&ttb) != WG_OK) {
                 std::fprintf(stderr, "two-tone backward: %s\n", wg_last_hip_error());
                 return 18;
             }

@@ -149,7 +149,7 @@ def _verdict(rep, radii, ref_radii, acc, ref):
 
 
 def check_two_colour(case, ref_hip, seed=0):
-    """`colors_precomp2=` (wg_second_colors): one call, two images, beside two runs of the reference."""
+    """`colors_precomp2=` (wg_second_image): one call, two images, beside two runs of the reference."""
     from diff_gaussian_rasterization import GaussianRasterizer
     cloud, cam, deg, kw, W, H = case
     assert "colors_precomp" in cloud
@@ -191,7 +191,7 @@ def tone_host(sh, mul, off, pre, post):
 
 
 def check_two_tone(case, ref_hip, seed=0, second_plain=False):
-    """`sh_second=True` (wg_rasterize_*_two_tone): both tones of one SH block in one call, beside two runs of the reference on the toned
+    """`sh_second=True` (wg_forward_args::sh_second): both tones of one SH block in one call, beside two runs of the reference on the toned
     coefficients.  second_plain: WildGaussians' own shape -- the second set is the clamped coefficients alone."""
     from diff_gaussian_rasterization import GaussianRasterizer
     cloud, cam, deg, kw, W, H = case
@@ -235,7 +235,7 @@ def check_two_tone(case, ref_hip, seed=0, second_plain=False):
 
 
 def check_one_tone(case, ref_hip, seed=0):
-    """`sh_mul=` / `sh_offset=` / clamps (wg_sh_tone; wg_rasterize_*_toned): one toned image beside the reference on the toned coefficients."""
+    """`sh_mul=` / `sh_offset=` / clamps (wg_sh_tone; wg_sh_tone): one toned image beside the reference on the toned coefficients."""
     from diff_gaussian_rasterization import GaussianRasterizer
     cloud, cam, deg, kw, W, H = case
     P, M = cloud["shs"].shape[:2]

@@ -40,10 +40,13 @@ def test_library_exports_every_declared_symbol(lib):
 def test_options_round_trip_and_roctx_is_optional(lib):
     lib.wg_set_option.restype, lib.wg_set_option.argtypes = C.c_int, [C.c_char_p, C.c_int]
     lib.wg_get_option.restype, lib.wg_get_option.argtypes = C.c_int, [C.c_char_p]
-    assert lib.wg_get_option(b"grad_record") == 1 and lib.wg_get_option(b"no_such_option") == -1
-    assert lib.wg_set_option(b"grad_record", 0) == 0 and lib.wg_get_option(b"grad_record") == 0
-    assert lib.wg_set_option(b"grad_record", 1) == 0
+    assert lib.wg_get_option(b"lazy_sort") == 1 and lib.wg_get_option(b"no_such_option") == -1
+    assert lib.wg_set_option(b"lazy_sort", 0) == 0 and lib.wg_get_option(b"lazy_sort") == 0
+    assert lib.wg_set_option(b"lazy_sort", 1) == 0
     assert lib.wg_set_option(b"no_such_option", 1) == -1
+    # the three RESULT-AFFECTING switches are per call (wg_call_options), not options of the process: the library does not know the names
+    for name in (b"exact_compositing", b"deterministic_backward", b"grad_record"):
+        assert lib.wg_get_option(name) == -1 and lib.wg_set_option(name, 0) == -1
     r = lib.wg_set_option(b"roctx", 1)   # the marker library is looked up at run time: present in a ROCm image, optional elsewhere
     assert r in (0, -1) and lib.wg_get_option(b"roctx") == (1 if r == 0 else 0)
     assert lib.wg_set_option(b"roctx", 0) == 0 and lib.wg_get_option(b"roctx") == 0
@@ -95,110 +98,115 @@ def test_invalid_arguments_are_rejected_before_any_device_work(lib):
     assert lib.wg_mark_visible(0, None, None, None, None, None) == 0
 
 
-def test_round3_entry_points_reject_invalid_arguments_before_any_device_work(lib):
-    """wg_rasterize_forward_fixed / _recolor / wg_forward_status: the same rule as the forward pass -- no allocator callback and no
-    HIP call before the arguments have been checked (this test runs on a box without a GPU)."""
-    ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
-    vp, i, f = C.c_void_p, C.c_int, C.c_float
+def test_struct_entry_points_reject_invalid_arguments_before_any_device_work(lib):
+    """wg_rasterize_forward_ex / _backward_ex (one struct, optional blocks: tone, second image, raw parameters, recolouring, fixed capacity,
+    per-call options) and wg_forward_status: no allocator callback and no HIP call before the arguments have been checked (this test runs on a
+    box without a GPU)."""
+    from diff_gaussian_rasterization import _C
+    A, B = _C._ForwardArgs, _C._BackwardArgs
+    ALLOC = _C._ALLOC_FN
     called = []
     cb = ALLOC(lambda n, u: called.append(n) or 0)
-    one = C.c_void_p(16)
-    lib.wg_rasterize_forward_fixed.restype = i
-    lib.wg_rasterize_forward_fixed.argtypes = [ALLOC, vp, ALLOC, vp, ALLOC, vp, i, i, i, vp, i, i, vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp,
-                                               f, f, f, vp, i, vp, vp, vp, vp, i]
+    one = 16   # a non-NULL address that is never dereferenced: validation fails first
+    fx, bx = lib.wg_rasterize_forward_ex, lib.wg_rasterize_backward_ex
+    fx.restype, fx.argtypes, bx.restype, bx.argtypes = C.c_int, [C.POINTER(A)], C.c_int, [C.POINTER(B)]
 
-    def fixed(capacity, P=10, W=64, H=64, colors=one):
-        return lib.wg_rasterize_forward_fixed(cb, None, cb, None, cb, None, P, 0, 0, one, W, H, one, None, colors, one, one, 1.0, one, None,
-                                              one, one, one, 1.0, 1.0, 0.1, None, 0, one, None, None, None, capacity)
-    assert fixed(0) == -1 and fixed(-5) == -1       # the capacity is the caller's to give
-    assert fixed(1024, P=-1) == -1 and fixed(1024, W=0) == -1 and fixed(1024, colors=None) == -1
-    assert fixed(1024, W=16 * 400, H=16 * 400) == -1  # 160 000 tiles: more than the LDS binning the capturable flow is restricted to
-
-    lib.wg_rasterize_forward_recolor.restype = i
-    lib.wg_rasterize_forward_recolor.argtypes = [ALLOC, vp, vp, vp, vp, i, i, vp, i, i, vp, vp, vp, vp, vp]
-
-    def recolor(alloc=cb, geom=one, binning=one, image=one, P=10, R=5, bg=one, W=64, H=64, colors=one, out=one):
-        return lib.wg_rasterize_forward_recolor(alloc, None, geom, binning, image, P, R, bg, W, H, colors, None, out, None, None)
-    for kw in (dict(alloc=C.cast(None, ALLOC)), dict(geom=None), dict(binning=None), dict(image=None), dict(P=0), dict(R=-1), dict(bg=None),
-               dict(W=0), dict(H=-2), dict(colors=None), dict(out=None)):
-        assert recolor(**kw) == -1, kw
-    assert recolor() == -2 and called == [called[0]]   # valid arguments: the allocator is asked once, returns NULL -> WG_ERR_ALLOC
+    def fwd(**kw):
+        a = A()
+        a.struct_size = C.sizeof(A)
+        a.geometry_alloc = a.binning_alloc = a.image_alloc = cb
+        a.P, a.width, a.height, a.scale_modifier, a.tan_fovx, a.tan_fovy, a.kernel_size = 10, 64, 64, 1.0, 1.0, 1.0, 0.1
+        for n in ("background", "means3D", "colors_precomp", "opacities", "scales", "rotations", "viewmatrix", "projmatrix", "cam_pos", "out_color"):
+            setattr(a, n, one)
+        keep = []
+        for k, v in kw.items():
+            if isinstance(v, C.Structure):
+                keep.append(v)
+                v = C.pointer(v)
+            setattr(a, k, v)
+        return fx(C.byref(a))
+    assert fx(None) == -1 and fwd(struct_size=C.sizeof(A) - 8) == -1                     # another header's struct
+    assert fwd(P=-1) == -1 and fwd(width=0) == -1 and fwd(colors_precomp=None) == -1       # the reference-shaped checks hold here too
+    # fixed capacity: the caller's to give; LDS binning only; no debug mode
+    assert fwd(binning_capacity=-5) == -1 and fwd(binning_capacity=1024, debug=1) == -1
+    assert fwd(binning_capacity=1024, width=16 * 400, height=16 * 400) == -1              # 160 000 tiles
+    # second image: the block needs its image; precomputed colours need the second set; SH colours need sh_second
+    S, R, T, Par = _C._SecondImage, _C._RawGaussians, _C._ShTone, _C._RecolorParent
+    assert fwd(second=S(None, None, None, None)) == -1 and fwd(second=S(None, one, None, None)) == -1
+    assert fwd(second=S(one, one, None, None), shs=one, colors_precomp=None, M=1) == -1
+    assert fwd(sh_second=1, shs=one, colors_precomp=None, M=1) == -1                       # two tones: the second image is required
+    assert fwd(sh_second=1, second=S(None, one, None, None)) == -1                         # ... and SH colours (the tones act on coefficients)
+    assert fwd(tone=T(None, None, 1.0, 1.0, None, None)) == -1                             # a tone without SH colours
+    # raw parameters: a filter, and a scale / rotation pair to act on
+    assert fwd(raw=R(None, None)) == -1 and fwd(raw=R(one, None), scales=None, rotations=None, cov3D_precomp=one) == -1
+    # recolouring: the parent's three buffers, a positive P, precomputed colours, nothing else
+    par = lambda **k: Par(**dict(dict(geom_buffer=one, binning_buffer=one, image_buffer=one, R=5), **k))
+    for kw in (dict(recolor=par(geom_buffer=None)), dict(recolor=par(binning_buffer=None)), dict(recolor=par(image_buffer=None)), dict(recolor=par(R=-1)),
+               dict(recolor=par(), P=0), dict(recolor=par(), background=None), dict(recolor=par(), width=0), dict(recolor=par(), colors_precomp=None),
+               dict(recolor=par(), out_color=None), dict(recolor=par(), geometry_alloc=C.cast(None, ALLOC)), dict(recolor=par(), raw=R(one, None)),
+               dict(recolor=par(), binning_capacity=8)):
+        assert fwd(**kw) == -1, kw
+    assert not called
+    assert fwd(recolor=par()) == -2 and len(called) == 1   # valid arguments: the allocator is asked once, returns NULL -> WG_ERR_ALLOC
     del called[:]
 
-    lib.wg_forward_status.restype, lib.wg_forward_status.argtypes = i, [vp, i, i, vp, vp, vp]
+    def bwd(**kw):
+        a = B()
+        a.struct_size = C.sizeof(B)
+        a.P, a.R, a.width, a.height, a.scale_modifier, a.tan_fovx, a.tan_fovy, a.kernel_size = 10, 5, 64, 64, 1.0, 1.0, 1.0, 0.1
+        for n in ("background", "means3D", "colors_precomp", "scales", "rotations", "viewmatrix", "projmatrix", "campos", "geom_buffer", "binning_buffer",
+                  "dL_dpix", "dL_dmean2D", "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D", "dL_dscale", "dL_drot"):
+            setattr(a, n, one)
+        keep = []
+        for k, v in kw.items():   # (image_buffer stays NULL: a deferred-ticket lookup is skipped, its NULL check comes after the blocks' own)
+            if isinstance(v, C.Structure):
+                keep.append(v)
+                v = C.pointer(v)
+            setattr(a, k, v)
+        return bx(C.byref(a))
+    assert bx(None) == -1 and bwd(struct_size=8) == -1
+    assert bwd(second=S(None, None, None, one)) == -1 and bwd(second=S(None, None, one, None)) == -1   # no second cotangent / no place for dL_dcolor2
+    assert bwd(raw=R(one, None)) == -1                                                                  # the raw opacities are needed again
+    assert bwd(raw=R(one, one), options=_C._CallOptions(1, 0, 0)) == -1                                 # raw parameters need the gradient record
+    assert bwd(sh_second=1, shs=one, M=1, dL_dsh=one) == -1                                             # two tones: no second cotangent
+    assert bwd(sh_second=1, second=S(None, None, one, None)) == -1                                      # ... no SH coefficients
+    assert bwd(sh_second=1, second=S(None, None, one, None), shs=one, M=1, dL_dsh=one, tone2=T(one, None, 1.0, 1.0, None, None)) == -1   # a multiplier without a place for its gradient
+    assert bwd(tone=T(one, None, 1.0, 1.0, None, None), shs=one, M=1, dL_dsh=one) == -1
+
+    lib.wg_forward_status.restype, lib.wg_forward_status.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     assert lib.wg_forward_status(None, 64, 64, None, None, None) == -1
     assert lib.wg_forward_status(one, 0, 64, None, None, None) == -1
-    lib.wg_image_accumulation_offset.restype, lib.wg_image_accumulation_offset.argtypes = C.c_size_t, [i, i]
-    lib.wg_image_buffer_size.restype, lib.wg_image_buffer_size.argtypes = C.c_size_t, [i, i]
+    lib.wg_image_accumulation_offset.restype, lib.wg_image_accumulation_offset.argtypes = C.c_size_t, [C.c_int, C.c_int]
+    lib.wg_image_buffer_size.restype, lib.wg_image_buffer_size.argtypes = C.c_size_t, [C.c_int, C.c_int]
     off = lib.wg_image_accumulation_offset(1920, 1080)
     assert off % 256 == 0 and off + 1920 * 1080 * 4 <= lib.wg_image_buffer_size(1920, 1080)
     assert not called
+    lib.wg_get_option.restype, lib.wg_get_option.argtypes = C.c_int, [C.c_char_p]
+    assert lib.wg_get_option(b"geometry_reuse") == 0   # opt-in since round 4
 
 
-def test_round4_entry_points_reject_invalid_arguments_before_any_device_work(lib):
-    """wg_rasterize_{forward,backward}_dual (two colour sets in one call) and _raw (get_gaussians() inside the preprocess kernels): no
-    allocator callback and no HIP call before the arguments have been checked (this test runs on a box without a GPU)."""
-    ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
-    vp, i, f = C.c_void_p, C.c_int, C.c_float
-    called = []
-    cb = ALLOC(lambda n, u: called.append(n) or 0)
-    one = C.c_void_p(16)
-
-    class Second(C.Structure):
-        _fields_ = [("colors_precomp2", vp), ("out_color2", vp), ("dL_dpix2", vp), ("dL_dcolor2", vp)]
-
-    class Raw(C.Structure):
-        _fields_ = [("filter_3D", vp), ("raw_opacities", vp)]
-    fwd_args = [ALLOC, vp, ALLOC, vp, ALLOC, vp, i, i, i, vp, i, i, vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, f, vp, i, vp, vp, i, vp]
-    lib.wg_rasterize_forward_dual.restype, lib.wg_rasterize_forward_dual.argtypes = i, fwd_args + [C.POINTER(Second)]
-    lib.wg_rasterize_forward_raw.restype, lib.wg_rasterize_forward_raw.argtypes = i, fwd_args + [vp, C.POINTER(Raw)]
-
-    def fwd(fn, extra, shs=None, colors=one, scales=one, cov=None):
-        return fn(cb, None, cb, None, cb, None, 10, 0, 0, one, 64, 64, one, shs, colors, one, scales, 1.0, one, cov, one, one, one, 1.0, 1.0, 0.1,
-                  None, 0, one, None, 0, None, *extra)
-    dual = lib.wg_rasterize_forward_dual
-    assert fwd(dual, (None,)) == -1                                                     # the block itself is required
-    assert fwd(dual, (C.byref(Second(None, 16, None, None)),)) == -1                    # no second colour set
-    assert fwd(dual, (C.byref(Second(16, None, None, None)),)) == -1                    # no second image
-    assert fwd(dual, (C.byref(Second(16, 16, None, None)),), shs=one, colors=None) == -1   # SH colours: precomputed only
-    raw = lib.wg_rasterize_forward_raw
-    assert fwd(raw, (None, None)) == -1
-    assert fwd(raw, (None, C.byref(Raw(None, None)))) == -1                              # no filter
-    assert fwd(raw, (None, C.byref(Raw(16, None))), scales=None, cov=one) == -1          # acts on scale / rotation pairs
-    # two tones of one SH block in one call: SH colours only, the second image required
-    class Tone(C.Structure):
-        _fields_ = [("mul", vp), ("offset", vp), ("pre_clamp_max", f), ("post_clamp_max", f), ("dL_dmul", vp), ("dL_doffset", vp)]
-    two = lib.wg_rasterize_forward_two_tone
-    two.restype, two.argtypes = i, fwd_args + [C.POINTER(Tone), C.POINTER(Tone), C.POINTER(Raw), vp]
-    assert fwd(two, (None, None, None, None), shs=one, colors=None) == -1               # no second image
-    assert fwd(two, (None, None, None, one)) == -1                                      # precomputed colours: the tones act on SH coefficients
-    assert fwd(two, (None, None, C.byref(Raw(None, None)), one), shs=one, colors=None) == -1   # raw block without a filter
-    assert not called
-
-    bwd_args = [i, i, i, i, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, f, vp, vp, vp, vp, vp, vp] + [vp] * 9 + [i, vp]
-    lib.wg_rasterize_backward_dual.restype, lib.wg_rasterize_backward_dual.argtypes = i, bwd_args + [C.POINTER(Second)]
-    lib.wg_rasterize_backward_raw.restype, lib.wg_rasterize_backward_raw.argtypes = i, bwd_args + [vp, C.POINTER(Raw)]
-
-    def bwd(fn, extra, shs=None, scales=one):
-        return fn(10, 0, 0, 5, one, 64, 64, one, shs, one, scales, 1.0, one, None, one, one, one, 1.0, 1.0, 0.1, None, None, one, one, None,
-                  one, one, None, one, one, one, one, None, one, one, 0, None, *extra)
-    # (image_buffer NULL throughout: a deferred-ticket lookup is skipped and the NULL check comes after the block's own checks)
-    assert bwd(lib.wg_rasterize_backward_dual, (None,)) == -1
-    assert bwd(lib.wg_rasterize_backward_dual, (C.byref(Second(None, None, None, 16)),)) == -1   # no second cotangent
-    assert bwd(lib.wg_rasterize_backward_dual, (C.byref(Second(None, None, 16, None)),)) == -1   # no place for the second colour gradient
-    assert bwd(lib.wg_rasterize_backward_raw, (None, None)) == -1
-    assert bwd(lib.wg_rasterize_backward_raw, (None, C.byref(Raw(16, None)))) == -1              # raw opacities are needed again
-    two_b = lib.wg_rasterize_backward_two_tone
-    two_b.restype, two_b.argtypes = i, bwd_args + [C.POINTER(Tone), C.POINTER(Tone), C.POINTER(Raw), vp, vp]
-    assert bwd(two_b, (None, None, None, None, None), shs=one) == -1                                  # no second cotangent
-    assert bwd(two_b, (None, None, None, one, None)) == -1                                            # no SH coefficients
-    assert bwd(two_b, (None, C.byref(Tone(16, None, 1.0, 1.0, None, None)), None, one, None), shs=one) == -1   # a multiplier without a place for its gradient
-    lib.wg_set_option.restype, lib.wg_set_option.argtypes = i, [C.c_char_p, i]
-    lib.wg_get_option.restype, lib.wg_get_option.argtypes = i, [C.c_char_p]
-    assert lib.wg_get_option(b"exact_compositing") == 1 and lib.wg_get_option(b"geometry_reuse") == 0   # round-4 defaults
-    assert lib.wg_set_option(b"exact_compositing", 0) == 0 and lib.wg_get_option(b"exact_compositing") == 0
-    assert lib.wg_set_option(b"exact_compositing", 1) == 0
-
+def test_per_call_options_are_resolved_per_thread_and_scoped():
+    """The binding's side of wg_call_options: keyword > `with call_options(...)` > the calling thread's defaults; another thread is not affected."""
+    import threading
+    from diff_gaussian_rasterization import _C
+    assert _C.resolve_call_options(None) == (1, 0, 1) == _C.resolve_call_options({})
+    assert _C.resolve_call_options(dict(deterministic_backward=True, grad_record=None)) == (1, 1, 1)
+    with _C.call_options(exact_compositing=0):
+        assert _C.resolve_call_options(None) == (0, 0, 1) and _C.resolve_call_options(dict(exact_compositing=1)) == (1, 0, 1)
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(_C.resolve_call_options(None)))
+        t.start()
+        t.join()
+        assert seen == [(1, 0, 1)]
+    assert _C.resolve_call_options(None) == (1, 0, 1)
+    _C.set_option("deterministic_backward", 1)       # (the tests' and bench.py's spelling: the calling thread's default)
+    try:
+        assert _C.get_option("deterministic_backward") == 1 and _C.resolve_call_options(None) == (1, 1, 1)
+    finally:
+        _C.set_option("deterministic_backward", 0)
+    assert _C.resolve_call_options((0, 1, 0)) == (0, 1, 0)   # an already resolved triple (what the autograd ctx carries to the backward call)
+    with pytest.raises(ValueError):
+        _C.resolve_call_options(dict(no_such_option=1))
 
 def test_python_surface_matches_the_reference_operator():
     import diff_gaussian_rasterization as dgr
@@ -570,9 +578,9 @@ def test_geometry_reuse_tokens_are_by_object_and_version_never_by_address():
         assert not _C._same_token(_C._tensor_token(d), _C._tensor_token(d))
     # the remembered call ends with the next backward call of the process (writes through `.data` move no version counter)
     g = [torch.zeros(5, 3) for _ in range(9)]
-    key = (tuple(_C._tensor_token(t) for t in g), (1.0, 0.5, 0.5, 0.1, 32, 32, False, "cpu", 0))   # as _reuse_key builds it
+    key = (tuple(_C._tensor_token(t) for t in g), (1.0, 0.5, 0.5, 0.1, 32, 32, False, "cpu", 0), (1, 0, 1))   # as _reuse_key builds it (+ the call's options)
     try:
-        _C._reuse.last = dict(tensors=key[0], scalars=key[1], epoch=_C._reuse_epoch)
+        _C._reuse.last = dict(tensors=key[0], scalars=key[1], opts=key[2], epoch=_C._reuse_epoch)
         assert _C._reuse_lookup(key) is _C._reuse.last
         g[0].data.add_(1.0)                                               # invisible to the token ...
         assert _C._reuse_lookup(key) is _C._reuse.last

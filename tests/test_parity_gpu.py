@@ -1096,7 +1096,7 @@ def test_geometry_reuse_gives_what_two_separate_calls_give(record_option, scene)
     """Option "geometry_reuse" (opt-in): WildGaussians rasterizes the same Gaussians through the same camera
     with raw and then with toned colours (method.py:1573-1611).  The second call -- same geometry tensor OBJECTS at the same version,
     same settings, other precomputed colours -- copies the projected state with the new colours and composites along the first
-    call's sorted lists (wg_rasterize_forward_recolor): no projection, no binning.  Images, accumulation and radii are bit-identical to
+    call's sorted lists (wg_forward_args::recolor): no projection, no binning.  Images, accumulation and radii are bit-identical to
     two separate calls; in the deterministic backward mode so is every gradient (incl. the sums in the shared means2D carrier)."""
     from diff_gaussian_rasterization import GaussianRasterizer
     _C = record_option
@@ -1145,7 +1145,7 @@ def test_geometry_reuse_gives_what_two_separate_calls_give(record_option, scene)
 
 @pytest.mark.parametrize("scene", ["sparse", "dense_lazy", "near_far"])
 def test_two_colour_sets_in_one_call_give_what_two_calls_give(record_option, scene):
-    """`colors_precomp2=` (wg_second_colors): WildGaussians' raw and toned colours (method.py:1573-1611) composited in
+    """`colors_precomp2=` (wg_second_image): WildGaussians' raw and toned colours (method.py:1573-1611) composited in
     ONE forward and ONE backward walk.  Both images, the accumulation and radii are bit-identical to two separate calls (the decisions do
     not depend on the colours, the colour sums are the same operations in the same order); each colour set's gradient and the geometry
     gradients -- which here are the gradients of BOTH losses, what autograd's addition of the two calls' results gives -- agree to
@@ -1221,7 +1221,7 @@ def test_two_colour_sets_in_one_call_give_what_two_calls_give(record_option, sce
 
 @pytest.mark.parametrize("layout", ["sh3_fast", "sh2_generic", "sh3_raw_parameters", "first_set_plain"])
 def test_two_tones_of_one_sh_block_in_one_call_give_what_two_toned_calls_give(record_option, layout):
-    """`sh_second=True` (wg_rasterize_*_two_tone): WildGaussians' whole step before the loss -- the raw colours (SH block, clamped) and the
+    """`sh_second=True` (wg_forward_args::sh_second): WildGaussians' whole step before the loss -- the raw colours (SH block, clamped) and the
     toned colours (the same block through the appearance MLP's affine) -- in ONE call: the preprocess kernel evaluates the polynomial
     twice from one read of the coefficients, the walk composites both sets, the per-Gaussian backward kernel sends both sets' dL/dRGB
     through their tones into one dL_dsh.  Images, accumulation, radii bit-identical to two `sh_mul=` calls; gradients to rounding."""
@@ -1441,7 +1441,7 @@ def test_deferred_speculation_checks_the_previous_frame_at_the_next_call():
 
 
 def test_fixed_capacity_forward_needs_no_host_rendezvous_and_can_be_captured_in_a_graph(record_option):
-    """wg_rasterize_forward_fixed (`binning_capacity=`; VERDICT r2 item 3's stretch goal): the caller supplies the binning capacity,
+    """wg_forward_args::binning_capacity (`binning_capacity=`; VERDICT r2 item 3's stretch goal): the caller supplies the binning capacity,
     the call enqueues everything and never reads anything back.  (1) a frame that fits: bit-identical to the classic flow, forward
     and (deterministic mode) backward; forward_status reports the real count; (2) a frame that does not fit: NaN image, zero
     gradients, fits == False, nothing faults; (3) forward + backward captured ONCE in a hipGraph (torch.cuda.CUDAGraph) and replayed

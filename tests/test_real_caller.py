@@ -320,7 +320,7 @@ def test_training_trajectory_on_the_product_and_on_the_reference_kernels():
 @needs_staged
 def test_real_render_internal_reuses_the_geometry_of_its_first_rasterizer_call(trained):
     """The real `_render_internal` (method.py:1573-1611) rasterizes raw and toned colours over identical geometry: with the binding's
-    geometry reuse (opt-in) the second call takes wg_rasterize_forward_recolor.  Same images, bit for bit, as with the reuse off."""
+    geometry reuse (opt-in) the second call takes wg_forward_args::recolor.  Same images, bit for bit, as with the reuse off."""
     from diff_gaussian_rasterization import _C
     m, wg, _ = trained
     cam = wg.train_cameras[2]

@@ -21,21 +21,22 @@ needs_binding = pytest.mark.skipif(not built, reason="compiled binding not built
 def binding():
     from diff_gaussian_rasterization import _C
     yield _C
-    _C.use_binding("ctypes")
+    _C.use_binding("torch" if built else "ctypes")
 
 
 @needs_binding
 def test_compiled_binding_has_the_reference_modules_surface_and_errors(binding):
     _C = binding
     from diff_gaussian_rasterization import _C_torch as m
-    assert {"rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"} <= set(dir(m))
+    assert {"rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible", "rasterize_gaussians_ex", "rasterize_gaussians_backward_ex"} <= set(dir(m))
     e = torch.Tensor([])
     args = lambda m3: (torch.zeros(3), m3, e, torch.zeros(5, 1), e, e, 1.0, e, torch.eye(4), torch.eye(4), 1.0, 1.0, 0.1, e, 8, 8, e, 0, torch.zeros(3), False, False)
     with pytest.raises(RuntimeError, match="num_points, 3"):      # rasterize_points.cu:59-61
         m.rasterize_gaussians(*args(torch.zeros(5, 2)))
     with pytest.raises(RuntimeError, match="no CPU path"):
         m.rasterize_gaussians(*args(torch.zeros(5, 3)))
-    assert _C.binding_name() == "ctypes" and _C.use_binding("torch") == "ctypes" and _C.binding_name() == "torch"
+    assert _C.binding_name() == "torch"          # the default when it has been built (round 5)
+    assert _C.use_binding("ctypes") == "torch" and _C.binding_name() == "ctypes" and _C.use_binding("torch") == "ctypes" and _C.binding_name() == "torch"
     with pytest.raises(ValueError):
         _C.use_binding("pybind")
 

@@ -28,7 +28,7 @@ def make_settings(cam, sh_degree, kernel_size=0.1, bg=None, subpixel_offset=None
 def run_hip(cloud, cam, sh_degree=3, kernel_size=0.1, bg=None, subpixel_offset=None, cotangent=None, scale_modifier=1.0,
             device="cuda", binning_capacity=None):
     """Forward (+ backward when a cotangent is given) through GaussianRasterizer; numpy results.  binning_capacity: the
-    fixed-capacity forward (wg_rasterize_forward_fixed)."""
+    fixed-capacity forward (wg_forward_args::binning_capacity)."""
     from diff_gaussian_rasterization import GaussianRasterizer
     rs = make_settings(cam, sh_degree, kernel_size, bg, subpixel_offset, scale_modifier, device=device)
     t = {k: to_dev(v, device).requires_grad_(cotangent is not None) for k, v in cloud.items()}

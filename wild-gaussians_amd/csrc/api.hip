@@ -270,7 +270,7 @@ bool read_mailbox(Mailbox* mbox, uint32_t seq, wg::BinStats& st, bool* waited) {
 }
 
 // A deferred frame's verdict, taken by the thread's next call.  WG_ERR_SPECULATION when that frame did not fit the buffer it was given:
-// its image is NaN and its gradients are zero (see wg_rasterize_forward_fixed); the caller repeats the step.  The history learns the
+// its image is NaN and its gradients are zero (see wg_forward_args::binning_capacity); the caller repeats the step.  The history learns the
 // frame's real size either way, so the repeat fits.
 int settle_deferred() {
     if (!t_deferred.pending) return WG_OK;
@@ -386,7 +386,7 @@ size_t wg_binning_buffer_size(int R) {  // upper bound over both binning paths
     return required_bytes([&](char*& c) { wg::BinningState::fromChunk(c, (size_t)(R > 0 ? R : 0), true); });
 }
 
-// sh_second (wg_rasterize_*_two_tone): the tone kernels run even when a set has no tone of its own (NULL = identity: no affine, clamps at
+// sh_second (wg_forward_args::sh_second): the tone kernels run even when a set has no tone of its own (NULL = identity: no affine, clamps at
 // +infinity -- min(x, inf) = x, x * 1 + 0 = x)
 static wg::ShTone device_tone(const wg_sh_tone* t, const wg_sh_tone* t2 = nullptr, bool sh_second = false) {
     wg::ShTone d;
@@ -412,6 +412,37 @@ static wg::ShTone device_tone(const wg_sh_tone* t, const wg_sh_tone* t2 = nullpt
     return d;
 }
 
+// ---- the frame's exact_compositing, remembered per image buffer: a backward or recolouring call that carries another value
+// than the forward call that made the image state would differentiate / recomposite decisions the stored per-pixel state does not hold.
+// Host-side only (no device traffic): the last 64 frames, keyed by the 256-byte-aligned image-state address; an address handed out
+// again by the caller's allocator is simply overwritten by the next forward call that gets it.
+struct FrameMode { const void* image; int exact; };
+std::mutex g_mode_mu;
+FrameMode g_modes[64];
+unsigned g_mode_head = 0;
+const void* image_key(const char* image_buffer) {
+    return reinterpret_cast<const void*>((reinterpret_cast<uintptr_t>(image_buffer) + wg::ALIGN - 1) & ~(uintptr_t)(wg::ALIGN - 1));
+}
+void remember_mode(const char* image_buffer, int exact) {
+    const void* k = image_key(image_buffer);
+    std::lock_guard<std::mutex> l(g_mode_mu);
+    for (auto& m : g_modes)
+        if (m.image == k) { m.exact = exact; return; }
+    g_modes[g_mode_head++ % 64] = {k, exact};
+}
+// -1: not remembered (older than 64 frames: the caller is trusted)
+int remembered_mode(const char* image_buffer) {
+    const void* k = image_key(image_buffer);
+    std::lock_guard<std::mutex> l(g_mode_mu);
+    for (auto& m : g_modes)
+        if (m.image == k) return m.exact;
+    return -1;
+}
+
+static int forward_impl(const wg_forward_args& a);
+static int recolor_impl(const wg_forward_args& a);
+static int backward_impl(const wg_backward_args& a);
+
 int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
                          wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
                          int height, const float* means3D, const float* shs, const float* colors_precomp,
@@ -419,86 +450,23 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
                          const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                          float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
                          float* out_color, int* radii, int debug, void* stream_) {
-    return wg_rasterize_forward_toned(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
-                                      width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
-                                      cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, kernel_size, subpixel_offset,
-                                      prefiltered, out_color, radii, debug, stream_, nullptr);
+    wg_forward_args a{};
+    a.struct_size = sizeof(a);
+    a.geometry_alloc = geometry_alloc; a.geometry_user = geometry_user;
+    a.binning_alloc = binning_alloc; a.binning_user = binning_user;
+    a.image_alloc = image_alloc; a.image_user = image_user;
+    a.P = P; a.D = D; a.M = M; a.width = width; a.height = height; a.prefiltered = prefiltered; a.debug = debug;
+    a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.kernel_size = kernel_size;
+    a.background = background; a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities;
+    a.scales = scales; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
+    a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.cam_pos = cam_pos; a.subpixel_offset = subpixel_offset;
+    a.out_color = out_color; a.radii = radii; a.stream = stream_;
+    return forward_impl(a);
 }
 
-static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
-                        wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
-                        int height, const float* means3D, const float* shs, const float* colors_precomp,
-                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                        float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
-                        float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, int fixed_capacity,
-                        const wg_second_colors* second = nullptr, const wg_raw_gaussians* raw = nullptr, const wg_sh_tone* tone2 = nullptr,
-                        bool sh_second = false);
-
-int wg_rasterize_forward_toned(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
-                               wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
-                               int height, const float* means3D, const float* shs, const float* colors_precomp,
-                               const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                               float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
-                               float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone) {
-    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
-                        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
-                        tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, out_color, radii, debug, stream_, tone, 0);
-}
-
-int wg_rasterize_forward_dual(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
-                              wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
-                              int height, const float* means3D, const float* shs, const float* colors_precomp,
-                              const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                              const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                              float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
-                              float* out_color, int* radii, int debug, void* stream_, const wg_second_colors* second) {
-    if (second == nullptr) return WG_ERR_INVALID_ARGUMENT;
-    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
-                        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
-                        tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, out_color, radii, debug, stream_, nullptr, 0, second);
-}
-
-int wg_rasterize_forward_raw(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
-                             wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
-                             int height, const float* means3D, const float* shs, const float* colors_precomp,
-                             const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                             const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                             float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
-                             float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, const wg_raw_gaussians* raw) {
-    if (raw == nullptr) return WG_ERR_INVALID_ARGUMENT;
-    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
-                        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
-                        tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, out_color, radii, debug, stream_, tone, 0, nullptr, raw);
-}
-
-int wg_rasterize_forward_two_tone(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
-                                  wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
-                                  int height, const float* means3D, const float* shs, const float* colors_precomp,
-                                  const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                                  float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
-                                  float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, const wg_sh_tone* tone2,
-                                  const wg_raw_gaussians* raw, float* out_color2) {
-    wg_second_colors second{nullptr, out_color2, nullptr, nullptr};
-    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
-                        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
-                        tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, out_color, radii, debug, stream_, tone, 0, &second, raw,
-                        tone2, true);
-}
-
-int wg_rasterize_forward_fixed(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
-                               wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
-                               int height, const float* means3D, const float* shs, const float* colors_precomp,
-                               const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                               float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
-                               float* out_color, int* radii, void* stream_, const wg_sh_tone* tone, int binning_capacity) {
-    if (binning_capacity <= 0) return WG_ERR_INVALID_ARGUMENT;
-    return forward_impl(geometry_alloc, geometry_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height,
-                        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos,
-                        tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, out_color, radii, 0, stream_, tone, binning_capacity);
+int wg_rasterize_forward_ex(const wg_forward_args* args) {
+    if (args == nullptr || args->struct_size != sizeof(wg_forward_args)) return WG_ERR_INVALID_ARGUMENT;
+    return args->recolor != nullptr ? recolor_impl(*args) : forward_impl(*args);
 }
 
 int wg_forward_status(char* image_buffer, int width, int height, int* num_rendered, int* fits, void* stream_) {
@@ -515,18 +483,35 @@ int wg_forward_status(char* image_buffer, int width, int height, int* num_render
     return WG_OK;
 }
 
-static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_alloc_fn binning_alloc, void* binning_user,
-                        wg_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
-                        int height, const float* means3D, const float* shs, const float* colors_precomp,
-                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
-                        float tan_fovx, float tan_fovy, float kernel_size, const float* subpixel_offset, int prefiltered,
-                        float* out_color, int* radii, int debug, void* stream_, const wg_sh_tone* tone, int fixed_capacity,
-                        const wg_second_colors* second, const wg_raw_gaussians* raw, const wg_sh_tone* tone2, bool sh_second) {
+static int forward_impl(const wg_forward_args& a) {
+    // (the body below reads the arguments under the reference interface's names)
+    const wg_alloc_fn geometry_alloc = a.geometry_alloc, binning_alloc = a.binning_alloc, image_alloc = a.image_alloc;
+    void* const geometry_user = a.geometry_user; void* const binning_user = a.binning_user; void* const image_user = a.image_user;
+    const int P = a.P, D = a.D, M = a.M, width = a.width, height = a.height, prefiltered = a.prefiltered;
+    const float scale_modifier = a.scale_modifier, tan_fovx = a.tan_fovx, tan_fovy = a.tan_fovy, kernel_size = a.kernel_size;
+    const float *background = a.background, *means3D = a.means3D, *shs = a.shs, *colors_precomp = a.colors_precomp, *opacities = a.opacities,
+                *scales = a.scales, *rotations = a.rotations, *cov3D_precomp = a.cov3D_precomp, *viewmatrix = a.viewmatrix,
+                *projmatrix = a.projmatrix, *cam_pos = a.cam_pos, *subpixel_offset = a.subpixel_offset;
+    float* const out_color = a.out_color;
+    int* const radii = a.radii;
+    void* const stream_ = a.stream;
+    const wg_sh_tone *tone = a.tone, *tone2 = a.tone2;
+    const wg_second_image* second = a.second;
+    const wg_raw_gaussians* raw = a.raw;
+    const bool sh_second = a.sh_second != 0;
+    const int fixed_capacity = a.binning_capacity;
+    if (fixed_capacity < 0 || (fixed_capacity > 0 && a.debug)) return WG_ERR_INVALID_ARGUMENT;
+    const int debug = fixed_capacity > 0 ? 0 : a.debug;
+    if (a.recolor != nullptr) return WG_ERR_INVALID_ARGUMENT;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    const wg::Options opt = options_snapshot();
-    // two colour sets over one walk: a second set of precomputed colours (wg_second_colors), or the SAME SH coefficients through a
-    // second tone (sh_second; wg_rasterize_forward_two_tone).  The second image is required either way.
+    wg::Options opt = options_snapshot();
+    {   // the result-affecting switches are the CALL's (wg_call_options), never the process's
+        const wg_call_options dflt = WG_CALL_OPTIONS_DEFAULT;
+        const wg_call_options& co = a.options ? *a.options : dflt;
+        opt.exact_compositing = co.exact_compositing != 0; opt.deterministic_backward = co.deterministic_backward != 0; opt.grad_record = co.grad_record != 0;
+    }
+    // two colour sets over one walk: a second set of precomputed colours (wg_second_image), or the SAME SH coefficients through a
+    // second tone (sh_second; wg_forward_args::sh_second).  The second image is required either way.
     float* out_color2 = nullptr;
     if (second != nullptr) {   // (the second image is written whatever P is: the background alone when there is nothing to composite)
         if (!second->out_color2) return WG_ERR_INVALID_ARGUMENT;
@@ -563,6 +548,7 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
     char* geom_chunk = geometry_alloc(required_bytes([&](char*& c) { wg::GeometryState::fromChunk(c, (size_t)P, band_lists); }), geometry_user);
     char* img_chunk = image_alloc(wg_image_buffer_size(width, height), image_user);
     if (!geom_chunk || !img_chunk) return WG_ERR_ALLOC;
+    remember_mode(img_chunk, opt.exact_compositing ? 1 : 0);
     wg::GeometryState geom = wg::GeometryState::fromChunk(geom_chunk, (size_t)P, band_lists);
     wg::ImageState img = wg::ImageState::fromChunk(img_chunk, (size_t)width * height, (size_t)tiles);
 
@@ -809,23 +795,30 @@ static int forward_impl(wg_alloc_fn geometry_alloc, void* geometry_user, wg_allo
     return num_rendered;
 }
 
-int wg_rasterize_forward_recolor(wg_alloc_fn geometry_alloc, void* geometry_user, char* parent_geom_buffer, char* parent_binning_buffer,
-                                 char* parent_image_buffer, int P, int R, const float* background, int width, int height,
-                                 const float* colors_precomp, const float* subpixel_offset, float* out_color, int* radii, void* stream_) {
-    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+// wg_recolor_parent (include/wg_rasterizer.h): other precomputed colours over a parent call's projection, binning and per-pixel stops
+static int recolor_impl(const wg_forward_args& a) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(a.stream);
     const bool debug = false;
-    if (!geometry_alloc || !parent_geom_buffer || !parent_binning_buffer || !parent_image_buffer) return WG_ERR_INVALID_ARGUMENT;
-    if (P <= 0 || R < 0 || width <= 0 || height <= 0 || !background || !colors_precomp || !out_color) return WG_ERR_INVALID_ARGUMENT;
+    const wg_recolor_parent& par = *a.recolor;
+    const int P = a.P, R = par.R, width = a.width, height = a.height;
+    if (a.tone || a.tone2 || a.sh_second || a.second || a.raw || a.binning_capacity != 0 || a.shs) return WG_ERR_INVALID_ARGUMENT;
+    if (!a.geometry_alloc || !par.geom_buffer || !par.binning_buffer || !par.image_buffer) return WG_ERR_INVALID_ARGUMENT;
+    if (P <= 0 || R < 0 || width <= 0 || height <= 0 || !a.background || !a.colors_precomp || !a.out_color) return WG_ERR_INVALID_ARGUMENT;
+    const wg_call_options dflt = WG_CALL_OPTIONS_DEFAULT;
+    const int exact = (a.options ? a.options->exact_compositing : dflt.exact_compositing) != 0 ? 1 : 0;
+    const int parent_mode = remembered_mode(par.image_buffer);
+    if (parent_mode >= 0 && parent_mode != exact) return WG_ERR_INVALID_ARGUMENT;   // the parent's per-pixel stops were taken in the other arithmetic
     const int gx = (width + wg::TILE_X - 1) / wg::TILE_X, gy = (height + wg::TILE_Y - 1) / wg::TILE_Y;
-    wg::GeometryState parent = wg::GeometryState::fromChunk(parent_geom_buffer, (size_t)P, false);
-    wg::BinningState bin = wg::BinningState::fromChunk(parent_binning_buffer, (size_t)R, false);  // point_list only
-    wg::ImageState img = wg::ImageState::fromChunk(parent_image_buffer, (size_t)width * height, (size_t)gx * gy);
-    char* chunk = geometry_alloc(required_bytes([&](char*& c) { wg::GeometryState::fromChunk(c, (size_t)P, false); }), geometry_user);
+    char *pg = par.geom_buffer, *pb = par.binning_buffer, *pi = par.image_buffer;   // (fromChunk advances its argument)
+    wg::GeometryState parent = wg::GeometryState::fromChunk(pg, (size_t)P, false);
+    wg::BinningState bin = wg::BinningState::fromChunk(pb, (size_t)R, false);  // point_list only
+    wg::ImageState img = wg::ImageState::fromChunk(pi, (size_t)width * height, (size_t)gx * gy);
+    char* chunk = a.geometry_alloc(required_bytes([&](char*& c) { wg::GeometryState::fromChunk(c, (size_t)P, false); }), a.geometry_user);
     if (!chunk) return WG_ERR_ALLOC;
     wg::GeometryState geom = wg::GeometryState::fromChunk(chunk, (size_t)P, false);
-    WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_recolor(P, parent, geom, colors_precomp, radii, stream), "recolor");
+    WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_recolor(P, parent, geom, a.colors_precomp, a.radii, stream), "recolor");
     WG_STAGE(WG_STAGE_RENDER_FORWARD,
-             wg::launch_render_forward_replay(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, options_snapshot().exact_compositing != 0, stream),
+             wg::launch_render_forward_replay(width, height, gx, gy, img, bin, geom, a.subpixel_offset, a.background, a.out_color, exact != 0, stream),
              "render_forward_replay");
     return R;
 }
@@ -838,93 +831,51 @@ int wg_rasterize_backward(int P, int D, int M, int R, const float* background, i
                           char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                           float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                           float* dL_drot, int debug, void* stream_) {
-    return wg_rasterize_backward_toned(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
-                                       cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, subpixel_offset, radii,
-                                       geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
-                                       dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream_, nullptr);
+    wg_backward_args a{};
+    a.struct_size = sizeof(a);
+    a.P = P; a.D = D; a.M = M; a.R = R; a.width = width; a.height = height; a.debug = debug;
+    a.scale_modifier = scale_modifier; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy; a.kernel_size = kernel_size;
+    a.background = background; a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.scales = scales; a.rotations = rotations;
+    a.cov3D_precomp = cov3D_precomp; a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.campos = campos; a.subpixel_offset = subpixel_offset;
+    a.radii = radii; a.geom_buffer = geom_buffer; a.binning_buffer = binning_buffer; a.image_buffer = image_buffer; a.dL_dpix = dL_dpix;
+    a.dL_dmean2D = dL_dmean2D; a.dL_dconic = dL_dconic; a.dL_dopacity = dL_dopacity; a.dL_dcolor = dL_dcolor; a.dL_dmean3D = dL_dmean3D;
+    a.dL_dcov3D = dL_dcov3D; a.dL_dsh = dL_dsh; a.dL_dscale = dL_dscale; a.dL_drot = dL_drot; a.stream = stream_;
+    return backward_impl(a);
 }
 
-static int backward_impl(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                         const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                         const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
-                         const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
-                         const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
-                         char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                         float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                         float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_second_colors* second,
-                         const wg_raw_gaussians* raw = nullptr, const wg_sh_tone* tone2 = nullptr, bool sh_second = false);
-
-int wg_rasterize_backward_toned(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                                const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                                const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
-                                const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
-                                const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
-                                char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                                float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone) {
-    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
-                         viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, subpixel_offset, radii, geom_buffer, binning_buffer,
-                         image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
-                         debug, stream_, tone, nullptr);
+int wg_rasterize_backward_ex(const wg_backward_args* args) {
+    if (args == nullptr || args->struct_size != sizeof(wg_backward_args)) return WG_ERR_INVALID_ARGUMENT;
+    return backward_impl(*args);
 }
 
-int wg_rasterize_backward_raw(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                              const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                              const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
-                              const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
-                              const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
-                              char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                              float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                              float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_raw_gaussians* raw) {
-    if (raw == nullptr) return WG_ERR_INVALID_ARGUMENT;
-    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
-                         viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, subpixel_offset, radii, geom_buffer, binning_buffer,
-                         image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
-                         debug, stream_, tone, nullptr, raw);
-}
-
-int wg_rasterize_backward_dual(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                               const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                               const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
-                               const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
-                               const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
-                               char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                               float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                               float* dL_drot, int debug, void* stream_, const wg_second_colors* second) {
-    if (second == nullptr) return WG_ERR_INVALID_ARGUMENT;
-    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
-                         viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, subpixel_offset, radii, geom_buffer, binning_buffer,
-                         image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
-                         debug, stream_, nullptr, second);
-}
-
-int wg_rasterize_backward_two_tone(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                                   const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                                   const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
-                                   const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
-                                   const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
-                                   char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                   float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                                   float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_sh_tone* tone2,
-                                   const wg_raw_gaussians* raw, const float* dL_dpix2, float* dL_dcolor2) {
-    wg_second_colors second{nullptr, nullptr, dL_dpix2, dL_dcolor2};
-    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp,
-                         viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, subpixel_offset, radii, geom_buffer, binning_buffer,
-                         image_buffer, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
-                         debug, stream_, tone, &second, raw, tone2, true);
-}
-
-static int backward_impl(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                         const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                         const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
-                         const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, float kernel_size,
-                         const float* subpixel_offset, const int* radii, char* geom_buffer, char* binning_buffer,
-                         char* image_buffer, const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                         float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                         float* dL_drot, int debug, void* stream_, const wg_sh_tone* tone, const wg_second_colors* second,
-                         const wg_raw_gaussians* raw, const wg_sh_tone* tone2, bool sh_second) {
+static int backward_impl(const wg_backward_args& a) {
+    // (the body below reads the arguments under the reference interface's names)
+    const int P = a.P, D = a.D, M = a.M, R = a.R, width = a.width, height = a.height, debug = a.debug;
+    const float scale_modifier = a.scale_modifier, tan_fovx = a.tan_fovx, tan_fovy = a.tan_fovy, kernel_size = a.kernel_size;
+    const float *background = a.background, *means3D = a.means3D, *shs = a.shs, *colors_precomp = a.colors_precomp, *scales = a.scales,
+                *rotations = a.rotations, *cov3D_precomp = a.cov3D_precomp, *viewmatrix = a.viewmatrix, *projmatrix = a.projmatrix,
+                *campos = a.campos, *subpixel_offset = a.subpixel_offset, *dL_dpix = a.dL_dpix;
+    const int* radii = a.radii;
+    char *geom_buffer = a.geom_buffer, *binning_buffer = a.binning_buffer, *image_buffer = a.image_buffer;   // (fromChunk advances its argument)
+    float *const dL_dmean2D = a.dL_dmean2D, *const dL_dconic = a.dL_dconic, *const dL_dopacity = a.dL_dopacity, *const dL_dcolor = a.dL_dcolor,
+          *const dL_dmean3D = a.dL_dmean3D, *const dL_dcov3D = a.dL_dcov3D, *const dL_dsh = a.dL_dsh, *const dL_dscale = a.dL_dscale,
+          *const dL_drot = a.dL_drot;
+    void* const stream_ = a.stream;
+    const wg_sh_tone *tone = a.tone, *tone2 = a.tone2;
+    const wg_second_image* second = a.second;
+    const wg_raw_gaussians* raw = a.raw;
+    const bool sh_second = a.sh_second != 0;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    const wg::Options opt = options_snapshot();
+    wg::Options opt = options_snapshot();
+    {   // the result-affecting switches are the CALL's (wg_call_options), never the process's
+        const wg_call_options dflt = WG_CALL_OPTIONS_DEFAULT;
+        const wg_call_options& co = a.options ? *a.options : dflt;
+        opt.exact_compositing = co.exact_compositing != 0; opt.deterministic_backward = co.deterministic_backward != 0; opt.grad_record = co.grad_record != 0;
+    }
+    if (image_buffer != nullptr && P > 0) {   // the frame was composited with the other arithmetic: its stored decisions are not this call's
+        const int fwd_mode = remembered_mode(image_buffer);
+        if (fwd_mode >= 0 && fwd_mode != (opt.exact_compositing ? 1 : 0)) return WG_ERR_INVALID_ARGUMENT;
+    }
     // two colour sets over one walk: the thirteen sums go to the gradient record (or, deterministic mode, to fourteen-float slots)
     const bool dual = second != nullptr && P > 0;
     // raw-parameter mode: the per-Gaussian kernel turns the gradients of the activated values into those of the raw parameters where it
@@ -1092,8 +1043,6 @@ int wg_set_option(const char* name, int value) {
     wg::Options& o = g_opt;
     if (std::strcmp(name, "force_global_sort") == 0) { o.force_global_sort = value != 0; return WG_OK; }
     if (std::strcmp(name, "host_mailbox") == 0) { o.use_mailbox = value != 0; return WG_OK; }
-    if (std::strcmp(name, "grad_record") == 0) { o.grad_record = value != 0; return WG_OK; }
-    if (std::strcmp(name, "exact_compositing") == 0) { o.exact_compositing = value != 0; return WG_OK; }
     if (std::strcmp(name, "geometry_reuse") == 0) { o.geometry_reuse = value != 0; return WG_OK; }
     if (std::strcmp(name, "fused_scan") == 0) { o.fused_scan = value != 0; return WG_OK; }
     if (std::strcmp(name, "speculative_forward") == 0) {  // (a deferred frame still pending is dropped: its verdict goes unread)
@@ -1102,7 +1051,6 @@ int wg_set_option(const char* name, int value) {
         return WG_OK;
     }
     if (std::strcmp(name, "spec_margin_pct") == 0) { if (value < 0 || value > 1000) return WG_ERR_INVALID_ARGUMENT; o.spec_margin_pct = value; return WG_OK; }
-    if (std::strcmp(name, "deterministic_backward") == 0) { o.deterministic_backward = value != 0; return WG_OK; }
     if (std::strcmp(name, "band_list_min_p") == 0) { o.band_list_min_p = value > 0 ? value : 1; return WG_OK; }
     if (std::strcmp(name, "near_split") == 0) {  // (also clears the calling thread's back-off and density hint: a fresh start)
         o.near_split = value < 0 ? -1 : (value != 0);
@@ -1144,13 +1092,10 @@ int wg_get_option(const char* name) {
     if (std::strcmp(name, "forward_wait_us_total") == 0) return (int)std::min(t_wait.wait_us, 2147483647.0);
     if (std::strcmp(name, "forward_wait_us_last") == 0) return (int)std::min(t_wait.last_wait_us, 2147483647.0);
     const wg::Options o = options_snapshot();
-    if (std::strcmp(name, "grad_record") == 0) return o.grad_record;
-    if (std::strcmp(name, "exact_compositing") == 0) return o.exact_compositing;
     if (std::strcmp(name, "geometry_reuse") == 0) return o.geometry_reuse;
     if (std::strcmp(name, "fused_scan") == 0) return o.fused_scan;
     if (std::strcmp(name, "speculative_forward") == 0) return o.speculative;
     if (std::strcmp(name, "spec_margin_pct") == 0) return o.spec_margin_pct;
-    if (std::strcmp(name, "deterministic_backward") == 0) return o.deterministic_backward;
     if (std::strcmp(name, "force_global_sort") == 0) return o.force_global_sort ? 1 : 0;
     if (std::strcmp(name, "host_mailbox") == 0) return o.use_mailbox ? 1 : 0;
     if (std::strcmp(name, "lazy_sort") == 0) return o.lazy.enabled ? 1 : 0;
@@ -1219,6 +1164,6 @@ const char* wg_status_string(int status) {
 
 const char* wg_last_hip_error(void) { return g_last_hip_error.c_str(); }
 
-const char* wg_version(void) { return "wg_rasterizer 0.4 (gfx950)"; }
+const char* wg_version(void) { return "wg_rasterizer 0.5 (gfx950)"; }
 
 }  // extern "C"

@@ -365,7 +365,7 @@ hipError_t launch_preprocess(const FwdParams& p, const ShTone& tone_in, const Ge
     return hipGetLastError();
 }
 
-// Geometry reuse (api.hip: wg_rasterize_forward_recolor): a second rasterization of the SAME Gaussians through the same camera with
+// Geometry reuse (api.hip: wg_forward_args::recolor): a second rasterization of the SAME Gaussians through the same camera with
 // other precomputed colours -- WildGaussians renders raw and toned colours over identical geometry, method.py:1573-1611 -- needs none
 // of K1's projection and none of the binning again.  This kernel gives the call a geometry state of its own (its backward pass
 // accumulates into its own gradient records): everything the backward kernels read is copied from the parent state, the splat

@@ -138,7 +138,7 @@ __device__ __forceinline__ float butterfly13(float v0, float v1, float v2, float
 #else
 #define WG_BWD_OCC
 #endif
-// DUAL (RECORD): two colour sets over one walk (wg_second_colors, include/wg_rasterizer.h).  The record's spare floats carry the second
+// DUAL (RECORD): two colour sets over one walk (wg_second_image, include/wg_rasterizer.h).  The record's spare floats carry the second
 // colour; each set keeps its own dL_dalpha chain (accum_rec, background term), their sum feeds the nine geometry sums -- linear in it --
 // and the abs-gradient takes |q1| + |q2|, as two calls would accumulate it; thirteen sums are reduced per instance instead of 2 x 10.  Sums 10, 11 go to the record's two spare floats, sum 12 to grad_aux[id].
 #ifndef WG_BWD_DUAL_WAVES
@@ -454,47 +454,61 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* 
 #pragma unroll
     for (int v = 0; v < NV; v++) acc[v] = 0.f;
     unsigned char* heads = sheads[wave];
-    for (uint32_t clo = wlo; clo < whi; clo += 64u) {  // wave-uniform trip count
-        const uint32_t k = clo + (uint32_t)lane;
-        const bool flagged = k < whi && (size_t)k < slot_capacity && det_flags[k] != 0;
-        float x[NV];
-        {
-            const float2* sl = reinterpret_cast<const float2*>(det_slots + (size_t)(flagged ? k : clo) * NV);  // 40- / 56-byte slots: 8-byte aligned
+    // G chunks of 64 slots per trip: their flags are fetched together and then their flagged slots together -- two dependent memory round
+    // trips per G chunks instead of per chunk (an average wave owns ~470 slots: two trips)
+    constexpr int G = 4;
+    for (uint32_t glo = wlo; glo < whi; glo += 64u * G) {  // wave-uniform trip count
+        bool flagged[G];
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const uint32_t k = glo + 64u * u + (uint32_t)lane;
+            flagged[u] = k < whi && (size_t)k < slot_capacity && det_flags[k] != 0;
+        }
+        float x[G][NV];
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const uint32_t k = glo + 64u * u + (uint32_t)lane;
+            const float2* sl = reinterpret_cast<const float2*>(det_slots + (size_t)(flagged[u] ? k : glo) * NV);  // 40- / 56-byte slots: 8-byte aligned
 #pragma unroll
             for (int h = 0; h < NF2; h++) {
-                const float2 t = flagged ? sl[h] : make_float2(0.f, 0.f);
-                x[2 * h] = t.x;
-                x[2 * h + 1] = t.y;
+                const float2 t = flagged[u] ? sl[h] : make_float2(0.f, 0.f);
+                x[u][2 * h] = t.x;
+                x[u][2 * h + 1] = t.y;
             }
         }
-        // segment heads of this chunk: a Gaussian with slots of its own starts one at its first slot (two Gaussians never share one)
-        __builtin_amdgcn_wave_barrier();
-        heads[lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-        if (n != 0u && base >= clo && base < clo + 64u) heads[base - clo] = 1;
-        __builtin_amdgcn_wave_barrier();
-        int head = (lane == 0 || heads[lane] != 0) ? 1 : 0;
-        // segmented inclusive scan over the 64 lanes (Hillis-Steele; a lane stops taking once a head lies in its window)
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int hup = __shfl_up(head, d);
-            float up[NV];
+        for (int u = 0; u < G; u++) {
+            const uint32_t clo = glo + 64u * u;
+            if (clo >= whi) break;  // wave-uniform
+            // segment heads of this chunk: a Gaussian with slots of its own starts one at its first slot (two Gaussians never share one)
+            __builtin_amdgcn_wave_barrier();
+            heads[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (n != 0u && base >= clo && base < clo + 64u) heads[base - clo] = 1;
+            __builtin_amdgcn_wave_barrier();
+            int head = (lane == 0 || heads[lane] != 0) ? 1 : 0;
+            // segmented inclusive scan over the 64 lanes (Hillis-Steele; a lane stops taking once a head lies in its window)
 #pragma unroll
-            for (int v = 0; v < NV; v++) up[v] = __shfl_up(x[v], d);
-            if (lane >= d && head == 0) {
+            for (int d = 1; d < 64; d <<= 1) {
+                const int hup = __shfl_up(head, d);
+                float up[NV];
 #pragma unroll
-                for (int v = 0; v < NV; v++) x[v] += up[v];
-                head = hup;
+                for (int v = 0; v < NV; v++) up[v] = __shfl_up(x[u][v], d);
+                if (lane >= d && head == 0) {
+#pragma unroll
+                    for (int v = 0; v < NV; v++) x[u][v] += up[v];
+                    head = hup;
+                }
             }
-        }
-        // the Gaussian's own lane takes the total of its segment's part in this chunk from that part's last lane
-        const uint32_t lo = max(base, clo), hi = min(end, clo + 64u);
-        const bool mine = n != 0u && lo < hi;
-        const int src = mine ? (int)(hi - 1u - clo) : 0;
+            // the Gaussian's own lane takes the total of its segment's part in this chunk from that part's last lane
+            const uint32_t lo = max(base, clo), hi = min(end, clo + 64u);
+            const bool mine = n != 0u && lo < hi;
+            const int src = mine ? (int)(hi - 1u - clo) : 0;
 #pragma unroll
-        for (int v = 0; v < NV; v++) {
-            const float t = __shfl(x[v], src);
-            if (mine) acc[v] += t;
+            for (int v = 0; v < NV; v++) {
+                const float t = __shfl(x[u][v], src);
+                if (mine) acc[v] += t;
+            }
         }
     }
     if (valid) {

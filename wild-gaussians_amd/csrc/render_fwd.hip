@@ -49,7 +49,7 @@ __device__ unsigned long long g_fwd_counters[8];
 // One wave owns a tile.  The walk is resumable: it composites list positions [pos_begin, pos_end) and can be continued
 // later from the state parked in the output buffers (fwd_store with complete == false / fwd_init with resume == true).
 
-// DUAL (two colour sets composited in ONE walk: wg_second_colors in include/wg_rasterizer.h; WildGaussians renders raw and toned colours over
+// DUAL (two colour sets composited in ONE walk: wg_second_image in include/wg_rasterizer.h; WildGaussians renders raw and toned colours over
 // identical geometry, method.py:1573-1611): the splat record's three spare floats (r1.z, r2.z, r2.w) carry the second set, the tile
 // state three more sums per pixel, out_color2 receives the second image.  Every decision (alpha, T, n_contrib) is shared.
 template <bool DUAL = false>

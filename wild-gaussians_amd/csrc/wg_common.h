@@ -147,7 +147,7 @@ struct ShTone {
     float pre_clamp = 0.f, post_clamp = 0.f;
     float* dL_dmul = nullptr;       // backward: [P,3] each, written for every Gaussian (zeros when culled)
     float* dL_doffset = nullptr;
-    // second != 0 (wg_rasterize_*_two_tone): a SECOND colour set from the same coefficients through a tone of its own, composited in
+    // second != 0 (wg_forward_args::sh_second): a SECOND colour set from the same coefficients through a tone of its own, composited in
     // the same walk (render_fwd.hip / render_bwd.hip: DUAL); its colour-clamp flags take bits 3-5 of GeometryState::clamped
     int second = 0;
     const float* mul2 = nullptr;
@@ -237,7 +237,7 @@ struct Options {
     int spec_margin_pct = 25;         //   binning buffer = the recent frames' largest count + this margin
     int fused_scan = 0;               // column scan + tile scan in one launch (last-workgroup hand-over); see EXPERIMENTS.md for the A/B
     int geometry_reuse = 0;           // read by the torch binding (_C.py; opt-in since round 4): consecutive calls over identical geometry and
-                                      // camera share the projection and the binning of the first (wg_rasterize_forward_recolor)
+                                      // camera share the projection and the binning of the first (wg_forward_args::recolor)
     int exact_compositing = 1;        // 1: the render kernels take every skip / stop decision (power > 0, alpha < 1/255, T (1 - alpha) < 1e-4) on values
                                       // computed with the reference's own float32 operations (wg_alpha.h): n_contrib, final_T and the blended set are
                                       // the reference's bit for bit.  0: exp2 of a pre-scaled fused form (round 1-3; ~2 ppm of pixels flip).  Must not
@@ -264,7 +264,7 @@ hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState&
                                  float* out_color, float* out_color2, bool lazy, bool exact, const BinStats* guard, hipStream_t stream);
 // the compositing of a frame whose binning and per-pixel stops are known (img.tile_last, img.n_contrib of an earlier pass over the
 // same geometry): each tile walks exactly its list's first tile_last entries and stores final outputs
-// capturable forward (api.hip: wg_rasterize_forward_fixed): when the frame did not fit (BinStats::spec_fail) the image and the
+// capturable forward (api.hip: wg_forward_args::binning_capacity): when the frame did not fit (BinStats::spec_fail) the image and the
 // accumulation become NaN and tile_last / n_contrib zero
 hipError_t launch_poison_unfit(const ImageState& img, int W, int H, int tiles, float* out_color, float* out_color2, hipStream_t stream);
 hipError_t launch_render_forward_replay(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,

@@ -73,38 +73,49 @@ class _ShTone(C.Structure):  # include/wg_rasterizer.h: wg_sh_tone
     _fields_ = [("mul", _vp), ("offset", _vp), ("pre_clamp_max", _f), ("post_clamp_max", _f), ("dL_dmul", _vp), ("dL_doffset", _vp)]
 
 
-_lib.wg_rasterize_forward_toned.restype = _i
-_lib.wg_rasterize_forward_toned.argtypes = _lib.wg_rasterize_forward.argtypes + [C.POINTER(_ShTone)]
-_lib.wg_rasterize_backward_toned.restype = _i
-_lib.wg_rasterize_backward_toned.argtypes = _lib.wg_rasterize_backward.argtypes + [C.POINTER(_ShTone)]
-
-
-class _SecondColors(C.Structure):  # include/wg_rasterizer.h: wg_second_colors
+class _SecondImage(C.Structure):  # wg_second_image
     _fields_ = [("colors_precomp2", _vp), ("out_color2", _vp), ("dL_dpix2", _vp), ("dL_dcolor2", _vp)]
 
 
-class _RawGaussians(C.Structure):  # include/wg_rasterizer.h: wg_raw_gaussians
+class _RawGaussians(C.Structure):  # wg_raw_gaussians
     _fields_ = [("filter_3D", _vp), ("raw_opacities", _vp)]
 
 
-_lib.wg_rasterize_forward_raw.restype = _i
-_lib.wg_rasterize_forward_raw.argtypes = _lib.wg_rasterize_forward.argtypes + [C.POINTER(_ShTone), C.POINTER(_RawGaussians)]
-_lib.wg_rasterize_backward_raw.restype = _i
-_lib.wg_rasterize_backward_raw.argtypes = _lib.wg_rasterize_backward.argtypes + [C.POINTER(_ShTone), C.POINTER(_RawGaussians)]
-_lib.wg_rasterize_forward_dual.restype = _i
-_lib.wg_rasterize_forward_two_tone.argtypes = _lib.wg_rasterize_forward.argtypes + [C.POINTER(_ShTone), C.POINTER(_ShTone), C.POINTER(_RawGaussians), _vp]
-_lib.wg_rasterize_forward_two_tone.restype = _i
-_lib.wg_rasterize_backward_two_tone.argtypes = _lib.wg_rasterize_backward.argtypes + [C.POINTER(_ShTone), C.POINTER(_ShTone), C.POINTER(_RawGaussians), _vp, _vp]
-_lib.wg_rasterize_backward_two_tone.restype = _i
-_lib.wg_rasterize_forward_dual.argtypes = _lib.wg_rasterize_forward.argtypes + [C.POINTER(_SecondColors)]
-_lib.wg_rasterize_backward_dual.restype = _i
-_lib.wg_rasterize_backward_dual.argtypes = _lib.wg_rasterize_backward.argtypes + [C.POINTER(_SecondColors)]
-_lib.wg_rasterize_forward_fixed.restype = _i
-_lib.wg_rasterize_forward_fixed.argtypes = _lib.wg_rasterize_forward.argtypes[:-2] + [_vp, C.POINTER(_ShTone), _i]   # no debug flag; + tone, capacity
+class _RecolorParent(C.Structure):  # wg_recolor_parent
+    _fields_ = [("geom_buffer", _vp), ("binning_buffer", _vp), ("image_buffer", _vp), ("R", _i)]
+
+
+class _CallOptions(C.Structure):  # wg_call_options
+    _fields_ = [("exact_compositing", _i), ("deterministic_backward", _i), ("grad_record", _i)]
+
+
+class _ForwardArgs(C.Structure):  # wg_forward_args
+    _fields_ = ([("struct_size", C.c_size_t), ("geometry_alloc", _ALLOC_FN), ("geometry_user", _vp), ("binning_alloc", _ALLOC_FN), ("binning_user", _vp),
+                 ("image_alloc", _ALLOC_FN), ("image_user", _vp)] +
+                [(n, _i) for n in ("P", "D", "M", "width", "height", "prefiltered", "debug")] +
+                [(n, _f) for n in ("scale_modifier", "tan_fovx", "tan_fovy", "kernel_size")] +
+                [(n, _vp) for n in ("background", "means3D", "shs", "colors_precomp", "opacities", "scales", "rotations", "cov3D_precomp", "viewmatrix",
+                                    "projmatrix", "cam_pos", "subpixel_offset", "out_color", "radii", "stream")] +
+                [("tone", C.POINTER(_ShTone)), ("tone2", C.POINTER(_ShTone)), ("sh_second", _i), ("second", C.POINTER(_SecondImage)),
+                 ("raw", C.POINTER(_RawGaussians)), ("recolor", C.POINTER(_RecolorParent)), ("binning_capacity", _i), ("options", C.POINTER(_CallOptions))])
+
+
+class _BackwardArgs(C.Structure):  # wg_backward_args
+    _fields_ = ([("struct_size", C.c_size_t)] + [(n, _i) for n in ("P", "D", "M", "R", "width", "height", "debug")] +
+                [(n, _f) for n in ("scale_modifier", "tan_fovx", "tan_fovy", "kernel_size")] +
+                [(n, _vp) for n in ("background", "means3D", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp", "viewmatrix", "projmatrix",
+                                    "campos", "subpixel_offset", "radii", "geom_buffer", "binning_buffer", "image_buffer", "dL_dpix", "dL_dmean2D",
+                                    "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot", "stream")] +
+                [("tone", C.POINTER(_ShTone)), ("tone2", C.POINTER(_ShTone)), ("sh_second", _i), ("second", C.POINTER(_SecondImage)),
+                 ("raw", C.POINTER(_RawGaussians)), ("options", C.POINTER(_CallOptions))])
+
+
+_lib.wg_rasterize_forward_ex.restype = _i
+_lib.wg_rasterize_forward_ex.argtypes = [C.POINTER(_ForwardArgs)]
+_lib.wg_rasterize_backward_ex.restype = _i
+_lib.wg_rasterize_backward_ex.argtypes = [C.POINTER(_BackwardArgs)]
 _lib.wg_forward_status.restype = _i
 _lib.wg_forward_status.argtypes = [_vp, _i, _i, C.POINTER(_i), C.POINTER(_i), _vp]
-_lib.wg_rasterize_forward_recolor.restype = _i
-_lib.wg_rasterize_forward_recolor.argtypes = [_ALLOC_FN, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]
 _lib.wg_mark_visible.restype = _i
 _lib.wg_mark_visible.argtypes = [_i, _vp, _vp, _vp, _vp, _vp]
 for _name in ("wg_geometry_buffer_size", "wg_binning_buffer_size"):
@@ -228,7 +239,7 @@ def _tone_block(sh_tone, device, P, grads=None):
 # depth -- and the reference projects, bins and sorts each time.  With the option on the binding remembers the LAST full forward call
 # of the calling thread: when the next call hands over the very same geometry tensors (same Python objects, same autograd versions,
 # same data pointers: nothing wrote to them that autograd knows of), the same camera tensors and scalars and only other precomputed
-# colours, it takes wg_rasterize_forward_recolor -- a copy of the projected state with the new colours and the compositing along the
+# colours, it takes wg_forward_args::recolor -- a copy of the projected state with the new colours and the compositing along the
 # parent's sorted lists; binning and image-state buffers are shared with the parent call's (the per-pixel values are identical).
 # Identity is by object (weak references), never by address alone: a freed tensor's address can be handed to a new one.
 # WHY OPT-IN: a write through `tensor.data` (or `set_()` to equal-shaped storage at the same address) moves no version counter, and the
@@ -302,7 +313,7 @@ def _reuse_key(background, means3D, opacity, scales, rotations, scale_modifier, 
 
 def _reuse_lookup(key):
     last = _reuse.last
-    if last is None or last.get("epoch") != _reuse_epoch or last["scalars"] != key[1] or len(last["tensors"]) != len(key[0]):
+    if last is None or last.get("epoch") != _reuse_epoch or last["scalars"] != key[1] or last.get("opts") != key[2] or len(last["tensors"]) != len(key[0]):
         return None
     if not all(_same_token(a, b) for a, b in zip(last["tensors"], key[0])):
         return None
@@ -314,25 +325,94 @@ def forget_geometry():
     _reuse.last = None
 
 
+# ----------------------------------------------------------------------------------------------------------
+# Per-call options (wg_call_options in include/wg_rasterizer.h): the three switches that AFFECT RESULTS travel with every call; the
+# library has no process-wide state for them.  A call's values: the `options=` argument (a dict, or the resolved 3-tuple the autograd
+# layer keeps on its ctx so that a frame's backward call carries its forward call's values), else the CALLING THREAD's defaults --
+# which `call_options(...)` overrides for a `with` block and `set_option(name, value)` sets for the thread (what the tests' and
+# bench.py's `--option deterministic_backward=1` use; other threads, and other callers in the process, are not affected).
+CALL_OPTION_DEFAULTS = dict(exact_compositing=1, deterministic_backward=0, grad_record=1)
+_tls = threading.local()
+
+
+def _thread_call_options() -> dict:
+    d = getattr(_tls, "call_options", None)
+    if d is None:
+        d = _tls.call_options = dict(CALL_OPTION_DEFAULTS)
+    return d
+
+
+def resolve_call_options(options=None):
+    """-> (exact_compositing, deterministic_backward, grad_record) as ints: `options` (dict with any of the three names, None values = not
+    given; or an already resolved 3-tuple) over the calling thread's defaults."""
+    if isinstance(options, tuple):
+        return options
+    d = _thread_call_options()
+    if options:
+        unknown = set(options) - set(CALL_OPTION_DEFAULTS)
+        if unknown:
+            raise ValueError(f"unknown call option(s) {sorted(unknown)}")
+        d = dict(d, **{k: int(v) for k, v in options.items() if v is not None})
+    return (int(bool(d["exact_compositing"])), int(bool(d["deterministic_backward"])), int(bool(d["grad_record"])))
+
+
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def call_options(**kw):
+    """`with _C.call_options(deterministic_backward=1): ...` -- the calling thread's defaults for the block (for callers that cannot pass
+    keywords, e.g. the reference's unedited method.py)."""
+    unknown = set(kw) - set(CALL_OPTION_DEFAULTS)
+    if unknown:
+        raise ValueError(f"unknown call option(s) {sorted(unknown)}")
+    d = _thread_call_options()
+    saved = dict(d)
+    d.update({k: int(v) for k, v in kw.items()})
+    try:
+        yield
+    finally:
+        d.clear()
+        d.update(saved)
+
+
+def _options_block(opts):
+    return _CallOptions(*opts)
+
+
+def _forward_args(geom, binning, img, P, degree, M, H, W, background, means3D, sh, colors, opacity, scales, scale_modifier, rotations, cov3D_precomp,
+                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, debug, out_color, radii, device):
+    a = _ForwardArgs()
+    a.struct_size = C.sizeof(_ForwardArgs)
+    a.geometry_alloc = geom.callback
+    if binning is not None:
+        a.binning_alloc, a.image_alloc = binning.callback, img.callback
+    a.P, a.D, a.M, a.width, a.height, a.prefiltered, a.debug = P, int(degree), M, W, H, int(bool(prefiltered)), int(bool(debug))
+    a.scale_modifier, a.tan_fovx, a.tan_fovy, a.kernel_size = float(scale_modifier), float(tan_fovx), float(tan_fovy), float(kernel_size)
+    for name, t in (("background", background), ("means3D", means3D), ("shs", sh), ("colors_precomp", colors), ("opacities", opacity), ("scales", scales),
+                    ("rotations", rotations), ("cov3D_precomp", cov3D_precomp), ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("cam_pos", campos),
+                    ("subpixel_offset", subpixel_offset)):
+        setattr(a, name, None if t is None else _ptr(t))
+    a.out_color = out_color.data_ptr()
+    a.radii = None if radii is None else radii.data_ptr()
+    a.stream = _stream(device)
+    return a
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, image_height, image_width, sh, degree,
-                        campos, prefiltered, debug, sh_tone=None, binning_capacity=None, colors2=None, filter_3D=None, sh_second=None):
-    """sh_second (beyond the reference: wg_rasterize_forward_two_tone): a 4-tuple like sh_tone (all four may be None: the plain
-    coefficients) -- a SECOND colour set evaluated from the same SH coefficients through this tone and composited in the same walk; the
-    tuple then ends with a seventh element, the second image.  Composes with sh_tone (the first set's) and filter_3D.
-    filter_3D (beyond the reference: wg_raw_gaussians): opacity / scales / rotations are the caller's RAW parameters and
-    get_gaussians() (method.py:1060-1086) runs inside the preprocess kernel.
-    colors2 (beyond the reference: wg_second_colors, include/wg_rasterizer.h): a second [P,3] set of precomputed colours composited in
-    the same walk; the tuple then ends with a seventh element, the second image.
-    binning_capacity (beyond the reference): an int makes the call wg_rasterize_forward_fixed -- no host rendezvous, capturable in
-    a hipGraph; the returned `rendered` is then the capacity, and forward_status(imgBuffer, H, W) tells the real count and whether
-    the frame fit (include/wg_rasterizer.h)."""
-    if (_torch_ext is not None and sh_tone is None and binning_capacity is None and colors2 is None and filter_3D is None and sh_second is None
-            and subpixel_offset is not None and _lib.wg_get_option(b"geometry_reuse") == 0):
-        _reuse.last = None
-        return _torch_ext.rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp,
-                                              viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), float(kernel_size), subpixel_offset,
-                                              int(image_height), int(image_width), sh, int(degree), campos, bool(prefiltered), bool(debug))
+                        campos, prefiltered, debug, sh_tone=None, binning_capacity=None, colors2=None, filter_3D=None, sh_second=None, options=None):
+    """The reference's `rasterize_gaussians` (rasterize_points.h:18-40) plus, by keyword, everything beyond it (include/wg_rasterizer.h:
+    the optional blocks of wg_rasterize_forward_ex):
+    sh_tone: (mul [P,3] | None, offset [P,3] | None, pre_clamp_max | None, post_clamp_max | None) on the SH coefficients (wg_sh_tone).
+    sh_second: a 4-tuple like sh_tone (all four may be None): a SECOND image from the same SH coefficients through this tone, composited in
+      the same walk; the result then ends with a seventh element, the second image.  Composes with sh_tone and filter_3D.
+    colors2: a second [P,3] set of precomputed colours composited in the same walk (wg_second_image); seventh element likewise.
+    filter_3D: opacity / scales / rotations are the caller's RAW parameters, get_gaussians() (method.py:1060-1086) runs in-kernel.
+    binning_capacity: an int = no host rendezvous at all (capturable in a hipGraph); `rendered` is then the capacity, and
+      forward_status(imgBuffer, H, W) tells the real count and whether the frame fit.
+    options: per-call options (see resolve_call_options)."""
+    opts = resolve_call_options(options)
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:59-61
     if not means3D.is_cuda:
@@ -340,7 +420,6 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     device = means3D.device
     P, H, W = means3D.size(0), int(image_height), int(image_width)
 
-    # precomputed colours over remembered geometry: no projection, no binning
     if filter_3D is not None and (colors2 is not None or binning_capacity is not None or scales.numel() == 0 or filter_3D.numel() != P):
         raise RuntimeError("filter_3D (raw-parameter mode) needs scales and rotations, P filter values, and neither colors2 nor binning_capacity")
     if sh_second is not None and (colors2 is not None or binning_capacity is not None or sh.numel() == 0 or colors.numel() != 0):
@@ -348,150 +427,154 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     if colors2 is not None:
         if sh_tone is not None or binning_capacity is not None or sh.numel() != 0 or colors.numel() != 3 * P or colors2.numel() != 3 * P:
             raise RuntimeError("colors2 needs precomputed colours of P x 3 in both sets (no SH, no sh_tone, no binning_capacity)")
+    if binning_capacity is not None and debug:
+        raise RuntimeError("binning_capacity (the fixed-capacity forward) has no debug mode")
+    # precomputed colours over remembered geometry: no projection, no binning
     reusable = (P != 0 and sh_tone is None and not debug and colors.numel() == 3 * P and sh.numel() == 0 and colors2 is None
                 and filter_3D is None and sh_second is None and _lib.wg_get_option(b"geometry_reuse") == 1)
-    if binning_capacity is not None and debug:
-        raise RuntimeError("binning_capacity (wg_rasterize_forward_fixed) has no debug mode")
     key = None
     if reusable:
         key = _reuse_key(background, means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
-                         tan_fovy, kernel_size, subpixel_offset, H, W, prefiltered, device)
+                         tan_fovy, kernel_size, subpixel_offset, H, W, prefiltered, device) + (opts,)
         last = _reuse_lookup(key)
         if last is not None:
             geom = _Scratch(device)
             out_color = torch.empty((3, H, W), dtype=torch.float32, device=device)
             colors_f, bg_f = _f32(colors, device), _f32(background, device)
-            so = torch.Tensor([]) if subpixel_offset is None else _f32(subpixel_offset, device)
+            so = None if subpixel_offset is None else _f32(subpixel_offset, device)
+            a = _forward_args(geom, None, None, P, 0, 0, H, W, bg_f, None, None, colors_f, None, None, 1.0, None, None, None, None, None, 1.0, 1.0, 0.0, so,
+                              False, False, out_color, None, device)
+            parent = _RecolorParent(last["geom"].data_ptr(), last["binning"].data_ptr(), last["img"].data_ptr(), int(last["R"]))
+            ob = _options_block(opts)
+            a.recolor, a.options = C.pointer(parent), C.pointer(ob)
             try:
                 with torch.cuda.device(device):
-                    rendered = _lib.wg_rasterize_forward_recolor(
-                        geom.callback, None, last["geom"].data_ptr(), last["binning"].data_ptr(), last["img"].data_ptr(), P, int(last["R"]),
-                        _ptr(bg_f), W, H, _ptr(colors_f), _ptr(so), out_color.data_ptr(), None, _stream(device))
+                    rendered = _lib.wg_rasterize_forward_ex(C.byref(a))
             finally:
                 child = geom.take()
-            _check(rendered, "wg_rasterize_forward_recolor")
+            _check(rendered, "wg_rasterize_forward_ex (recolor)")
             _reuse.hits += 1
             # (a fresh radii tensor, as every call of the reference returns: 4 bytes per Gaussian)
             return (rendered, out_color, last["radii"].clone(), child, last["binning"], last["img"])
     else:
         _reuse.last = None   # any other kind of call ends the remembered one's reach
 
+    if _torch_ext is not None:   # the compiled binding (csrc/torch_binding.cpp), when it is loaded: the whole surface but the recolouring above
+        res = _torch_ext.rasterize_gaussians_ex(background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp, viewmatrix,
+                                                projmatrix, float(tan_fovx), float(tan_fovy), float(kernel_size), subpixel_offset, H, W, sh, int(degree),
+                                                campos, bool(prefiltered), bool(debug), sh_tone, binning_capacity, colors2, filter_3D, sh_second, opts)
+    else:
+        res = _forward_ctypes(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
+                              tan_fovy, kernel_size, subpixel_offset, H, W, sh, degree, campos, prefiltered, debug, sh_tone, binning_capacity, colors2,
+                              filter_3D, sh_second, opts, device, P)
+    rendered, radii, buffers = res[0], res[2], res[3:6]
+    if binning_capacity is not None:
+        _reuse.last_fixed = (buffers[2], H, W)
+    # (never a parent whose verdict is not in yet: see "Geometry reuse" above)
+    if key is not None and P != 0 and binning_capacity is None and _lib.wg_get_option(b"speculative_forward") != 2:
+        _reuse.last = dict(tensors=key[0], scalars=key[1], opts=key[2], R=rendered, radii=radii, geom=buffers[0], binning=buffers[1], img=buffers[2],
+                           epoch=_reuse_epoch)
+    return res
+
+
+def _forward_ctypes(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                    kernel_size, subpixel_offset, H, W, sh, degree, campos, prefiltered, debug, sh_tone, binning_capacity, colors2, filter_3D, sh_second,
+                    opts, device, P):
     geom, binning, img = _Scratch(device), _Scratch(device), _Scratch(device)
+    two = colors2 is not None or sh_second is not None
     if P == 0:  # rasterize_points.cu:83: nothing is launched, the image stays zero
         return (0, torch.zeros((3, H, W), dtype=torch.float32, device=device), torch.zeros((0,), dtype=torch.int32, device=device),
-                geom.take(), binning.take(), img.take()) + (() if colors2 is None and sh_second is None else (torch.zeros((3, H, W), dtype=torch.float32, device=device),))
+                geom.take(), binning.take(), img.take()) + ((torch.zeros((3, H, W), dtype=torch.float32, device=device),) if two else ())
     # both outputs are fully written by the kernels (every pixel, every Gaussian): no need for the reference's zero fill
     out_color = torch.empty((3, H, W), dtype=torch.float32, device=device)
     radii = torch.empty((P,), dtype=torch.int32, device=device)
-
     means3D = _f32(means3D, device)
     background, colors, opacity = _f32(background, device), _f32(colors, device), _f32(opacity, device)
     scales, rotations, cov3D_precomp = _f32(scales, device), _f32(rotations, device), _f32(cov3D_precomp, device)
     viewmatrix, projmatrix, campos = _f32(viewmatrix, device), _f32(projmatrix, device), _f32(campos, device)
-    if subpixel_offset is None:  # opt-in beyond the reference: no offsets, nothing allocated or read
-        subpixel_offset = torch.Tensor([])
-    subpixel_offset, sh = _f32(subpixel_offset, device), _f32(sh, device)
+    subpixel_offset = None if subpixel_offset is None else _f32(subpixel_offset, device)   # None: no offsets, nothing allocated or read
+    sh = _f32(sh, device)
     M = sh.size(1) if sh.numel() != 0 else 0  # rasterize_points.cu:85-89
-
-    tone, _keep = (None, None) if sh_tone is None else _tone_block(sh_tone, device, P)
-    out_color2 = None
+    a = _forward_args(geom, binning, img, P, degree, M, H, W, background, means3D, sh, colors, opacity, scales, scale_modifier, rotations, cov3D_precomp,
+                      viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, kernel_size, subpixel_offset, prefiltered, debug, out_color, radii, device)
+    keep = []
+    if sh_tone is not None:
+        tone, k = _tone_block(sh_tone, device, P)
+        keep += [tone, k]
+        a.tone = C.pointer(tone)
+    out_color2 = torch.empty((3, H, W), dtype=torch.float32, device=device) if two else None
+    if sh_second is not None:
+        tone2, k = _tone_block(sh_second, device, P)
+        second = _SecondImage(None, out_color2.data_ptr(), None, None)
+        keep += [tone2, k, second]
+        a.tone2, a.sh_second, a.second = C.pointer(tone2), 1, C.pointer(second)
+    elif colors2 is not None:
+        colors2 = _f32(colors2, device)
+        second = _SecondImage(colors2.data_ptr(), out_color2.data_ptr(), None, None)
+        keep += [colors2, second]
+        a.second = C.pointer(second)
+    if filter_3D is not None:
+        filter_3D = _f32(filter_3D, device)
+        rawg = _RawGaussians(filter_3D.data_ptr(), None)
+        keep += [filter_3D, rawg]
+        a.raw = C.pointer(rawg)
+    if binning_capacity is not None:
+        if int(binning_capacity) <= 0:
+            raise RuntimeError("binning_capacity must be positive")
+        a.binning_capacity = int(binning_capacity)
+    ob = _options_block(opts)
+    a.options = C.pointer(ob)
     try:
         with torch.cuda.device(device):
-            if sh_second is not None:
-                tone2, _keep2 = _tone_block(sh_second, device, P)
-                out_color2 = torch.empty((3, H, W), dtype=torch.float32, device=device)
-                rawg = None
-                if filter_3D is not None:
-                    filter_3D = _f32(filter_3D, device)
-                    rawg = _RawGaussians(filter_3D.data_ptr(), None)
-                rendered = _lib.wg_rasterize_forward_two_tone(
-                    geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
-                    _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
-                    _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                    float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
-                    int(bool(debug)), _stream(device), None if tone is None else C.byref(tone), C.byref(tone2),
-                    None if rawg is None else C.byref(rawg), out_color2.data_ptr())
-            elif colors2 is not None:
-                colors2 = _f32(colors2, device)
-                out_color2 = torch.empty((3, H, W), dtype=torch.float32, device=device)
-                second = _SecondColors(colors2.data_ptr(), out_color2.data_ptr(), None, None)
-                rendered = _lib.wg_rasterize_forward_dual(
-                    geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
-                    _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
-                    _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                    float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
-                    int(bool(debug)), _stream(device), C.byref(second))
-            elif filter_3D is not None:
-                filter_3D = _f32(filter_3D, device)
-                rawg = _RawGaussians(filter_3D.data_ptr(), None)
-                rendered = _lib.wg_rasterize_forward_raw(
-                    geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
-                    _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
-                    _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                    float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
-                    int(bool(debug)), _stream(device), None if tone is None else C.byref(tone), C.byref(rawg))
-            elif binning_capacity is None:
-                rendered = _lib.wg_rasterize_forward_toned(
-                    geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
-                    _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
-                    _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                    float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
-                    int(bool(debug)), _stream(device), None if tone is None else C.byref(tone))
-            else:
-                rendered = _lib.wg_rasterize_forward_fixed(
-                    geom.callback, None, binning.callback, None, img.callback, None, P, int(degree), M, _ptr(background), W, H,
-                    _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales), float(scale_modifier), _ptr(rotations),
-                    _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy),
-                    float(kernel_size), _ptr(subpixel_offset), int(bool(prefiltered)), out_color.data_ptr(), radii.data_ptr(),
-                    _stream(device), None if tone is None else C.byref(tone), int(binning_capacity))
+            rendered = _lib.wg_rasterize_forward_ex(C.byref(a))
     finally:
         buffers = (geom.take(), binning.take(), img.take())
     _check(rendered, "wg_rasterize_forward")
-    if binning_capacity is not None:
-        _reuse.last_fixed = (buffers[2], H, W)
-    # (never a parent whose verdict is not in yet: see "Geometry reuse" above)
-    if key is not None and rendered >= 0 and binning_capacity is None and _lib.wg_get_option(b"speculative_forward") != 2:
-        _reuse.last = dict(tensors=key[0], scalars=key[1], R=rendered, radii=radii, geom=buffers[0], binning=buffers[1], img=buffers[2],
-                           epoch=_reuse_epoch)
     return (rendered, out_color, radii) + buffers + (() if out_color2 is None else (out_color2,))
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, kernel_size, subpixel_offset, dL_dout_color, sh,
                                  degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, sh_tone=None, dL_dout_color2=None, raw=None,
-                                 sh_second=None):
-    """sh_second (a frame rasterized with sh_second; needs dL_dout_color2): the result is the eight tensors + (dL_dsh_mul, dL_dsh_offset,
-    dL_dsh_mul2, dL_dsh_offset2), None where the input was None; dL_dsh is the gradient of both images' losses.
-    raw = (filter_3D, raw_opacities) of a raw-parameter forward call: dL_dopacity / dL_dscales / dL_drotations are then the gradients
-    of the RAW parameters.
+                                 sh_second=None, options=None):
+    """The reference's `rasterize_gaussians_backward` (rasterize_points.h:42-66) -> the eight tensors, plus by keyword:
+    sh_tone: two more tensors are appended, dL_dsh_mul, dL_dsh_offset (None where the input was None); dL_dsh is then the gradient of the raw
+      coefficients.
+    sh_second (a frame rasterized with sh_second; needs dL_dout_color2): the eight + (dL_dsh_mul, dL_dsh_offset, dL_dsh_mul2, dL_dsh_offset2).
     dL_dout_color2 (a frame rasterized with colors2): the second image's cotangent; the result ends with dL_dcolors2 [P,3].
-    With sh_tone (see rasterize_gaussians) two more tensors are appended to the result: dL_dsh_mul, dL_dsh_offset (None where the
-    input was None), and dL_dsh is the gradient w.r.t. the raw coefficients."""
+    raw = (filter_3D, raw_opacities) of a raw-parameter forward call: dL_dopacity / dL_dscales / dL_drotations are the RAW parameters' gradients.
+    options: the frame's forward call's per-call options (resolve_call_options)."""
     global _reuse_epoch
-    if _torch_ext is not None and sh_tone is None and dL_dout_color2 is None and raw is None and sh_second is None and subpixel_offset is not None:
-        _reuse_epoch += 1
-        return _torch_ext.rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, float(scale_modifier), cov3D_precomp,
-                                                       viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), float(kernel_size), subpixel_offset,
-                                                       dL_dout_color, sh, int(degree), campos, geomBuffer, int(R), binningBuffer, imageBuffer,
-                                                       bool(debug))
+    opts = resolve_call_options(options)
     _reuse_epoch += 1   # what the forward calls remembered ends here (see "Geometry reuse" above) ...
     alive = {t.ident for t in threading.enumerate()}
     for ident, st in list(_PerThread._states.items()):   # ... and so do the references that kept those frames' scratch alive (any thread's)
         st.last = None
         if ident not in alive:                           # (a thread that has ended: its state goes with it)
             _PerThread._states.pop(ident, None)
-    device = means3D.device
+    if sh_second is not None and dL_dout_color2 is None:
+        raise RuntimeError("sh_second needs the second image's cotangent (dL_dout_color2)")
+    record = bool(opts[2] or opts[1])
+    dual = dL_dout_color2 is not None and sh_second is None
     P = means3D.size(0)
+    if raw is not None and (not record or dual):
+        raise RuntimeError("the raw-parameter backward pass needs grad_record = 1 and cannot be combined with the two-colour call")
+    if (dual or sh_second is not None) and ((dual and sh_tone is not None) or (not record and P != 0)):
+        raise RuntimeError("the two-colour backward pass needs the gradient record (grad_record = 1 or deterministic_backward = 1) and no sh_tone")
+    if _torch_ext is not None:
+        return _torch_ext.rasterize_gaussians_backward_ex(background, means3D, radii, colors, scales, rotations, float(scale_modifier), cov3D_precomp,
+                                                          viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), float(kernel_size), subpixel_offset,
+                                                          dL_dout_color, sh, int(degree), campos, geomBuffer, int(R), binningBuffer, imageBuffer,
+                                                          bool(debug), sh_tone, dL_dout_color2, raw, sh_second, opts)
+    device = means3D.device
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     sh = _f32(sh, device)
     M = sh.size(1) if sh.numel() != 0 else 0
 
-    # The reference zero-fills nine gradient tensors per call (rasterize_points.cu:157-165).  Here only the four
-    # accumulation targets of the per-tile pass need clearing -- they share one allocation, hence one memset -- and
-    # everything else is fully written by the per-Gaussian kernel (zeros for culled Gaussians).
-    # With the gradient record (the default, include/wg_rasterizer.h) the library clears its own accumulator and these four are
-    # plain outputs too.
-    record = P != 0 and (_lib.wg_get_option(b"grad_record") == 1 or _lib.wg_get_option(b"deterministic_backward") == 1)
+    # The reference zero-fills nine gradient tensors per call (rasterize_points.cu:157-165).  With the gradient record (the default,
+    # include/wg_rasterizer.h) the library clears its own accumulator and every output is fully written by the per-Gaussian kernel
+    # (zeros for culled Gaussians); without it the four accumulation targets of the per-tile pass share one zeroed allocation.
+    record = P != 0 and record
     if record:
         dL_dconic = None   # the reference's intermediate: not returned (rasterize_points.cu:201), so not requested
         dL_dmeans2D = torch.empty((P, 3), dtype=torch.float32, device=device)
@@ -510,13 +593,6 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dsh = alloc((P, M, 3), dtype=torch.float32, device=device)
     dL_dscales = (alloc if have_scales else torch.zeros)((P, 3), dtype=torch.float32, device=device)
     dL_drotations = (alloc if have_scales else torch.zeros)((P, 4), dtype=torch.float32, device=device)
-    if raw is not None and (not record or (dL_dout_color2 is not None and sh_second is None)):
-        raise RuntimeError("the raw-parameter backward pass needs grad_record = 1 and cannot be combined with the two-colour call")
-    if sh_second is not None and dL_dout_color2 is None:
-        raise RuntimeError("sh_second needs the second image's cotangent (dL_dout_color2)")
-    dual = dL_dout_color2 is not None and sh_second is None
-    if (dual or sh_second is not None) and ((dual and sh_tone is not None) or (not record and P != 0)):
-        raise RuntimeError("the two-colour backward pass needs the gradient record (grad_record = 1 or deterministic_backward = 1) and no sh_tone")
     dL_dcolors2 = alloc((P, 3), dtype=torch.float32, device=device) if dual else None
     tone_grads = None
     if sh_tone is not None:
@@ -530,38 +606,46 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         background, colors = _f32(background, device), _f32(colors, device)
         scales, rotations, cov3D_precomp = _f32(scales, device), _f32(rotations, device), _f32(cov3D_precomp, device)
         viewmatrix, projmatrix, campos = _f32(viewmatrix, device), _f32(projmatrix, device), _f32(campos, device)
-        if subpixel_offset is None:
-            subpixel_offset = torch.Tensor([])
-        subpixel_offset, dL_dout_color = _f32(subpixel_offset, device), _f32(dL_dout_color, device)
+        subpixel_offset = None if subpixel_offset is None else _f32(subpixel_offset, device)
+        dL_dout_color = _f32(dL_dout_color, device)
         radii = radii if radii.is_contiguous() else radii.contiguous()
-        tone, _keep = (None, None) if sh_tone is None else _tone_block(sh_tone, device, P, tone_grads)
-        common = (P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
-                  float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
-                  float(tan_fovx), float(tan_fovy), float(kernel_size), _ptr(subpixel_offset), _ptr(radii),
-                  geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL_dout_color),
-                  dL_dmeans2D.data_ptr(), None if dL_dconic is None else dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
-                  dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr(), dL_drotations.data_ptr(),
-                  int(bool(debug)), _stream(device))
+        a = _BackwardArgs()
+        a.struct_size = C.sizeof(_BackwardArgs)
+        a.P, a.D, a.M, a.R, a.width, a.height, a.debug = P, int(degree), M, int(R), W, H, int(bool(debug))
+        a.scale_modifier, a.tan_fovx, a.tan_fovy, a.kernel_size = float(scale_modifier), float(tan_fovx), float(tan_fovy), float(kernel_size)
+        for name, t in (("background", background), ("means3D", means3D), ("shs", sh), ("colors_precomp", colors), ("scales", scales),
+                        ("rotations", rotations), ("cov3D_precomp", cov3D_precomp), ("viewmatrix", viewmatrix), ("projmatrix", projmatrix),
+                        ("campos", campos), ("subpixel_offset", subpixel_offset), ("radii", radii), ("dL_dpix", dL_dout_color), ("dL_dsh", dL_dsh)):
+            setattr(a, name, None if t is None else _ptr(t))
+        a.geom_buffer, a.binning_buffer, a.image_buffer = geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr()
+        a.dL_dmean2D, a.dL_dconic = dL_dmeans2D.data_ptr(), None if dL_dconic is None else dL_dconic.data_ptr()
+        a.dL_dopacity, a.dL_dcolor, a.dL_dmean3D, a.dL_dcov3D = dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr()
+        a.dL_dscale, a.dL_drot, a.stream = dL_dscales.data_ptr(), dL_drotations.data_ptr(), _stream(device)
+        keep = []
+        if sh_tone is not None:
+            tone, k = _tone_block(sh_tone, device, P, tone_grads)
+            keep += [tone, k]
+            a.tone = C.pointer(tone)
+        if sh_second is not None:
+            dL2 = _f32(dL_dout_color2, device)
+            tone2, k = _tone_block(sh_second, device, P, tone2_grads)
+            second = _SecondImage(None, None, dL2.data_ptr(), None)
+            keep += [dL2, tone2, k, second]
+            a.tone2, a.sh_second, a.second = C.pointer(tone2), 1, C.pointer(second)
+        elif dual:
+            dL2 = _f32(dL_dout_color2, device)
+            second = _SecondImage(None, None, dL2.data_ptr(), dL_dcolors2.data_ptr())
+            keep += [dL2, second]
+            a.second = C.pointer(second)
+        if raw is not None:
+            f3d, rop = _f32(raw[0], device), _f32(raw[1], device)
+            rawg = _RawGaussians(f3d.data_ptr(), rop.data_ptr())
+            keep += [f3d, rop, rawg]
+            a.raw = C.pointer(rawg)
+        ob = _options_block(opts)
+        a.options = C.pointer(ob)
         with torch.cuda.device(device):
-            if sh_second is not None:
-                dL2 = _f32(dL_dout_color2, device)
-                tone2, _keep2 = _tone_block(sh_second, device, P, tone2_grads)
-                rawg = None
-                if raw is not None:
-                    f3d, rop = _f32(raw[0], device), _f32(raw[1], device)
-                    rawg = _RawGaussians(f3d.data_ptr(), rop.data_ptr())
-                status = _lib.wg_rasterize_backward_two_tone(*common, None if tone is None else C.byref(tone), C.byref(tone2),
-                                                             None if rawg is None else C.byref(rawg), dL2.data_ptr(), None)
-            elif dual:
-                dL2 = _f32(dL_dout_color2, device)
-                second = _SecondColors(None, None, dL2.data_ptr(), dL_dcolors2.data_ptr())
-                status = _lib.wg_rasterize_backward_dual(*common, C.byref(second))
-            elif raw is not None:
-                f3d, rop = _f32(raw[0], device), _f32(raw[1], device)
-                rawg = _RawGaussians(f3d.data_ptr(), rop.data_ptr())
-                status = _lib.wg_rasterize_backward_raw(*common, None if tone is None else C.byref(tone), C.byref(rawg))
-            else:
-                status = _lib.wg_rasterize_backward_toned(*common, None if tone is None else C.byref(tone))
+            status = _lib.wg_rasterize_backward_ex(C.byref(a))
         _check(status, "wg_rasterize_backward")
     out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     if sh_second is not None:
@@ -651,8 +735,13 @@ _lib.wg_set_option.argtypes = [C.c_char_p, _i]
 
 
 def set_option(name: str, value: int) -> None:
-    """wg_set_option: e.g. set_option("force_global_sort", 1) selects the rocPRIM global-sort binning path."""
-    _check(_lib.wg_set_option(name.encode(), int(value)), f"wg_set_option({name})")
+    """wg_set_option: a tuning switch of the library (process-wide; every setting gives identical results: docs/OPTIONS.md), e.g.
+    set_option("force_global_sort", 1).  For the three RESULT-AFFECTING names (exact_compositing, deterministic_backward, grad_record), which
+    the library takes per call, it sets the CALLING THREAD's default instead (see call_options)."""
+    if name in CALL_OPTION_DEFAULTS:
+        _thread_call_options()[name] = int(bool(int(value)))
+    else:
+        _check(_lib.wg_set_option(name.encode(), int(value)), f"wg_set_option({name})")
     forget_geometry()   # a remembered forward call was made under the old options
 
 
@@ -662,7 +751,9 @@ def geometry_reuse_hits() -> int:
 
 
 def get_option(name: str) -> int:
-    """wg_get_option: current value of a library option (-1: unknown name)."""
+    """wg_get_option: current value of a library option (-1: unknown name); for the three per-call names, the calling thread's default."""
+    if name in CALL_OPTION_DEFAULTS:
+        return int(_thread_call_options()[name])
     return int(_lib.wg_get_option(name.encode()))
 
 
@@ -709,5 +800,14 @@ for _kv in filter(None, os.environ.get("WG_OPTIONS", "").split(",")):
     set_option(_k.strip(), int(_v or "1"))
 
 
-if os.environ.get("WG_BINDING", "ctypes") != "ctypes":
-    use_binding(os.environ["WG_BINDING"])
+# Which binding serves the calls: the compiled module (csrc/torch_binding.cpp -> _C_torch*.so) when it has been built and links this very
+# library -- it carries the whole surface and costs less host time per call --, the ctypes code above otherwise.  WG_BINDING=ctypes|torch
+# forces one (torch: ImportError if it has not been built).
+_want = os.environ.get("WG_BINDING", "")
+if _want:
+    use_binding(_want)
+elif _LIB_PATH == os.path.join(_HERE, "libwg_rasterizer.so"):
+    try:
+        use_binding("torch")
+    except ImportError:
+        pass

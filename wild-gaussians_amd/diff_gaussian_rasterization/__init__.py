@@ -25,6 +25,7 @@ import torch.nn as nn
 from . import _C
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians"]
+call_options = _C.call_options   # `with call_options(deterministic_backward=1): ...` (thread-local, scoped; see _C.py)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -75,51 +76,49 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                 sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None, colors_precomp2=None,
-                filter_3D=None, sh_second=False, sh_mul2=None, sh_offset2=None, sh_pre_clamp_max2=None, sh_post_clamp_max2=None):
+                filter_3D=None, sh_second=False, sh_mul2=None, sh_offset2=None, sh_pre_clamp_max2=None, sh_post_clamp_max2=None, call_options=None):
         rs = raster_settings
         native_args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                        rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset,
                        rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
-        # beyond the reference (opt-in, see GaussianRasterizer.forward): per-Gaussian affine + clamps on the SH coefficients in-kernel
+        # Everything below is beyond the reference (opt-in by keyword, see GaussianRasterizer.forward) and goes to the native module as the
+        # optional blocks of ONE call (include/wg_rasterizer.h: wg_forward_args).
+        # per-call options: resolved ONCE here (keyword > the calling thread's defaults) and carried to the backward call on ctx
+        ctx.call_options = _C.resolve_call_options(call_options)
+        extra = dict(options=ctx.call_options)
+        # per-Gaussian affine + clamps on the SH coefficients in-kernel (wg_sh_tone)
         ctx.sh_tone = None
         if sh_mul is not None or sh_offset is not None or sh_pre_clamp_max is not None or sh_post_clamp_max is not None:
             if sh.numel() == 0:
                 raise Exception("sh_mul / sh_offset / sh_*_clamp_max act on SH coefficients: provide shs, not colors_precomp")
             ctx.sh_tone = (None if sh_mul is None else sh_mul.detach(), None if sh_offset is None else sh_offset.detach(),
                            sh_pre_clamp_max, sh_post_clamp_max)
-            native_args = native_args + (ctx.sh_tone,)
-        if binning_capacity is not None:   # beyond the reference: no host rendezvous (wg_rasterize_forward_fixed), capturable in a hipGraph
-            native_args = native_args + ((None,) if ctx.sh_tone is None else ()) + (int(binning_capacity),)
-        # beyond the reference: a second set of precomputed colours composited in the same walk (wg_second_colors)
+            extra["sh_tone"] = ctx.sh_tone
+        if binning_capacity is not None:   # no host rendezvous (wg_forward_args::binning_capacity), capturable in a hipGraph
+            extra["binning_capacity"] = int(binning_capacity)
+        # a second set of precomputed colours composited in the same walk (wg_second_image)
         ctx.dual = colors_precomp2 is not None
-        color2 = None
-        # beyond the reference: opacities / scales / rotations are the RAW parameters, get_gaussians() runs in-kernel (wg_raw_gaussians)
+        # opacities / scales / rotations are the RAW parameters, get_gaussians() runs in-kernel (wg_raw_gaussians)
         ctx.raw = filter_3D is not None
         if ctx.raw and (ctx.dual or binning_capacity is not None):
             raise Exception("filter_3D (raw-parameter mode) cannot be combined with colors_precomp2 / binning_capacity")
-        # beyond the reference: both colour sets from the same SH block, each through its own tone (wg_rasterize_forward_two_tone)
+        if ctx.raw:
+            extra["filter_3D"] = filter_3D
+        # both colour sets from the same SH block, each through its own tone (wg_forward_args::sh_second + tone2)
         ctx.sh_second = None
         if sh_second:
             if sh.numel() == 0 or ctx.dual or binning_capacity is not None:
                 raise Exception("sh_second renders a second tone of the SH coefficients: provide shs, and neither colors_precomp2 nor binning_capacity")
             ctx.sh_second = (None if sh_mul2 is None else sh_mul2.detach(), None if sh_offset2 is None else sh_offset2.detach(),
                              sh_pre_clamp_max2, sh_post_clamp_max2)
-            tone_arg, second_arg = ctx.sh_tone, ctx.sh_second
-            num_rendered, color, radii, geom_buf, binning_buf, img_buf, color2 = _call_native(
-                lambda *a: _C.rasterize_gaussians(*a[:21], sh_tone=tone_arg, filter_3D=filter_3D, sh_second=second_arg), native_args, rs.debug,
-                "snapshot_fw.dump", "forward")
+            extra["sh_second"] = ctx.sh_second
         elif ctx.dual:
             if ctx.sh_tone is not None or binning_capacity is not None:
                 raise Exception("colors_precomp2 cannot be combined with sh_mul / sh_offset / binning_capacity")
-            num_rendered, color, radii, geom_buf, binning_buf, img_buf, color2 = _call_native(
-                lambda *a: _C.rasterize_gaussians(*a, colors2=colors_precomp2), native_args, rs.debug, "snapshot_fw.dump", "forward")
-        elif ctx.raw:
-            tone_arg = ctx.sh_tone
-            num_rendered, color, radii, geom_buf, binning_buf, img_buf = _call_native(
-                lambda *a: _C.rasterize_gaussians(*a[:21], sh_tone=tone_arg, filter_3D=filter_3D), native_args, rs.debug, "snapshot_fw.dump", "forward")
-        else:
-            num_rendered, color, radii, geom_buf, binning_buf, img_buf = _call_native(
-                _C.rasterize_gaussians, native_args, rs.debug, "snapshot_fw.dump", "forward")
+            extra["colors2"] = colors_precomp2
+        res = _call_native(lambda *a: _C.rasterize_gaussians(*a, **extra), native_args, rs.debug, "snapshot_fw.dump", "forward")
+        num_rendered, color, radii, geom_buf, binning_buf, img_buf = res[:6]
+        color2 = res[6] if len(res) > 6 else None
 
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
@@ -143,58 +142,45 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_out_color, _grad_radii, _grad_accumulation, grad_out_color2=None):
         rs = ctx.raster_settings
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buf, binning_buf, img_buf = ctx.saved_tensors[:10]
+        zeros = lambda: torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
         if grad_out_color is None:  # the image itself took no gradient (only radii / accumulation were used downstream)
-            grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
+            grad_out_color = zeros()
         native_args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
                        rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset, grad_out_color, sh,
                        rs.sh_degree, rs.campos, geom_buf, ctx.num_rendered, binning_buf, img_buf, rs.debug)
-        g_mul = g_offset = g_colors2 = g_mul2 = g_offset2 = None
+        extra = dict(options=ctx.call_options)   # the frame's forward call's
+        if ctx.sh_tone is not None:
+            extra["sh_tone"] = ctx.sh_tone
+        if ctx.raw:
+            extra["raw"] = tuple(ctx.saved_tensors[10:12])
+        if ctx.sh_second is not None or ctx.dual:
+            extra["dL_dout_color2"] = zeros() if grad_out_color2 is None else grad_out_color2   # (None: the second image took no gradient)
         if ctx.sh_second is not None:
-            if grad_out_color2 is None:   # the second image took no gradient
-                grad_out_color2 = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
-            raw = tuple(ctx.saved_tensors[10:12]) if ctx.raw else None
-            res = _call_native(lambda *a: _C.rasterize_gaussians_backward(*a[:23], sh_tone=ctx.sh_tone, raw=raw, dL_dout_color2=grad_out_color2,
-                                                                           sh_second=ctx.sh_second), native_args, rs.debug, "snapshot_bw.dump", "backward")
-            (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations, g_mul, g_offset, g_mul2, g_offset2) = res
+            extra["sh_second"] = ctx.sh_second
+        res = _call_native(lambda *a: _C.rasterize_gaussians_backward(*a, **extra), native_args, rs.debug, "snapshot_bw.dump", "backward")
+        (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations) = res[:8]
+        g_mul = g_offset = g_colors2 = g_mul2 = g_offset2 = None
+        shaped = lambda g, like: None if (g is None or like is None) else g.view(like.shape)
+        if ctx.sh_second is not None:
+            g_mul, g_offset, g_mul2, g_offset2 = res[8:12]
             if ctx.sh_tone is not None:
-                g_mul = None if g_mul is None else g_mul.view(ctx.sh_tone[0].shape)
-                g_offset = None if g_offset is None else g_offset.view(ctx.sh_tone[1].shape)
-            g_mul2 = None if g_mul2 is None else g_mul2.view(ctx.sh_second[0].shape)
-            g_offset2 = None if g_offset2 is None else g_offset2.view(ctx.sh_second[1].shape)
+                g_mul, g_offset = shaped(g_mul, ctx.sh_tone[0]), shaped(g_offset, ctx.sh_tone[1])
+            g_mul2, g_offset2 = shaped(g_mul2, ctx.sh_second[0]), shaped(g_offset2, ctx.sh_second[1])
         elif ctx.dual:
-            if grad_out_color2 is None:   # the second image took no gradient
-                grad_out_color2 = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
-            (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations, g_colors2) = _call_native(
-                lambda *a: _C.rasterize_gaussians_backward(*a, dL_dout_color2=grad_out_color2), native_args, rs.debug, "snapshot_bw.dump", "backward")
-        elif ctx.raw:
-            raw = tuple(ctx.saved_tensors[10:12])
-            res = _call_native(lambda *a: _C.rasterize_gaussians_backward(*a[:23], sh_tone=ctx.sh_tone, raw=raw), native_args, rs.debug,
-                               "snapshot_bw.dump", "backward")
-            (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations) = res[:8]
-            if ctx.sh_tone is not None:
-                mul, offset = ctx.sh_tone[:2]
-                g_mul = None if mul is None else res[8].view(mul.shape)
-                g_offset = None if offset is None else res[9].view(offset.shape)
-        elif ctx.sh_tone is None:
-            (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations) = _call_native(
-                _C.rasterize_gaussians_backward, native_args, rs.debug, "snapshot_bw.dump", "backward")
-        else:
-            (g_means2D, g_colors, g_opacities, g_means3D, g_cov3Ds, g_sh, g_scales, g_rotations, g_mul, g_offset) = _call_native(
-                _C.rasterize_gaussians_backward, native_args + (ctx.sh_tone,), rs.debug, "snapshot_bw.dump", "backward")
-            mul, offset = ctx.sh_tone[:2]
-            g_mul = None if mul is None else g_mul.view(mul.shape)
-            g_offset = None if offset is None else g_offset.view(offset.shape)
-        # order of forward()'s inputs; None for raster_settings and the two clamp constants
+            g_colors2 = res[8]
+        elif ctx.sh_tone is not None:
+            g_mul, g_offset = shaped(res[8], ctx.sh_tone[0]), shaped(res[9], ctx.sh_tone[1])
+        # order of forward()'s inputs; None for raster_settings, the clamp constants and the options
         return (g_means3D, g_means2D, g_sh, g_colors, g_opacities, g_scales, g_rotations, g_cov3Ds, None, g_mul, g_offset, None, None, None, g_colors2, None,
-                None, g_mul2, g_offset2, None, None)
+                None, g_mul2, g_offset2, None, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
                         sh_mul=None, sh_offset=None, sh_pre_clamp_max=None, sh_post_clamp_max=None, binning_capacity=None, colors_precomp2=None,
-                        filter_3D=None, sh_second=False, sh_mul2=None, sh_offset2=None, sh_pre_clamp_max2=None, sh_post_clamp_max2=None):
+                        filter_3D=None, sh_second=False, sh_mul2=None, sh_offset2=None, sh_pre_clamp_max2=None, sh_post_clamp_max2=None, call_options=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                      raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity, colors_precomp2,
-                                     filter_3D, sh_second, sh_mul2, sh_offset2, sh_pre_clamp_max2, sh_post_clamp_max2)
+                                     filter_3D, sh_second, sh_mul2, sh_offset2, sh_pre_clamp_max2, sh_post_clamp_max2, call_options)
 
 
 class GaussianRasterizer(nn.Module):
@@ -216,8 +202,13 @@ class GaussianRasterizer(nn.Module):
                 binning_capacity: Optional[int] = None, colors_precomp2: Optional[torch.Tensor] = None,
                 filter_3D: Optional[torch.Tensor] = None, sh_second: bool = False, sh_mul2: Optional[torch.Tensor] = None,
                 sh_offset2: Optional[torch.Tensor] = None, sh_pre_clamp_max2: Optional[float] = None,
-                sh_post_clamp_max2: Optional[float] = None):
-        """`sh_second=True` (keyword-only, beyond the reference; with `shs`): a SECOND image from the same SH coefficients through a tone
+                sh_post_clamp_max2: Optional[float] = None, exact_compositing: Optional[bool] = None,
+                deterministic_backward: Optional[bool] = None, grad_record: Optional[bool] = None):
+        """`exact_compositing=` / `deterministic_backward=` / `grad_record=` (keyword-only, beyond the reference): the three switches that affect
+        results, PER CALL (wg_call_options, include/wg_rasterizer.h); None = the calling thread's default (`_C.call_options(...)` sets it for a
+        `with` block -- for callers that cannot pass keywords); the frame's backward pass runs with its forward call's values.
+
+        `sh_second=True` (keyword-only, beyond the reference; with `shs`): a SECOND image from the same SH coefficients through a tone
         of its own (`sh_mul2` / `sh_offset2` / `sh_*_clamp_max2`, each optional), composited in the SAME call as the first -- WildGaussians'
         step (method.py:1573-1611) renders the raw and the toned colours of one SH block: `rast(shs=f, sh_mul=mul, sh_offset=offset / C0,
         sh_pre_clamp_max=1, sh_post_clamp_max=1, sh_second=True, sh_pre_clamp_max2=1)` returns `(toned, radii, accumulation, raw)` from one
@@ -235,7 +226,7 @@ class GaussianRasterizer(nn.Module):
         tensors, the geometry gradients are those of both images' losses together.
 
         `binning_capacity=` (keyword-only, beyond the reference): the forward pass without any host rendezvous
-        (wg_rasterize_forward_fixed: the caller supplies the number of (tile, Gaussian) instances the binning buffer holds), for steps
+        (wg_forward_args::binning_capacity: the caller supplies the number of (tile, Gaussian) instances the binning buffer holds), for steps
         captured in a hipGraph; a frame that does not fit comes back as NaN, `_C.forward_status` tells.  Otherwise:
 
         The reference's signature (diff_gaussian_rasterization/__init__.py:208-241) plus four keyword-only opt-ins (SURVEY.md 8f
@@ -261,4 +252,6 @@ class GaussianRasterizer(nn.Module):
             _absent() if rotations is None else rotations,
             _absent() if cov3D_precomp is None else cov3D_precomp,
             self.raster_settings, sh_mul, sh_offset, sh_pre_clamp_max, sh_post_clamp_max, binning_capacity, colors_precomp2, filter_3D,
-            sh_second, sh_mul2, sh_offset2, sh_pre_clamp_max2, sh_post_clamp_max2)
+            sh_second, sh_mul2, sh_offset2, sh_pre_clamp_max2, sh_post_clamp_max2,
+            None if exact_compositing is None and deterministic_backward is None and grad_record is None else
+            dict(exact_compositing=exact_compositing, deterministic_backward=deterministic_backward, grad_record=grad_record))

@@ -105,11 +105,11 @@ def real_caller(args):
     m, wg = harness.make_method(P, W, H, n_cams=args.cameras, cloud_shapes="bench", gt="random")
     wg.model.active_sh_degree.fill_(3)   # the state a trained model is in (oneupSHdegree every 1000 iterations, method.py:1896)
     which = "two_tone" if args.two_tone_edit else "two_colour" if args.two_colour_edit else None
+    import render_edits as wg_render_edits   # tests/real_caller/render_edits.py: INTEGRATION.md section 5's edits applied in memory (test tool)
     if args.optins:   # the run-time opt-ins that need no source edit (wg_integration.apply_optins): fused SSIM, FusedAdam, fused densification
         import wg_integration   # statistics, fused activations, fused eval_sh; render_edit: INTEGRATION.md section 5's edit of _render_internal, in memory
-        wg_integration.apply_optins(m, model=wg.model, render_edit=which)
+        wg_integration.apply_optins(m, model=wg.model, edited_module=(wg_render_edits.import_edited_method(m, which=which) if which else None))
     elif which:   # the edit alone
-        import wg_render_edits
         m.GaussianModel._render_internal = wg_render_edits.import_edited_method(m, which=which).GaussianModel._render_internal
     if args.tall_linear and wg.model.appearance_mlp is not None:   # measurement scaffolding for the caller's MLP (see _TallLinear)
         for lin in wg.model.appearance_mlp.mlp:

@@ -1,4 +1,5 @@
-"""The two caller edits INTEGRATION.md section 5 documents for `_render_internal` (wildgaussians/method.py:1479-1632), as text replacements
+"""TEST TOOL (moved out of the product package in round 5: the documented diff of INTEGRATION.md section 5 is the deliverable, a source
+rewriter is not).  The two caller edits INTEGRATION.md section 5 documents for `_render_internal` (wildgaussians/method.py:1479-1632), as text replacements
 applied IN MEMORY to the caller's own `method.py` -- nothing is written to disk; a replacement whose original text is not found exactly once
 raises (an edit stays one that applies to the reference as it is):
 
@@ -8,8 +9,8 @@ raises (an edit stays one that applies to the reference as it is):
   EDITS_TWO_TONE  "two_tone": the one call takes the SH features themselves and the appearance MLP's affine (`shs=`, `sh_mul=`,
                   `sh_offset=`, `sh_second=True`): no eval_sh, no P x 48 toned tensor in torch.
 
-`wg_integration.apply_optins(method, render_edit="two_tone")` applies one at run time; tests/test_real_caller.py holds both to the unedited
-function's results.  The `old` halves are the reference's own lines, quoted as anchors -- the only way to say where an edit goes."""
+`wg_integration.apply_optins(method, edited_module=import_edited_method(method, "two_tone"))` takes the edited function at run time;
+tests/test_real_caller.py holds both edits to the unedited function's results.  The `old` halves are the reference's own lines, quoted as anchors -- the only way to say where an edit goes."""
 from __future__ import annotations
 
 import importlib.util

@@ -10,6 +10,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "real_caller"))
 import harness  # noqa: E402
+import render_edits  # noqa: E402  (test tool: INTEGRATION.md section 5's edits applied in memory)
 import stage_reference_caller as stage  # noqa: E402
 
 # The staged copy of the reference's caller travels with the tree like oracle/_ref (git-ignored, not gpurun-ignored).  Without it the
@@ -56,10 +57,10 @@ def test_omegaconf_stand_in_builds_the_config_the_caller_expects():
 
 @needs_staged
 def test_documented_render_edits_apply_to_the_caller_as_it_is_and_compile():
-    """wg_render_edits: every replacement's anchor is found exactly once in the staged, byte-identical method.py,
+    """tests/real_caller/render_edits.py: every replacement's anchor is found exactly once in the staged, byte-identical method.py,
     the edited source compiles, and an anchor that has gone raises instead of silently leaving the function as it was.  (CPU: text only.)"""
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "wild-gaussians_amd"))
-    import wg_render_edits as E
+    import render_edits as E
     path = os.path.join(stage.DST, "method.py")
     for which, edits in E.EDIT_SETS.items():
         src = E.edited_source(path, edits)
@@ -187,7 +188,7 @@ def test_runtime_optins_leave_the_real_step_where_it_was(render_edit):
     def run(optins, steps):
         random.seed(7), np.random.seed(7), torch.manual_seed(7)
         m, wg = harness.make_method(30_000, 480, 320, n_cams=3, overrides=ov)
-        undo = wg_integration.apply_optins(m, model=wg.model, render_edit=render_edit) if optins else (lambda: None)
+        undo = wg_integration.apply_optins(m, model=wg.model, edited_module=(render_edits.import_edited_method(m, which=render_edit) if render_edit else None)) if optins else (lambda: None)
         try:
             random.seed(11)
             with harness.RasterizerTap(m) as tap:
@@ -351,7 +352,7 @@ def test_render_internal_with_the_two_colour_edit_gives_the_unedited_results(tra
     the same trained model and camera: one rasterizer call instead of two; render, raw render, accumulation and radii bit-identical; the
     gradients of the step's real loss shape (L1 on the toned image + a term on the raw one, method.py:1948-1960) on every parameter
     equal to rounding (2e-4 of a tensor's largest magnitude; observed <= 2.2e-5)."""
-    import wg_render_edits
+    import render_edits as wg_render_edits
     from diff_gaussian_rasterization import _C
     m, wg, _ = trained
     m2 = wg_render_edits.import_edited_method(m, which="two_colour")
@@ -395,7 +396,7 @@ def test_render_internal_with_the_two_tone_edit_gives_the_unedited_results(train
     unedited method, same trained model and camera: one call instead of two; accumulation, radii bit-identical (the geometry path does
     not see colours); both renders to 2e-6 (the polynomial is evaluated by the kernel instead of torch's eval_sh: rounding); the real
     loss shape's gradients on every parameter to 2e-4 of a tensor's largest magnitude."""
-    import wg_render_edits
+    import render_edits as wg_render_edits
     m, wg, _ = trained
     m2 = wg_render_edits.import_edited_method(m, which="two_tone")
     cam = wg.train_cameras[1]

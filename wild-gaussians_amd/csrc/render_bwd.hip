@@ -423,21 +423,29 @@ render_backward_kernel(
 
 // Per-Gaussian sum of the deterministic mode, in a FIXED order.  The 64 Gaussians of a wave own ONE contiguous range of slots
 // [prefix(first) .. prefix(last) + tiles_touched(last)) -- slot = exclusive prefix of tiles_touched + the tile's index inside the
-// Gaussian's rectangle --, so the wave walks that range 64 slots at a time with EVERY lane busy: lane l takes slot clo + l (its flag: 64
-// consecutive bytes per wave; if flagged, its ten floats: consecutive 40-byte slots, i.e. coalesced), a segmented inclusive scan over the
-// lanes (segment heads = the Gaussians' first slots) adds each Gaussian's slots of the chunk in a fixed tree, and the Gaussian's own lane
-// picks its segment's total from the segment's last lane and adds it to its accumulator -- chunk after chunk, in slot order.  The shape of
-// the tree depends only on tiles_touched, never on timing: bit-identical gradients run to run.  Only flagged slots are read (the slot array
-// is never cleared, only the 1-byte flags are); the kernel WRITES the whole 48-byte record, zeros for a Gaussian nothing was added to.
-// (Rounds 3-4: one thread per Gaussian scanning its own flags and gathering its flagged slots, three dependent round trips with one lane
-// in ~4 doing anything: 121 us at the headline scene, a latency problem.  This form streams: see profiles/r5/ab_deterministic_backward*.)
+// Gaussian's rectangle.  Only about a quarter of the slots were written (the per-tile pass reduces an instance only where a pixel
+// contributed; it flags those), so the wave first COMPACTS: it walks its range's flag bytes 64 at a time (coalesced), and the flagged slots'
+// indices are appended, in slot order, to a 64-entry batch in LDS.  A full batch (and the last, partial one) is reduced with every lane
+// busy: lane l loads batch entry l's ten floats, finds its owner among the wave's Gaussians (a 6-step search over their end offsets), a
+// segmented inclusive scan over the lanes (segment = run of equal owners) adds each Gaussian's slots of the batch in a fixed tree, the last
+// lane of each segment hands the total to its owner's lane through LDS, which adds it to its accumulator -- batch after batch, in slot
+// order.  The shape of the trees depends only on tiles_touched and on which slots were flagged (i.e. on the frame), never on timing:
+// bit-identical gradients run to run.  The slot array is never cleared, only the 1-byte flags are; the kernel WRITES the whole 48-byte
+// record, zeros for a Gaussian nothing was added to.
+// (Rounds 3-4: one thread per Gaussian scanning its own flags and gathering its flagged slots: 121 us at the headline scene, one lane in ~4
+// doing anything.  Round 5, first form: a segmented scan over ALL slots 64 at a time: 107 us -- 76 LDS shuffles per 64 slots of which 15 hold
+// anything.  This form scans a quarter as many lanes: profiles/r5/ab_deterministic_backward*.)
 // NF2 = float2 per slot: 5 (ten sums) or 7 (the two-colour walk's thirteen, padded to fourteen: sums 10, 11 go to the record's two spare
 // floats, sum 12 to grad_aux[g] = grad_rec[12 P + g])
 template <int NF2>
 __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* __restrict__ offsets_incl, const uint32_t* __restrict__ tiles_touched,
                                                          const float* __restrict__ det_slots, const unsigned char* __restrict__ det_flags,
                                                          float* __restrict__ grad_rec, size_t slot_capacity) {
-    __shared__ unsigned char sheads[4][64];
+    constexpr int NV = 2 * NF2;
+    __shared__ uint32_t s_ends[4][64];
+    __shared__ uint32_t s_batch[4][64];
+    __shared__ float s_out[4][64][NV + 1];   // (+1: an odd row stride keeps the owners' reads off one bank)
+    __shared__ unsigned char s_touch[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = g < P;
@@ -449,14 +457,68 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* 
     const int last_lane = min(63, P - 1 - g0);
     const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
     const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)end, last_lane);
-    constexpr int NV = 2 * NF2;
+    uint32_t* ends = s_ends[wave];
+    uint32_t* batch = s_batch[wave];
+    ends[lane] = valid ? end : 0xffffffffu;   // nondecreasing over the lanes (inclusive prefix sums); lanes past P: beyond every slot
     float acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) acc[v] = 0.f;
-    unsigned char* heads = sheads[wave];
-    // G chunks of 64 slots per trip: their flags are fetched together and then their flagged slots together -- two dependent memory round
-    // trips per G chunks instead of per chunk (an average wave owns ~470 slots: two trips)
-    constexpr int G = 4;
+
+    auto reduce_batch = [&](uint32_t cnt) {   // cnt (wave-uniform, 1..64) slot indices in batch[], in slot order
+        __builtin_amdgcn_wave_barrier();
+        const bool act = (uint32_t)lane < cnt;
+        const uint32_t k = act ? batch[lane] : 0u;
+        float x[NV];
+        {
+            const float2* sl = reinterpret_cast<const float2*>(det_slots + (size_t)k * NV);  // 40- / 56-byte slots: 8-byte aligned
+#pragma unroll
+            for (int h = 0; h < NF2; h++) {
+                const float2 t = act ? sl[h] : make_float2(0.f, 0.f);
+                x[2 * h] = t.x;
+                x[2 * h + 1] = t.y;
+            }
+        }
+        // owner = the wave's Gaussian whose slot range holds k = the number of end offsets <= k
+        int owner = 0;
+#pragma unroll
+        for (int st = 32; st >= 1; st >>= 1)
+            if (ends[owner + st - 1] <= k) owner += st;
+        if (!act) owner = 64 + lane;   // idle lanes: segments of their own
+        // (the two shuffles stand alone: behind a short-circuit `lane == 0 ||` the compiler runs them with that lane masked off, and a
+        //  ds_bpermute returns 0 for a source lane that is not executing -- lane 1 then saw "owner 0" to its left and opened a segment)
+        const int owner_left = __shfl_up(owner, 1), owner_right = __shfl_down(owner, 1);
+        int head = (lane == 0 || owner_left != owner) ? 1 : 0;
+        const bool seg_last = act && (lane == 63 || owner_right != owner);
+        // segmented inclusive scan over the 64 lanes (Hillis-Steele; a lane stops taking once a head lies in its window)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int hup = __shfl_up(head, d);
+            float up[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) up[v] = __shfl_up(x[v], d);
+            if (lane >= d && head == 0) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) x[v] += up[v];
+                head = hup;
+            }
+        }
+        s_touch[wave][lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (seg_last) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) s_out[wave][owner][v] = x[v];
+            s_touch[wave][owner] = 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (s_touch[wave][lane]) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) acc[v] += s_out[wave][lane][v];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    uint32_t nb = 0;   // slots in the batch (wave-uniform)
+    constexpr int G = 4;   // flag bytes of G x 64 slots are fetched together: one memory round trip per 256 slots
     for (uint32_t glo = wlo; glo < whi; glo += 64u * G) {  // wave-uniform trip count
         bool flagged[G];
 #pragma unroll
@@ -464,53 +526,17 @@ __global__ void __launch_bounds__(256) det_reduce_kernel(int P, const uint32_t* 
             const uint32_t k = glo + 64u * u + (uint32_t)lane;
             flagged[u] = k < whi && (size_t)k < slot_capacity && det_flags[k] != 0;
         }
-        float x[G][NV];
 #pragma unroll
         for (int u = 0; u < G; u++) {
-            const uint32_t k = glo + 64u * u + (uint32_t)lane;
-            const float2* sl = reinterpret_cast<const float2*>(det_slots + (size_t)(flagged[u] ? k : glo) * NV);  // 40- / 56-byte slots: 8-byte aligned
-#pragma unroll
-            for (int h = 0; h < NF2; h++) {
-                const float2 t = flagged[u] ? sl[h] : make_float2(0.f, 0.f);
-                x[u][2 * h] = t.x;
-                x[u][2 * h + 1] = t.y;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < G; u++) {
-            const uint32_t clo = glo + 64u * u;
-            if (clo >= whi) break;  // wave-uniform
-            // segment heads of this chunk: a Gaussian with slots of its own starts one at its first slot (two Gaussians never share one)
-            __builtin_amdgcn_wave_barrier();
-            heads[lane] = 0;
-            __builtin_amdgcn_wave_barrier();
-            if (n != 0u && base >= clo && base < clo + 64u) heads[base - clo] = 1;
-            __builtin_amdgcn_wave_barrier();
-            int head = (lane == 0 || heads[lane] != 0) ? 1 : 0;
-            // segmented inclusive scan over the 64 lanes (Hillis-Steele; a lane stops taking once a head lies in its window)
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int hup = __shfl_up(head, d);
-                float up[NV];
-#pragma unroll
-                for (int v = 0; v < NV; v++) up[v] = __shfl_up(x[u][v], d);
-                if (lane >= d && head == 0) {
-#pragma unroll
-                    for (int v = 0; v < NV; v++) x[u][v] += up[v];
-                    head = hup;
-                }
-            }
-            // the Gaussian's own lane takes the total of its segment's part in this chunk from that part's last lane
-            const uint32_t lo = max(base, clo), hi = min(end, clo + 64u);
-            const bool mine = n != 0u && lo < hi;
-            const int src = mine ? (int)(hi - 1u - clo) : 0;
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                const float t = __shfl(x[u][v], src);
-                if (mine) acc[v] += t;
-            }
+            const uint64_t m = __ballot(flagged[u]);
+            const uint32_t c = (uint32_t)__popcll(m);
+            if (c == 0u) continue;   // wave-uniform
+            if (nb + c > 64u) { reduce_batch(nb); nb = 0u; }
+            if (flagged[u]) batch[nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = glo + 64u * u + (uint32_t)lane;
+            nb += c;
         }
     }
+    if (nb != 0u) reduce_batch(nb);
     if (valid) {
         float4* out = reinterpret_cast<float4*>(grad_rec + (size_t)g * GRAD_REC_FLOATS);
         out[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);

@@ -413,6 +413,16 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
       forward_status(imgBuffer, H, W) tells the real count and whether the frame fit.
     options: per-call options (see resolve_call_options)."""
     opts = resolve_call_options(options)
+    if _torch_ext is not None and not _geometry_reuse_on:
+        # the usual path: the compiled binding (csrc/torch_binding.cpp) checks its arguments itself (same messages), nothing is remembered
+        _reuse.last = None
+        res = _torch_ext.rasterize_gaussians_ex(background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp, viewmatrix,
+                                                projmatrix, float(tan_fovx), float(tan_fovy), float(kernel_size), subpixel_offset, int(image_height),
+                                                int(image_width), sh, int(degree), campos, bool(prefiltered), bool(debug), sh_tone, binning_capacity, colors2,
+                                                filter_3D, sh_second, opts)
+        if binning_capacity is not None:
+            _reuse.last_fixed = (res[5], int(image_height), int(image_width))
+        return res
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:59-61
     if not means3D.is_cuda:
@@ -431,7 +441,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         raise RuntimeError("binning_capacity (the fixed-capacity forward) has no debug mode")
     # precomputed colours over remembered geometry: no projection, no binning
     reusable = (P != 0 and sh_tone is None and not debug and colors.numel() == 3 * P and sh.numel() == 0 and colors2 is None
-                and filter_3D is None and sh_second is None and _lib.wg_get_option(b"geometry_reuse") == 1)
+                and filter_3D is None and sh_second is None and _geometry_reuse_on)
     key = None
     if reusable:
         key = _reuse_key(background, means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx,
@@ -547,11 +557,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     global _reuse_epoch
     opts = resolve_call_options(options)
     _reuse_epoch += 1   # what the forward calls remembered ends here (see "Geometry reuse" above) ...
-    alive = {t.ident for t in threading.enumerate()}
-    for ident, st in list(_PerThread._states.items()):   # ... and so do the references that kept those frames' scratch alive (any thread's)
+    states = _PerThread._states
+    for st in list(states.values()):                     # ... and so do the references that kept those frames' scratch alive (any thread's)
         st.last = None
-        if ident not in alive:                           # (a thread that has ended: its state goes with it)
-            _PerThread._states.pop(ident, None)
+    if len(states) > 8:                                  # (threads that have ended: their states go with them)
+        alive = {t.ident for t in threading.enumerate()}
+        for ident in [i for i in states if i not in alive]:
+            states.pop(ident, None)
     if sh_second is not None and dL_dout_color2 is None:
         raise RuntimeError("sh_second needs the second image's cotangent (dL_dout_color2)")
     record = bool(opts[2] or opts[1])
@@ -734,14 +746,20 @@ _lib.wg_set_option.restype = _i
 _lib.wg_set_option.argtypes = [C.c_char_p, _i]
 
 
+_geometry_reuse_on = False   # the option "geometry_reuse" is read by this binding only: kept here too, so that no call has to ask the library
+
+
 def set_option(name: str, value: int) -> None:
     """wg_set_option: a tuning switch of the library (process-wide; every setting gives identical results: docs/OPTIONS.md), e.g.
     set_option("force_global_sort", 1).  For the three RESULT-AFFECTING names (exact_compositing, deterministic_backward, grad_record), which
     the library takes per call, it sets the CALLING THREAD's default instead (see call_options)."""
+    global _geometry_reuse_on
     if name in CALL_OPTION_DEFAULTS:
         _thread_call_options()[name] = int(bool(int(value)))
     else:
         _check(_lib.wg_set_option(name.encode(), int(value)), f"wg_set_option({name})")
+        if name == "geometry_reuse":
+            _geometry_reuse_on = bool(int(value))
     forget_geometry()   # a remembered forward call was made under the old options
 
 

@@ -17,8 +17,9 @@ needs the few-line edits INTEGRATION.md lists.  What IS swapped, each with the r
   activations           `GaussianModel.get_gaussians` (method.py:1060-1086)          -> wg_fused_gaussians.activate (same dict)
   eval_sh               `method.eval_sh` (method.py:493-548, called at :1564, :1597) -> wg_fused_gaussians.eval_sh; calls it does not cover
                         (degree 4, a channel count other than 3, CPU tensors) go to the original function
-  render_edit           (off by default) `GaussianModel._render_internal` -> the same function with INTEGRATION.md section 5's "two_colour" or
-                        "two_tone" edit, compiled in memory from the caller's own file (wg_render_edits.py)
+  edited_module         (off by default) `GaussianModel._render_internal` -> the one of a module the INTEGRATOR supplies: a copy of the caller with
+                        INTEGRATION.md section 5's "two_colour" or "two_tone" edit applied (the documented diff is the deliverable; this package
+                        does not rewrite anybody's source -- tests/real_caller/render_edits.py is the test tool that builds such a module in memory)
   geometry_reuse        library option "geometry_reuse" = 1 (opt-in since round 4): the toned and depth calls of `_render_internal`
                         (method.py:1573-1631) ride on the raw call's projection and binning.  The caller's training loop qualifies
                         (it writes geometry only between a backward pass and the next forward pass); undo() switches it off again
@@ -29,12 +30,12 @@ import torch
 
 
 def apply_optins(method_module, model=None, ssim: bool = True, adam: bool = True, densification_stats: bool = True, activations: bool = True,
-                 eval_sh: bool = True, geometry_reuse: bool = True, render_edit: str | None = None):
+                 eval_sh: bool = True, geometry_reuse: bool = True, edited_module=None):
     """-> a function that restores everything that was replaced.  `model`: an already constructed GaussianModel (e.g.
     `WildGaussians(...).model`) whose existing optimizer should be adopted too.
-    render_edit = "two_colour" / "two_tone" (default None): ALSO replace `GaussianModel._render_internal` by the function compiled from
-    the caller's own source with that edit of INTEGRATION.md section 5 applied in memory (wg_render_edits: the raw and the toned render in
-    ONE rasterizer call; raises if the edit's anchor lines are not found exactly once) -- the file on disk stays as it is."""
+    edited_module (default None): a module object holding a copy of the caller with INTEGRATION.md section 5's edit of `_render_internal`
+    applied (the raw and the toned render in ONE rasterizer call); its `GaussianModel._render_internal` ALSO replaces the caller's, and it is
+    handed the swapped `ssim` / `eval_sh`."""
     import wg_fused_gaussians as FG
     import wg_fused_ssim
     saved = []
@@ -84,9 +85,8 @@ def apply_optins(method_module, model=None, ssim: bool = True, adam: bool = True
             return FG.eval_sh(d, sh, dirs)
         swap(method_module, "eval_sh", fused_eval_sh)
 
-    if render_edit is not None:
-        import wg_render_edits
-        edited = wg_render_edits.import_edited_method(method_module, which=render_edit)
+    if edited_module is not None:
+        edited = edited_module
         for name in ("ssim", "eval_sh"):   # the edited function looks module-level names up in ITS module: hand it the swapped ones
             swap(edited, name, getattr(method_module, name))   # (undo() puts its own back: the module object is cached in sys.modules)
         swap(GM, "_render_internal", edited.GaussianModel._render_internal)

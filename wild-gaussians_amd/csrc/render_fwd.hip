@@ -120,7 +120,13 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
         last[s] = st.last[s];
         if (DUAL) { C2r[s] = st.C2r[s]; C2g[s] = st.C2g[s]; C2b[s] = st.C2b[s]; }
     }
-    uint32_t alive = st.alive, strips_alive = st.strips_alive;
+    // Which pixels are still accumulating, as four WAVE-UNIFORM 64-bit masks (bit l of alive_m[s]: lane l's pixel of strip s): they live in
+    // scalar registers, a strip evaluation applies one with a scalar AND on the execution mask (inverse_ballot) instead of two vector
+    // instructions on a per-lane bit field, and the liveness of the strips is scalar arithmetic (round 5: -2 VALU of ~37 per strip evaluation).
+    uint64_t alive_m[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) alive_m[s] = __builtin_amdgcn_ballot_w64(((st.alive >> s) & 1u) != 0u);
+    uint32_t strips_alive = st.strips_alive;
     const StripBounds sb = st.sb;
 
     // Records travel list -> registers -> LDS one batch ahead of the walk, their ids two batches ahead, so that neither of the two
@@ -183,49 +189,53 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
             if (DUAL) { const float4 q2 = lds[3 * j + 2]; gb = make_float2(q2.x, q2.y); gb2 = make_float2(q2.z, q2.w); }  // green, blue of both sets
             else gb = *reinterpret_cast<const float2*>(&lds[3 * j + 2]);
             const uint32_t pos = (uint32_t)(pos_begin + base + j + 1);
-            const uint32_t alive_before = alive;
+            uint64_t stopped_any = 0ull;
             WG_CNT(0, 1);
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 if (((reach[s] >> j) & 1ull) == 0ull) continue;  // wave-uniform
                 WG_CNT(1, 1);
-                WG_CNT(2, __popcll(__ballot((alive >> s) & 1u)));
-                bool pass;
+                WG_CNT(2, __popcll(alive_m[s]));
+                // The decisions as wave-wide masks built from the compares' own results (a ballot of a DIRECT compare is the compare's scalar
+                // output; combining them is scalar arithmetic): no vector instruction is spent on a predicate.
                 float alpha;
+                uint64_t pass_m;
                 if (EXACT) {
                     float dx, dy, G;
-                    pass = eval_alpha_exact(xc, pfx[s], pfy[s], dx, dy, G, alpha);
+                    const float power = eval_alpha_exact_values(xc, pfx[s], pfy[s], dx, dy, G, alpha);
+                    pass_m = __builtin_amdgcn_ballot_w64(!(power > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha < (1.0f / 255.0f)));
                 } else {
                     PairEval e;
-                    pass = eval_alpha(sc, pfx[s], pfy[s], e);
+                    const float p2 = eval_alpha_values(sc, pfx[s], pfy[s], e);
                     alpha = e.alpha;
+                    pass_m = __builtin_amdgcn_ballot_w64(p2 <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha >= (1.0f / 255.0f));
                 }
-                WG_CNT(3, __popcll(__ballot(((alive >> s) & 1u) && pass)));
-                if (((alive >> s) & 1u) && pass) {
-                    const float w = alpha * T[s];
-                    // T (1 - alpha), forward.cu:367: as spelled there (EXACT), or one rounding step apart
-                    const float test_T = EXACT ? ref_test_T(T[s], alpha) : T[s] - w;
-                    if (test_T < 0.0001f) {
-                        alive &= ~(1u << s);  // done (forward.cu:368-372): this instance is not blended
-                    } else {
-                        Cr[s] += r1.w * w;
-                        Cg[s] += gb.x * w;
-                        Cb[s] += gb.y * w;
-                        if (DUAL) {
-                            C2r[s] += r1.z * w;
-                            C2g[s] += gb2.x * w;
-                            C2b[s] += gb2.y * w;
-                        }
-                        T[s] = test_T;
-                        last[s] = pos;
+                const uint64_t go_m = pass_m & alive_m[s];
+                WG_CNT(3, __popcll(go_m));
+                const float w = alpha * T[s];
+                // T (1 - alpha), forward.cu:367: as spelled there (EXACT), or one rounding step apart
+                const float test_T = EXACT ? ref_test_T(T[s], alpha) : T[s] - w;
+                const uint64_t stop_m = go_m & __builtin_amdgcn_ballot_w64(test_T < 0.0001f);   // done (forward.cu:368-372): this instance is not blended
+                if (__builtin_amdgcn_inverse_ballot_w64(go_m & ~stop_m)) {
+                    Cr[s] += r1.w * w;
+                    Cg[s] += gb.x * w;
+                    Cb[s] += gb.y * w;
+                    if (DUAL) {
+                        C2r[s] += r1.z * w;
+                        C2g[s] += gb2.x * w;
+                        C2b[s] += gb2.y * w;
                     }
+                    T[s] = test_T;
+                    last[s] = pos;
                 }
+                alive_m[s] &= ~stop_m;
+                stopped_any |= stop_m;
             }
-            if (__ballot(alive != alive_before) != 0ull) {  // some pixel saturated: refresh the strip liveness
+            if (stopped_any != 0ull) {  // some pixel saturated: refresh the strip liveness (scalar)
                 strips_alive = 0;
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    if (__ballot((alive >> s) & 1u) != 0ull) strips_alive |= 1u << s;
+                    if (alive_m[s] != 0ull) strips_alive |= 1u << s;
                     else reach[s] = 0ull;
                 }
                 if (strips_alive == 0) break;
@@ -233,6 +243,9 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
             }
         }
     }
+    uint32_t alive = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) alive |= (uint32_t)((alive_m[s] >> lane) & 1ull) << s;
 #if WG_COUNT_PAIRS
 #pragma unroll
     for (int s = 0; s < 4; s++) WG_CNT(4, __popcll(__ballot((st.alive >> s) & 1u)) - __popcll(__ballot((alive >> s) & 1u)));

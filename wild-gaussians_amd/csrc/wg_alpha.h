@@ -51,6 +51,19 @@ __device__ __forceinline__ bool eval_alpha(const SplatCoef& c, float pfx, float 
     return p2 <= 0.0f && e.alpha >= (1.0f / 255.0f);
 }
 
+// eval_alpha() handing p2 (= log2(e) * power) back instead of the decision
+__device__ __forceinline__ float eval_alpha_values(const SplatCoef& c, float pfx, float pfy, PairEval& e) {
+    e.dx = c.mx - pfx;
+    e.dy = c.my - pfy;
+    e.xx = e.dx * e.dx;
+    e.xy = e.dx * e.dy;
+    e.yy = e.dy * e.dy;
+    const float p2 = c.ca * e.xx + c.cb * e.xy + c.cc * e.yy;
+    e.G = __builtin_amdgcn_exp2f(p2);
+    e.alpha = fminf(0.99f, c.o * e.G);
+    return p2;
+}
+
 // ---- decision-exact compositing (Options::exact_compositing, default on) ------------------------------------------------------------
 // The skips of forward.cu:356-372 / backward.cu:536-546 are threshold decisions on float32 values; a value that differs from the
 // reference's in its last bits lands on the other side of a threshold once in ~10^8 pairs, and one flipped decision moves a pixel by
@@ -109,6 +122,17 @@ __device__ __forceinline__ float ref_power(const ExactCoef& c, float dx, float d
     const float s = t2 + t4;
     const float t6 = (c.B * dx) * dy;
     return s - t6;
+}
+// The same evaluation handing the two decided-upon VALUES back (-> power; alpha by reference): render_fwd.hip turns the compares into
+// wave-wide masks itself.
+__device__ __forceinline__ float eval_alpha_exact_values(const ExactCoef& c, float pfx, float pfy, float& dx, float& dy, float& G, float& alpha) {
+#pragma clang fp contract(off)
+    dx = c.mx - pfx;
+    dy = c.my - pfy;
+    const float power = ref_power(c, dx, dy);
+    G = ref_expf_nonpos(power);
+    alpha = fminf(0.99f, c.o * G);
+    return power;
 }
 // Returns the reference's decision for the pair (power <= 0 and alpha >= 1/255) and its alpha, G = exp(power), dx, dy.
 __device__ __forceinline__ bool eval_alpha_exact(const ExactCoef& c, float pfx, float pfy, float& dx, float& dy, float& G, float& alpha) {

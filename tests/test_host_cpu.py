@@ -102,7 +102,10 @@ def test_struct_entry_points_reject_invalid_arguments_before_any_device_work(lib
     """wg_rasterize_forward_ex / _backward_ex (one struct, optional blocks: tone, second image, raw parameters, recolouring, fixed capacity,
     per-call options) and wg_forward_status: no allocator callback and no HIP call before the arguments have been checked (this test runs on a
     box without a GPU)."""
-    from diff_gaussian_rasterization import _C
+    import importlib.util   # (the struct definitions alone: pure ctypes, so that this test also runs under ASan, where torch cannot be imported)
+    spec = importlib.util.spec_from_file_location("wg_abi", os.path.join(ROOT, "wild-gaussians_amd", "diff_gaussian_rasterization", "_abi.py"))
+    _C = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(_C)
     A, B = _C._ForwardArgs, _C._BackwardArgs
     ALLOC = _C._ALLOC_FN
     called = []

@@ -44,17 +44,17 @@ lib.wg_debug_fwd_counters(u8, 1)
 lib.wg_debug_bwd_counters(u8, 1)
 h = run_hip(cloud, cam, sh_degree=d, cotangent=None if a.forward_only else S.make_cotangent(W, H))
 lib.wg_debug_fwd_counters(u8, 1)
-fwd = list(u8)[:5]
+fwd = list(u8)[:6]
 lib.wg_debug_bwd_counters(u8, 1)
-bwd = list(u8)[:5]
+bwd = list(u8)[:6]
 import bench  # noqa: E402
 out = {"workload": f"{P} Gaussians, {W}x{H}, {a.colors}" + ("" if a.scale_mult == 1.0 else f", scales x{a.scale_mult:g}"),
        "kernel_source_sha": bench.kernel_source_sha(), "collected": time.strftime("%Y-%m-%d"), "device": torch.cuda.get_device_name(0),
        "render_forward": {"instances_visited": fwd[0], "strip_evaluations": fwd[1], "pairs_evaluated": 64 * fwd[1], "pairs_evaluated_on_accumulating_pixels": fwd[2],
-                          "pairs_passing_both_skips": fwd[3], "pixels_stopped": fwd[4], "pairs_blended": fwd[3] - fwd[4]},
+                          "pairs_passing_both_skips": fwd[3], "pixels_stopped": fwd[4], "pairs_blended": fwd[3] - fwd[4], "strip_evaluations_without_a_passing_pair": fwd[5]},
        "render_backward": None if a.forward_only else {"instances_visited": bwd[0], "strip_evaluations": bwd[1], "pairs_evaluated": 64 * bwd[1],
                                                        "pairs_at_or_before_the_last_contributor": bwd[2], "pairs_contributing": bwd[3],
-                                                       "instances_reduced": bwd[4]},
+                                                       "instances_reduced": bwd[4], "strip_evaluations_without_a_contributing_pair": bwd[5]},
        "what": "per launch; a strip evaluation is one wave-wide evaluation of an instance on an 8x8 strip = 64 (pixel, entry) pairs"}
 # the reference's walk on the same frame (forward.cu:340-381: every pixel looks at every entry of its tile's list until it stops)
 from oracle import oracle  # noqa: E402

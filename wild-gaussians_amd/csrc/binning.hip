@@ -1034,7 +1034,12 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint32_t* __restri
     if constexpr (EMAX == 32) {
         tile_sort_body<32>(skeys, n, bucket_ids + begin, depths, point_list + begin, id_mask);
     } else {
-        if (EMAX == 4 || n <= 1024) tile_sort_body<4>(skeys, n, bucket_ids + begin, depths, point_list + begin, id_mask);
+        // the smallest network that holds the list: its keys are then spread over all four waves (a 450-key list in the 1024-key network
+        // leaves waves 2 and 3 sorting padding while waves 0 and 1 carry the whole dependency chain: config 2's sort 0.049 -> 0.041 ms)
+        // (only in the launch for frames whose longest list is <= 1024: a frame with longer lists has hardly any this short, and the third
+        //  network in that kernel's code cost the headline frame 3 us)
+        if (EMAX == 4 && n <= 512) tile_sort_body<2>(skeys, n, bucket_ids + begin, depths, point_list + begin, id_mask);
+        else if (EMAX == 4 || n <= 1024) tile_sort_body<4>(skeys, n, bucket_ids + begin, depths, point_list + begin, id_mask);
         else if (EMAX == 8 || n <= 2048) tile_sort_body<(EMAX >= 8 ? 8 : 4)>(skeys, n, bucket_ids + begin, depths, point_list + begin, id_mask);
         else tile_sort_body<(EMAX >= 16 ? 16 : 4)>(skeys, n, bucket_ids + begin, depths, point_list + begin, id_mask);
     }

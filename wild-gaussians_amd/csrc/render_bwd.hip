@@ -27,7 +27,7 @@ constexpr int BATCH = 64;
 
 // WG_COUNT_PAIRS (a VARIANT build only, see render_fwd.hip): [0] instances visited, [1] strip evaluations (one = 64 (pixel, entry) pairs),
 // [2] of those pairs, the ones at or before their pixel's last contributor, [3] contributing pairs (what backward.cu:536-600
-// differentiates), [4] instances reduced and added to their Gaussian's record.
+// differentiates), [4] instances reduced and added to their Gaussian's record, [5] strip evaluations in which no pair contributed.
 #ifndef WG_COUNT_PAIRS
 #define WG_COUNT_PAIRS 0
 #endif
@@ -255,7 +255,7 @@ render_backward_kernel(
 #define sq p4.y
 
 #if WG_COUNT_PAIRS
-    unsigned long long wgc[5] = {0, 0, 0, 0, 0};
+    unsigned long long wgc[6] = {0, 0, 0, 0, 0, 0};
 #endif
     for (int hi = hi0; hi > 0; hi -= BATCH) {
         // lane l stages the instance at list position hi-1-l (back to front, backward.cu:517)
@@ -340,6 +340,7 @@ render_backward_kernel(
                     pass = eval_alpha(sc, pfx[s], pfy[s], e);
                 }
                 WG_CNT(3, __popcll(__ballot(pos < last[s] && pass)));
+                WG_CNT(5, __ballot(pos < last[s] && pass) == 0ull ? 1 : 0);
                 if (pos < last[s] && pass) {
                     any = true;
                     const float a = e.alpha;
@@ -406,7 +407,7 @@ render_backward_kernel(
     }
 #if WG_COUNT_PAIRS
     if (lane == 0)
-        for (int i = 0; i < 5; i++) atomicAdd(&g_bwd_counters[i], wgc[i]);
+        for (int i = 0; i < 6; i++) atomicAdd(&g_bwd_counters[i], wgc[i]);
 #endif
 }
 

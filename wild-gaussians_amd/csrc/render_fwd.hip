@@ -136,7 +136,7 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
     // on the "prefetch" it had just issued.
     if (n <= 0 || strips_alive == 0) return;  // nothing to do: st is unchanged
 #if WG_COUNT_PAIRS
-    unsigned long long wgc[5] = {0, 0, 0, 0, 0};
+    unsigned long long wgc[6] = {0, 0, 0, 0, 0, 0};
 #endif
     const int nl = n - 1;
     float4 a0, a1, a2;
@@ -212,6 +212,7 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
                 }
                 const uint64_t go_m = pass_m & alive_m[s];
                 WG_CNT(3, __popcll(go_m));
+                WG_CNT(5, go_m == 0ull ? 1 : 0);
                 const float w = alpha * T[s];
                 // T (1 - alpha), forward.cu:367: as spelled there (EXACT), or one rounding step apart
                 const float test_T = EXACT ? ref_test_T(T[s], alpha) : T[s] - w;
@@ -250,7 +251,7 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
 #pragma unroll
     for (int s = 0; s < 4; s++) WG_CNT(4, __popcll(__ballot((st.alive >> s) & 1u)) - __popcll(__ballot((alive >> s) & 1u)));
     if (lane == 0)
-        for (int i = 0; i < 5; i++) atomicAdd(&g_fwd_counters[i], wgc[i]);
+        for (int i = 0; i < 6; i++) atomicAdd(&g_fwd_counters[i], wgc[i]);
 #endif
 #pragma unroll
     for (int s = 0; s < 4; s++) {

@@ -58,8 +58,7 @@ def binding_name() -> str:
     return "ctypes" if _torch_ext is None else "torch"
 
 
-_ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
-_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+from ._abi import _ALLOC_FN, _vp, _i, _f  # noqa: E402
 
 _lib.wg_rasterize_forward.restype = _i
 _lib.wg_rasterize_forward.argtypes = [_ALLOC_FN, _vp, _ALLOC_FN, _vp, _ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
@@ -69,46 +68,7 @@ _lib.wg_rasterize_backward.argtypes = [_i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _v
                                        _vp, _vp, _vp, _vp, _vp, _vp] + [_vp] * 9 + [_i, _vp]
 
 
-class _ShTone(C.Structure):  # include/wg_rasterizer.h: wg_sh_tone
-    _fields_ = [("mul", _vp), ("offset", _vp), ("pre_clamp_max", _f), ("post_clamp_max", _f), ("dL_dmul", _vp), ("dL_doffset", _vp)]
-
-
-class _SecondImage(C.Structure):  # wg_second_image
-    _fields_ = [("colors_precomp2", _vp), ("out_color2", _vp), ("dL_dpix2", _vp), ("dL_dcolor2", _vp)]
-
-
-class _RawGaussians(C.Structure):  # wg_raw_gaussians
-    _fields_ = [("filter_3D", _vp), ("raw_opacities", _vp)]
-
-
-class _RecolorParent(C.Structure):  # wg_recolor_parent
-    _fields_ = [("geom_buffer", _vp), ("binning_buffer", _vp), ("image_buffer", _vp), ("R", _i)]
-
-
-class _CallOptions(C.Structure):  # wg_call_options
-    _fields_ = [("exact_compositing", _i), ("deterministic_backward", _i), ("grad_record", _i)]
-
-
-class _ForwardArgs(C.Structure):  # wg_forward_args
-    _fields_ = ([("struct_size", C.c_size_t), ("geometry_alloc", _ALLOC_FN), ("geometry_user", _vp), ("binning_alloc", _ALLOC_FN), ("binning_user", _vp),
-                 ("image_alloc", _ALLOC_FN), ("image_user", _vp)] +
-                [(n, _i) for n in ("P", "D", "M", "width", "height", "prefiltered", "debug")] +
-                [(n, _f) for n in ("scale_modifier", "tan_fovx", "tan_fovy", "kernel_size")] +
-                [(n, _vp) for n in ("background", "means3D", "shs", "colors_precomp", "opacities", "scales", "rotations", "cov3D_precomp", "viewmatrix",
-                                    "projmatrix", "cam_pos", "subpixel_offset", "out_color", "radii", "stream")] +
-                [("tone", C.POINTER(_ShTone)), ("tone2", C.POINTER(_ShTone)), ("sh_second", _i), ("second", C.POINTER(_SecondImage)),
-                 ("raw", C.POINTER(_RawGaussians)), ("recolor", C.POINTER(_RecolorParent)), ("binning_capacity", _i), ("options", C.POINTER(_CallOptions))])
-
-
-class _BackwardArgs(C.Structure):  # wg_backward_args
-    _fields_ = ([("struct_size", C.c_size_t)] + [(n, _i) for n in ("P", "D", "M", "R", "width", "height", "debug")] +
-                [(n, _f) for n in ("scale_modifier", "tan_fovx", "tan_fovy", "kernel_size")] +
-                [(n, _vp) for n in ("background", "means3D", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp", "viewmatrix", "projmatrix",
-                                    "campos", "subpixel_offset", "radii", "geom_buffer", "binning_buffer", "image_buffer", "dL_dpix", "dL_dmean2D",
-                                    "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_dmean3D", "dL_dcov3D", "dL_dsh", "dL_dscale", "dL_drot", "stream")] +
-                [("tone", C.POINTER(_ShTone)), ("tone2", C.POINTER(_ShTone)), ("sh_second", _i), ("second", C.POINTER(_SecondImage)),
-                 ("raw", C.POINTER(_RawGaussians)), ("options", C.POINTER(_CallOptions))])
-
+from ._abi import (_ShTone, _SecondImage, _RawGaussians, _RecolorParent, _CallOptions, _ForwardArgs, _BackwardArgs)  # noqa: E402  (pure ctypes)
 
 _lib.wg_rasterize_forward_ex.restype = _i
 _lib.wg_rasterize_forward_ex.argtypes = [C.POINTER(_ForwardArgs)]

@@ -315,34 +315,42 @@ render_backward_kernel(
             //   dL_dmean2D.y = -o * 0.5H * sum(q v)           dL_dconic.xy = -0.5 o * sum(q dx dy)
             //   dL_dmean2D.z =  o * sum(|q| (0.5W |u| + 0.5H |v|))   dL_dconic.yy = -0.5 o * sum(q dy dy)
             //   dL_dopacity  = sum(q)
-            bool any = false;
+            // Predicates as wave-wide masks in scalar registers, built from the compares' own outputs (as in render_fwd.hip, round 5): the
+            // contribution block is entered through one scalar AND on the execution mask, and "did anybody contribute" is a scalar compare.
+            uint64_t any_m = 0ull;
             WG_CNT(0, 1);
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 if (((reach[s] >> j) & 1ull) == 0ull) continue;  // wave-uniform
                 WG_CNT(1, 1);
-                WG_CNT(2, __popcll(__ballot(pos < last[s])));
+                const uint64_t before_last_m = __builtin_amdgcn_ballot_w64(pos < last[s]);
+                WG_CNT(2, __popcll(before_last_m));
                 PairEval e;
-                bool pass;
+                uint64_t pass_m;
                 if (EXACT) {
                     float margin, band;
-                    pass = eval_alpha_banded(sc, pfx[s], pfy[s], e, margin, band);
-                    const bool fragile = pos < last[s] && fabsf(margin) < band;
-                    if (__ballot(fragile) != 0ull) {  // rare: the reference's arithmetic on the record as preprocess wrote it
+                    eval_alpha_banded(sc, pfx[s], pfy[s], e, margin, band);
+                    pass_m = __builtin_amdgcn_ballot_w64(margin >= 0.0f);
+                    const uint64_t fragile_m = before_last_m & __builtin_amdgcn_ballot_w64(fabsf(margin) < band);
+                    if (fragile_m != 0ull) {  // rare: the reference's arithmetic on the record as preprocess wrote it
                         const size_t r = 3 * (size_t)point_list[range.x + pos];
                         float4 q0 = splats[r], q1 = splats[r + 1];
                         halve_conic(q0, q1);
                         float dx, dy, G, alpha;
-                        const bool px = eval_alpha_exact(exact_coef_of(q0, q1), pfx[s], pfy[s], dx, dy, G, alpha);
-                        if (fragile) { pass = px; e.G = G; e.alpha = alpha; }
+                        const float power = eval_alpha_exact_values(exact_coef_of(q0, q1), pfx[s], pfy[s], dx, dy, G, alpha);
+                        const uint64_t px_m = __builtin_amdgcn_ballot_w64(!(power > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha < (1.0f / 255.0f)));
+                        pass_m = (pass_m & ~fragile_m) | (px_m & fragile_m);
+                        if (__builtin_amdgcn_inverse_ballot_w64(fragile_m)) { e.G = G; e.alpha = alpha; }
                     }
                 } else {
-                    pass = eval_alpha(sc, pfx[s], pfy[s], e);
+                    const float p2 = eval_alpha_values(sc, pfx[s], pfy[s], e);
+                    pass_m = __builtin_amdgcn_ballot_w64(p2 <= 0.0f) & __builtin_amdgcn_ballot_w64(e.alpha >= (1.0f / 255.0f));
                 }
-                WG_CNT(3, __popcll(__ballot(pos < last[s] && pass)));
-                WG_CNT(5, __ballot(pos < last[s] && pass) == 0ull ? 1 : 0);
-                if (pos < last[s] && pass) {
-                    any = true;
+                const uint64_t go_m = before_last_m & pass_m;
+                WG_CNT(3, __popcll(go_m));
+                WG_CNT(5, go_m == 0ull ? 1 : 0);
+                any_m |= go_m;
+                if (__builtin_amdgcn_inverse_ballot_w64(go_m)) {
                     const float a = e.alpha;
                     const float inv = __builtin_amdgcn_rcpf(1.0f - a);
                     const float Tn = T[s] * inv;  // T / (1 - alpha), backward.cu:548
@@ -383,7 +391,7 @@ render_backward_kernel(
                     syy += q * e.yy;
                 }
             }
-            if (__ballot(any) == 0ull) continue;
+            if (any_m == 0ull) continue;
             WG_CNT(4, 1);
             const float total = DUAL ? butterfly13(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, ac2r, ac2g, ac2b, lane)
                                      : butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);

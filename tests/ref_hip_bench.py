@@ -75,7 +75,13 @@ def main():
         out.pop("train_ms"), out.pop("train_iters_per_s")
     if not args.no_parity:
         pv = args.parity_variant or args.variant
+        timed_build = None
         if pv != args.variant:
+            # parity against BOTH builds of the reference.  The timed (compiler-default, contracting) build's forward outputs are
+            # kept for a second comparison: what a user's default build of the reference would give on this GPU
+            s.forward()
+            torch.cuda.synchronize()
+            timed_build = dict(color=s.color.cpu().numpy(), radii=s.radii.cpu().numpy(), n_contrib=s.n_contrib.cpu().numpy().reshape(H, W).astype(np.int64))
             ref_hip._lib(args.variant).refhip_release()
             del s
             torch.cuda.empty_cache()
@@ -108,6 +114,17 @@ def main():
         }
         if ref_g:
             out["product_vs_reference"]["grad_max_rel_err_worst"] = max(out["product_vs_reference"]["grad_max_rel_err"].values())
+        if timed_build is not None:
+            e2 = np.abs(h["color"].astype(np.float64) - timed_build["color"]).max(axis=0)
+            between = np.abs(ref_color.astype(np.float64) - timed_build["color"]).max(axis=0)
+            out["product_vs_reference_default_build"] = {
+                "reference_build": args.variant + " (compiler defaults: contraction on -- its fused multiply-adds move a radius or a threshold decision by an ulp here and there)",
+                "pixels_over_1e-4": int((e2 > 1e-4).sum()), "color_max_abs": float(e2.max()),
+                "radii_mismatch": int((h["radii"] != timed_build["radii"]).sum()),
+                "n_contrib_mismatch": int((nv["n_contrib"].cpu().numpy().reshape(H, W).astype(np.int64) != timed_build["n_contrib"]).sum()),
+                "the_reference's_two_builds_differ_from_each_other": {"pixels_over_1e-4": int((between > 1e-4).sum()),
+                                                                      "radii": int((ref_radii != timed_build["radii"]).sum())},
+                "pixels_over_1e-4_where_the_two_reference_builds_agree": int(((e2 > 1e-4) & ~(between > 1e-4)).sum())}
     print(json.dumps(out))
 
 

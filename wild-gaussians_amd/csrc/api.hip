@@ -942,11 +942,9 @@ static int backward_impl(const wg_backward_args& a) {
         StageScope scope_(WG_STAGE_RENDER_BACKWARD, stream);
         const size_t slot_bytes = (((size_t)R * (dual ? 14 : 10) * sizeof(float)) + 255) & ~(size_t)255;   // (the two-colour walk: thirteen sums, padded to fourteen)
         hipError_t e = wg::run_scan(geom, P, stream);
-        if (e == hipSuccess) e = hipMallocAsync(reinterpret_cast<void**>(&det_slots), slot_bytes + (size_t)R + 4, stream);  // (+4: the flags are read as 32-bit words)
-        if (e == hipSuccess) {
-            det_flags = reinterpret_cast<unsigned char*>(det_slots) + slot_bytes;
-            e = hipMemsetAsync(det_flags, 0, (size_t)R, stream);
-        }
+        // (the flags: a whole number of 16-byte words, cleared by the launch that orders the tiles -- no memset of their own)
+        if (e == hipSuccess) e = hipMallocAsync(reinterpret_cast<void**>(&det_slots), slot_bytes + (((size_t)R + 15) & ~(size_t)15), stream);
+        if (e == hipSuccess) det_flags = reinterpret_cast<unsigned char*>(det_slots) + slot_bytes;
         if (e != hipSuccess) return hip_fail(e, "deterministic backward scratch");
     }
     // the gradient records are cleared by the launch that orders the tiles (one launch instead of a fill kernel + the ordering);
@@ -958,8 +956,10 @@ static int backward_impl(const wg_backward_args& a) {
         if (e != hipSuccess) return hip_fail(e, "gradient record memset");
     }
     if (R > 0) {
-        WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_order(img.tile_last, nullptr, img.order_bwd, gx * gy, clear_records ? geom.grad_rec : nullptr,
-                                                             (size_t)P * (wg::GRAD_REC_FLOATS + (dual ? 1 : 0)), stream), "tile_order");
+        // what the ordering launch clears on the side: the gradient records -- or, deterministic mode, the slots' flag bytes
+        float* const clear_ptr = det ? reinterpret_cast<float*>(det_flags) : (clear_records ? geom.grad_rec : nullptr);
+        const size_t clear_floats = det ? ((size_t)R + 3) / 4 : (size_t)P * (wg::GRAD_REC_FLOATS + (dual ? 1 : 0));
+        WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_order(img.tile_last, nullptr, img.order_bwd, gx * gy, clear_ptr, clear_floats, stream), "tile_order");
         WG_STAGE(WG_STAGE_RENDER_BACKWARD, wg::launch_render_backward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, dL_dpix,
                                             dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, opt.exact_compositing != 0, dual ? second->dL_dpix2 : nullptr, det_slots, det_flags, (size_t)R, P, stream),
                  "render_backward");

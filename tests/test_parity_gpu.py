@@ -872,6 +872,17 @@ def test_bench_flow_with_two_ranks(tmp_path):
     assert d["collective_backend"] == ("gloo" if torch.cuda.device_count() < 2 else "nccl")
     assert max(d["per_rank_ms_per_step"].values()) <= d["ms_per_step"] * 1.001
     assert abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) <= 1e-2 * d["value"]  # whole-job rate: both ranks' steps over the slowest rank's time
+    assert all(v["views"] == 1 and v["instances"] > 0 for v in d["per_rank_num_rendered"].values())
+    # BASELINE config 4's shape: a FIXED batch of views dealt round-robin over the ranks (`--views`, strong scaling): rank 0 renders views
+    # 0 and 2, rank 1 views 1 and 3 of every step; the job's value counts the batch's four iterations per step
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--views", "4", "--steps", "10", "--warmup", "2",
+                        "--gaussians", "200000", "--width", "640", "--height", "360"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["views_per_step"] == 4 and d["config"]["views_of_rank0"] == [0, 2]
+    assert {k: v["views"] for k, v in d["per_rank_num_rendered"].items()} == {"0": 2, "1": 2}
+    assert abs(d["value"] - 4 * 1000.0 / d["ms_per_step"]) <= 1e-2 * d["value"]
 
 
 def test_input_layouts_and_partial_gradients():

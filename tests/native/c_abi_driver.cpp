@@ -5,7 +5,7 @@
 //   * evidence that the boundary really is "plain pointers and sizes, no torch types" (tests/test_native_driver.py).
 // Since round 5 everything beyond the reference goes through wg_rasterize_{forward,backward}_ex (one struct, optional blocks, per-call
 // options): the two-colour, raw-parameter, toned, two-tone and recolouring calls are driven through it and their images checked, bit for bit, against plain
-// (toned) calls.
+// (toned) calls; the deterministic backward runs twice (bit-identical) beside the atomic one.
 // Prints one line "ok num_rendered=... checksum=..." and exits 0, or a diagnostic and a non-zero code.
 // With a fourth argument (a path) it also DUMPS its inputs and every output of the three calls there, raw little-endian:
 //   int32 {P, W, H, D, M, R}, float32 {tanx, tany}, then float32 arrays means[3P] scales[3P] rots[4P] opac[P] shs[3MP] view[16] proj[16]
@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <utility>
 #include <vector>
 #include "wg_rasterizer.h"
@@ -175,6 +176,47 @@ int main(int argc, char** argv) {
             std::fprintf(stderr, "a result-affecting switch is still process-wide\n");
             return 9;
         }
+    }
+    {   // deterministic backward (per-call option, backward only): three passes over the one frame, a synchronisation between them (what
+        // retain_graph=True does), must agree bit for bit -- and with the atomic sums' gradients up to the order of the additions.
+        // (Round 5: with the scratch taken from the device's DEFAULT memory pool the second pass lost sums -- api.hip: det_scratch_alloc.)
+        auto fetch = [&](const float* d, size_t n, std::vector<float>& h) { h.resize(n); return hipMemcpy(h.data(), d, n * 4, hipMemcpyDeviceToHost); };
+        struct { const char* name; const float* d; size_t n; } arr[] = {{"dL_dmean2D", g2d, 3 * (size_t)P}, {"dL_dconic", gcon, 4 * (size_t)P},
+            {"dL_dopacity", gop, (size_t)P}, {"dL_dcolor", gcol, 3 * (size_t)P}, {"dL_dmean3D", g3d, 3 * (size_t)P}, {"dL_dcov3D", gcov, 6 * (size_t)P},
+            {"dL_dsh", gsh, 3 * (size_t)P * M}, {"dL_dscale", gsc, 3 * (size_t)P}, {"dL_drot", grot, 4 * (size_t)P}};
+        constexpr int NA = 9;
+        std::vector<float> ref[NA], first[NA], cur;
+        CHECK_HIP(hipStreamSynchronize(stream));
+        for (int a = 0; a < NA; a++) CHECK_HIP(fetch(arr[a].d, arr[a].n, ref[a]));
+        const wg_call_options det = {1, 1, 1};
+        for (int rep = 0; rep < 3; rep++) {
+            wg_backward_args da = bwd_args(D, M, R, d_shs, nullptr, d_scales, d_rots, geom.p, bin.p, img.p, gcon, gcol, gsh);
+            da.options = &det;
+            const int sd = wg_rasterize_backward_ex(&da);
+            if (sd != WG_OK) { std::fprintf(stderr, "deterministic backward: %s (%s)\n", wg_status_string(sd), wg_last_hip_error()); return 16; }
+            CHECK_HIP(hipStreamSynchronize(stream));
+            for (int a = 0; a < NA; a++) {
+                CHECK_HIP(fetch(arr[a].d, arr[a].n, rep ? cur : first[a]));
+                if (!rep) continue;
+                size_t bad = 0, k0 = 0;
+                for (size_t k = 0; k < arr[a].n; k++)
+                    if (std::memcmp(&first[a][k], &cur[k], 4)) { if (!bad++) k0 = k; }
+                if (bad) {
+                    std::fprintf(stderr, "deterministic backward: pass %d differs from pass 0 in %zu of %zu elements of %s, first at %zu: %.9g vs %.9g\n", rep, bad,
+                                 arr[a].n, arr[a].name, k0, cur[k0], first[a][k0]);
+                    return 16;
+                }
+            }
+        }
+        for (int a = 0; a < NA; a++) {
+            double mx = 0, md = 0;
+            for (size_t k = 0; k < arr[a].n; k++) { mx = std::fmax(mx, std::fabs(ref[a][k])); md = std::fmax(md, std::fabs(first[a][k] - ref[a][k])); }
+            if (!(md <= 1e-4 * mx)) { std::fprintf(stderr, "deterministic backward: %s off the atomic sums by %g of %g\n", arr[a].name, md, mx); return 16; }
+        }
+        if (wg_set_option("release_scratch", 1) != WG_OK) { std::fprintf(stderr, "release_scratch: %s\n", wg_last_hip_error()); return 16; }
+        // and an atomic-sum call straight after it
+        wg_backward_args pa = bwd_args(D, M, R, d_shs, nullptr, d_scales, d_rots, geom.p, bin.p, img.p, gcon, gcol, gsh);
+        if (wg_rasterize_backward_ex(&pa) != WG_OK) { std::fprintf(stderr, "plain backward after the deterministic ones: %s\n", wg_last_hip_error()); return 16; }
     }
     // geometry reuse: the same Gaussians and camera with other (precomputed) colours ride on the first call's projection and binning
     {

@@ -1013,6 +1013,34 @@ def test_deterministic_backward_mode_is_bit_reproducible(oracle, record_option):
         assert e <= 1e-3, (k, e)
 
 
+def test_deterministic_backward_passes_over_one_frame_agree(record_option):
+    """retain_graph=True: several deterministic backward passes over ONE forward call's buffers, the host synchronising in between.
+    (tests/native/c_abi_driver.cpp found the second such pass losing sums when the scratch came from the device's default memory pool:
+    api.hip det_scratch_alloc.)  Also: the scratch pool can be emptied between calls ("release_scratch")."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    _C = record_option
+    W, H, P = 320, 200, 20_000
+    cam, cot = S.make_camera(W, H), to_dev(S.make_cotangent(W, H))
+    cloud = S.make_cloud(P, W, H, sh_degree=1, seed=5, scale_mult=8.0)
+    t = {k: to_dev(v).requires_grad_(True) for k, v in cloud.items()}
+    m2 = torch.zeros_like(t["means3D"], requires_grad=True)
+    leaves = [t["means3D"], m2, t["opacities"], t["shs"], t["scales"], t["rotations"]]
+    color, _, _ = GaussianRasterizer(make_settings(cam, 1))(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], shs=t["shs"], scales=t["scales"],
+                                                            rotations=t["rotations"], deterministic_backward=True)
+    first = None
+    for rep in range(4):
+        g = torch.autograd.grad(color, leaves, cot, retain_graph=True)
+        g = [x.cpu() for x in g]   # (synchronises)
+        if rep == 2:
+            _C.set_option("release_scratch", 1)
+        if first is None:
+            first = g
+            assert all(bool(x.abs().max() > 0) for x in g)
+        else:
+            for a, b in zip(first, g):
+                assert torch.equal(a, b), rep
+
+
 def test_deterministic_backward_without_any_instance_gives_zeros(record_option):
     """deterministic_backward = 1 with grad_record = 0 and NO instance rendered (every Gaussian behind the camera).  The
     binding passes no dL_dconic and uninitialised accumulation targets on the strength of the options alone, so the library must take

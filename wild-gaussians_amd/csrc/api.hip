@@ -416,6 +416,48 @@ static wg::ShTone device_tone(const wg_sh_tone* t, const wg_sh_tone* t2 = nullpt
 // than the forward call that made the image state would differentiate / recomposite decisions the stored per-pixel state does not hold.
 // Host-side only (no device traffic): the last 64 frames, keyed by the 256-byte-aligned image-state address; an address handed out
 // again by the caller's allocator is simply overwritten by the next forward call that gets it.
+#ifdef WG_DET_POISON
+extern "C" { float* wg_debug_det_slots = nullptr; unsigned char* wg_debug_det_flags = nullptr; }
+#endif
+// Stream-ordered scratch of the deterministic backward, from a memory pool OF THE LIBRARY'S OWN (one per device) that keeps what it
+// holds (release threshold = everything) until wg_set_option("release_scratch", 1).  Not the device's default pool: with its default
+// release threshold (0) that pool hands its free memory back to the system at every synchronisation of the caller, the next
+// hipMallocAsync maps it again -- and on ROCm 7.2 / MI355X the first kernels to write such re-acquired memory lost some of their stores
+// (repeated deterministic backward passes over one frame with a hipStreamSynchronize between them, as retain_graph=True makes them:
+// the second pass missed the sums of ~6 % of the Gaussians; never when the block was kept, leaked, or came from hipMalloc --
+// tests/native/c_abi_driver.cpp holds the case, EXPERIMENTS.md R5.10).  Keeping the memory also saves the map / unmap per call.
+std::mutex g_pool_mu;
+hipMemPool_t g_det_pools[64] = {};
+hipError_t det_scratch_alloc(void** out, size_t bytes, hipStream_t stream) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    hipMemPool_t pool;
+    {
+        std::lock_guard<std::mutex> l(g_pool_mu);
+        if (!g_det_pools[dev]) {
+            hipMemPoolProps props = {};
+            props.allocType = hipMemAllocationTypePinned;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = dev;
+            e = hipMemPoolCreate(&g_det_pools[dev], &props);
+            uint64_t keep = ~0ull;
+            if (e == hipSuccess) e = hipMemPoolSetAttribute(g_det_pools[dev], hipMemPoolAttrReleaseThreshold, &keep);
+            if (e != hipSuccess) { if (g_det_pools[dev]) (void)hipMemPoolDestroy(g_det_pools[dev]); g_det_pools[dev] = nullptr; return e; }
+        }
+        pool = g_det_pools[dev];
+    }
+    return hipMallocFromPoolAsync(out, bytes, pool, stream);
+}
+// wg_set_option("release_scratch", 1): what the pools hold and no call is using goes back to the system
+int det_scratch_release() {
+    std::lock_guard<std::mutex> l(g_pool_mu);
+    for (hipMemPool_t p : g_det_pools)
+        if (p && hipMemPoolTrimTo(p, 0) != hipSuccess) return WG_ERR_HIP;
+    return WG_OK;
+}
+
 struct FrameMode { const void* image; int exact; };
 std::mutex g_mode_mu;
 FrameMode g_modes[64];
@@ -928,13 +970,18 @@ static int backward_impl(const wg_backward_args& a) {
     // slot scratch, its scan and the ordered sum need instances to exist.  With nothing rendered the cleared record gives zeros.
     const bool det = opt.deterministic_backward != 0 && R > 0;
     const bool record = g_grad_record != 0 || opt.deterministic_backward != 0;
-    // stream-ordered scratch of the deterministic mode, released on every way out of this function
+    // stream-ordered scratch of the deterministic mode (from the library's own pool: det_scratch_alloc), handed back on every way out of this function
     struct DetSlots {
         float* p = nullptr;
         hipStream_t s;
         explicit DetSlots(hipStream_t st) : s(st) {}
+#ifdef WG_DET_POISON   // (the debugging build leaks the scratch so that the caller can look at it: wg_debug_det_slots / _flags)
+        ~DetSlots() {}
+        hipError_t release() { p = nullptr; return hipSuccess; }
+#else
         ~DetSlots() { if (p) (void)hipFreeAsync(p, s); }
         hipError_t release() { float* q = p; p = nullptr; return q ? hipFreeAsync(q, s) : hipSuccess; }
+#endif
     } det_guard(stream);
     float*& det_slots = det_guard.p;
     unsigned char* det_flags = nullptr;
@@ -943,8 +990,13 @@ static int backward_impl(const wg_backward_args& a) {
         const size_t slot_bytes = (((size_t)R * (dual ? 14 : 10) * sizeof(float)) + 255) & ~(size_t)255;   // (the two-colour walk: thirteen sums, padded to fourteen)
         hipError_t e = wg::run_scan(geom, P, stream);
         // (the flags: a whole number of 16-byte words, cleared by the launch that orders the tiles -- no memset of their own)
-        if (e == hipSuccess) e = hipMallocAsync(reinterpret_cast<void**>(&det_slots), slot_bytes + (((size_t)R + 15) & ~(size_t)15), stream);
+        if (e == hipSuccess) e = det_scratch_alloc(reinterpret_cast<void**>(&det_slots), slot_bytes + (((size_t)R + 15) & ~(size_t)15), stream);
         if (e == hipSuccess) det_flags = reinterpret_cast<unsigned char*>(det_slots) + slot_bytes;
+#ifdef WG_DET_POISON   // debugging aid: a slot that is read without having been written in THIS call shows up as NaN gradients
+        if (e == hipSuccess) e = hipMemsetAsync(det_slots, 0xFF, slot_bytes, stream);
+        if (e == hipSuccess) std::fprintf(stderr, "[det] slots %p, %zu + %zu bytes, R %d\n", (void*)det_slots, slot_bytes, (size_t)(((size_t)R + 15) & ~(size_t)15), R);
+        wg_debug_det_slots = det_slots; wg_debug_det_flags = det_flags;
+#endif
         if (e != hipSuccess) return hip_fail(e, "deterministic backward scratch");
     }
     // the gradient records are cleared by the launch that orders the tiles (one launch instead of a fill kernel + the ordering);
@@ -1039,6 +1091,7 @@ int wg_set_option(const char* name, int value) {
         g_roctx.enabled = value != 0;
         return WG_OK;
     }
+    if (std::strcmp(name, "release_scratch") == 0) return value != 0 ? det_scratch_release() : WG_OK;   // (an action, not a setting)
     std::lock_guard<std::mutex> l(g_opt_mu);
     wg::Options& o = g_opt;
     if (std::strcmp(name, "force_global_sort") == 0) { o.force_global_sort = value != 0; return WG_OK; }

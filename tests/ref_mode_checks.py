@@ -300,3 +300,31 @@ def check_raw(case, ref_hip, seed=0):
     g["means2D_abs_column"] = rel_err(got[:, 2], r["grads"]["means2D"][:, 2])
     rep["grads"] = g
     return _verdict(rep, radii, r["radii"], acc, r)
+
+
+# ---- geometry outside the reference's domain (NaN / Inf / zero / negative parameters): tests/tools/nonfinite_inputs.py explores, the suite pins ----
+_NAN, _INF = np.float32(np.nan), np.float32(np.inf)
+NONFINITE_CATEGORIES = {   # name -> (cloud key, component or None = the whole row, value)
+    "means x NaN": ("means3D", 0, _NAN), "means z NaN": ("means3D", 2, _NAN), "means x +Inf": ("means3D", 0, _INF), "means y -Inf": ("means3D", 1, -_INF),
+    "means z +Inf": ("means3D", 2, _INF), "means z 1e30": ("means3D", 2, np.float32(1e30)),
+    "scale NaN": ("scales", 0, _NAN), "scale +Inf": ("scales", 1, _INF), "scale 0": ("scales", 2, np.float32(0)), "scale -1": ("scales", 0, np.float32(-1)),
+    "scale 1e20": ("scales", 0, np.float32(1e20)),
+    "rot NaN": ("rotations", 0, _NAN), "rot all zero": ("rotations", None, np.float32(0)), "rot +Inf": ("rotations", 1, _INF),
+    "opacity NaN": ("opacities", 0, _NAN), "opacity +Inf": ("opacities", 0, _INF), "opacity -1": ("opacities", 0, np.float32(-1)), "opacity 7": ("opacities", 0, np.float32(7)),
+}
+# The two categories in which the product does NOT do what the reference's kernels do: a NaN opacity, or a NaN conic (from a NaN
+# quaternion component with finite cov2D diagonal), makes the reference's alpha = min(0.99f, NaN) = 0.99 on EVERY pixel of the Gaussian's
+# tile rectangle (forward.cu:358: fminf returns its non-NaN argument) -- an opaque block.  The product draws nothing for such a Gaussian
+# (NaN fails its reach test and its exp expansion's clamp).  Neither is meaningful; the suite pins "finite image, same radii".
+NONFINITE_DEVIATING = ("rot NaN", "opacity NaN")
+
+
+def poison(cloud, name, ids):
+    """A copy of the cloud with category `name` applied to the Gaussians `ids`."""
+    key, comp, val = NONFINITE_CATEGORIES[name]
+    c = {k: v.copy() for k, v in cloud.items()}
+    if comp is None:
+        c[key][ids] = val
+    else:
+        c[key][ids, comp] = val
+    return c

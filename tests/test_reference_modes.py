@@ -96,3 +96,36 @@ def test_call_modes_at_config3_size_beside_the_reference(ref_hip, mode):
     print(rep)
     _assert_ok(rep)
     torch.cuda.empty_cache()
+
+
+def test_geometry_outside_the_reference_domain(ref_hip):
+    """NaN / +-Inf / zero / negative means, scales, quaternions and opacities (tests/ref_mode_checks.py: NONFINITE_CATEGORIES), eight
+    Gaussians of 20 000 each: in sixteen of the eighteen categories the product does exactly what the reference's kernels do (radii and
+    accumulation bit-identical, image within 1e-6); in the other two (NONFINITE_DEVIATING: the reference composites alpha = fminf(0.99,
+    NaN) = 0.99 over the Gaussian's whole tile rectangle, the product draws nothing) the radii agree and the image stays finite.  All
+    eighteen at once -- on which the reference's own kernels end in a memory access fault (profiles/r5/nonfinite_inputs_ref.log) -- leave
+    the product with a finite image and no fault (tests/tools/nonfinite_inputs.py prints the table)."""
+    from wg_testlib import run_hip
+    W, H, P = 640, 360, 20_000
+    cam = S.make_camera(W, H)
+    base = S.make_cloud(P, W, H, sh_degree=1, seed=11, scale_mult=2.0)
+    rng = np.random.default_rng(3)
+    every, untouched = base, np.ones(P, bool)
+    for name in RC.NONFINITE_CATEGORIES:
+        ids = rng.choice(P, size=8, replace=False)
+        every = RC.poison(every, name, ids)
+        untouched[ids] = False
+        cloud = RC.poison(base, name, ids)
+        h = run_hip(cloud, cam, sh_degree=1)
+        r = ref_hip.run_scene(cloud, cam, sh_degree=1, variant="nofma")
+        assert np.array_equal(h["radii"], r["radii"]), name
+        assert np.isfinite(h["color"]).all() and np.isfinite(h["accumulation"]).all(), name
+        if name not in RC.NONFINITE_DEVIATING:
+            assert np.array_equal(h["accumulation"], r["accumulation"]), name
+            assert float(np.abs(h["color"].astype(np.float64) - r["color"]).max()) <= 1e-6, name
+    cot = S.make_cotangent(W, H)
+    h = run_hip(every, cam, sh_degree=1, cotangent=cot)
+    assert np.isfinite(h["color"]).all() and np.isfinite(h["accumulation"]).all()
+    for k, g in h["grads"].items():   # the poisoned Gaussians' own gradients may be anything; nobody else's may be non-finite
+        bad = ~np.isfinite(g.reshape(P, -1)[untouched]).all(axis=1)
+        assert not bad.any(), (k, int(bad.sum()))

@@ -15,7 +15,7 @@ export WG_RASTERIZER_LIB=$PWD/wild-gaussians_amd/build/asan/libwg_rasterizer.so
   # 1. no interpreter in between: the torch-free driver (tests/native/c_abi_driver.cpp), itself built with ASan, runs a forward +
   #    backward + markVisible through the instrumented library on the GPU (nothing to run without one)
   if [ -e /dev/kfd ]; then
-    echo "== C-ABI driver under ASan (forward + backward + markVisible + recolor + two-colour + raw-parameter + two-tone calls, 20000 Gaussians @ 320x200, then 200000 @ 1280x720)"
+    echo "== C-ABI driver under ASan (forward + backward + markVisible + recolor + two-colour + raw-parameter + two-tone calls, three deterministic passes over one frame, three concurrent callers; 20000 Gaussians @ 320x200, then 200000 @ 1280x720)"
     env -u LD_PRELOAD wild-gaussians_amd/build/asan/c_abi_driver 2>&1 | tail -20; echo "rc=${PIPESTATUS[0]}"
     env -u LD_PRELOAD wild-gaussians_amd/build/asan/c_abi_driver 200000 1280 720 2>&1 | tail -20; echo "rc=${PIPESTATUS[0]}"
   fi

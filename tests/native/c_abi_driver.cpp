@@ -5,18 +5,21 @@
 //   * evidence that the boundary really is "plain pointers and sizes, no torch types" (tests/test_native_driver.py).
 // Since round 5 everything beyond the reference goes through wg_rasterize_{forward,backward}_ex (one struct, optional blocks, per-call
 // options): the two-colour, raw-parameter, toned, two-tone and recolouring calls are driven through it and their images checked, bit for bit, against plain
-// (toned) calls; the deterministic backward runs twice (bit-identical) beside the atomic one.
+// (toned) calls; the deterministic backward runs three times over one frame (bit-identical) beside the atomic one; three host threads then
+// call forward + backward concurrently on their own streams.
 // Prints one line "ok num_rendered=... checksum=..." and exits 0, or a diagnostic and a non-zero code.
 // With a fourth argument (a path) it also DUMPS its inputs and every output of the three calls there, raw little-endian:
 //   int32 {P, W, H, D, M, R}, float32 {tanx, tany}, then float32 arrays means[3P] scales[3P] rots[4P] opac[P] shs[3MP] view[16] proj[16]
 //   campos[3] bg[3] cot[3WH] | color[3WH] g2d[3P] gcon[4P] gop[P] gcol[3P] g3d[3P] gcov[6P] gsh[3MP] gsc[3P] grot[4P], int32 radii[P],
 //   uint8 vis[P] -- tests/test_native_driver.py feeds the same inputs to the CPU oracle and compares everything.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <utility>
 #include <vector>
 #include "wg_rasterizer.h"
@@ -385,6 +388,61 @@ int main(int argc, char** argv) {
     for (float v : gm) { if (!std::isfinite(v)) { std::fprintf(stderr, "non-finite gradient\n"); return 7; } gsum += std::fabs(v); }
     for (int i = 0; i < P; i++) { nvis += vis[i]; nrad += radii[i] > 0; }
     if (nrad == 0 || nvis < nrad || gsum <= 0) { std::fprintf(stderr, "implausible outputs: nrad %d nvis %d gsum %g\n", nrad, nvis, gsum); return 8; }
+    {   // concurrent callers: three host threads, a stream and scratch buffers each, the same frame, eight forward + backward calls each, all
+        // in flight together (no interpreter lock in the way): every image bit for bit the one above, dL_dmean3D within the atomic sums'
+        // rounding -- thread 1 in the deterministic mode (bit for bit across its calls), thread 2 without speculation
+        std::atomic<int> failures{0};
+        auto caller = [&](int tid) {
+            hipStream_t st;
+            Grow g, b, i;
+            float *out = nullptr, *t2d = nullptr, *tcon = nullptr, *top = nullptr, *tcol = nullptr, *t3d = nullptr, *tcov = nullptr, *tsh = nullptr, *tsc = nullptr, *trot = nullptr;
+            int* rad = nullptr;
+            bool ok = hipStreamCreate(&st) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&out), (size_t)3 * W * H * 4) == hipSuccess &&
+                      hipMalloc(reinterpret_cast<void**>(&rad), (size_t)P * 4) == hipSuccess;
+            const std::pair<float**, size_t> gr[] = {{&t2d, 3u * (size_t)P}, {&tcon, 4u * (size_t)P}, {&top, (size_t)P}, {&tcol, 3u * (size_t)P}, {&t3d, 3u * (size_t)P},
+                                                     {&tcov, 6u * (size_t)P}, {&tsh, (size_t)P * M * 3}, {&tsc, 3u * (size_t)P}, {&trot, 4u * (size_t)P}};
+            for (const auto& q : gr) ok = ok && hipMalloc(reinterpret_cast<void**>(q.first), q.second * 4) == hipSuccess;
+            std::vector<float> himg(color.size()), hg(gm.size()), hg0;
+            const wg_call_options det = {1, 1, 1};
+            for (int it = 0; ok && it < 8; it++) {
+                wg_forward_args fa{};
+                fa.struct_size = sizeof(fa);
+                fa.geometry_alloc = Grow::alloc; fa.geometry_user = &g; fa.binning_alloc = Grow::alloc; fa.binning_user = &b; fa.image_alloc = Grow::alloc; fa.image_user = &i;
+                fa.P = P; fa.D = D; fa.M = M; fa.width = W; fa.height = H; fa.scale_modifier = 1.0f; fa.tan_fovx = tanx; fa.tan_fovy = tany; fa.kernel_size = 0.1f;
+                fa.background = d_bg; fa.means3D = d_means; fa.shs = d_shs; fa.opacities = d_opac; fa.scales = d_scales; fa.rotations = d_rots;
+                fa.viewmatrix = d_view; fa.projmatrix = d_proj; fa.cam_pos = d_campos; fa.out_color = out; fa.radii = rad; fa.stream = st;
+                const int Rt = wg_rasterize_forward_ex(&fa);
+                wg_backward_args ba{};
+                ba.struct_size = sizeof(ba);
+                ba.P = P; ba.D = D; ba.M = M; ba.R = Rt; ba.width = W; ba.height = H; ba.scale_modifier = 1.0f; ba.tan_fovx = tanx; ba.tan_fovy = tany; ba.kernel_size = 0.1f;
+                ba.background = d_bg; ba.means3D = d_means; ba.shs = d_shs; ba.scales = d_scales; ba.rotations = d_rots; ba.viewmatrix = d_view; ba.projmatrix = d_proj;
+                ba.campos = d_campos; ba.radii = rad; ba.geom_buffer = g.p; ba.binning_buffer = b.p; ba.image_buffer = i.p; ba.dL_dpix = d_cot;
+                ba.dL_dmean2D = t2d; ba.dL_dconic = tcon; ba.dL_dopacity = top; ba.dL_dcolor = tcol; ba.dL_dmean3D = t3d; ba.dL_dcov3D = tcov; ba.dL_dsh = tsh;
+                ba.dL_dscale = tsc; ba.dL_drot = trot; ba.stream = st;
+                if (tid == 1) ba.options = &det;
+                ok = Rt == R && wg_rasterize_backward_ex(&ba) == WG_OK && hipStreamSynchronize(st) == hipSuccess &&
+                     hipMemcpy(himg.data(), out, himg.size() * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                     hipMemcpy(hg.data(), t3d, hg.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+                if (!ok) { std::fprintf(stderr, "concurrent caller %d, call %d: R %d (%s)\n", tid, it, Rt, wg_last_hip_error()); break; }
+                if (std::memcmp(himg.data(), color.data(), himg.size() * 4)) { std::fprintf(stderr, "concurrent caller %d, call %d: another image\n", tid, it); ok = false; break; }
+                double mx = 0, md = 0;
+                for (size_t k = 0; k < hg.size(); k++) { mx = std::fmax(mx, std::fabs(gm[k])); md = std::fmax(md, std::fabs(hg[k] - gm[k])); }
+                if (!(md <= 1e-5 * mx)) { std::fprintf(stderr, "concurrent caller %d, call %d: dL_dmean3D off by %g of %g\n", tid, it, md, mx); ok = false; break; }
+                if (tid == 1) {
+                    if (it == 0) hg0 = hg;
+                    else if (std::memcmp(hg0.data(), hg.data(), hg.size() * 4)) { std::fprintf(stderr, "concurrent caller 1, call %d: deterministic gradients differ\n", it); ok = false; break; }
+                }
+            }
+            if (!ok) failures++;
+            for (const auto& q : gr) (void)hipFree(*q.first);
+            for (void* q : {(void*)out, (void*)rad, (void*)g.p, (void*)b.p, (void*)i.p}) (void)hipFree(q);
+            (void)hipStreamDestroy(st);
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < 3; t++) th.emplace_back(caller, t);
+        for (auto& t : th) t.join();
+        if (failures.load()) { std::fprintf(stderr, "%d of 3 concurrent callers failed\n", failures.load()); return 17; }
+    }
     if (argc > 4) {
         std::FILE* f = std::fopen(argv[4], "wb");
         if (!f) { std::fprintf(stderr, "cannot open %s\n", argv[4]); return 9; }

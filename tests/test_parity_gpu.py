@@ -299,6 +299,56 @@ def test_runs_on_non_default_stream_and_is_deterministic_forward():
     assert torch.equal(out, ref)  # forward is bit-reproducible (no atomics on the forward path)
 
 
+def test_concurrent_callers_on_their_own_streams():
+    """Four host threads, a stream each, different frames (sizes, SH degrees, a dense one on the lazy-sort path, one with precomputed
+    colours, one in the deterministic backward mode), 20 forward + backward calls each, all in flight together: every call's image,
+    radii and accumulation are bit for bit what the frame gives alone, its gradients within the atomic sums' rounding (the
+    deterministic one's bit for bit).  What is shared between the callers: the library's option / mode / mailbox / pool tables, the
+    device, and (PyTorch's design) the one autograd thread every backward call runs on."""
+    import threading
+    frames = [dict(P=30_000, W=640, H=360, deg=3, seed=21, scale=1.0, det=False),
+              dict(P=60_000, W=800, H=448, deg=1, seed=22, scale=3.0, det=False),
+              dict(P=20_000, W=320, H=200, deg=None, seed=23, scale=2.0, det=False),
+              dict(P=50_000, W=960, H=544, deg=2, seed=24, scale=2.0, det=True)]
+    from diff_gaussian_rasterization import call_options
+    jobs = []
+    for f in frames:
+        cam, cot = S.make_camera(f["W"], f["H"]), S.make_cotangent(f["W"], f["H"], seed=f["seed"])
+        cloud = S.make_cloud(f["P"], f["W"], f["H"], sh_degree=f["deg"], seed=f["seed"], scale_mult=f["scale"])
+        with call_options(deterministic_backward=f["det"]):
+            alone = run_hip(cloud, cam, sh_degree=f["deg"] or 0, cotangent=cot)
+        jobs.append((f, cam, cot, cloud, alone))
+    torch.cuda.synchronize()
+    errors, start = [], threading.Barrier(len(jobs))
+
+    def caller(f, cam, cot, cloud, alone):
+        try:
+            stream = torch.cuda.Stream()
+            start.wait(timeout=60)
+            with torch.cuda.stream(stream), call_options(deterministic_backward=f["det"]):
+                for it in range(20):
+                    h = run_hip(cloud, cam, sh_degree=f["deg"] or 0, cotangent=cot)
+                    for k in ("color", "radii", "accumulation"):
+                        if not np.array_equal(h[k], alone[k]):
+                            errors.append((f["seed"], it, k, "differs from the frame alone"))
+                    for k, g in h["grads"].items():
+                        if f["det"]:
+                            if not np.array_equal(g, alone["grads"][k]):
+                                errors.append((f["seed"], it, k, "deterministic gradients differ"))
+                        elif rel_err(g, alone["grads"][k]) > 2e-6:
+                            errors.append((f["seed"], it, k, rel_err(g, alone["grads"][k])))
+        except Exception as ex:   # noqa: BLE001  (reported by the main thread)
+            errors.append((f["seed"], repr(ex)))
+
+    threads = [threading.Thread(target=caller, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a caller is stuck"
+    assert not errors, errors[:8]
+
+
 def test_all_culled_and_single_gaussian(oracle):
     W, H = 64, 48
     cam = S.make_camera(W, H)

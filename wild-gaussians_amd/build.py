@@ -91,7 +91,7 @@ def build_driver(force: bool = False) -> str:
     out = os.path.join(OBJ, "c_abi_driver")
     lib = build(force)
     if force or _newer(out, [src, lib, os.path.join(INCLUDE, "wg_rasterizer.h")]):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-I" + INCLUDE] + EXTRA + [src, "-o", out, "-L" + os.path.dirname(lib),
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-pthread", "-I" + INCLUDE] + EXTRA + [src, "-o", out, "-L" + os.path.dirname(lib),
                "-lwg_rasterizer", "-Wl,-rpath," + os.path.dirname(lib)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

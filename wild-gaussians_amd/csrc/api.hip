@@ -416,9 +416,6 @@ static wg::ShTone device_tone(const wg_sh_tone* t, const wg_sh_tone* t2 = nullpt
 // than the forward call that made the image state would differentiate / recomposite decisions the stored per-pixel state does not hold.
 // Host-side only (no device traffic): the last 64 frames, keyed by the 256-byte-aligned image-state address; an address handed out
 // again by the caller's allocator is simply overwritten by the next forward call that gets it.
-#ifdef WG_DET_POISON
-extern "C" { float* wg_debug_det_slots = nullptr; unsigned char* wg_debug_det_flags = nullptr; }
-#endif
 // Stream-ordered scratch of the deterministic backward, from a memory pool OF THE LIBRARY'S OWN (one per device) that keeps what it
 // holds (release threshold = everything) until wg_set_option("release_scratch", 1).  Not the device's default pool: with its default
 // release threshold (0) that pool hands its free memory back to the system at every synchronisation of the caller, the next
@@ -975,13 +972,8 @@ static int backward_impl(const wg_backward_args& a) {
         float* p = nullptr;
         hipStream_t s;
         explicit DetSlots(hipStream_t st) : s(st) {}
-#ifdef WG_DET_POISON   // (the debugging build leaks the scratch so that the caller can look at it: wg_debug_det_slots / _flags)
-        ~DetSlots() {}
-        hipError_t release() { p = nullptr; return hipSuccess; }
-#else
         ~DetSlots() { if (p) (void)hipFreeAsync(p, s); }
         hipError_t release() { float* q = p; p = nullptr; return q ? hipFreeAsync(q, s) : hipSuccess; }
-#endif
     } det_guard(stream);
     float*& det_slots = det_guard.p;
     unsigned char* det_flags = nullptr;
@@ -992,10 +984,8 @@ static int backward_impl(const wg_backward_args& a) {
         // (the flags: a whole number of 16-byte words, cleared by the launch that orders the tiles -- no memset of their own)
         if (e == hipSuccess) e = det_scratch_alloc(reinterpret_cast<void**>(&det_slots), slot_bytes + (((size_t)R + 15) & ~(size_t)15), stream);
         if (e == hipSuccess) det_flags = reinterpret_cast<unsigned char*>(det_slots) + slot_bytes;
-#ifdef WG_DET_POISON   // debugging aid: a slot that is read without having been written in THIS call shows up as NaN gradients
+#ifdef WG_DET_POISON   // debugging aid (variant build): a slot that is read without having been written in THIS call shows up as NaN gradients
         if (e == hipSuccess) e = hipMemsetAsync(det_slots, 0xFF, slot_bytes, stream);
-        if (e == hipSuccess) std::fprintf(stderr, "[det] slots %p, %zu + %zu bytes, R %d\n", (void*)det_slots, slot_bytes, (size_t)(((size_t)R + 15) & ~(size_t)15), R);
-        wg_debug_det_slots = det_slots; wg_debug_det_flags = det_flags;
 #endif
         if (e != hipSuccess) return hip_fail(e, "deterministic backward scratch");
     }

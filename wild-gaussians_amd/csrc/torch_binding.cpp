@@ -336,7 +336,12 @@ py::tuple RasterizeGaussiansBackwardEx(const torch::Tensor& background, const to
             a.raw = &raw;
         }
         a.options = &co;
-        check(wg_rasterize_backward_ex(&a), "wg_rasterize_backward");
+        int status;
+        {
+            py::gil_scoped_release nogil;   // (as the forward call: a deferred frame's verdict may be waited for here)
+            status = wg_rasterize_backward_ex(&a);
+        }
+        check(status, "wg_rasterize_backward");
     }
     py::list out;
     for (const auto& t : {dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations}) out.append(t);   // :201

@@ -95,9 +95,91 @@ def kernel_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
+PRODUCT_LIB = os.path.join(ROOT, "wild-gaussians_amd", "diff_gaussian_rasterization", "libwg_rasterizer.so")
+
+
+def _elf_sections(b: bytes) -> dict:
+    """name -> [(offset, size)] of a little-endian ELF64 image (the library, or a gfx950 code object inside its fat binary)."""
+    import struct
+    shoff = struct.unpack_from("<Q", b, 0x28)[0]
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+    sh = lambda i: struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize)   # noqa: E731
+    so = sh(shstrndx)
+    names = b[so[4]:so[4] + so[5]]
+    out = {}
+    for i in range(shnum):
+        s_ = sh(i)
+        out.setdefault(names[s_[0]:names.index(b"\0", s_[0])].decode(), []).append((s_[4], s_[5]))
+    return out
+
+
+_DEVICE_SHA = {}
+RUNNING_LIB = PRODUCT_LIB   # main() sets it to the library the binding loaded (a variant build under WG_RASTERIZER_LIB is stamped as itself)
+
+
+def device_code_sha(lib_path: str = PRODUCT_LIB) -> str:
+    """Identity of the DEVICE code of a built library: SHA-256 over the `.text` and `.rodata` (instructions + kernel descriptors) of every
+    gfx950 code object in its `.hip_fatbin` section, in link order.  Symbol names, notes and the per-file `__hip_cuid_<hash of the path>`
+    symbols are not in it, so the same sources and flags give the same value from any build directory, and an edit of host code or of a
+    comment leaves it alone.  The profiles under profiles/ (PMC traffic, pair counts) are measurements of device code: they carry this
+    stamp beside `kernel_source_sha`, and either one matching the running tree makes them current."""
+    import hashlib
+    import struct
+    if lib_path in _DEVICE_SHA:
+        return _DEVICE_SHA[lib_path]
+    with open(lib_path, "rb") as fh:
+        b = fh.read()
+    (off, size), = _elf_sections(b)[".hip_fatbin"]
+    fb = b[off:off + size]
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    h = hashlib.sha256()
+    n = 0
+    pos = fb.find(magic)
+    while pos >= 0:   # one bundle per translation unit
+        cnt, = struct.unpack_from("<Q", fb, pos + 24)
+        p = pos + 32
+        for _ in range(cnt):
+            o, sz, ts = struct.unpack_from("<QQQ", fb, p)
+            triple = fb[p + 24:p + 24 + ts]
+            p += 24 + ts
+            if b"gfx950" in triple and sz:
+                co = fb[pos + o:pos + o + sz]
+                secs = _elf_sections(co)
+                for name in (".text", ".rodata"):
+                    for so_, ss in secs.get(name, []):
+                        h.update(name.encode() + struct.pack("<Q", ss) + co[so_:so_ + ss])
+                n += 1
+        pos = fb.find(magic, pos + 1)
+    if n == 0:
+        raise RuntimeError(f"{lib_path}: no gfx950 code object found in .hip_fatbin")
+    _DEVICE_SHA[lib_path] = h.hexdigest()[:16]
+    return _DEVICE_SHA[lib_path]
+
+
+def profile_stamps() -> dict:
+    """The two stamps a profile file is matched on (and that pmc_traffic.py / count_pairs.py write): the operator's kernel sources + build
+    script, and the device code of the product library as built."""
+    out = {"kernel_source_sha": kernel_source_sha()}
+    try:
+        out["device_code_sha"] = device_code_sha(RUNNING_LIB)
+    except (OSError, KeyError, ValueError, RuntimeError) as ex:
+        out["device_code_sha"] = None
+        out["device_code_sha_error"] = f"{type(ex).__name__}: {ex}"[:200]
+    return out
+
+
+def stamp_matches(rec: dict) -> bool:
+    """True when a profile record was measured on what is running now: same kernel sources, or -- sources edited without touching device
+    code (host code, comments, the build script's host parts) -- the same device code."""
+    now = profile_stamps()
+    if rec.get("kernel_source_sha") == now["kernel_source_sha"]:
+        return True
+    return bool(rec.get("device_code_sha")) and rec.get("device_code_sha") == now.get("device_code_sha")
+
+
 def load_pmc(workload_key: str):
     """PMC HBM traffic per stage (separate rocprofv3 --pmc passes, scripts/profile_gpu.sh), only when it was collected on this very
-    workload AND on these very kernel sources; otherwise {} and the reason."""
+    workload AND on this very device code (stamp_matches); otherwise {} and the reason."""
     import glob
     why = "no profiles/pmc_traffic*.json"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_traffic*.json"))):   # one file per profiled workload
@@ -110,16 +192,18 @@ def load_pmc(workload_key: str):
         if pt.get("workload") != workload_key:
             why = f"{name} is for another workload ({pt.get('workload')})" if why.startswith("no ") else why
             continue
-        if pt.get("kernel_source_sha") != kernel_source_sha():
-            why = f"{name} is stale: measured on kernel sources {pt.get('kernel_source_sha')}, these are {kernel_source_sha()}"
+        if not stamp_matches(pt):
+            why = (f"{name} is stale: measured on kernel sources {pt.get('kernel_source_sha')} / device code {pt.get('device_code_sha')}, "
+                   f"these are {profile_stamps()}")
             continue
-        return pt.get("stages", {}), f"{name}: pmc passes of {pt.get('collected', '?')} on kernel sources {pt.get('kernel_source_sha')}"
+        return pt.get("stages", {}), (f"{name}: pmc passes of {pt.get('collected', '?')} on kernel sources {pt.get('kernel_source_sha')}, "
+                                      f"device code {pt.get('device_code_sha')}")
     return {}, why
 
 
 def load_pair_counts(workload_key: str):
     """Per-launch pair counts of K8 / K9 from the counting variant build (tests/tools/count_pairs.py -> profiles/pair_counts*.json), only
-    when collected on this workload and these kernel sources; else None."""
+    when collected on this workload and this device code (stamp_matches); else None."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pair_counts*.json"))):
         try:
@@ -127,7 +211,7 @@ def load_pair_counts(workload_key: str):
                 pc = json.load(f)
         except (OSError, ValueError):
             continue
-        if pc.get("workload") == workload_key and pc.get("kernel_source_sha") == kernel_source_sha():
+        if pc.get("workload") == workload_key and stamp_matches(pc):
             pc["file"] = os.path.basename(path)
             return pc
     return None
@@ -273,6 +357,8 @@ def main():
     # with other precomputed colours skip projection and binning: WildGaussians' second call per step) would turn every step after the
     # first into a recolouring here, where the same tensors are rasterized again and again: off, whatever the caller's options say.
     _C.set_option("geometry_reuse", 0)
+    global RUNNING_LIB
+    RUNNING_LIB = _C._LIB_PATH
     for kv in args.option:
         k, v = kv.split("=", 1)
         if k == "geometry_reuse" and int(v) != 0:
@@ -459,7 +545,7 @@ def main():
         "workload_stats": {"P": P, "V": V, "R": int(R), "N": N, "tiles": tiles, "instances_walked": walked,
                            **({"views_of_this_rank": view_stats} if nv > 1 else {})},
         "library": {"version": _C.version(), "path": os.path.relpath(_C._LIB_PATH, ROOT), "options": args.option,
-                    "kernel_source_sha": kernel_source_sha(), "geometry_reuse": _C.get_option("geometry_reuse"),
+                    **profile_stamps(), "geometry_reuse": _C.get_option("geometry_reuse"),
                     # speculative forward (rasterizer_impl.cu:284's rendezvous moved behind the call's last launch): how it fared in this process
                     "speculative_forward": {k: _C.get_option(k) for k in ("speculative_forward", "spec_frames", "spec_misses", "forward_polls",
                                                                           "forward_polls_waited", "forward_wait_us_total")}},

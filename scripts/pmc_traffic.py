@@ -35,10 +35,10 @@ for line in open(sys.argv[1]):
         d[key] = d.get(key, 0) + int(m.group(3))
 try:
     import bench
-    src_sha = bench.kernel_source_sha()
+    st = bench.profile_stamps()   # kernel sources + the device code of the library as built (bench.device_code_sha)
 except Exception:  # noqa: BLE001
-    src_sha = None
-out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "kernel_source_sha": src_sha, "collected": time.strftime("%Y-%m-%d"), "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving; WRITE_SIZE as reported)",
+    st = {"kernel_source_sha": None, "device_code_sha": None}
+out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "kernel_source_sha": st["kernel_source_sha"], "device_code_sha": st.get("device_code_sha"), "collected": time.strftime("%Y-%m-%d"), "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving; WRITE_SIZE as reported)",
        "stages": {k: dict(v, hbm_bytes=(2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024) for k, v in vals.items()}}
 # Lane utilisation of the vector ALU from counters alone (rocprofiler's VALUUtilization): SQ_THREAD_CYCLES_VALU counts thread-cycles of VALU
 # execution, SQ_ACTIVE_INST_VALU the (quad-)cycles waves spent executing VALU instructions:

@@ -460,6 +460,37 @@ def test_bench_self_launch_builds_the_launcher_command(monkeypatch):
     assert ex.value.code == 0 and seen["env"]["WG_DIST_BACKEND"] == "gloo"
 
 
+def test_profile_stamps_follow_the_device_code(tmp_path):
+    """profiles/pmc_traffic*.json and pair_counts*.json are measurements of DEVICE code: bench.py takes them as current when their
+    kernel_source_sha OR their device_code_sha (the .text + .rodata of the library's gfx950 code objects) equals the running tree's, so a
+    host-only edit does not silently turn `roofline.traffic` into null (it did at the end of round 5's first session)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    if not os.path.exists(bench.PRODUCT_LIB):
+        pytest.skip("library not built")
+    st = bench.profile_stamps()
+    assert len(st["kernel_source_sha"]) == 16 and st["device_code_sha"] and len(st["device_code_sha"]) == 16, st
+    assert bench.device_code_sha(bench.PRODUCT_LIB) == st["device_code_sha"]          # cached, deterministic
+    assert bench.stamp_matches({"kernel_source_sha": st["kernel_source_sha"]})
+    assert bench.stamp_matches({"kernel_source_sha": "0" * 16, "device_code_sha": st["device_code_sha"]})
+    assert not bench.stamp_matches({"kernel_source_sha": "0" * 16, "device_code_sha": "1" * 16})
+    assert not bench.stamp_matches({"kernel_source_sha": "0" * 16})                     # (no device stamp: only the sources can vouch)
+    # a library without device code is an error, not an empty hash
+    junk = tmp_path / "not_a_library.so"
+    junk.write_bytes(b"\x7fELF" + bytes(200))
+    with pytest.raises((RuntimeError, KeyError, ValueError, Exception)):
+        bench.device_code_sha(str(junk))
+    # the committed profiles of the bench's two profiled workloads are current for this tree (a warning, not a failure, when a kernel edit has
+    # not been re-profiled yet: the bench line then says `traffic: null` and why)
+    import warnings
+    for wl in ("1000000 Gaussians, 1920x1080, sh", "10000000 Gaussians, 3840x2160, sh"):
+        stages, why = bench.load_pmc(wl)
+        if not stages:
+            warnings.warn(f"profiles/pmc_traffic*.json not current for '{wl}': {why}")
+        if bench.load_pair_counts(wl) is None:
+            warnings.warn(f"profiles/pair_counts*.json not current for '{wl}'")
+
+
 def test_bench_byte_model():
     sys.path.insert(0, ROOT)
     import bench

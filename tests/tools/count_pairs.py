@@ -49,7 +49,7 @@ lib.wg_debug_bwd_counters(u8, 1)
 bwd = list(u8)[:6]
 import bench  # noqa: E402
 out = {"workload": f"{P} Gaussians, {W}x{H}, {a.colors}" + ("" if a.scale_mult == 1.0 else f", scales x{a.scale_mult:g}"),
-       "kernel_source_sha": bench.kernel_source_sha(), "collected": time.strftime("%Y-%m-%d"), "device": torch.cuda.get_device_name(0),
+       **{k: v for k, v in bench.profile_stamps().items() if k.endswith("_sha")}, "collected": time.strftime("%Y-%m-%d"), "device": torch.cuda.get_device_name(0),
        "render_forward": {"instances_visited": fwd[0], "strip_evaluations": fwd[1], "pairs_evaluated": 64 * fwd[1], "pairs_evaluated_on_accumulating_pixels": fwd[2],
                           "pairs_passing_both_skips": fwd[3], "pixels_stopped": fwd[4], "pairs_blended": fwd[3] - fwd[4], "strip_evaluations_without_a_passing_pair": fwd[5]},
        "render_backward": None if a.forward_only else {"instances_visited": bwd[0], "strip_evaluations": bwd[1], "pairs_evaluated": 64 * bwd[1],

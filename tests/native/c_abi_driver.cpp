@@ -18,7 +18,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -182,7 +184,8 @@ int main(int argc, char** argv) {
     }
     {   // deterministic backward (per-call option, backward only): three passes over the one frame, a synchronisation between them (what
         // retain_graph=True does), must agree bit for bit -- and with the atomic sums' gradients up to the order of the additions.
-        // (Round 5: with the scratch taken from the device's DEFAULT memory pool the second pass lost sums -- api.hip: det_scratch_alloc.)
+        // (Round 5: with the scratch taken from the device's DEFAULT memory pool the second pass lost sums -- api.hip: det_scratch_alloc;
+        //  the concurrent callers further down then caught the library's own keep-everything pool doing the same: the scratch is hipMalloc blocks now.)
         auto fetch = [&](const float* d, size_t n, std::vector<float>& h) { h.resize(n); return hipMemcpy(h.data(), d, n * 4, hipMemcpyDeviceToHost); };
         struct { const char* name; const float* d; size_t n; } arr[] = {{"dL_dmean2D", g2d, 3 * (size_t)P}, {"dL_dconic", gcon, 4 * (size_t)P},
             {"dL_dopacity", gop, (size_t)P}, {"dL_dcolor", gcol, 3 * (size_t)P}, {"dL_dmean3D", g3d, 3 * (size_t)P}, {"dL_dcov3D", gcov, 6 * (size_t)P},
@@ -390,8 +393,16 @@ int main(int argc, char** argv) {
     if (nrad == 0 || nvis < nrad || gsum <= 0) { std::fprintf(stderr, "implausible outputs: nrad %d nvis %d gsum %g\n", nrad, nvis, gsum); return 8; }
     {   // concurrent callers: three host threads, a stream and scratch buffers each, the same frame, eight forward + backward calls each, all
         // in flight together (no interpreter lock in the way): every image bit for bit the one above, dL_dmean3D within the atomic sums'
-        // rounding -- thread 1 in the deterministic mode (bit for bit across its calls), thread 2 without speculation
-        std::atomic<int> failures{0};
+        // rounding -- thread 1 in the deterministic mode (bit for bit across its calls).
+        // Diagnostic knobs (environment; defaults = the test): WG_DRV_THREADS (3), WG_DRV_ITERS (8), WG_DRV_DET_MASK (bit t: caller t runs the
+        // deterministic backward; 2), WG_DRV_REPEAT (the whole block that many times; 1), WG_DRV_KEEP (1: callers free nothing until all have
+        // joined), WG_DRV_VERBOSE (1: every deviating call is described -- how many elements, where, what was there -- and the run goes on).
+        auto env_int = [](const char* n, int d) { const char* v = std::getenv(n); return v && *v ? std::atoi(v) : d; };
+        const int n_threads = env_int("WG_DRV_THREADS", 3), n_iters = env_int("WG_DRV_ITERS", 8), det_mask = env_int("WG_DRV_DET_MASK", 2),
+                  n_repeat = env_int("WG_DRV_REPEAT", 1), keep = env_int("WG_DRV_KEEP", 0), verbose = env_int("WG_DRV_VERBOSE", 0);
+        std::atomic<int> failures{0}, bad_calls{0};
+        std::vector<void*> kept;
+        std::mutex kept_mu;
         auto caller = [&](int tid) {
             hipStream_t st;
             Grow g, b, i;
@@ -404,7 +415,8 @@ int main(int argc, char** argv) {
             for (const auto& q : gr) ok = ok && hipMalloc(reinterpret_cast<void**>(q.first), q.second * 4) == hipSuccess;
             std::vector<float> himg(color.size()), hg(gm.size()), hg0;
             const wg_call_options det = {1, 1, 1};
-            for (int it = 0; ok && it < 8; it++) {
+            const bool is_det = ((det_mask >> tid) & 1) != 0;
+            for (int it = 0; ok && it < n_iters; it++) {
                 wg_forward_args fa{};
                 fa.struct_size = sizeof(fa);
                 fa.geometry_alloc = Grow::alloc; fa.geometry_user = &g; fa.binning_alloc = Grow::alloc; fa.binning_user = &b; fa.image_alloc = Grow::alloc; fa.image_user = &i;
@@ -419,29 +431,50 @@ int main(int argc, char** argv) {
                 ba.campos = d_campos; ba.radii = rad; ba.geom_buffer = g.p; ba.binning_buffer = b.p; ba.image_buffer = i.p; ba.dL_dpix = d_cot;
                 ba.dL_dmean2D = t2d; ba.dL_dconic = tcon; ba.dL_dopacity = top; ba.dL_dcolor = tcol; ba.dL_dmean3D = t3d; ba.dL_dcov3D = tcov; ba.dL_dsh = tsh;
                 ba.dL_dscale = tsc; ba.dL_drot = trot; ba.stream = st;
-                if (tid == 1) ba.options = &det;
+                if (is_det) ba.options = &det;
                 ok = Rt == R && wg_rasterize_backward_ex(&ba) == WG_OK && hipStreamSynchronize(st) == hipSuccess &&
                      hipMemcpy(himg.data(), out, himg.size() * 4, hipMemcpyDeviceToHost) == hipSuccess &&
                      hipMemcpy(hg.data(), t3d, hg.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
                 if (!ok) { std::fprintf(stderr, "concurrent caller %d, call %d: R %d (%s)\n", tid, it, Rt, wg_last_hip_error()); break; }
-                if (std::memcmp(himg.data(), color.data(), himg.size() * 4)) { std::fprintf(stderr, "concurrent caller %d, call %d: another image\n", tid, it); ok = false; break; }
+                bool call_ok = true;
+                if (std::memcmp(himg.data(), color.data(), himg.size() * 4)) { std::fprintf(stderr, "concurrent caller %d, call %d: another image\n", tid, it); call_ok = false; }
                 double mx = 0, md = 0;
                 for (size_t k = 0; k < hg.size(); k++) { mx = std::fmax(mx, std::fabs(gm[k])); md = std::fmax(md, std::fabs(hg[k] - gm[k])); }
-                if (!(md <= 1e-5 * mx)) { std::fprintf(stderr, "concurrent caller %d, call %d: dL_dmean3D off by %g of %g\n", tid, it, md, mx); ok = false; break; }
-                if (tid == 1) {
-                    if (it == 0) hg0 = hg;
-                    else if (std::memcmp(hg0.data(), hg.data(), hg.size() * 4)) { std::fprintf(stderr, "concurrent caller 1, call %d: deterministic gradients differ\n", it); ok = false; break; }
+                if (!(md <= 1e-5 * mx)) {
+                    std::fprintf(stderr, "concurrent caller %d%s, call %d: dL_dmean3D off by %g of %g\n", tid, is_det ? " (deterministic)" : "", it, md, mx);
+                    call_ok = false;
+                    if (verbose) {   // how many Gaussians, where, and what stood there
+                        size_t n_off = 0, n_zero = 0, first = hg.size(), last = 0;
+                        for (size_t k = 0; k < hg.size(); k++)
+                            if (std::fabs(hg[k] - gm[k]) > 1e-5 * mx) { n_off++; n_zero += hg[k] == 0.0f; first = std::min(first, k / 3); last = std::max(last, k / 3); }
+                        std::fprintf(stderr, "    %zu elements off (%zu of them zero) in Gaussians %zu .. %zu of %d;", n_off, n_zero, first, last, P);
+                        int shown = 0;
+                        for (size_t k = 0; k < hg.size() && shown < 6; k++)
+                            if (std::fabs(hg[k] - gm[k]) > 1e-5 * mx) { std::fprintf(stderr, " [%zu] %g vs %g", k, hg[k], gm[k]); shown++; }
+                        std::fprintf(stderr, "\n");
+                    }
                 }
+                if (is_det) {
+                    if (hg0.empty()) { if (call_ok) hg0 = hg; }
+                    else if (std::memcmp(hg0.data(), hg.data(), hg.size() * 4)) { std::fprintf(stderr, "concurrent caller %d, call %d: deterministic gradients differ\n", tid, it); call_ok = false; }
+                }
+                if (!call_ok) { bad_calls++; if (!verbose) { ok = false; break; } }
             }
             if (!ok) failures++;
-            for (const auto& q : gr) (void)hipFree(*q.first);
-            for (void* q : {(void*)out, (void*)rad, (void*)g.p, (void*)b.p, (void*)i.p}) (void)hipFree(q);
+            std::vector<void*> mine = {(void*)out, (void*)rad, (void*)g.p, (void*)b.p, (void*)i.p};
+            for (const auto& q : gr) mine.push_back(*q.first);
+            if (keep) { std::lock_guard<std::mutex> l(kept_mu); kept.insert(kept.end(), mine.begin(), mine.end()); }
+            else for (void* q : mine) (void)hipFree(q);
             (void)hipStreamDestroy(st);
         };
-        std::vector<std::thread> th;
-        for (int t = 0; t < 3; t++) th.emplace_back(caller, t);
-        for (auto& t : th) t.join();
-        if (failures.load()) { std::fprintf(stderr, "%d of 3 concurrent callers failed\n", failures.load()); return 17; }
+        for (int rep = 0; rep < n_repeat; rep++) {
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_threads; t++) th.emplace_back(caller, t);
+            for (auto& t : th) t.join();
+        }
+        for (void* q : kept) (void)hipFree(q);
+        if (verbose) std::fprintf(stderr, "concurrent block: %d deviating call(s) in %d x %d x %d\n", bad_calls.load(), n_repeat, n_threads, n_iters);
+        if (failures.load() || bad_calls.load()) { std::fprintf(stderr, "%d of %d concurrent callers failed\n", failures.load(), n_threads); return 17; }
     }
     if (argc > 4) {
         std::FILE* f = std::fopen(argv[4], "wb");

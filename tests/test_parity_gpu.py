@@ -301,13 +301,14 @@ def test_runs_on_non_default_stream_and_is_deterministic_forward():
 
 def test_concurrent_callers_on_their_own_streams():
     """Four host threads, a stream each, different frames (sizes, SH degrees, a dense one on the lazy-sort path, one with precomputed
-    colours, one in the deterministic backward mode), 20 forward + backward calls each, all in flight together: every call's image,
+    colours, TWO in the deterministic backward mode), 20 forward + backward calls each, all in flight together: every call's image,
     radii and accumulation are bit for bit what the frame gives alone, its gradients within the atomic sums' rounding (the
-    deterministic one's bit for bit).  What is shared between the callers: the library's option / mode / mailbox / pool tables, the
-    device, and (PyTorch's design) the one autograd thread every backward call runs on."""
+    deterministic ones' bit for bit).  What is shared between the callers: the library's option / mode / mailbox / scratch-block tables, the
+    device, and (PyTorch's design) the one autograd thread every backward call runs on.  (The deterministic mode's scratch came from the
+    runtime's stream-ordered allocator until the torch-free driver's concurrent callers lost sums with it: api.hip det_scratch_alloc.)"""
     import threading
     frames = [dict(P=30_000, W=640, H=360, deg=3, seed=21, scale=1.0, det=False),
-              dict(P=60_000, W=800, H=448, deg=1, seed=22, scale=3.0, det=False),
+              dict(P=60_000, W=800, H=448, deg=1, seed=22, scale=3.0, det=True),
               dict(P=20_000, W=320, H=200, deg=None, seed=23, scale=2.0, det=False),
               dict(P=50_000, W=960, H=544, deg=2, seed=24, scale=2.0, det=True)]
     from diff_gaussian_rasterization import call_options
@@ -1065,8 +1066,8 @@ def test_deterministic_backward_mode_is_bit_reproducible(oracle, record_option):
 
 def test_deterministic_backward_passes_over_one_frame_agree(record_option):
     """retain_graph=True: several deterministic backward passes over ONE forward call's buffers, the host synchronising in between.
-    (tests/native/c_abi_driver.cpp found the second such pass losing sums when the scratch came from the device's default memory pool:
-    api.hip det_scratch_alloc.)  Also: the scratch pool can be emptied between calls ("release_scratch")."""
+    (tests/native/c_abi_driver.cpp found the second such pass losing sums when the scratch came from the runtime's stream-ordered allocator:
+    api.hip det_scratch_alloc.)  Also: the library's scratch blocks can be handed back between calls ("release_scratch")."""
     from diff_gaussian_rasterization import GaussianRasterizer
     _C = record_option
     W, H, P = 320, 200, 20_000
@@ -1089,6 +1090,44 @@ def test_deterministic_backward_passes_over_one_frame_agree(record_option):
         else:
             for a, b in zip(first, g):
                 assert torch.equal(a, b), rep
+
+
+def test_deterministic_backward_scratch_moves_between_streams(record_option):
+    """The deterministic mode's scratch is a block of the library's own, leased per call (api.hip det_scratch_alloc): a call on ANOTHER stream
+    than the block's last user has to wait for that user (an event), a frame larger than the block grows it.  One host thread, two streams
+    taking turns with NO host synchronisation between the calls, a small and a large frame alternating: every pass's gradients are bit for
+    bit those of the frame alone."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    frames = []
+    for (W, H, P, seed) in ((320, 200, 20_000, 5), (640, 360, 60_000, 6)):
+        cam, cot = S.make_camera(W, H), to_dev(S.make_cotangent(W, H, seed=seed))
+        cloud = S.make_cloud(P, W, H, sh_degree=1, seed=seed, scale_mult=4.0)
+        t = {k: to_dev(v).requires_grad_(True) for k, v in cloud.items()}
+        m2 = torch.zeros_like(t["means3D"], requires_grad=True)
+        frames.append((GaussianRasterizer(make_settings(cam, 1)), t, m2, cot))
+
+    def step(f):
+        rast, t, m2, cot = f
+        color, _, _ = rast(means3D=t["means3D"], means2D=m2, opacities=t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"],
+                           deterministic_backward=True)
+        return torch.autograd.grad(color, [t["means3D"], m2, t["opacities"], t["shs"], t["scales"], t["rotations"]], cot)
+
+    alone = [[x.clone() for x in step(f)] for f in frames]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = []
+    for it in range(12):
+        s = streams[it % 2]
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            got.append((it, step(frames[(it // 2) % 2])))   # small, small, large, large, ... : each frame on both streams, the block grown once
+    torch.cuda.synchronize()
+    for it, g in got:
+        for a, b in zip(alone[(it // 2) % 2], g):
+            assert torch.equal(a, b), it
+    record_option.set_option("release_scratch", 1)
+    for a, b in zip(alone[1], step(frames[1])):
+        assert torch.equal(a, b)
 
 
 def test_deterministic_backward_without_any_instance_gives_zeros(record_option):

@@ -416,43 +416,84 @@ static wg::ShTone device_tone(const wg_sh_tone* t, const wg_sh_tone* t2 = nullpt
 // than the forward call that made the image state would differentiate / recomposite decisions the stored per-pixel state does not hold.
 // Host-side only (no device traffic): the last 64 frames, keyed by the 256-byte-aligned image-state address; an address handed out
 // again by the caller's allocator is simply overwritten by the next forward call that gets it.
-// Stream-ordered scratch of the deterministic backward, from a memory pool OF THE LIBRARY'S OWN (one per device) that keeps what it
-// holds (release threshold = everything) until wg_set_option("release_scratch", 1).  Not the device's default pool: with its default
-// release threshold (0) that pool hands its free memory back to the system at every synchronisation of the caller, the next
-// hipMallocAsync maps it again -- and on ROCm 7.2 / MI355X the first kernels to write such re-acquired memory lost some of their stores
-// (repeated deterministic backward passes over one frame with a hipStreamSynchronize between them, as retain_graph=True makes them:
-// the second pass missed the sums of ~6 % of the Gaussians; never when the block was kept, leaked, or came from hipMalloc --
-// tests/native/c_abi_driver.cpp holds the case, EXPERIMENTS.md R5.10).  Keeping the memory also saves the map / unmap per call.
+// Scratch of the deterministic backward: plain hipMalloc blocks of the library's own, LEASED to a call and kept between calls until
+// wg_set_option("release_scratch", 1).  A call takes a block that no other call is holding (one it used before on the same stream when there
+// is one: stream order then makes the reuse safe by itself), grows it when it is too small, and hands it back behind its last launch together
+// with an event recorded on its stream; a later call on ANOTHER stream makes its stream wait for that event first.  Two calls in flight at
+// once -- other streams, other host threads, or two threads feeding one stream -- therefore never share a block.
+// Why not the runtime's stream-ordered allocator (hipMallocAsync / hipMallocFromPoolAsync), which does the same on paper: on ROCm 7.2 /
+// MI355X kernels writing memory that came from it LOSE STORES.  Round 5 met it twice: (1) repeated deterministic backward passes over one
+// frame with a hipStreamSynchronize between them (what retain_graph=True does) on the device's default pool: the second pass missed the sums
+// of ~6 % of the Gaussians -- gone when the pool was told to keep its memory, so a pool of the library's own with release threshold =
+// everything replaced it; (2) that pool with OTHER host threads calling the runtime at the same time (three callers on their own streams,
+// tests/native/c_abi_driver.cpp): 10 of 14 runs had a deterministic call with thousands of Gaussians' sums missing or short, 0 of 10 with
+// hipMalloc blocks, 0 of 7 with nobody in the deterministic mode or one thread alone (scripts/r5/r5_concurrent_diag.sh,
+// profiles/r5/concurrent_callers_diag.log; EXPERIMENTS.md R5.10, R5.12).  Nothing else in the library uses that allocator.
+struct ScratchBlock { int dev; void* p; size_t cap; hipStream_t last_stream; hipEvent_t done; bool recorded; bool busy; };
 std::mutex g_pool_mu;
-hipMemPool_t g_det_pools[64] = {};
-hipError_t det_scratch_alloc(void** out, size_t bytes, hipStream_t stream) {
+std::vector<ScratchBlock*> g_scratch;   // (blocks are never moved: a lease is a pointer)
+hipError_t det_scratch_alloc(ScratchBlock** lease, size_t bytes, hipStream_t stream) {
+    *lease = nullptr;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    hipMemPool_t pool;
+    ScratchBlock* b = nullptr;
     {
         std::lock_guard<std::mutex> l(g_pool_mu);
-        if (!g_det_pools[dev]) {
-            hipMemPoolProps props = {};
-            props.allocType = hipMemAllocationTypePinned;
-            props.location.type = hipMemLocationTypeDevice;
-            props.location.id = dev;
-            e = hipMemPoolCreate(&g_det_pools[dev], &props);
-            uint64_t keep = ~0ull;
-            if (e == hipSuccess) e = hipMemPoolSetAttribute(g_det_pools[dev], hipMemPoolAttrReleaseThreshold, &keep);
-            if (e != hipSuccess) { if (g_det_pools[dev]) (void)hipMemPoolDestroy(g_det_pools[dev]); g_det_pools[dev] = nullptr; return e; }
+        for (int pass = 0; pass < 3 && !b; pass++)   // large enough + same stream; large enough; anything idle (it will be grown)
+            for (ScratchBlock* x : g_scratch)
+                if (!x->busy && x->dev == dev && (pass == 2 || x->cap >= bytes) && (pass != 0 || x->last_stream == stream)) { b = x; break; }
+        if (!b) {
+            b = new ScratchBlock{dev, nullptr, 0, nullptr, nullptr, false, false};
+            e = hipEventCreateWithFlags(&b->done, hipEventDisableTiming);
+            if (e != hipSuccess) { delete b; return e; }
+            g_scratch.push_back(b);
         }
-        pool = g_det_pools[dev];
+        b->busy = true;
     }
-    return hipMallocFromPoolAsync(out, bytes, pool, stream);
+    // (outside the lock: hipFree / hipMalloc may wait for the device)
+    if (b->cap < bytes) {
+        if (b->p) e = hipFree(b->p);   // waits for everything in flight on the device: the block's last user included
+        b->p = nullptr; b->cap = 0; b->recorded = false;
+        if (e == hipSuccess) e = hipMalloc(&b->p, bytes);
+        if (e == hipSuccess) b->cap = bytes;
+    } else if (b->recorded && b->last_stream != stream) {
+        e = hipStreamWaitEvent(stream, b->done, 0);
+    }
+    if (e != hipSuccess) {
+        std::lock_guard<std::mutex> l(g_pool_mu);
+        b->busy = false;
+        return e;
+    }
+    *lease = b;
+    return hipSuccess;
 }
-// wg_set_option("release_scratch", 1): what the pools hold and no call is using goes back to the system
+// behind the call's last launch on `stream`
+hipError_t det_scratch_free(ScratchBlock* b, hipStream_t stream) {
+    const hipError_t e = hipEventRecord(b->done, stream);
+    std::lock_guard<std::mutex> l(g_pool_mu);
+    b->last_stream = stream;
+    b->recorded = e == hipSuccess;
+    b->busy = false;
+    if (e != hipSuccess && b->p) {   // no event to order the next user behind this call: do not hand the memory out again
+        (void)hipFree(b->p);
+        b->p = nullptr; b->cap = 0;
+    }
+    return e;
+}
+// wg_set_option("release_scratch", 1): the blocks no call is holding go back to the system (hipFree waits for the device first)
 int det_scratch_release() {
     std::lock_guard<std::mutex> l(g_pool_mu);
-    for (hipMemPool_t p : g_det_pools)
-        if (p && hipMemPoolTrimTo(p, 0) != hipSuccess) return WG_ERR_HIP;
-    return WG_OK;
+    int rc = WG_OK;
+    for (ScratchBlock* b : g_scratch)
+        if (!b->busy && b->p) {
+            int cur = 0;
+            const bool sw = hipGetDevice(&cur) == hipSuccess && cur != b->dev && hipSetDevice(b->dev) == hipSuccess;
+            if (hipFree(b->p) != hipSuccess) rc = WG_ERR_HIP;
+            if (sw) (void)hipSetDevice(cur);
+            b->p = nullptr; b->cap = 0; b->recorded = false;
+        }
+    return rc;
 }
 
 struct FrameMode { const void* image; int exact; };
@@ -967,13 +1008,14 @@ static int backward_impl(const wg_backward_args& a) {
     // slot scratch, its scan and the ordered sum need instances to exist.  With nothing rendered the cleared record gives zeros.
     const bool det = opt.deterministic_backward != 0 && R > 0;
     const bool record = g_grad_record != 0 || opt.deterministic_backward != 0;
-    // stream-ordered scratch of the deterministic mode (from the library's own pool: det_scratch_alloc), handed back on every way out of this function
+    // scratch of the deterministic mode (a leased block of the library's own: det_scratch_alloc), handed back on every way out of this function
     struct DetSlots {
         float* p = nullptr;
+        ScratchBlock* lease = nullptr;
         hipStream_t s;
         explicit DetSlots(hipStream_t st) : s(st) {}
-        ~DetSlots() { if (p) (void)hipFreeAsync(p, s); }
-        hipError_t release() { float* q = p; p = nullptr; return q ? hipFreeAsync(q, s) : hipSuccess; }
+        ~DetSlots() { if (lease) (void)det_scratch_free(lease, s); }
+        hipError_t release() { ScratchBlock* q = lease; lease = nullptr; p = nullptr; return q ? det_scratch_free(q, s) : hipSuccess; }
     } det_guard(stream);
     float*& det_slots = det_guard.p;
     unsigned char* det_flags = nullptr;
@@ -982,7 +1024,8 @@ static int backward_impl(const wg_backward_args& a) {
         const size_t slot_bytes = (((size_t)R * (dual ? 14 : 10) * sizeof(float)) + 255) & ~(size_t)255;   // (the two-colour walk: thirteen sums, padded to fourteen)
         hipError_t e = wg::run_scan(geom, P, stream);
         // (the flags: a whole number of 16-byte words, cleared by the launch that orders the tiles -- no memset of their own)
-        if (e == hipSuccess) e = det_scratch_alloc(reinterpret_cast<void**>(&det_slots), slot_bytes + (((size_t)R + 15) & ~(size_t)15), stream);
+        if (e == hipSuccess) e = det_scratch_alloc(&det_guard.lease, slot_bytes + (((size_t)R + 15) & ~(size_t)15), stream);
+        if (e == hipSuccess) det_slots = static_cast<float*>(det_guard.lease->p);
         if (e == hipSuccess) det_flags = reinterpret_cast<unsigned char*>(det_slots) + slot_bytes;
 #ifdef WG_DET_POISON   // debugging aid (variant build): a slot that is read without having been written in THIS call shows up as NaN gradients
         if (e == hipSuccess) e = hipMemsetAsync(det_slots, 0xFF, slot_bytes, stream);

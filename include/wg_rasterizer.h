@@ -95,7 +95,8 @@ int wg_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
  *     reference's own float32 operations and hipcc's float32 `exp` expansion: n_contrib, final_T and the blended set equal the
  *     reference's -ffp-contract=off build bit for bit (image within ~2e-7).  0: exp2 of a fused form, ~2 pixels per million flip, 5 % faster.
  *   deterministic_backward (0): 1 = every (tile, Gaussian) instance stores its wave-reduced sums in a slot of its own and a
- *     per-Gaussian pass adds them in a fixed order instead of float atomics: bit-identical gradients run to run.
+ *     per-Gaussian pass adds them in a fixed order instead of float atomics: bit-identical gradients run to run.  Its scratch is a block
+ *     of the library's own, leased for the call: not inside a stream capture (WG_ERR_INVALID_ARGUMENT -- a replay would write a block others hold).
  *   grad_record (1): the per-tile pass accumulates into a 48-byte record per Gaussian inside geom_buffer (see wg_rasterize_backward);
  *     0 = into dL_dmean2D / dL_dconic / dL_dopacity / dL_dcolor themselves, which must then be non-NULL and zero on entry. */
 typedef struct wg_call_options {

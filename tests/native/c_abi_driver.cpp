@@ -396,10 +396,13 @@ int main(int argc, char** argv) {
         // rounding -- thread 1 in the deterministic mode (bit for bit across its calls).
         // Diagnostic knobs (environment; defaults = the test): WG_DRV_THREADS (3), WG_DRV_ITERS (8), WG_DRV_DET_MASK (bit t: caller t runs the
         // deterministic backward; 2), WG_DRV_REPEAT (the whole block that many times; 1), WG_DRV_KEEP (1: callers free nothing until all have
-        // joined), WG_DRV_VERBOSE (1: every deviating call is described -- how many elements, where, what was there -- and the run goes on).
+        // joined), WG_DRV_SHARED_STREAM (1: all callers feed ONE stream), WG_DRV_VERBOSE (1: every deviating call is described -- how many elements, where, what was there -- and the run goes on).
         auto env_int = [](const char* n, int d) { const char* v = std::getenv(n); return v && *v ? std::atoi(v) : d; };
         const int n_threads = env_int("WG_DRV_THREADS", 3), n_iters = env_int("WG_DRV_ITERS", 8), det_mask = env_int("WG_DRV_DET_MASK", 2),
-                  n_repeat = env_int("WG_DRV_REPEAT", 1), keep = env_int("WG_DRV_KEEP", 0), verbose = env_int("WG_DRV_VERBOSE", 0);
+                  n_repeat = env_int("WG_DRV_REPEAT", 1), keep = env_int("WG_DRV_KEEP", 0), verbose = env_int("WG_DRV_VERBOSE", 0),
+                  shared_stream = env_int("WG_DRV_SHARED_STREAM", 0);
+        hipStream_t one_stream = nullptr;
+        if (shared_stream) CHECK_HIP(hipStreamCreate(&one_stream));
         std::atomic<int> failures{0}, bad_calls{0};
         std::vector<void*> kept;
         std::mutex kept_mu;
@@ -408,7 +411,7 @@ int main(int argc, char** argv) {
             Grow g, b, i;
             float *out = nullptr, *t2d = nullptr, *tcon = nullptr, *top = nullptr, *tcol = nullptr, *t3d = nullptr, *tcov = nullptr, *tsh = nullptr, *tsc = nullptr, *trot = nullptr;
             int* rad = nullptr;
-            bool ok = hipStreamCreate(&st) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&out), (size_t)3 * W * H * 4) == hipSuccess &&
+            bool ok = (shared_stream ? (st = one_stream, true) : hipStreamCreate(&st) == hipSuccess) && hipMalloc(reinterpret_cast<void**>(&out), (size_t)3 * W * H * 4) == hipSuccess &&
                       hipMalloc(reinterpret_cast<void**>(&rad), (size_t)P * 4) == hipSuccess;
             const std::pair<float**, size_t> gr[] = {{&t2d, 3u * (size_t)P}, {&tcon, 4u * (size_t)P}, {&top, (size_t)P}, {&tcol, 3u * (size_t)P}, {&t3d, 3u * (size_t)P},
                                                      {&tcov, 6u * (size_t)P}, {&tsh, (size_t)P * M * 3}, {&tsc, 3u * (size_t)P}, {&trot, 4u * (size_t)P}};
@@ -465,7 +468,7 @@ int main(int argc, char** argv) {
             for (const auto& q : gr) mine.push_back(*q.first);
             if (keep) { std::lock_guard<std::mutex> l(kept_mu); kept.insert(kept.end(), mine.begin(), mine.end()); }
             else for (void* q : mine) (void)hipFree(q);
-            (void)hipStreamDestroy(st);
+            if (!shared_stream) (void)hipStreamDestroy(st);
         };
         for (int rep = 0; rep < n_repeat; rep++) {
             std::vector<std::thread> th;
@@ -473,6 +476,7 @@ int main(int argc, char** argv) {
             for (auto& t : th) t.join();
         }
         for (void* q : kept) (void)hipFree(q);
+        if (shared_stream) (void)hipStreamDestroy(one_stream);
         if (verbose) std::fprintf(stderr, "concurrent block: %d deviating call(s) in %d x %d x %d\n", bad_calls.load(), n_repeat, n_threads, n_iters);
         if (failures.load() || bad_calls.load()) { std::fprintf(stderr, "%d of %d concurrent callers failed\n", failures.load(), n_threads); return 17; }
     }

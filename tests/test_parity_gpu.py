@@ -1634,6 +1634,21 @@ def test_fixed_capacity_forward_needs_no_host_rendezvous_and_can_be_captured_in_
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             color, radii, grads, ib = fwd_bwd()
+        # the deterministic mode leases its scratch per call and refuses to be captured (docs/OPTIONS.md); the capture itself survives the refusal
+        g_det = torch.cuda.CUDAGraph()
+        refused = None
+        with torch.cuda.graph(g_det):
+            Rr_, _c, radii_, gb_, bb_, ib_ = _C.rasterize_gaussians(rs.bg, static["means3D"], static["colors_precomp"], static["opacities"], static["scales"],
+                                                                   static["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+                                                                   rs.kernel_size, rs.subpixel_offset, H, W, e, 0, rs.campos, False, False, None, cap)
+            try:
+                _C.rasterize_gaussians_backward(rs.bg, static["means3D"], radii_, static["colors_precomp"], static["scales"], static["rotations"], 1.0, e,
+                                                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset, cot, e, 0,
+                                                rs.campos, gb_, Rr_, bb_, ib_, False, options=dict(deterministic_backward=1))
+            except RuntimeError as ex:
+                refused = str(ex)
+        assert refused is not None and "invalid argument" in refused.lower(), refused
+        del g_det
         for i in (1, 2, 0):
             for k, v in clouds[i].items():
                 static[k].copy_(to_dev(v))

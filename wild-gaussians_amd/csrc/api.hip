@@ -1022,6 +1022,9 @@ static int backward_impl(const wg_backward_args& a) {
     if (det) {  // slots: 40 B per tile instance, never cleared; flags: 1 B per instance behind them, cleared
         StageScope scope_(WG_STAGE_RENDER_BACKWARD, stream);
         const size_t slot_bytes = (((size_t)R * (dual ? 14 : 10) * sizeof(float)) + 255) & ~(size_t)255;   // (the two-colour walk: thirteen sums, padded to fourteen)
+        // a captured call would replay into a block that was only leased for the call's duration: refused (the atomic mode captures fine)
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) return WG_ERR_INVALID_ARGUMENT;
         hipError_t e = wg::run_scan(geom, P, stream);
         // (the flags: a whole number of 16-byte words, cleared by the launch that orders the tiles -- no memset of their own)
         if (e == hipSuccess) e = det_scratch_alloc(&det_guard.lease, slot_bytes + (((size_t)R + 15) & ~(size_t)15), stream);

@@ -445,6 +445,40 @@ def test_huge_splats_cover_every_tile(oracle):
         assert e <= 1e-3, (k, e)
 
 
+@pytest.mark.parametrize("P", [300_000, 600_000])
+def test_more_instances_than_an_int_holds_is_an_error_not_a_wrap(P):
+    """rasterizer_impl.cu:280-284 sums the instance count into a 32-bit int and sizes the binning buffer with it: 2^31 instances and more
+    wrap silently there.  Here the call fails with WG_ERR_OVERFLOW ("more than 2^31-1 tile instances") before any buffer is sized -- for a
+    count between 2^31 and 2^32 (300 000 screen-filling Gaussians x 8 160 tiles = 2.4e9) and one whose 32-bit sum itself wraps (600 000:
+    4.9e9) -- in the speculative and the classic flow; the fixed-capacity flow, which reads nothing back, reports "does not fit" (NaN image);
+    and the thread's next ordinary frame is what it is alone."""
+    from diff_gaussian_rasterization import _C
+    W, H = 1920, 1080
+    cam = S.make_camera(W, H)
+    big = S.make_cloud(P, W, H, sh_degree=None, seed=3)
+    big["scales"][:] = 50.0           # every rectangle is the whole 120 x 68 grid
+    assert P * 8160 > 2 ** 31
+    small = S.make_cloud(20_000, W, H, sh_degree=None, seed=4)
+    alone = run_hip(small, cam, sh_degree=0)
+    spec = _C.get_option("speculative_forward")
+    try:
+        for mode, cap in ((spec, None), (0, None), (spec, 50_000_000)):
+            _C.set_option("speculative_forward", mode)
+            if cap is None:
+                with pytest.raises(RuntimeError, match="2\\^31-1 tile instances"):
+                    run_hip(big, cam, sh_degree=0)
+            else:   # the fixed-capacity flow never reads anything back: a frame that does not fit is a NaN image and fits == False
+                out = run_hip(big, cam, sh_degree=0, binning_capacity=cap)
+                n, fits = _C.last_forward_status()
+                assert not fits and np.isnan(out["color"]).all(), (n, fits)
+            torch.cuda.synchronize()
+            again = run_hip(small, cam, sh_degree=0)
+            for k in ("color", "radii", "accumulation"):
+                assert np.array_equal(again[k], alone[k]), (mode, cap, k)
+    finally:
+        _C.set_option("speculative_forward", spec)
+
+
 # ---- size-independent properties at the BASELINE.json metric size (1M Gaussians @ 1920x1080), where the oracle is too slow
 # ---- to be the only check: linearity in colour / background, invariance under a permutation of the Gaussians,
 # ---- accumulation == alpha-only render, determinism of the forward pass.

@@ -350,6 +350,55 @@ def test_concurrent_callers_on_their_own_streams():
     assert not errors, errors[:8]
 
 
+def test_concurrent_callers_with_changing_frames():
+    """Three host threads on their own streams, each cycling through three cameras of its own cloud (the base camera yawed: the instance count
+    changes by up to 2x from call to call, so the threads' speculative forwards MISS and re-issue while the others are in flight, and the
+    binning buffers grow and shrink), one of them in the deterministic backward mode: every call equals its (cloud, camera) alone."""
+    import threading
+    from diff_gaussian_rasterization import call_options
+    W, H = 960, 544
+    cams = [S.make_camera(W, H, yaw_deg=y) for y in (0.0, 20.0, 35.0)]
+    cot = S.make_cotangent(W, H, seed=3)
+    jobs = []
+    for j, (P, deg, scale, det) in enumerate(((80_000, 1, 2.0, False), (120_000, None, 1.5, True), (60_000, 2, 3.0, False))):
+        cloud = S.make_cloud(P, W, H, sh_degree=deg, seed=30 + j, scale_mult=scale)
+        with call_options(deterministic_backward=det):
+            alone = [run_hip(cloud, c, sh_degree=deg or 0, cotangent=cot) for c in cams]
+        jobs.append((j, cloud, deg, det, alone))
+    sizes = [int((a["radii"] > 0).sum()) for a in jobs[0][4]]
+    assert max(sizes) > 1.3 * min(sizes), sizes          # the cameras really see different frames
+    torch.cuda.synchronize()
+    errors, start = [], threading.Barrier(len(jobs))
+
+    def caller(j, cloud, deg, det, alone):
+        try:
+            stream = torch.cuda.Stream()
+            start.wait(timeout=60)
+            with torch.cuda.stream(stream), call_options(deterministic_backward=det):
+                for it in range(15):
+                    k = (it * (j + 1)) % 3                  # every thread walks the cameras in its own order
+                    h = run_hip(cloud, cams[k], sh_degree=deg or 0, cotangent=cot)
+                    for name in ("color", "radii", "accumulation"):
+                        if not np.array_equal(h[name], alone[k][name]):
+                            errors.append((j, it, k, name, "differs from the frame alone"))
+                    for name, g in h["grads"].items():
+                        if det:
+                            if not np.array_equal(g, alone[k]["grads"][name]):
+                                errors.append((j, it, k, name, "deterministic gradients differ"))
+                        elif rel_err(g, alone[k]["grads"][name]) > 2e-6:
+                            errors.append((j, it, k, name, rel_err(g, alone[k]["grads"][name])))
+        except Exception as ex:   # noqa: BLE001  (reported by the main thread)
+            errors.append((j, repr(ex)))
+
+    threads = [threading.Thread(target=caller, args=job) for job in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a caller is stuck"
+    assert not errors, errors[:8]
+
+
 def test_all_culled_and_single_gaussian(oracle):
     W, H = 64, 48
     cam = S.make_camera(W, H)

@@ -149,7 +149,8 @@ typedef struct wg_recolor_parent {
 } wg_recolor_parent;
 
 typedef struct wg_forward_args {
-    size_t struct_size;   /* sizeof(wg_forward_args): lets the struct grow without breaking callers */
+    size_t struct_size;   /* the CALLER's sizeof(wg_forward_args): fields are only ever appended; a shorter (older) struct is accepted
+                             from version 0.5's 288 bytes on, its missing tail reads as absent; a longer (newer) one is refused */
     wg_alloc_fn geometry_alloc; void* geometry_user;
     wg_alloc_fn binning_alloc;  void* binning_user;
     wg_alloc_fn image_alloc;    void* image_user;
@@ -218,6 +219,8 @@ typedef struct wg_image_view {
     const uint32_t* tile_last;  /* [tiles] max n_contrib over the tile's pixels */
     const uint32_t* tile_near;  /* [tiles] near / far split: near instances of the tile */
     const uint32_t* split;      /* [2] {depth-code threshold of the split (0xffffffff = off), bands that needed their far instances} */
+    const uint32_t* order_fwd;  /* [tiles] launch order of the forward render kernel ("forward_order"; valid when order_key[0] != 0xffffffff) */
+    const uint32_t* order_key;  /* [4] {the camera's row in the launch-order table or 0xffffffff = none, tag lo, tag hi, 1 = the row held this camera} */
 } wg_image_view;
 int wg_view_geometry(char* geom_buffer, int P, wg_geometry_view* out);
 int wg_view_binning(char* binning_buffer, int R, wg_binning_view* out);

@@ -128,7 +128,9 @@ def test_struct_entry_points_reject_invalid_arguments_before_any_device_work(lib
                 v = C.pointer(v)
             setattr(a, k, v)
         return fx(C.byref(a))
-    assert fx(None) == -1 and fwd(struct_size=C.sizeof(A) - 8) == -1                     # another header's struct
+    assert fx(None) == -1 and fwd(struct_size=C.sizeof(A) - 8) == -1                     # shorter than the first published layout
+    assert fwd(struct_size=C.sizeof(A) + 8) == -1                                          # a NEWER header's struct: its tail may ask for something unknown
+    assert C.sizeof(A) >= 288 and C.sizeof(B) >= 312                                       # version 0.5's sizes stay acceptable: fields are only appended
     assert fwd(P=-1) == -1 and fwd(width=0) == -1 and fwd(colors_precomp=None) == -1       # the reference-shaped checks hold here too
     # fixed capacity: the caller's to give; LDS binning only; no debug mode
     assert fwd(binning_capacity=-5) == -1 and fwd(binning_capacity=1024, debug=1) == -1

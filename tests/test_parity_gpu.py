@@ -1761,3 +1761,61 @@ def test_backward_run_to_run_spread_is_at_rounding_level():
     assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["radii"], b["radii"])
     for k in a["grads"]:
         assert rel_err(a["grads"][k], b["grads"][k]) <= 2e-6, k
+
+
+# ---- launch order of the forward render kernel from the per-camera history (round 6) -------------------------------------------------
+@pytest.mark.parametrize("scene", ["sh3_640x360", "dense_lazy", "two_cameras_1080p"])
+def test_forward_launch_order_history_changes_no_result(lazy_options, scene):
+    """`forward_order` (default on): the forward render kernel launches its tiles in the order an earlier frame of the SAME camera suggests
+    (binning.hip: forward_order_kernel; the library's device-side table, keyed by a hash of the camera).  Pure scheduling: every output of
+    a frame rendered on a miss (image order), on a hit (snake order by the remembered costs) and with the history switched off is the same,
+    bit for bit -- image, accumulation, radii, n_contrib, final_T, tile_last, num_rendered -- and the order is a permutation inside every
+    XCD band.  Also on the lazy-sort path (resumable walks) and with two cameras alternating (each hits its own row)."""
+    from diff_gaussian_rasterization import _C
+    if scene == "sh3_640x360":
+        cloud, cam, deg = _scene(scene)
+        cams = [cam]
+    elif scene == "dense_lazy":
+        cloud, cam, W_, H_ = _dense_scene()
+        deg, cams = 1, [cam]
+        lazy_options(lazy_min_len=256, lazy_target=100, lazy_cap=256)
+    else:
+        W_, H_ = 1920, 1080
+        cloud = S.make_cloud(200_000, W_, H_, sh_degree=0, seed=4, scale_mult=2.0)
+        deg, cams = 0, [S.make_camera(W_, H_), S.make_camera(W_, H_, yaw_deg=7.0)]
+
+    def frame(cam_):
+        n = run_hip_native(cloud, cam_, sh_degree=deg)
+        im = n["views"]["image"]
+        out = dict(R=int(n["num_rendered"]), color=n["color"].cpu().numpy(), radii=n["radii"].cpu().numpy(),
+                   **{k: im[k].cpu().numpy().copy() for k in ("final_T", "accumulation", "n_contrib", "tile_last", "order_fwd", "order_key")})
+        return out
+    try:
+        _C.set_option("forward_order", 0)
+        off = [frame(c) for c in cams]
+        assert all(int(o["order_key"][0]) == -1 for o in off)     # no row: the kernel ran in image order
+        _C.set_option("forward_order", 1)
+        seen_hit = [False] * len(cams)
+        for rep in range(3):
+            for ci, c in enumerate(cams):
+                on = frame(c)
+                slot, hit = int(on["order_key"][0]), int(on["order_key"][3])
+                assert slot >= 0
+                seen_hit[ci] |= hit == 1
+                if rep > 0:
+                    assert hit == 1, (scene, rep, ci)             # the camera's earlier frame left its costs in the row
+                tiles = on["order_fwd"].size
+                q, rem = tiles // 8, tiles % 8
+                for x in range(8):                                # a permutation of each XCD band
+                    lo = x * q + min(x, rem)
+                    hi = lo + q + (1 if x < rem else 0)
+                    assert np.array_equal(np.sort(on["order_fwd"][lo:hi]), np.arange(lo, hi)), (scene, rep, x)
+                if hit:
+                    assert not np.array_equal(on["order_fwd"], np.arange(tiles))   # really another order than the image's
+                for k in ("color", "radii", "final_T", "accumulation", "n_contrib", "tile_last"):
+                    assert np.array_equal(on[k].view(np.uint32) if on[k].dtype == np.float32 else on[k],
+                                          off[ci][k].view(np.uint32) if off[ci][k].dtype == np.float32 else off[ci][k]), (scene, rep, ci, k)
+                assert on["R"] == off[ci]["R"]
+        assert all(seen_hit)
+    finally:
+        _C.set_option("forward_order", 1)

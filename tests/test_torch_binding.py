@@ -79,3 +79,47 @@ def test_compiled_binding_gives_the_ctypes_bindings_results(binding, colors):
     z = lambda *s: torch.zeros(*s, device="cuda")
     img, radii, acc = GaussianRasterizer(rs)(means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1), colors_precomp=z(0, 3), scales=z(0, 3), rotations=z(0, 4))
     assert img.shape == (3, H, W) and not img.any() and radii.numel() == 0 and acc.shape == (H, W)
+
+
+@pytest.mark.gpu
+@needs_binding
+@pytest.mark.parametrize("name", ["torch", "ctypes"])
+def test_wrong_size_tensors_raise_instead_of_reading_out_of_bounds(binding, name):
+    """the compiled binding is the default and its fast path skips the Python-side checks, so it repeats them itself -- a
+    filter_3D / colors_precomp2 / raw tuple of the wrong length, or filter_3D combined with colors_precomp2, must raise under BOTH
+    bindings (the preprocess kernels would otherwise index P entries of a shorter tensor)."""
+    _C = binding
+    _C.use_binding(name)
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from tests.wg_testlib import make_settings, to_dev
+    P, W, H = 2000, 160, 96
+    cloud = S.make_cloud(P, W, H, sh_degree=None, seed=3)
+    rast = GaussianRasterizer(make_settings(S.make_camera(W, H), 0))
+    t = {k: to_dev(v) for k, v in cloud.items()}
+    base = dict(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+    col = t["colors_precomp"]
+    with pytest.raises((RuntimeError, Exception), match="filter_3D"):
+        rast(**base, colors_precomp=col, filter_3D=torch.ones(P - 7, device="cuda"))
+    with pytest.raises((RuntimeError, Exception), match="colors2|colors_precomp2"):
+        rast(**base, colors_precomp=col, colors_precomp2=col[: P - 1])
+    with pytest.raises((RuntimeError, Exception), match="colors2|colors_precomp2"):
+        rast(**base, colors_precomp=col[: P - 1].contiguous(), colors_precomp2=col)
+    with pytest.raises((RuntimeError, Exception), match="filter_3D"):
+        rast(**base, colors_precomp=col, colors_precomp2=col, filter_3D=torch.ones(P, device="cuda"))
+    if name == "torch":   # the reference-shaped arguments too (the reference's own binding checks none of them)
+        with pytest.raises(RuntimeError, match="scales"):
+            rast(**{**base, "scales": t["scales"][: P - 3].contiguous()}, colors_precomp=col)
+        with pytest.raises(RuntimeError, match="opacities"):
+            rast(**{**base, "opacities": t["opacities"][: P - 3].contiguous()}, colors_precomp=col)
+    # the raw tuple of the backward call
+    e = torch.Tensor([])
+    rs = rast.raster_settings
+    R, color, radii, gb, bb, ib = _C.rasterize_gaussians(rs.bg, t["means3D"], col, t["opacities"], t["scales"], t["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix,
+                                                         rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset, H, W, e, 0, rs.campos, False, False)[:6]
+    with pytest.raises(RuntimeError, match="raw"):
+        _C.rasterize_gaussians_backward(rs.bg, t["means3D"], radii, col, t["scales"], t["rotations"], 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+                                        rs.kernel_size, rs.subpixel_offset, torch.zeros(3, H, W, device="cuda"), e, 0, rs.campos, gb, R, bb, ib, False,
+                                        raw=(torch.ones(P - 5, device="cuda"), t["opacities"]))
+    # and a well-formed call still works afterwards
+    img = rast(**base, colors_precomp=col)[0]
+    assert torch.isfinite(img).all()

@@ -41,12 +41,13 @@ cam = S.make_camera(W, H)
 lib = C.CDLL(LIB)
 u8 = (C.c_ulonglong * 8)()
 lib.wg_debug_fwd_counters(u8, 1)
-lib.wg_debug_bwd_counters(u8, 1)
+lib.wg_debug_bwd_counters((C.c_ulonglong * 16)(), 1)
 h = run_hip(cloud, cam, sh_degree=d, cotangent=None if a.forward_only else S.make_cotangent(W, H))
 lib.wg_debug_fwd_counters(u8, 1)
 fwd = list(u8)[:6]
-lib.wg_debug_bwd_counters(u8, 1)
-bwd = list(u8)[:6]
+u16 = (C.c_ulonglong * 16)()
+lib.wg_debug_bwd_counters(u16, 1)
+bwd = list(u16)[:14]
 import bench  # noqa: E402
 out = {"workload": f"{P} Gaussians, {W}x{H}, {a.colors}" + ("" if a.scale_mult == 1.0 else f", scales x{a.scale_mult:g}"),
        **{k: v for k, v in bench.profile_stamps().items() if k.endswith("_sha")}, "collected": time.strftime("%Y-%m-%d"), "device": torch.cuda.get_device_name(0),
@@ -54,7 +55,9 @@ out = {"workload": f"{P} Gaussians, {W}x{H}, {a.colors}" + ("" if a.scale_mult =
                           "pairs_passing_both_skips": fwd[3], "pixels_stopped": fwd[4], "pairs_blended": fwd[3] - fwd[4], "strip_evaluations_without_a_passing_pair": fwd[5]},
        "render_backward": None if a.forward_only else {"instances_visited": bwd[0], "strip_evaluations": bwd[1], "pairs_evaluated": 64 * bwd[1],
                                                        "pairs_at_or_before_the_last_contributor": bwd[2], "pairs_contributing": bwd[3],
-                                                       "instances_reduced": bwd[4], "strip_evaluations_without_a_contributing_pair": bwd[5]},
+                                                       "instances_reduced": bwd[4], "strip_evaluations_without_a_contributing_pair": bwd[5],
+                                                       "instances_reduced_by_contributing_lanes": {"1": bwd[6], "2-4": bwd[7], "5-16": bwd[8], "17-64": bwd[9]},
+                                                       "strip_evaluations_by_contributing_lanes": {"1-8": bwd[10], "9-24": bwd[11], "25-48": bwd[12], "49-64": bwd[13]}},
        "what": "per launch; a strip evaluation is one wave-wide evaluation of an instance on an 8x8 strip = 64 (pixel, entry) pairs"}
 # the reference's walk on the same frame (forward.cu:340-381: every pixel looks at every entry of its tile's list until it stops)
 from oracle import oracle  # noqa: E402

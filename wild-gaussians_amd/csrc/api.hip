@@ -496,6 +496,57 @@ int det_scratch_release() {
     return rc;
 }
 
+// ---- the forward render kernel's launch-order history (binning.hip: forward_order_kernel) -------------------------------------------
+// One table per device, plain hipMalloc memory of the library's own, allocated at the first forward call that wants it (never inside a
+// stream capture; a call that cannot have it runs in image order) and kept: [2 * slots] tag words, then slots rows of ORDER_STRIDE costs.
+// Read and written by kernels only; which row a camera takes is decided on the device.  Never freed or moved while the process lives --
+// captured graphs hold its address -- except by wg_set_option("release_scratch", 1), whose caller vouches that no graph replays it.
+constexpr uint32_t ORDER_STRIDE = 9216;   // tiles per row: 1080p (8160) fits one row, a 4K frame (32 400) takes four
+struct OrderTable { int dev; uint32_t* mem; uint32_t slots; };
+std::mutex g_order_mu;
+std::vector<OrderTable> g_order_tables;
+// nullptr: no table (switched off, frame too large, capturing with none allocated yet, or out of memory -- the forward pass runs without)
+uint32_t* order_table_for(const wg::Options& opt, int tiles, hipStream_t stream, uint32_t* slots_out) {
+    *slots_out = 0;
+    if (!opt.forward_order || opt.forward_order_slots <= 0 || tiles < 64) return nullptr;
+    const uint32_t per = ((uint32_t)tiles + ORDER_STRIDE - 1u) / ORDER_STRIDE;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> l(g_order_mu);
+    for (const OrderTable& t : g_order_tables)
+        if (t.dev == dev) {
+            if (t.slots < per) return nullptr;
+            *slots_out = t.slots;
+            return t.mem;
+        }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    const uint32_t slots = (uint32_t)opt.forward_order_slots;
+    if (slots < per) return nullptr;
+    const size_t bytes = (2 * (size_t)slots + (size_t)slots * ORDER_STRIDE) * sizeof(uint32_t);
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, 2 * (size_t)slots * sizeof(uint32_t)) != hipSuccess) {   // (only the tags must start empty)
+        (void)hipGetLastError();
+        if (p) (void)hipFree(p);
+        g_order_tables.push_back({dev, nullptr, 0});   // do not try again on every call
+        return nullptr;
+    }
+    g_order_tables.push_back({dev, static_cast<uint32_t*>(p), slots});
+    *slots_out = slots;
+    return static_cast<uint32_t*>(p);
+}
+void order_tables_release() {
+    std::lock_guard<std::mutex> l(g_order_mu);
+    for (OrderTable& t : g_order_tables)
+        if (t.mem) {
+            int cur = 0;
+            const bool sw = hipGetDevice(&cur) == hipSuccess && cur != t.dev && hipSetDevice(t.dev) == hipSuccess;
+            (void)hipFree(t.mem);
+            if (sw) (void)hipSetDevice(cur);
+        }
+    g_order_tables.clear();
+}
+
 struct FrameMode { const void* image; int exact; };
 std::mutex g_mode_mu;
 FrameMode g_modes[64];
@@ -544,9 +595,17 @@ int wg_rasterize_forward(wg_alloc_fn geometry_alloc, void* geometry_user, wg_all
     return forward_impl(a);
 }
 
+// struct_size: a caller built against an OLDER header hands over a shorter struct (fields are only ever appended): accepted from the
+// first published layout on, the missing tail reads as zero / NULL = absent.  A larger one (a newer header) is refused: its tail may ask
+// for something this library does not know.
+constexpr size_t FORWARD_ARGS_V05 = 288, BACKWARD_ARGS_V05 = 312;   // sizeof of the first published layouts (version 0.5, LP64)
+static_assert(sizeof(wg_forward_args) >= FORWARD_ARGS_V05 && sizeof(wg_backward_args) >= BACKWARD_ARGS_V05, "fields are appended, never removed");
 int wg_rasterize_forward_ex(const wg_forward_args* args) {
-    if (args == nullptr || args->struct_size != sizeof(wg_forward_args)) return WG_ERR_INVALID_ARGUMENT;
-    return args->recolor != nullptr ? recolor_impl(*args) : forward_impl(*args);
+    if (args == nullptr || args->struct_size < FORWARD_ARGS_V05 || args->struct_size > sizeof(wg_forward_args)) return WG_ERR_INVALID_ARGUMENT;
+    wg_forward_args a{};
+    std::memcpy(&a, args, args->struct_size);
+    a.struct_size = sizeof(a);
+    return a.recolor != nullptr ? recolor_impl(a) : forward_impl(a);
 }
 
 int wg_forward_status(char* image_buffer, int width, int height, int* num_rendered, int* fits, void* stream_) {
@@ -648,6 +707,8 @@ static int forward_impl(const wg_forward_args& a) {
     uint32_t max_tile_count = 0;
     bool huge_frame = false;
     Mailbox* mbox = nullptr;
+    uint32_t order_slots = 0;
+    uint32_t* const order_table = (P > 0 && !debug) ? order_table_for(opt, tiles, stream, &order_slots) : nullptr;
     // Near / far split of dense frames (binning.hip): attempted from band_list_min_p Gaussians on (or whenever forced), on the LDS
     // binning path with the lazy sort available; whether it is ACTIVE for this frame is decided on the device (dense enough?) and
     // comes back with the instance count.
@@ -710,7 +771,7 @@ static int forward_impl(const wg_forward_args& a) {
         if (lazy) WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort_lazy(img, bin, geom, tiles, code_bits, opt.lazy, try_split, guard, stream), "tile_sort_lazy");
         else WG_STAGE(WG_STAGE_SORT, wg::launch_tile_sort(img, bin, geom, tiles, longest, guard, stream), "tile_sort");
         WG_STAGE(WG_STAGE_RENDER_FORWARD,
-                 wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, out_color2, lazy, opt.exact_compositing != 0, guard, stream),
+                 wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, out_color2, lazy, opt.exact_compositing != 0, guard, order_table, order_slots, ORDER_STRIDE, stream),
                  "render_forward");
         if (lazy) {
             WG_STAGE(WG_STAGE_RENDER_FIXUP,
@@ -728,6 +789,19 @@ static int forward_impl(const wg_forward_args& a) {
 
     bool rendered = false;  // the render kernels of this frame are already in the stream (a speculation that held)
     if (P > 0) {
+        if (!order_table) {   // (what wg_view_image's order_key says then: no row)
+            hipError_t e0 = hipMemsetAsync(img.order_key, 0xff, sizeof(uint32_t), stream);
+            if (e0 != hipSuccess) return hip_fail(e0, "order_key memset");
+        }
+        wg::FwdOrderArgs fo;   // the forward render kernel's launch order: eight workgroups riding along in the tile scan's launch
+        if (order_table) {
+            fo.viewmatrix = viewmatrix; fo.projmatrix = projmatrix; fo.W = width; fo.H = height; fo.table = order_table; fo.slots = order_slots;
+            fo.stride = ORDER_STRIDE; fo.order = img.order_fwd; fo.key_out = img.order_key; fo.period = (uint32_t)std::max(opt.order_period, 0);
+            if (tiles > wg::BIN_MAX_TILES || opt.fused_scan) {   // no stand-alone tile scan on these paths: a launch of its own, first in the stream
+                WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_forward_order(fo, tiles, stream), "forward_order");
+                fo.table = nullptr;
+            }
+        }
         WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, device_tone(tone, tone2, sh_second), geom, radii, stream), "preprocess");
         wg::SpecLimits spec;   // all zero: the classic flow
         char* spec_chunk = nullptr;
@@ -768,7 +842,7 @@ static int forward_impl(const wg_forward_args& a) {
                     if (!spec_chunk) return WG_ERR_ALLOC;
                 }
             }
-            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, mbox ? mbox->dev : nullptr, mbox ? mbox->seq : 0, try_split, spec, opt.fused_scan != 0, stream), "tile_scan");
+            WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_scan(img, tiles, mbox ? mbox->dev : nullptr, mbox ? mbox->seq : 0, try_split, spec, opt.fused_scan != 0, fo, stream), "tile_scan");
             // "speculative_forward" = 2: do not even look at the verdict before returning -- the thread's next call does (settle_deferred)
             const bool deferred = !fixed && spec.capacity != 0u && opt.speculative == 2;
             if (spec.capacity != 0u) {
@@ -870,7 +944,7 @@ static int forward_impl(const wg_forward_args& a) {
         if (huge_frame) WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_ranges(num_rendered, bin, img, tiles, stream), "tile_ranges");
     }
     WG_STAGE(WG_STAGE_RENDER_FORWARD,
-             wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, out_color2, false, opt.exact_compositing != 0, nullptr, stream),
+             wg::launch_render_forward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, out_color2, false, opt.exact_compositing != 0, nullptr, order_table, order_slots, ORDER_STRIDE, stream),
              "render_forward");
     return num_rendered;
 }
@@ -924,8 +998,11 @@ int wg_rasterize_backward(int P, int D, int M, int R, const float* background, i
 }
 
 int wg_rasterize_backward_ex(const wg_backward_args* args) {
-    if (args == nullptr || args->struct_size != sizeof(wg_backward_args)) return WG_ERR_INVALID_ARGUMENT;
-    return backward_impl(*args);
+    if (args == nullptr || args->struct_size < BACKWARD_ARGS_V05 || args->struct_size > sizeof(wg_backward_args)) return WG_ERR_INVALID_ARGUMENT;
+    wg_backward_args a{};
+    std::memcpy(&a, args, args->struct_size);
+    a.struct_size = sizeof(a);
+    return backward_impl(a);
 }
 
 static int backward_impl(const wg_backward_args& a) {
@@ -1047,7 +1124,7 @@ static int backward_impl(const wg_backward_args& a) {
         // what the ordering launch clears on the side: the gradient records -- or, deterministic mode, the slots' flag bytes
         float* const clear_ptr = det ? reinterpret_cast<float*>(det_flags) : (clear_records ? geom.grad_rec : nullptr);
         const size_t clear_floats = det ? ((size_t)R + 3) / 4 : (size_t)P * (wg::GRAD_REC_FLOATS + (dual ? 1 : 0));
-        WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_order(img.tile_last, nullptr, img.order_bwd, gx * gy, clear_ptr, clear_floats, stream), "tile_order");
+        WG_STAGE(WG_STAGE_TILE_RANGES, wg::launch_tile_order(img.tile_last, nullptr, img.order_bwd, gx * gy, clear_ptr, clear_floats, opt.backward_order_period, stream), "tile_order");
         WG_STAGE(WG_STAGE_RENDER_BACKWARD, wg::launch_render_backward(width, height, gx, gy, img, bin, geom, subpixel_offset, background, dL_dpix,
                                             dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, record, opt.exact_compositing != 0, dual ? second->dL_dpix2 : nullptr, det_slots, det_flags, (size_t)R, P, stream),
                  "render_backward");
@@ -1117,6 +1194,8 @@ int wg_view_image(char* image_buffer, int width, int height, wg_image_view* out)
     out->tile_last = img.tile_last;
     out->tile_near = img.tile_near;
     out->split = reinterpret_cast<const uint32_t*>(img.split);
+    out->order_fwd = img.order_fwd;
+    out->order_key = img.order_key;
     return WG_OK;
 }
 
@@ -1127,13 +1206,21 @@ int wg_set_option(const char* name, int value) {
         g_roctx.enabled = value != 0;
         return WG_OK;
     }
-    if (std::strcmp(name, "release_scratch") == 0) return value != 0 ? det_scratch_release() : WG_OK;   // (an action, not a setting)
+    if (std::strcmp(name, "release_scratch") == 0) {   // (an action, not a setting)
+        if (value == 0) return WG_OK;
+        order_tables_release();
+        return det_scratch_release();
+    }
     std::lock_guard<std::mutex> l(g_opt_mu);
     wg::Options& o = g_opt;
     if (std::strcmp(name, "force_global_sort") == 0) { o.force_global_sort = value != 0; return WG_OK; }
     if (std::strcmp(name, "host_mailbox") == 0) { o.use_mailbox = value != 0; return WG_OK; }
     if (std::strcmp(name, "geometry_reuse") == 0) { o.geometry_reuse = value != 0; return WG_OK; }
     if (std::strcmp(name, "fused_scan") == 0) { o.fused_scan = value != 0; return WG_OK; }
+    if (std::strcmp(name, "forward_order") == 0) { o.forward_order = value != 0; return WG_OK; }
+    if (std::strcmp(name, "forward_order_slots") == 0) { if (value < 0 || value > (1 << 16)) return WG_ERR_INVALID_ARGUMENT; o.forward_order_slots = value; return WG_OK; }   // (read when a device's table is allocated)
+    if (std::strcmp(name, "order_period") == 0) { if (value < 0 || value > 4096) return WG_ERR_INVALID_ARGUMENT; o.order_period = value; return WG_OK; }
+    if (std::strcmp(name, "backward_order_period") == 0) { if (value < 0 || value > 4096) return WG_ERR_INVALID_ARGUMENT; o.backward_order_period = value; return WG_OK; }
     if (std::strcmp(name, "speculative_forward") == 0) {  // (a deferred frame still pending is dropped: its verdict goes unread)
         if (value < 0 || value > 2) return WG_ERR_INVALID_ARGUMENT;
         o.speculative = value; t_spec.clear(); t_wait.clear(); t_deferred.pending = false;
@@ -1183,6 +1270,10 @@ int wg_get_option(const char* name) {
     const wg::Options o = options_snapshot();
     if (std::strcmp(name, "geometry_reuse") == 0) return o.geometry_reuse;
     if (std::strcmp(name, "fused_scan") == 0) return o.fused_scan;
+    if (std::strcmp(name, "forward_order") == 0) return o.forward_order;
+    if (std::strcmp(name, "forward_order_slots") == 0) return o.forward_order_slots;
+    if (std::strcmp(name, "order_period") == 0) return o.order_period;
+    if (std::strcmp(name, "backward_order_period") == 0) return o.backward_order_period;
     if (std::strcmp(name, "speculative_forward") == 0) return o.speculative;
     if (std::strcmp(name, "spec_margin_pct") == 0) return o.spec_margin_pct;
     if (std::strcmp(name, "force_global_sort") == 0) return o.force_global_sort ? 1 : 0;

@@ -74,6 +74,8 @@ ImageState ImageState::fromChunk(char*& chunk, size_t N, size_t tiles) {
     carve(chunk, img.tile_offset, tiles + 1);
     carve(chunk, img.chunk_hist, (tiles ? tiles : 1) * (size_t)BIN_CHUNKS);
     carve(chunk, img.order_bwd, tiles ? tiles : 1);
+    carve(chunk, img.order_fwd, tiles ? tiles : 1);
+    carve(chunk, img.order_key, 4);
     carve(chunk, img.seg_end, tiles ? tiles : 1);
     carve(chunk, img.tile_state, tiles ? tiles : 1);
     carve(chunk, img.stats, 1);
@@ -528,13 +530,120 @@ __device__ __forceinline__ void tile_scan_body(const uint32_t* tile_count, uint3
     }
 }
 
+// One XCD band's tiles [start, start + cnt) in (roughly) descending cost order: a 256-bin counting sort by one 1024-thread workgroup.
+// period == 0: plain descending order (the backward kernel: its second residency round is dealt dynamically, shortest tiles last).
+// period > 0 (the forward kernel, whose ~8 k waves are ALL resident at once): the hardware places a band's workgroups on its XCD's 128
+// SIMDs with period 128 (workgroups i and i + 128 of the band share a SIMD: measured with the probe build, scripts/probe_balance.py --
+// 83 - 100 % of the SIMDs exactly, the rest one phase jump of 32), so the sorted tiles are dealt in rounds of `period`, every other round
+// reversed ("snake"): each SIMD gets one tile of every size class and the classes' slopes cancel.
+template <typename CostFn>
+__device__ __forceinline__ void order_band(CostFn cost_of, uint32_t start, uint32_t cnt, uint32_t* __restrict__ order, uint32_t period,
+                                           uint32_t* hist, uint32_t* wmax) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t m = 0;
+    for (uint32_t i = tid; i < cnt; i += 1024) m = max(m, cost_of(i));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+    if (lane == 0) wmax[wave] = m;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    m = 0;
+    for (int w = 0; w < 16; w++) m = max(m, wmax[w]);
+    const float scale = 255.0f / (float)max(m, 1u);
+    auto bin_of = [&](uint32_t c) { return 255u - min(255u, (uint32_t)((float)c * scale)); };  // bin 0 = the most expensive tiles
+    for (uint32_t i = tid; i < cnt; i += 1024) atomicAdd(&hist[bin_of(cost_of(i))], 1u);
+    __syncthreads();
+    if (tid < 64) {  // exclusive scan of the 256 bins: 4 per lane
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = hist[4 * tid + k]; sum += v[k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= (uint32_t)d) incl += up;
+        }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { hist[4 * tid + k] = run; run += v[k]; }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < cnt; i += 1024) {
+        uint32_t rank = atomicAdd(&hist[bin_of(cost_of(i))], 1u);
+        if (period != 0u) {
+            const uint32_t r = rank / period, j = rank - r * period;
+            const uint32_t len = min(period, cnt - r * period);   // (the last round of a band is a partial one)
+            rank = r * period + ((r & 1u) ? len - 1u - j : j);
+        }
+        order[start + rank] = start + i;
+    }
+}
+
+// ---- launch order of the FORWARD render kernel: tile costs remembered per camera ------------------------------------------------------
+// The forward kernel's tile costs (the walked lengths, tile_last) are only known once it has run -- but training renders the same cameras
+// over and over while the Gaussians move slowly, and an earlier frame of the same camera predicts them well.  The library keeps, per device, a
+// direct-mapped table in device memory (api.hip: OrderTable): row = hash(viewmatrix, projmatrix, W, H) -> {64-bit tag, uint32 cost[tiles]}.
+// Everything happens ON THE DEVICE (the camera matrices are device memory: the host never sees their values): eight workgroups -- one per
+// XCD band, riding along in the launch of the single-workgroup tile scan, which leaves the chip idle anyway -- hash the camera, look the
+// row up and write the launch order -- order_band()'s snake on a hit, the identity on a miss -- plus the row's index into the frame's image
+// state; the render kernel writes every tile's walked length (and the tag) back into the row.  Pure scheduling: a stale, torn or colliding
+// row costs balance, never a result.
+__device__ __forceinline__ void forward_order_body(int band, const FwdOrderArgs& a, int tiles, uint32_t* hist, uint32_t* wmax, uint32_t* s_key) {
+    if (threadIdx.x == 0) {
+        unsigned long long h = 0xcbf29ce484222325ull;   // FNV-1a over the 34 words
+        auto mix = [&](uint32_t w) { h = (h ^ (unsigned long long)w) * 0x100000001b3ull; };
+        for (int i = 0; i < 16; i++) mix(__float_as_uint(a.viewmatrix[i]));
+        for (int i = 0; i < 16; i++) mix(__float_as_uint(a.projmatrix[i]));
+        mix((uint32_t)a.W); mix((uint32_t)a.H);
+        h ^= h >> 29;
+        const uint32_t per = ((uint32_t)tiles + a.stride - 1u) / a.stride;   // table rows a frame of this size takes
+        const uint32_t groups = a.slots / per;
+        const uint32_t slot = (uint32_t)(h % (unsigned long long)groups) * per;
+        const uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32) | 1u;   // (hi != 0: an empty row never matches)
+        const uint32_t* tag = a.table + 2 * (size_t)slot;
+        s_key[0] = slot; s_key[1] = lo; s_key[2] = hi;
+        s_key[3] = (tag[0] == lo && tag[1] == hi) ? 1u : 0u;
+        if (band == 0) { a.key_out[0] = slot; a.key_out[1] = lo; a.key_out[2] = hi; a.key_out[3] = s_key[3]; }
+    }
+    __syncthreads();
+    const int q = tiles >> 3, rem = tiles & 7, x = band;
+    const uint32_t start = x * q + min(x, rem), cnt = q + (x < rem ? 1 : 0);
+    if (s_key[3] == 0u) {   // no earlier frame of this camera: image order
+        for (uint32_t i = threadIdx.x; i < cnt; i += 1024) a.order[start + i] = start + i;
+        return;
+    }
+    const uint32_t* cost = a.table + 2 * (size_t)a.slots + (size_t)s_key[0] * a.stride;
+    order_band([&](uint32_t i) { return cost[start + i]; }, start, cnt, a.order, a.period, hist, wmax);
+}
+
+// stand-alone form (frames whose tile scan takes another path: the fused scan, more tiles than the LDS histogram holds)
+__global__ void __launch_bounds__(1024) forward_order_kernel(FwdOrderArgs a, int tiles) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wmax[16];
+    __shared__ uint32_t s_key[4];
+    forward_order_body((int)blockIdx.x, a, tiles, hist, wmax, s_key);
+}
+
+hipError_t launch_forward_order(const FwdOrderArgs& a, int tiles, hipStream_t stream) {
+    if (tiles <= 0 || !a.table) return hipSuccess;
+    hipLaunchKernelGGL(forward_order_kernel, dim3(8), dim3(1024), 0, stream, a, tiles);
+    return hipGetLastError();
+}
+
 template <int PER>
 __global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
                                                          uint2* __restrict__ ranges, BinStats* __restrict__ stats, int tiles,
-                                                         HostMailbox* mailbox, uint32_t seq, const SplitState* __restrict__ split, SpecLimits spec) {
+                                                         HostMailbox* mailbox, uint32_t seq, const SplitState* __restrict__ split, SpecLimits spec,
+                                                         FwdOrderArgs fo) {
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t wave_max[16];
     __shared__ uint32_t wave_ovf[16];
+    if (blockIdx.x != 0) {   // workgroups 1..8 (present when fo.table != nullptr): the forward render kernel's launch order, one XCD band each
+        __shared__ uint32_t hist[256];
+        __shared__ uint32_t s_key[4];
+        forward_order_body((int)blockIdx.x - 1, fo, tiles, hist, wave_sum, s_key);
+        return;
+    }
     tile_scan_body<PER>(tile_count, tile_offset, ranges, stats, tiles, mailbox, seq, split, spec, wave_sum, wave_max, wave_ovf);
 }
 
@@ -1087,14 +1196,16 @@ __global__ void __launch_bounds__(256) tile_front_sort_kernel(const uint32_t* __
 // gives every SIMD one tile of each size class.  One workgroup per band orders its tiles.  Pure scheduling: results do not
 // depend on it.  Used for the backward kernel, whose
 // per-tile cost (tile_last, the walked length) is known exactly from the forward pass: 0.752 -> 0.660 ms.  The forward
-// kernel's only predictor, the list length, did not help (its walked fraction is what varies), so it keeps image order.
+// kernel's only predictor within the frame, the list length, did not help (its walked fraction is what varies): it is ordered by the tile costs
+// of an EARLIER frame of the same camera (forward_order_kernel below).
 // The order only has to be roughly descending, so it is a 256-bin counting sort (bin = cost scaled by the band's maximum; 5
 // barriers) rather than a comparison sort of the band's ~1000 keys (55 barriers: 14 us of pure latency in front of the backward
 // kernel).
 // Blocks 8 and up (when asked for) clear the backward pass's gradient records: the clear and the ordering are both needed in front of
 // the per-tile kernel and depend on nothing of each other, so they share a launch instead of queueing as a fill kernel + this one.
 __global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __restrict__ cost, const uint2* __restrict__ ranges,
-                                                          uint32_t* __restrict__ order, int tiles, float4* __restrict__ clear, size_t clear_vec4) {
+                                                          uint32_t* __restrict__ order, int tiles, float4* __restrict__ clear, size_t clear_vec4,
+                                                          uint32_t period) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wmax[16];
     if (blockIdx.x >= 8) {
@@ -1104,47 +1215,17 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const uint32_t* __rest
     }
     const int q = tiles >> 3, rem = tiles & 7, x = blockIdx.x;
     const uint32_t start = x * q + min(x, rem), cnt = q + (x < rem ? 1 : 0);
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    auto cost_of = [&](uint32_t i) { return cost ? cost[start + i] : (ranges[start + i].y - ranges[start + i].x); };
-    uint32_t m = 0;
-    for (uint32_t i = tid; i < cnt; i += 1024) m = max(m, cost_of(i));
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
-    if (lane == 0) wmax[wave] = m;
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    m = 0;
-    for (int w = 0; w < 16; w++) m = max(m, wmax[w]);
-    const float scale = 255.0f / (float)max(m, 1u);
-    auto bin_of = [&](uint32_t c) { return 255u - min(255u, (uint32_t)((float)c * scale)); };  // bin 0 = the most expensive tiles
-    for (uint32_t i = tid; i < cnt; i += 1024) atomicAdd(&hist[bin_of(cost_of(i))], 1u);
-    __syncthreads();
-    if (tid < 64) {  // exclusive scan of the 256 bins: 4 per lane
-        uint32_t v[4], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { v[k] = hist[4 * tid + k]; sum += v[k]; }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= (uint32_t)d) incl += up;
-        }
-        uint32_t run = incl - sum;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { hist[4 * tid + k] = run; run += v[k]; }
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < cnt; i += 1024) order[start + atomicAdd(&hist[bin_of(cost_of(i))], 1u)] = start + i;
+    order_band([&](uint32_t i) { return cost ? cost[start + i] : (ranges[start + i].y - ranges[start + i].x); }, start, cnt, order, period, hist, wmax);
 }
 
 hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_or_null, uint32_t* order, int tiles, float* clear, size_t clear_floats,
-                             hipStream_t stream) {
+                             int period, hipStream_t stream) {
     if (tiles <= 0) return hipSuccess;
     // clear: 16-byte aligned (the gradient records: 12 floats per Gaussian, + P floats in a two-colour call, in a 256-byte aligned array)
     const size_t vec4 = clear ? (clear_floats + 3) / 4 : 0;   // (rounded UP: 13 floats per Gaussian in a two-colour call; the array is carved to a whole float4)
     const unsigned clear_blocks = vec4 ? (unsigned)std::min<size_t>(2048, (vec4 + 4095) / 4096) : 0u;
     hipLaunchKernelGGL(tile_order_kernel, dim3(8 + clear_blocks), dim3(1024), 0, stream, cost_or_null, ranges_or_null, order, tiles,
-                       reinterpret_cast<float4*>(clear), vec4);
+                       reinterpret_cast<float4*>(clear), vec4, (uint32_t)std::max(period, 0));
     return hipGetLastError();
 }
 
@@ -1186,7 +1267,7 @@ hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& im
 }
 
 hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, bool split, const SpecLimits& spec,
-                            bool fused_scan, hipStream_t stream) {
+                            bool fused_scan, const FwdOrderArgs& fo, hipStream_t stream) {
     const SplitState* sp = split ? img.split : nullptr;
     if (fused_scan) {
         uint32_t* near = split ? img.tile_near : (uint32_t*)nullptr;
@@ -1200,11 +1281,11 @@ hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailb
     }
     // BIN_MAX_TILES / 1024 = 36 tiles per thread at most; 8 covers 1080p (8160 tiles)
     if (tiles <= 8 * 1024)
-        hipLaunchKernelGGL(tile_scan_kernel<8>, dim3(1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges, img.stats, tiles,
-                           mailbox_dev, seq, sp, spec);
+        hipLaunchKernelGGL(tile_scan_kernel<8>, dim3(fo.table ? 9 : 1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges, img.stats, tiles,
+                           mailbox_dev, seq, sp, spec, fo);
     else
-        hipLaunchKernelGGL((tile_scan_kernel<BIN_MAX_TILES / 1024>), dim3(1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges,
-                           img.stats, tiles, mailbox_dev, seq, sp, spec);
+        hipLaunchKernelGGL((tile_scan_kernel<BIN_MAX_TILES / 1024>), dim3(fo.table ? 9 : 1), dim3(1024), 0, stream, img.tile_count, img.tile_offset, img.ranges,
+                           img.stats, tiles, mailbox_dev, seq, sp, spec, fo);
     return hipGetLastError();
 }
 

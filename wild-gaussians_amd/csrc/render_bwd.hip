@@ -27,12 +27,14 @@ constexpr int BATCH = 64;
 
 // WG_COUNT_PAIRS (a VARIANT build only, see render_fwd.hip): [0] instances visited, [1] strip evaluations (one = 64 (pixel, entry) pairs),
 // [2] of those pairs, the ones at or before their pixel's last contributor, [3] contributing pairs (what backward.cu:536-600
-// differentiates), [4] instances reduced and added to their Gaussian's record, [5] strip evaluations in which no pair contributed.
+// differentiates), [4] instances reduced and added to their Gaussian's record, [5] strip evaluations in which no pair contributed,
+// [6..9] reduced instances by the number of LANES that contributed anything (1, 2-4, 5-16, 17-64: what a path without the butterfly would
+// have to serve), [10..13] strip evaluations by contributing lanes (1-8, 9-24, 25-48, 49-64).
 #ifndef WG_COUNT_PAIRS
 #define WG_COUNT_PAIRS 0
 #endif
 #if WG_COUNT_PAIRS
-__device__ unsigned long long g_bwd_counters[8];
+__device__ unsigned long long g_bwd_counters[16];
 #define WG_CNT(i, v) wgc[i] += (unsigned long long)(v)
 #else
 #define WG_CNT(i, v)
@@ -130,6 +132,12 @@ __device__ __forceinline__ float butterfly13(float v0, float v1, float v2, float
 // eval_alpha_exact).  This kernel keeps the fast evaluation (its values only have to be accurate) but must take the SAME decisions, so
 // a pair whose fast values are within a proven error band of a threshold is re-evaluated with that arithmetic (a rare,
 // wave-uniform branch; ~10^3 pairs of ~10^9 per frame) and its decision, alpha and G are taken from there.
+#ifndef WG_PROBE
+#define WG_PROBE 0   // a VARIANT build only (render_fwd.hip; scripts/probe_balance.py)
+#endif
+#if WG_PROBE
+__device__ unsigned long long g_bwd_probe[4 * 65536];
+#endif
 #ifndef WG_BWD_WAVES
 #define WG_BWD_WAVES 0
 #endif
@@ -162,8 +170,17 @@ render_backward_kernel(
     __shared__ float4 lds[BATCH * (DUAL ? 4 : 3)];
     constexpr int RS = DUAL ? 4 : 3;   // float4 per parked record
 
+#if WG_PROBE
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tile = (int)order[xcd_tile(blockIdx.x, tiles)];
     const int hi0 = (int)tile_last[tile];
+#if WG_PROBE
+    if (hi0 == 0 && threadIdx.x == 0 && blockIdx.x < 65536) {
+        g_bwd_probe[4 * blockIdx.x] = probe_t0; g_bwd_probe[4 * blockIdx.x + 1] = probe_t0; g_bwd_probe[4 * blockIdx.x + 3] = (unsigned long long)tile;
+        g_bwd_probe[4 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    }
+#endif
     if (hi0 == 0) return;
     const int lane = threadIdx.x;
     const int tx = tile % gx, ty = tile / gx;
@@ -255,7 +272,7 @@ render_backward_kernel(
 #define sq p4.y
 
 #if WG_COUNT_PAIRS
-    unsigned long long wgc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long wgc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     for (int hi = hi0; hi > 0; hi -= BATCH) {
         // lane l stages the instance at list position hi-1-l (back to front, backward.cu:517)
@@ -344,11 +361,14 @@ render_backward_kernel(
                     }
                 } else {
                     const float p2 = eval_alpha_values(sc, pfx[s], pfy[s], e);
-                    pass_m = __builtin_amdgcn_ballot_w64(p2 <= 0.0f) & __builtin_amdgcn_ballot_w64(e.alpha >= (1.0f / 255.0f));
+                    pass_m = __builtin_amdgcn_ballot_w64(!(p2 > 0.0f)) & __builtin_amdgcn_ballot_w64(!(e.alpha < (1.0f / 255.0f)));
                 }
                 const uint64_t go_m = before_last_m & pass_m;
                 WG_CNT(3, __popcll(go_m));
                 WG_CNT(5, go_m == 0ull ? 1 : 0);
+#if WG_COUNT_PAIRS
+                { const int c = __popcll(go_m); if (c) WG_CNT(c <= 8 ? 10 : c <= 24 ? 11 : c <= 48 ? 12 : 13, 1); }
+#endif
                 any_m |= go_m;
                 if (__builtin_amdgcn_inverse_ballot_w64(go_m)) {
                     const float a = e.alpha;
@@ -393,6 +413,9 @@ render_backward_kernel(
             }
             if (any_m == 0ull) continue;
             WG_CNT(4, 1);
+#if WG_COUNT_PAIRS
+            { const int c = __popcll(any_m); WG_CNT(c <= 1 ? 6 : c <= 4 ? 7 : c <= 16 ? 8 : 9, 1); }
+#endif
             const float total = DUAL ? butterfly13(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, ac2r, ac2g, ac2b, lane)
                                      : butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
             if (DET) {
@@ -415,7 +438,15 @@ render_backward_kernel(
     }
 #if WG_COUNT_PAIRS
     if (lane == 0)
-        for (int i = 0; i < 6; i++) atomicAdd(&g_bwd_counters[i], wgc[i]);
+        for (int i = 0; i < 14; i++) atomicAdd(&g_bwd_counters[i], wgc[i]);
+#endif
+#if WG_PROBE
+    if (lane == 0 && blockIdx.x < 65536) {
+        g_bwd_probe[4 * blockIdx.x] = probe_t0;
+        g_bwd_probe[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        g_bwd_probe[4 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        g_bwd_probe[4 * blockIdx.x + 3] = (unsigned long long)tile;
+    }
 #endif
 }
 
@@ -592,12 +623,19 @@ hipError_t launch_render_backward(int W, int H, int gx, int gy, const ImageState
 
 }  // namespace wg
 
-#if WG_COUNT_PAIRS
-extern "C" int wg_debug_bwd_counters(unsigned long long* out8, int reset) {
+#if WG_PROBE
+extern "C" int wg_probe_fetch_bwd(void* dst, size_t bytes) {
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess && out8) e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(wg::g_bwd_counters), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(wg::g_bwd_probe), bytes < sizeof(wg::g_bwd_probe) ? bytes : sizeof(wg::g_bwd_probe), 0, hipMemcpyDeviceToHost);
+    return (int)e;
+}
+#endif
+#if WG_COUNT_PAIRS
+extern "C" int wg_debug_bwd_counters(unsigned long long* out16, int reset) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && out16) e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(wg::g_bwd_counters), 16 * sizeof(unsigned long long));
     if (e == hipSuccess && reset) {
-        const unsigned long long z[8] = {};
+        const unsigned long long z[16] = {};
         e = hipMemcpyToSymbol(HIP_SYMBOL(wg::g_bwd_counters), z, sizeof(z));
     }
     return e == hipSuccess ? 0 : -3;

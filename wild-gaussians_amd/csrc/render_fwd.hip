@@ -208,7 +208,7 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
                     PairEval e;
                     const float p2 = eval_alpha_values(sc, pfx[s], pfy[s], e);
                     alpha = e.alpha;
-                    pass_m = __builtin_amdgcn_ballot_w64(p2 <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha >= (1.0f / 255.0f));
+                    pass_m = __builtin_amdgcn_ballot_w64(!(p2 > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha < (1.0f / 255.0f)));
                 }
                 const uint64_t go_m = pass_m & alive_m[s];
                 WG_CNT(3, __popcll(go_m));
@@ -264,8 +264,9 @@ __device__ __forceinline__ void fwd_walk(FwdTile& st, float4* lds, int lane, con
 
 // complete: the tile is finished (every pixel stopped, or its list is exhausted) -> final outputs.  Otherwise the state is
 // parked in the same buffers for a later fwd_init(resume): colour without background, -T for stopped pixels.
+// Returns the tile's walked length so far (max of its pixels' last contributors; wave-uniform).
 template <bool DUAL = false>
-__device__ void fwd_store(const FwdTile& st, bool complete, int W, int H, int tile, int lane, const float* __restrict__ bg,
+__device__ uint32_t fwd_store(const FwdTile& st, bool complete, int W, int H, int tile, int lane, const float* __restrict__ bg,
                           float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_last,
                           float* __restrict__ out_color, float* __restrict__ accum, float* __restrict__ out_color2 = nullptr,
                           bool colour_only = false) {
@@ -298,6 +299,7 @@ __device__ void fwd_store(const FwdTile& st, bool complete, int W, int H, int ti
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, m));
     if (lane == 0 && !colour_only) tile_last[tile] = lmax;
+    return lmax;
 }
 
 // seg_end == nullptr: the whole list is sorted (default).  Otherwise (lazy sort, binning.hip) only the first seg_end[tile]
@@ -314,15 +316,29 @@ __device__ void fwd_store(const FwdTile& st, bool complete, int W, int H, int ti
 #else
 #define WG_FWD_OCC
 #endif
+// WG_PROBE (a VARIANT build only: scripts/probe_balance.py): every wave records its start / end on the 100 MHz real-time counter, the SIMD it
+// ran on (HW_ID, XCC_ID) and its tile -- how evenly the launch order loads the 1 024 SIMDs.
+#ifndef WG_PROBE
+#define WG_PROBE 0
+#endif
+#if WG_PROBE
+__device__ unsigned long long g_fwd_probe[4 * 65536];
+#endif
 template <bool EXACT, bool DUAL>
 __device__ __forceinline__ void render_forward_body(
     float4* lds, int W, int H, int gx, int tiles, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     const uint32_t* seg_end, uint32_t* __restrict__ tile_state,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* tile_last,
-    float* __restrict__ out_color, const BinStats* __restrict__ guard, int replay, float* __restrict__ accum, float* __restrict__ out_color2) {
+    float* __restrict__ out_color, const BinStats* __restrict__ guard, int replay, float* __restrict__ accum, float* __restrict__ out_color2,
+    const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_key, uint32_t* __restrict__ order_table, uint32_t order_slots,
+    uint32_t order_stride) {
     if (guard && guard->spec_fail) return;  // speculative forward (api.hip): the frame did not fit what was enqueued; the host re-issues
-    const int tile = xcd_tile(blockIdx.x, tiles);
+#if WG_PROBE
+    const unsigned long long probe_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // order (binning.hip: forward_order_kernel): a permutation of each XCD band's tiles by the costs an earlier frame of this camera had
+    const int tile = order ? (int)order[xcd_tile(blockIdx.x, tiles)] : xcd_tile(blockIdx.x, tiles);
     const int lane = threadIdx.x;
     FwdTile st;
     fwd_init<DUAL>(st, W, H, gx, tile, lane, subpixel_offset, false, final_T, n_contrib, out_color, out_color2);
@@ -333,8 +349,22 @@ __device__ __forceinline__ void render_forward_body(
     // replay (geometry reuse): seg_end is the tile's walked length of an earlier pass over the same geometry -- nothing behind it
     // contributes, so the tile is complete whatever is left of the list
     const bool complete = st.strips_alive == 0 || end == n || replay != 0;
-    fwd_store<DUAL>(st, complete, W, H, tile, lane, bg, final_T, n_contrib, tile_last, out_color, accum, out_color2, replay != 0);
+    const uint32_t walked = fwd_store<DUAL>(st, complete, W, H, tile, lane, bg, final_T, n_contrib, tile_last, out_color, accum, out_color2, replay != 0);
     if (tile_state && lane == 0) tile_state[tile] = complete ? 0xffffffffu : (uint32_t)end;
+    if (order_table && lane == 0) {   // this frame's cost of the tile, for the next frame of the camera (a hint: no ordering, no atomics)
+        const uint32_t slot = order_key[0];
+        order_table[2 * (size_t)order_slots + (size_t)slot * order_stride + tile] = walked + 1u;   // (+1: staging and stores cost something for an empty tile too)
+        if (blockIdx.x == 0) { order_table[2 * (size_t)slot] = order_key[1]; order_table[2 * (size_t)slot + 1] = order_key[2]; }
+    }
+#if WG_PROBE
+    if (lane == 0 && blockIdx.x < 65536) {
+        g_fwd_probe[4 * blockIdx.x] = probe_t0;
+        g_fwd_probe[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        g_fwd_probe[4 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |   // XCC_ID
+                                          (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));                      // HW_ID
+        g_fwd_probe[4 * blockIdx.x + 3] = (unsigned long long)tile;
+    }
+#endif
 }
 
 // (seg_end and tile_last are the same array in the replay launch: neither is __restrict__)
@@ -344,10 +374,11 @@ __global__ void __launch_bounds__(64) WG_FWD_OCC render_forward_kernel(
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     const uint32_t* seg_end, uint32_t* __restrict__ tile_state,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* tile_last,
-    float* __restrict__ out_color, const BinStats* __restrict__ guard, int replay, float* __restrict__ accum) {
+    float* __restrict__ out_color, const BinStats* __restrict__ guard, int replay, float* __restrict__ accum,
+    const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_key, uint32_t* __restrict__ order_table, uint32_t order_slots, uint32_t order_stride) {
     __shared__ float4 lds[BATCH * 3];
     render_forward_body<EXACT, false>(lds, W, H, gx, tiles, ranges, point_list, splats, subpixel_offset, bg, seg_end, tile_state, final_T, n_contrib,
-                                      tile_last, out_color, guard, replay, accum, nullptr);
+                                      tile_last, out_color, guard, replay, accum, nullptr, order, order_key, order_table, order_slots, order_stride);
 }
 
 // the two-colour walk keeps twelve more sums per lane: its register allocation is left to the compiler (no occupancy pin)
@@ -365,25 +396,31 @@ __global__ void __launch_bounds__(64) WG_FWD_DUAL_OCC render_forward_dual_kernel
     const float4* __restrict__ splats, const float2* __restrict__ subpixel_offset, const float* __restrict__ bg,
     const uint32_t* seg_end, uint32_t* __restrict__ tile_state,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, uint32_t* tile_last,
-    float* __restrict__ out_color, const BinStats* __restrict__ guard, float* __restrict__ accum, float* __restrict__ out_color2) {
+    float* __restrict__ out_color, const BinStats* __restrict__ guard, float* __restrict__ accum, float* __restrict__ out_color2,
+    const uint32_t* __restrict__ order, const uint32_t* __restrict__ order_key, uint32_t* __restrict__ order_table, uint32_t order_slots, uint32_t order_stride) {
     __shared__ float4 lds[BATCH * 3];
     render_forward_body<EXACT, true>(lds, W, H, gx, tiles, ranges, point_list, splats, subpixel_offset, bg, seg_end, tile_state, final_T, n_contrib,
-                                     tile_last, out_color, guard, 0, accum, out_color2);
+                                     tile_last, out_color, guard, 0, accum, out_color2, order, order_key, order_table, order_slots, order_stride);
 }
 
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                  const GeometryState& g, const float* subpixel_offset, const float* background,
-                                 float* out_color, float* out_color2, bool lazy, bool exact, const BinStats* guard, hipStream_t stream) {
+                                 float* out_color, float* out_color2, bool lazy, bool exact, const BinStats* guard, uint32_t* order_table,
+                                 uint32_t order_slots, uint32_t order_stride, hipStream_t stream) {
     const int tiles = gx * gy;
     if (tiles <= 0) return hipSuccess;
+    const uint32_t* order = order_table ? img.order_fwd : (const uint32_t*)nullptr;
+    const uint32_t* okey = order_table ? img.order_key : (const uint32_t*)nullptr;
 #define WG_LAUNCH(EX)                                                                                                                       \
     hipLaunchKernelGGL(render_forward_kernel<EX>, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats,   \
                        reinterpret_cast<const float2*>(subpixel_offset), background, lazy ? img.seg_end : (const uint32_t*)nullptr,        \
-                       lazy ? img.tile_state : (uint32_t*)nullptr, img.final_T, img.n_contrib, img.tile_last, out_color, guard, 0, img.accum)
+                       lazy ? img.tile_state : (uint32_t*)nullptr, img.final_T, img.n_contrib, img.tile_last, out_color, guard, 0, img.accum, \
+                       order, okey, order_table, order_slots, order_stride)
 #define WG_LAUNCH_DUAL(EX)                                                                                                                  \
     hipLaunchKernelGGL(render_forward_dual_kernel<EX>, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats, \
                        reinterpret_cast<const float2*>(subpixel_offset), background, lazy ? img.seg_end : (const uint32_t*)nullptr,        \
-                       lazy ? img.tile_state : (uint32_t*)nullptr, img.final_T, img.n_contrib, img.tile_last, out_color, guard, img.accum, out_color2)
+                       lazy ? img.tile_state : (uint32_t*)nullptr, img.final_T, img.n_contrib, img.tile_last, out_color, guard, img.accum, out_color2, \
+                       order, okey, order_table, order_slots, order_stride)
     if (out_color2) { if (exact) WG_LAUNCH_DUAL(true); else WG_LAUNCH_DUAL(false); }
     else { if (exact) WG_LAUNCH(true); else WG_LAUNCH(false); }
 #undef WG_LAUNCH
@@ -399,7 +436,8 @@ hipError_t launch_render_forward_replay(int W, int H, int gx, int gy, const Imag
 #define WG_LAUNCH(EX)                                                                                                                       \
     hipLaunchKernelGGL(render_forward_kernel<EX>, dim3(tiles), dim3(64), 0, stream, W, H, gx, tiles, img.ranges, b.point_list, g.splats,   \
                        reinterpret_cast<const float2*>(subpixel_offset), background, (const uint32_t*)img.tile_last, (uint32_t*)nullptr,   \
-                       img.final_T, img.n_contrib, img.tile_last, out_color, (const BinStats*)nullptr, 1, img.accum)
+                       img.final_T, img.n_contrib, img.tile_last, out_color, (const BinStats*)nullptr, 1, img.accum,                        \
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, 0u)
     if (exact) WG_LAUNCH(true); else WG_LAUNCH(false);
 #undef WG_LAUNCH
     return hipGetLastError();
@@ -519,6 +557,13 @@ hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, cons
 
 }  // namespace wg
 
+#if WG_PROBE
+extern "C" int wg_probe_fetch(void* dst, size_t bytes) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(wg::g_fwd_probe), bytes < sizeof(wg::g_fwd_probe) ? bytes : sizeof(wg::g_fwd_probe), 0, hipMemcpyDeviceToHost);
+    return (int)e;
+}
+#endif
 #if WG_COUNT_PAIRS
 extern "C" int wg_debug_fwd_counters(unsigned long long* out8, int reset) {
     hipError_t e = hipDeviceSynchronize();

@@ -196,6 +196,27 @@ py::tuple RasterizeGaussiansEx(const torch::Tensor& background, const torch::Ten
     const auto bytes = torch::TensorOptions().dtype(torch::kUInt8).device(dev);
     torch::Tensor geomBuffer = torch::empty({0}, bytes), binningBuffer = torch::empty({0}, bytes), imgBuffer = torch::empty({0}, bytes);
     const bool two = colors2.has_value() || !sh_second.is_none();
+    // The checks of the ctypes binding (_C.py), same messages: a wrong-size tensor must raise, not send a kernel out of bounds.
+    {
+        const int64_t P64 = P;
+        const bool fixed = !binning_capacity.is_none();
+        if (filter_3D.has_value() && (colors2.has_value() || fixed || scales.numel() == 0 || filter_3D->numel() != P64))
+            throw std::runtime_error("filter_3D (raw-parameter mode) needs scales and rotations, P filter values, and neither colors2 nor binning_capacity");
+        if (!sh_second.is_none() && (colors2.has_value() || fixed || sh.numel() == 0 || colors.numel() != 0))
+            throw std::runtime_error("sh_second (two tones of one SH block) needs SH colours and neither colors2 nor binning_capacity");
+        if (colors2.has_value() && (!sh_tone.is_none() || fixed || sh.numel() != 0 || colors.numel() != 3 * P64 || colors2->numel() != 3 * P64))
+            throw std::runtime_error("colors2 needs precomputed colours of P x 3 in both sets (no SH, no sh_tone, no binning_capacity)");
+        if (fixed && debug) throw std::runtime_error("binning_capacity (the fixed-capacity forward) has no debug mode");
+        // (the reference's binding checks none of its per-Gaussian arguments, rasterize_points.cu:59-61 is all there is; these cost nothing)
+        auto sized = [&](const torch::Tensor& t, int64_t per, const char* name) {
+            if (t.numel() != 0 && t.numel() != per * P64)
+                throw std::runtime_error(std::string(name) + " must have " + std::to_string(per) + " * P elements");
+        };
+        sized(colors, 3, "colors_precomp"); sized(opacity, 1, "opacities"); sized(scales, 3, "scales"); sized(rotations, 4, "rotations");
+        sized(cov3D_precomp, 6, "cov3D_precomp");
+        if (sh.numel() != 0 && (sh.ndimension() != 3 || sh.size(0) != P64 || sh.size(2) != 3)) throw std::runtime_error("sh must have dimensions (P, M, 3)");
+        if (opacity.numel() != P64) throw std::runtime_error("opacities must have P elements");
+    }
     if (P == 0) {   // :83: nothing is launched, the image stays zero
         py::list out;
         out.append(0); out.append(torch::zeros({3, H, W}, f)); out.append(torch::zeros({0}, means3D.options().dtype(torch::kInt32)));
@@ -280,6 +301,12 @@ py::tuple RasterizeGaussiansBackwardEx(const torch::Tensor& background, const to
     const bool record = P != 0 && (co.grad_record != 0 || co.deterministic_backward != 0);
     const bool two_tone = !sh_second.is_none();
     const bool dual = dL_dout_color2.has_value() && !two_tone;
+    if (dL_dout_color.ndimension() != 3 || dL_dout_color.size(0) != 3) throw std::runtime_error("dL_dout_color must have dimensions (3, H, W)");
+    if (dL_dout_color2.has_value() && dL_dout_color2->numel() != dL_dout_color.numel()) throw std::runtime_error("dL_dout_color2 must have the first image's dimensions");
+    if (P != 0 && (radii.numel() != (int64_t)P || (colors.numel() != 0 && colors.numel() != 3 * (int64_t)P) || (scales.numel() != 0 && scales.numel() != 3 * (int64_t)P) ||
+                   (rotations.numel() != 0 && rotations.numel() != 4 * (int64_t)P) || (cov3D_precomp.numel() != 0 && cov3D_precomp.numel() != 6 * (int64_t)P) ||
+                   (sh.numel() != 0 && (sh.ndimension() != 3 || sh.size(0) != (int64_t)P || sh.size(2) != 3))))
+        throw std::runtime_error("a per-Gaussian argument of the backward call does not have P rows");
     // the reference zero-fills nine tensors (:157-165); with the gradient record every one of them is fully written by the library
     // (zeros for culled Gaussians), without it the four accumulation targets must arrive zeroed
     auto alloc = [&](std::initializer_list<int64_t> shape, bool accumulated) {
@@ -330,8 +357,10 @@ py::tuple RasterizeGaussiansBackwardEx(const torch::Tensor& background, const to
         torch::Tensor f3d, rop;
         if (!raw_in.is_none()) {
             const py::tuple tu = raw_in.cast<py::tuple>();
+            if (tu.size() != 2) throw std::runtime_error("raw is (filter_3D, raw_opacities)");
             f3d = f32(tu[0].cast<torch::Tensor>(), dev);
             rop = f32(tu[1].cast<torch::Tensor>(), dev);
+            if (f3d.numel() != (int64_t)P || rop.numel() != (int64_t)P) throw std::runtime_error("raw = (filter_3D, raw_opacities) must have P elements each");
             raw.filter_3D = ptr(f3d); raw.raw_opacities = ptr(rop);
             a.raw = &raw;
         }

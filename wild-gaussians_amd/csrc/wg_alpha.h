@@ -48,7 +48,7 @@ __device__ __forceinline__ bool eval_alpha(const SplatCoef& c, float pfx, float 
     const float p2 = c.ca * e.xx + c.cb * e.xy + c.cc * e.yy;  // log2(e) * power
     e.G = __builtin_amdgcn_exp2f(p2);
     e.alpha = fminf(0.99f, c.o * e.G);
-    return p2 <= 0.0f && e.alpha >= (1.0f / 255.0f);
+    return !(p2 > 0.0f) && !(e.alpha < (1.0f / 255.0f));   // the reference's comparisons (forward.cu:360,365): a NaN passes both
 }
 
 // eval_alpha() handing p2 (= log2(e) * power) back instead of the decision
@@ -95,22 +95,21 @@ __device__ __forceinline__ ExactCoef exact_coef_of(const float4 r0, const float4
 // below -103 (where it returns 0) the clamp keeps ldexp's result a denormal: either way alpha < 1/255 and the pair is skipped.
 // (The clamp is not optional: for |x| >~ 2^23 the split's low part pl is the rounding error of x * log2e, as large as ulp(ph) / 2, and
 //  v_exp_f32 of it would overflow.)
-// ONE documented exception to "the reference's decisions bit for bit" (ADVICE r4): a NaN power.  The reference keeps it -- `power > 0` is
-// false, min(0.99f, NaN) = 0.99f, the pair is blended at alpha 0.99 --; here v_max_f32 returns the other operand, the power becomes -104
-// and the pair is skipped.  A NaN power needs a NaN mean or conic in the splat record, and such a Gaussian never gets one: its radius
-// (ceil of a NaN, converted to int: 0) or its tile rectangle (built from NaN pixel coordinates: empty) removes it in K1, as in the reference
-// (forward.cu:241-250).  A NaN OPACITY does reach the walk and behaves as in the reference (alpha = min(0.99f, NaN) = 0.99f in both).
-// Guarding the clamp (x != x ? x : ...) would cost two VALU instructions per strip evaluation for an input no caller can produce.
+// A NaN power (a NaN conic or mean in the record) is KEPT, as the reference keeps it: `power > 0` is false, exp(NaN) = NaN, min(0.99f, NaN) =
+// 0.99f -- the pair is blended at alpha 0.99 (forward.cu:358-366).  v_max_f32 would swallow the NaN (it returns the other operand), so the
+// first fused multiply-add below takes the UNCLAMPED argument: for x >= -104 that is the clamped one, bit for bit; for x < -104 it makes pl
+// hugely negative, v_exp_f32 underflows to 0 and the result is 0 instead of a denormal -- alpha < 1/255 and the pair skipped either way --;
+// for a NaN it puts the NaN back.  No instruction is spent on it (rounds 4-5 documented the NaN case as a deviation instead).
 // tests/test_exp_expansion.py holds this function to the compiler's own `expf` (built -ffp-contract=off) over a dense range of arguments:
 // a toolchain whose exp lowering changes fails that test directly, not only the parity tests downstream.
 __device__ __forceinline__ float ref_expf_nonpos(float x) {
 #pragma clang fp contract(off)
-    x = fmaxf(x, -104.0f);
+    const float xc = fmaxf(x, -104.0f);
     const float c = 0x1.715476p+0f, cc = 0x1.4ae0bep-26f;
-    const float ph = x * c;
+    const float ph = xc * c;
     const float e = __builtin_rintf(ph);
-    float pl = __builtin_fmaf(x, c, -ph);
-    pl = __builtin_fmaf(x, cc, pl);
+    float pl = __builtin_fmaf(x, c, -ph);   // x, not xc: see above
+    pl = __builtin_fmaf(xc, cc, pl);
     const float a = (ph - e) + pl;
     return __builtin_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
 }
@@ -265,9 +264,12 @@ __device__ __forceinline__ uint32_t strip_mask_box(const float4 r0, const float4
 #endif
 __device__ __forceinline__ uint32_t strip_mask_exact(const float4 r0, const float4 r1, const StripBounds& sb) {
     const float mx = r0.x, my = r0.y, A = r0.z, B = r0.w, C = r1.x, o = r1.y;
-    const bool vis = o * 1.001f >= (1.0f / 255.0f);  // false for NaN
+    const bool vis = !(o * 1.001f < (1.0f / 255.0f));  // true for a NaN opacity: the reference blends it at alpha = min(0.99f, NaN) = 0.99f everywhere (forward.cu:364)
     const float AC = A * C;
     const bool definite = A > 0.0f && C > 0.0f && (AC - B * B) > 4e-6f * AC;
+    // A NaN anywhere in the record reaches every strip, whatever the opacity: the reference blends such a pair at alpha = min(0.99f, NaN) =
+    // 0.99f on every pixel of the Gaussian's tile rectangle (forward.cu:358-366; a NaN conic comes with opacity * coef = 0: `0 * exp(NaN)`)
+    const bool any_nan = !(A == A && B == B && C == C && o == o && mx == mx && my == my);
     const float tau2 = 2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(255.0f * o) * 1.002f + 0.002f;
     const float nBC = -B * __builtin_amdgcn_rcpf(C), nBA = -B * __builtin_amdgcn_rcpf(A), B2 = 2.0f * B;
     // the tile's sample box (wave-uniform; +-inf bounds of strips outside the image drop out of the min / max)
@@ -287,7 +289,7 @@ __device__ __forceinline__ uint32_t strip_mask_exact(const float4 r0, const floa
         const float fh = yf * (C * yf + B2 * u) + A * u * u;
         if (fminf(fv, fh) <= thr) m |= 1u << s;
     }
-    return vis ? (definite ? m : 15u) : 0u;
+    return any_nan ? 15u : (vis ? (definite ? m : 15u) : 0u);
 }
 // r0, r1, r2: the record as preprocess wrote it (conic unscaled)
 __device__ __forceinline__ uint32_t strip_mask(const float4 r0, const float4 r1, const float4 r2, const StripBounds& sb) {

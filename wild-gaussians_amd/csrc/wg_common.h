@@ -105,6 +105,8 @@ struct ImageState {
     uint32_t* tile_offset;  // exclusive prefix sum of tile_count
     uint32_t* chunk_hist;   // [chunks][tiles] per-chunk tile histogram, turned into per-chunk bases by the column scan
     uint32_t* order_bwd;    // launch order of the backward render: per XCD band, tiles by descending walked length
+    uint32_t* order_fwd;    // launch order of the forward render (binning.hip: forward_order_kernel), when the per-camera history is on
+    uint32_t* order_key;    // [4] {the camera's row in the library's order table, tag lo, tag hi, 1 = the row held this camera}
     uint32_t* seg_end;      // lazy sort: length of the tile's sorted front after the first round (== count when sorted in full)
     uint32_t* tile_state;   // lazy sort: 0xffffffff = tile finished, else the list length the forward pass has consumed
     BinStats* stats;
@@ -199,8 +201,22 @@ hipError_t launch_duplicate_keys(int P, const GeometryState& g, const BinningSta
 hipError_t run_sort(const BinningState& b, int R, int end_bit, hipStream_t stream);
 hipError_t launch_tile_ranges(int R, const BinningState& b, const ImageState& img, int tiles, hipStream_t stream);
 // clear != nullptr: the same launch zeroes clear_floats floats (the backward pass's gradient records)
+// period: 0 = descending cost; > 0 = dealt in rounds of that many tiles, every other round reversed (binning.hip: order_band)
 hipError_t launch_tile_order(const uint32_t* cost_or_null, const uint2* ranges_or_null, uint32_t* order, int tiles, float* clear, size_t clear_floats,
-                             hipStream_t stream);
+                             int period, hipStream_t stream);
+// the forward render kernel's launch order from the per-camera history table (table: 2 * slots tag words, then slots rows of `stride` costs;
+// nullptr = no table: nothing is ordered); order / key_out: the frame's ImageState::order_fwd / order_key
+struct FwdOrderArgs {
+    const float* viewmatrix = nullptr;
+    const float* projmatrix = nullptr;
+    int W = 0, H = 0;
+    uint32_t* table = nullptr;
+    uint32_t slots = 0, stride = 0;
+    uint32_t* order = nullptr;
+    uint32_t* key_out = nullptr;
+    uint32_t period = 0;
+};
+hipError_t launch_forward_order(const FwdOrderArgs& a, int tiles, hipStream_t stream);   // stand-alone; launch_tile_scan carries it along otherwise
 // split == nullptr: no near / far split attempted (small P): the kernels are exactly the ones without it
 hipError_t launch_split_threshold(int P, const GeometryState& g, const ImageState& img, int tiles, bool force, uint32_t near_per_tile,
                                   hipStream_t stream);
@@ -208,7 +224,7 @@ hipError_t launch_split_threshold(int P, const GeometryState& g, const ImageStat
 hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, bool split, bool box, bool fused_scan,
                              hipStream_t stream);
 hipError_t launch_tile_scan(const ImageState& img, int tiles, HostMailbox* mailbox_dev, uint32_t seq, bool split, const SpecLimits& spec,
-                            bool fused_scan, hipStream_t stream);
+                            bool fused_scan, const FwdOrderArgs& fo, hipStream_t stream);   // fo.table != nullptr (and !fused_scan): eight more workgroups order the bands
 // guard (everywhere below): nullptr, or the frame's BinStats -- the kernel returns at once when spec_fail is set there
 hipError_t launch_tile_scatter_far(int P, const GeometryState& g, const ImageState& img, const BinningState& b, int gx, int tiles, int code_bits,
                                    const BinStats* guard, hipStream_t stream);
@@ -250,6 +266,10 @@ struct Options {
     int box_count = -1;               // tile counting through a difference grid: -1 automatic (with the split's "large or dense" rule) / 0 / 1
     bool force_global_sort = false;   // exercise the fallback binning path
     bool use_mailbox = true;          // 0 restores the copy + synchronise read-back
+    int forward_order = 1;            // launch order of the forward render kernel from the per-camera tile-cost history (0 = image order, no table)
+    int forward_order_slots = 2048;   //   rows of that table (x 9216 tiles x 4 B = 75 MB of device memory, allocated at the first forward call)
+    int order_period = 128;           //   rounds of the snake dealing (the hardware's placement period per XCD; 0 = plain descending order)
+    int backward_order_period = 0;    //   the same for the backward kernel's order (0: descending, its tail is dealt dynamically)
 };
 hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, int code_bits,
                                  const LazyConfig& lazy, bool split, const BinStats* guard, hipStream_t stream);
@@ -259,9 +279,12 @@ hipError_t launch_render_fixup(int code_bits, int W, int H, int gx, int gy, cons
                                bool split, int phase, bool exact, HostMailbox* mailbox_dev, const BinStats* guard, hipStream_t stream);
 hipError_t launch_tile_sort(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, uint32_t max_count,
                             const BinStats* guard, hipStream_t stream);
+// order_table != nullptr: img.order_fwd / img.order_key are valid (launch_forward_order ran): tiles launch in that order and write their
+// walked lengths back into the camera's row of the table
 hipError_t launch_render_forward(int W, int H, int gx, int gy, const ImageState& img, const BinningState& b,
                                  const GeometryState& g, const float* subpixel_offset, const float* background,
-                                 float* out_color, float* out_color2, bool lazy, bool exact, const BinStats* guard, hipStream_t stream);
+                                 float* out_color, float* out_color2, bool lazy, bool exact, const BinStats* guard, uint32_t* order_table,
+                                 uint32_t order_slots, uint32_t order_stride, hipStream_t stream);
 // the compositing of a frame whose binning and per-pixel stops are known (img.tile_last, img.n_contrib of an earlier pass over the
 // same geometry): each tile walks exactly its list's first tile_last entries and stores final outputs
 // capturable forward (api.hip: wg_forward_args::binning_capacity): when the frame did not fit (BinStats::spec_fail) the image and the

@@ -33,13 +33,14 @@ if not os.path.exists(_LIB_PATH):
 _lib = C.CDLL(_LIB_PATH)
 
 # The compiled torch binding of the same C-ABI (csrc/torch_binding.cpp -> _C_torch*.so, built by build.py --torch-binding; INTEGRATION.md
-# section 2): the reference's three functions with the reference's signatures, nothing beyond them.  WG_BINDING=torch (or use_binding("torch"))
-# routes the plain calls through it; every opt-in beyond the reference's surface stays with the ctypes code below, which is the default.
+# section 2): the reference's three functions with the reference's signatures + the `_ex` pair carrying every optional block.  It is the
+# DEFAULT whenever it has been built (end of this file); WG_BINDING=ctypes (or use_binding("ctypes")) selects the ctypes code below, which
+# covers the same surface and is what serves a variant library (WG_RASTERIZER_LIB).
 _torch_ext = None
 
 
 def use_binding(name: str) -> str:
-    """"ctypes" (default) or "torch": which binding serves the reference-surface calls.  Returns the previous name."""
+    """"torch" (the default when built) or "ctypes": which binding serves the calls.  Returns the previous name."""
     global _torch_ext
     prev = "ctypes" if _torch_ext is None else "torch"
     if name == "torch":
@@ -104,7 +105,7 @@ class _BinningView(C.Structure):
 
 
 class _ImageView(C.Structure):
-    _fields_ = [(n, _vp) for n in ("final_T", "accumulation", "n_contrib", "ranges", "tile_last", "tile_near", "split")]
+    _fields_ = [(n, _vp) for n in ("final_T", "accumulation", "n_contrib", "ranges", "tile_last", "tile_near", "split", "order_fwd", "order_key")]
 
 
 _lib.wg_view_geometry.restype = _i
@@ -529,6 +530,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     record = bool(opts[2] or opts[1])
     dual = dL_dout_color2 is not None and sh_second is None
     P = means3D.size(0)
+    if raw is not None and (len(raw) != 2 or raw[0].numel() != P or raw[1].numel() != P):
+        raise RuntimeError("raw = (filter_3D, raw_opacities) must have P elements each")
     if raw is not None and (not record or dual):
         raise RuntimeError("the raw-parameter backward pass needs grad_record = 1 and cannot be combined with the two-colour call")
     if (dual or sh_second is not None) and ((dual and sh_tone is not None) or (not record and P != 0)):
@@ -699,7 +702,9 @@ def view_image(imageBuffer, H, W):
                 ranges=_from_ptr(v.ranges, (tiles, 2), torch.int32, imageBuffer),
                 tile_last=_from_ptr(v.tile_last, (tiles,), torch.int32, imageBuffer),
                 tile_near=_from_ptr(v.tile_near, (tiles,), torch.int32, imageBuffer),
-                split=_from_ptr(v.split, (2,), torch.int32, imageBuffer))
+                split=_from_ptr(v.split, (2,), torch.int32, imageBuffer),
+                order_fwd=_from_ptr(v.order_fwd, (tiles,), torch.int32, imageBuffer),
+                order_key=_from_ptr(v.order_key, (4,), torch.int32, imageBuffer))
 
 
 _lib.wg_set_option.restype = _i
@@ -772,10 +777,26 @@ def profile_read() -> dict:
     _check(_lib.wg_profile_read(C.byref(st)), "wg_profile_read")
     return {_lib.wg_stage_name(i).decode(): (float(st.total_ms[i]), int(st.launches[i])) for i in range(STAGE_COUNT)}
 
-# WG_OPTIONS="name=value,name=value": library options applied at import (e.g. WG_OPTIONS=force_global_sort=1)
+# WG_OPTIONS="name=value,name=value": library options applied at import (e.g. WG_OPTIONS=force_global_sort=1).  One of the three per-call
+# names sets the PROCESS default (CALL_OPTION_DEFAULTS: what every thread starts from, also threads created later), not only the importing
+# thread's -- WG_OPTIONS=deterministic_backward=1 has to reach worker and view-parallel threads too.
 for _kv in filter(None, os.environ.get("WG_OPTIONS", "").split(",")):
     _k, _, _v = _kv.partition("=")
-    set_option(_k.strip(), int(_v or "1"))
+    _k = _k.strip()
+    if _k in CALL_OPTION_DEFAULTS:
+        CALL_OPTION_DEFAULTS[_k] = int(bool(int(_v or "1")))
+        _thread_call_options()[_k] = CALL_OPTION_DEFAULTS[_k]
+    else:
+        set_option(_k, int(_v or "1"))
+
+
+def set_default_call_option(name: str, value: int) -> None:
+    """The PROCESS-wide default of a per-call option: what threads that have not set their own start from (set_option / call_options stay
+    per thread).  Threads that already resolved their defaults keep them; the calling thread takes the new value."""
+    if name not in CALL_OPTION_DEFAULTS:
+        raise ValueError(name)
+    CALL_OPTION_DEFAULTS[name] = int(bool(int(value)))
+    _thread_call_options()[name] = CALL_OPTION_DEFAULTS[name]
 
 
 # Which binding serves the calls: the compiled module (csrc/torch_binding.cpp -> _C_torch*.so) when it has been built and links this very

@@ -321,6 +321,100 @@ def self_launch(n: int):
     os.execve(sys.executable, cmd, env)
 
 
+def config_legs(device, deg_unused, with_oracle: bool, clouds: dict) -> dict:
+    """BASELINE.json configs 2, 3 and 5 at their QUOTED sizes, a short leg each, appended to the headline line as `configs` (VERDICT r5 item
+    4: until round 6 only builder-run files held these numbers).  Per leg: the rate over a short timed region (barrier-free, one GPU:
+    synchronize on both sides), `pins_ok` -- num_rendered and the SHA-256 of radii, n_contrib and final_T equal what the REFERENCE's own
+    kernels (-ffp-contract=off build) gave for this frame on an MI355X (tests/golden/ref_hip_fullsize_sha256.json; no reference binary
+    needed) --, and for the fwd+bwd legs `grad_worst`: max over the gradient tensors of max|g - g_oracle| / max|g_oracle| against the CPU
+    oracle on the same inputs.  clouds: name -> (cloud, cam, deg), generated by the caller (config 5's 10 M Gaussians take ~50 s of
+    single-threaded numpy: the caller starts that in a thread before its own passes)."""
+    import gc
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import fullsize_frames as FF
+    import wg_scenes as S
+    from diff_gaussian_rasterization import GaussianRasterizer, _C
+    from tests.wg_testlib import make_settings, to_dev, compare_grads
+    pins = json.load(open(FF.PINS))["frames"]
+    legs = {}
+    for key, name, fwd_only in (("2", "config2_500k_1080p_sh3", False), ("3", "config3_3M_1600x1200_precomp", False), ("5", "config5_10M_4K_sh3", True)):
+        try:
+            got = clouds[name]() if callable(clouds[name]) else clouds[name]
+            cloud, cam, deg = got
+            P, W, H, colours, _k = FF.FRAMES[name]
+            rs = make_settings(cam, deg, device=device)
+            rast = GaussianRasterizer(rs)
+            t = {k: to_dev(v, device).requires_grad_(not fwd_only) for k, v in cloud.items()}
+            means2D = torch.zeros((P, 3), device=device, requires_grad=not fwd_only)
+            cot_np = S.make_cotangent(W, H)
+            cot = to_dev(cot_np, device)
+
+            def call():
+                return rast(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t.get("shs"), colors_precomp=t.get("colors_precomp"),
+                            scales=t["scales"], rotations=t["rotations"])
+
+            def step():
+                if fwd_only:
+                    with torch.no_grad():
+                        return call()[0]
+                for v in t.values():
+                    v.grad = None
+                means2D.grad = None
+                color = call()[0]
+                color.backward(cot)
+                return color
+            # pins: the native module's image state of one forward pass
+            with torch.no_grad():
+                e = torch.Tensor([])
+                R_, _c, radii, gb, bb, ib = _C.rasterize_gaussians(
+                    rs.bg, t["means3D"], t["colors_precomp"] if "colors_precomp" in t else e, t["opacities"], t["scales"], t["rotations"], 1.0, e,
+                    rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.kernel_size, rs.subpixel_offset, H, W, t["shs"] if "shs" in t else e, deg,
+                    rs.campos, False, False)[:6]
+                im = _C.view_image(ib, H, W)
+                d = FF.digest(R_, radii.cpu().numpy(), im["n_contrib"].cpu().numpy(), im["final_T"].cpu().numpy())
+                del _c, gb, bb, ib, im
+            leg = {"workload": f"{P} Gaussians, {W}x{H}, {'SH deg 3' if colours == 'sh' else 'precomputed colours'}, {'forward only' if fwd_only else 'fwd+bwd'}",
+                   "pins_ok": d == pins[name], "num_rendered": int(R_)}
+            if d != pins[name]:
+                leg["pins_mismatch"] = [k for k in d if d[k] != pins[name][k]]
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize(device)
+            one = max(time.perf_counter() - t0, 1e-5)
+            steps = int(max(20, min(600, 1.2 / one)))   # ~1.2 s of steps
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            leg["steps"] = steps
+            leg["ms_per_step"] = round(1e3 * dt / steps, 4)
+            leg["fps" if fwd_only else "iters_per_s"] = round(steps / dt, 2)
+            if not fwd_only and with_oracle:
+                from oracle import oracle
+                o = oracle.run_scene(cloud, cam, sh_degree=deg, cotangent=cot_np)
+                step()
+                torch.cuda.synchronize(device)
+                grads = {"means3D": t["means3D"].grad, "means2D": means2D.grad, "opacities": t["opacities"].grad, "scales": t["scales"].grad,
+                         "rotations": t["rotations"].grad, ("sh" if "shs" in t else "colors_precomp"): (t["shs"] if "shs" in t else t["colors_precomp"]).grad}
+                errs = compare_grads({k: v.detach().cpu().numpy() for k, v in grads.items()}, o["grads"])
+                leg["grad_worst"] = float(f"{max(errs.values()):.3e}")
+                leg["grad_checker"] = "CPU oracle, same inputs: max over tensors of max|g - g_ref| / max|g_ref|"
+                del o
+            legs[key] = leg
+            del t, means2D, cot, rast, cloud, got
+            clouds[name] = None
+        except Exception as ex:  # noqa: BLE001 -- an extra of the line, never a reason to lose it
+            legs[key] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,6 +434,11 @@ def main():
     ap.add_argument("--views", type=int, default=None,
                     help="views per step over ALL ranks (default: one per rank = --gpus, weak scaling).  BASELINE config 4 is `--views 8`: a fixed batch of the "
                          "eight cameras, rank r renders views r, r+N, ... of it every step (strong scaling; `--gpus 1 --views 8` is its N = 1 point)")
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="skip the short legs at BASELINE configs 2, 3 and 5's quoted sizes that the default (headline) run appends as `configs`")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams a rank deals its views of a step to, round robin (view k of the rank on stream k %% S): independent views overlap on one "
+                         "GPU -- view k+1's projection / binning under view k's compositing.  1 = everything on one stream (the headline protocol)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="wg_set_option(NAME, VALUE) before the run (A/B of library options, e.g. grad_record=0); recorded in the JSON line")
     args = ap.parse_args()
@@ -373,6 +472,24 @@ def main():
     W, H, P = args.width, args.height, args.gaussians
     N = W * H
     sh_degree = 3 if args.colors == "sh" else None
+    # the default (headline) run also carries short legs at BASELINE configs 2, 3, 5 (config_legs): their clouds are generated on a host
+    # thread from here on (numpy releases the interpreter lock inside its generators), beside this process's own passes
+    want_legs = (world == 1 and rank == 0 and not args.no_config_legs and not args.forward_only and args.views is None and args.scale_mult == 1.0 and
+                 (P, W, H, args.colors) == (1_000_000, 1920, 1080, "sh") and args.streams == 1 and not args.option)
+    leg_clouds, leg_thread = {}, None
+    if want_legs:
+        import threading
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import fullsize_frames as FF
+
+        def _gen():
+            for nm in ("config2_500k_1080p_sh3", "config3_3M_1600x1200_precomp", "config5_10M_4K_sh3"):
+                try:
+                    leg_clouds[nm] = FF.frame_inputs(nm)
+                except Exception as ex:  # noqa: BLE001
+                    leg_clouds[nm] = ex
+        leg_thread = threading.Thread(target=_gen, daemon=True)
+        leg_thread.start()
     cloud = S.make_cloud(P, W, H, sh_degree=sh_degree, seed=0, scale_mult=args.scale_mult)
     V_total = args.views if args.views is not None else world
     if V_total < world:
@@ -397,26 +514,44 @@ def main():
                            colors_precomp=t.get("colors_precomp"), scales=t["scales"], rotations=t["rotations"])
 
     loss_stream = VP.LossStream(device)
+    # --streams S: the rank's views of a step are independent (the operator has no cross-view state), so view k goes to stream
+    # k % S.  Every timed region ends with a device-wide synchronize, which covers all of them; inputs are only read.  Each view's gradient
+    # tensors are allocated (and freed, when the next view of that stream drops them) on the stream that computes them.
+    n_streams = max(1, min(args.streams, len(rasts)))
+    side_streams = [torch.cuda.Stream(device) for _ in range(n_streams)] if n_streams > 1 else []
+    if side_streams:
+        torch.cuda.synchronize(device)   # the uploads above are through before another stream reads them
+
+    def one_view(r):
+        for v in t.values():
+            v.grad = None
+        means2D.grad = None
+        color, radii, acc = call(r)
+        color.backward(cot)
+        # the loss <image, cotangent> and the only collective (4 bytes, queued asynchronously: wg_viewparallel.LossStream); the timed
+        # region's closing synchronize covers it
+        return loss_stream.submit(color, cot_flat)
 
     def train_step():
         # one step = this rank's views of the batch, one full forward + backward pass each (one view per rank unless --views says otherwise)
         loss = None
-        for r in rasts:
-            for v in t.values():
-                v.grad = None
-            means2D.grad = None
-            color, radii, acc = call(r)
-            color.backward(cot)
-            # the loss <image, cotangent> and the only collective (4 bytes, queued asynchronously: wg_viewparallel.LossStream); the timed
-            # region's closing synchronize covers it
-            loss = loss_stream.submit(color, cot_flat)
+        for k, r in enumerate(rasts):
+            if side_streams:
+                with torch.cuda.stream(side_streams[k % n_streams]):
+                    loss = one_view(r)
+            else:
+                loss = one_view(r)
         return loss
 
     def fwd_step():
         with torch.no_grad():
             out = None
-            for r in rasts:
-                out = call(r)[0]
+            for k, r in enumerate(rasts):
+                if side_streams:
+                    with torch.cuda.stream(side_streams[k % n_streams]):
+                        out = call(r)[0]
+                else:
+                    out = call(r)[0]
             return out
 
     t_train_local = [0.0]
@@ -534,7 +669,8 @@ def main():
                                ("one view per GPU (view-parallel, loss all-reduce only)" if args.views is None else
                                 f"a fixed batch of {V_total} views per step dealt round-robin to {world} GPU(s) (view-parallel, loss all-reduce only; BASELINE config 4 "
                                 "is --views 8)"),
-                   "gaussians": P, "width": W, "height": H, "colors": args.colors, "views_per_step": V_total, "views_of_rank0": my_views},
+                   "gaussians": P, "width": W, "height": H, "colors": args.colors, "views_per_step": V_total, "views_of_rank0": my_views,
+                   "streams_per_rank": n_streams},
         "per_rank_num_rendered": job["per_rank_num_rendered"],
         "forward_fps": round(fwd_fps, 2),
         "forward_mpix_per_s": round(fwd_fps * N / 1e6, 1),
@@ -676,6 +812,35 @@ def main():
                                                      rs8.subpixel_offset, H, W, t["shs"] if "shs" in t else e, deg, rs8.campos, False, False)[0]))
         out["camera_sequence"]["num_rendered_per_camera"] = Rs
 
+    if side_streams and not args.forward_only:
+        # Every view dealt to the streams must come out as it does alone on one stream: image, radii and accumulation bit for bit, and --
+        # in the deterministic backward mode, whose sums do not depend on timing -- every gradient bit for bit.
+        import hashlib
+
+        def digest_views(streams_on):
+            out_ = []
+            with _C.call_options(deterministic_backward=1):
+                for k, r in enumerate(rasts):
+                    ctx_ = torch.cuda.stream(side_streams[k % n_streams]) if streams_on else contextlib.nullcontext()
+                    with ctx_:
+                        for v in t.values():
+                            v.grad = None
+                        means2D.grad = None
+                        color, radii, acc = call(r)
+                        color.backward(cot)
+                        keep_ = [color.detach(), radii, acc.detach(), means2D.grad] + [v.grad for v in t.values()]
+                    out_.append(keep_)
+                    if not streams_on:
+                        torch.cuda.synchronize(device)
+            torch.cuda.synchronize(device)
+            return [[hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest()[:16] for x in keep_] for keep_ in out_]
+        import contextlib
+        alone, dealt = digest_views(False), digest_views(True)
+        out["streams"] = {"streams": n_streams, "views": len(rasts),
+                          "every_view_bit_identical_to_its_run_alone": alone == dealt,
+                          "compared": "image, radii, accumulation, and (deterministic backward mode) all gradients: SHA-256 per tensor and view",
+                          "mismatching_views": [k for k in range(len(rasts)) if alone[k] != dealt[k]]}
+
     gc.enable()   # (off since the first pass: see above)
     # The same K steps once more as a training loop would run them: the interpreter's cycle collector ON inside the region (ADVICE r4:
     # round 3's protocol beside round 4's, so that a change of protocol and a change of the code can be told apart)
@@ -801,6 +966,23 @@ def main():
             out["roofline"]["compute"] = views.pop(roof_ctx["dom"])
         if views:
             out["render_compute"] = views
+    if want_legs:
+        t_legs = time.perf_counter()
+        leg_thread.join()
+        waited = time.perf_counter() - t_legs
+
+        def _take(nm):
+            v = leg_clouds.get(nm)
+            if isinstance(v, Exception):
+                raise v
+            return v
+        del cloud, t, means2D
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["configs"] = config_legs(device, deg, not args.no_cpu_baseline, {nm: (lambda nm=nm: _take(nm)) for nm in list(leg_clouds)})
+        out["configs"]["note"] = ("BASELINE.json configs 2, 3 (operator level: one call, fwd+bwd) and 5 at their quoted sizes, a ~1.2 s timed leg each after the headline's "
+                                  "passes; pins_ok = the frame's radii / n_contrib / final_T hash to the reference build's (tests/golden/ref_hip_fullsize_sha256.json); "
+                                  f"host seconds spent waiting for the legs' clouds after the headline passes: {waited:.1f}, legs in all: {time.perf_counter() - t_legs:.1f}")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

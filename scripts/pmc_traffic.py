@@ -3,7 +3,16 @@
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950
 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so it is doubled before comparing with a
-byte count; WRITE_SIZE (and narrow / gather access patterns) are uncalibrated and taken as reported.
+byte count.  CALIBRATED in round 6 on the render kernels' own access patterns (scripts/pmc_calibration.hip ->
+profiles/r6/pmc_calibration.json; kernels of known bytes, arrays past the Infinity Cache):
+  * streaming 16-B reads: known / FETCH_SIZE = 2.000; streaming 16-B writes: known / WRITE_SIZE = 1.000;
+  * 48-byte records gathered through a shuffled index list (the render kernels' staging): 2 x FETCH_SIZE = 163.4 B per record
+    = the 128-byte lines a 48-byte record touches (1.25 lines = 160 B) + its 4-byte index: the DOUBLING HOLDS for gathers -- it gives
+    the bytes MOVED (whole lines: 3.1 x the 52 useful bytes when nothing is reused);
+  * one global_atomic_add_f32 instruction of ten lanes on a 48-byte record (render_bwd.hip's gradient-record update):
+    WRITE_SIZE = 64.0 B and FETCH_SIZE = 32.0 B per instruction, whatever the 40 bytes of payload -- the backward kernel's
+    WRITE_SIZE is exactly 64 B x its reduced instances.
+So hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 are bytes moved over the fabric for every stage, render kernels included.
 usage: pmc_traffic.py pmc_summary.txt "<workload string>" > profiles/pmc_traffic.json"""
 import json
 import os
@@ -38,7 +47,11 @@ try:
     st = bench.profile_stamps()   # kernel sources + the device code of the library as built (bench.device_code_sha)
 except Exception:  # noqa: BLE001
     st = {"kernel_source_sha": None, "device_code_sha": None}
-out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "kernel_source_sha": st["kernel_source_sha"], "device_code_sha": st.get("device_code_sha"), "collected": time.strftime("%Y-%m-%d"), "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE halving; WRITE_SIZE as reported)",
+out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "", "kernel_source_sha": st["kernel_source_sha"], "device_code_sha": st.get("device_code_sha"), "collected": time.strftime("%Y-%m-%d"), "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: bytes MOVED (whole 128-B lines); factors measured on known byte counts in round 6 "
+                     "(profiles/r6/pmc_calibration.json): streaming reads 2.000, streaming writes 1.000, 48-byte record gathers 2 x FETCH = lines touched "
+                     "(163.4 B per record for 52 useful), atomic record updates 64 B of WRITE_SIZE + 32 B of FETCH_SIZE per instruction",
+       "correction_per_stage": {"render_forward": "gather-calibrated: 2 x FETCH_SIZE = lines moved", "render_backward": "gather-calibrated reads; WRITE_SIZE = 64 B per atomic instruction",
+                                "other stages": "streaming-calibrated (2.000 / 1.000)"},
        "stages": {k: dict(v, hbm_bytes=(2 * v["FETCH_SIZE_KiB"] + v["WRITE_SIZE_KiB"]) * 1024) for k, v in vals.items()}}
 # Lane utilisation of the vector ALU from counters alone (rocprofiler's VALUUtilization): SQ_THREAD_CYCLES_VALU counts thread-cycles of VALU
 # execution, SQ_ACTIVE_INST_VALU the (quad-)cycles waves spent executing VALU instructions:

@@ -73,6 +73,11 @@ for name, fn in (("render_forward", "wg_probe_fetch"), ("render_backward", "wg_p
         "mean_over_max_simd_finish": round(float(per_simd_end.mean() / per_simd_end.max()), 3),
         "latest_wave_start_us": round(float((t0.max() - t0.min()) / 100.0), 2),
     }
+if dump:   # the frame's per-tile walked lengths beside the probes (the cost the launch orders are built from)
+    from tests.wg_testlib import run_hip_native
+    nat = run_hip_native(cloud, S.make_camera(W, H), sh_degree=3, device=dev)
+    raw["tile_last"] = nat["views"]["image"]["tile_last"].cpu().numpy()
+    raw["ranges"] = nat["views"]["image"]["ranges"].cpu().numpy()
 print(json.dumps(out))
 if dump:
     np.savez_compressed(dump, **raw)

@@ -312,11 +312,15 @@ NONFINITE_CATEGORIES = {   # name -> (cloud key, component or None = the whole r
     "rot NaN": ("rotations", 0, _NAN), "rot all zero": ("rotations", None, np.float32(0)), "rot +Inf": ("rotations", 1, _INF),
     "opacity NaN": ("opacities", 0, _NAN), "opacity +Inf": ("opacities", 0, _INF), "opacity -1": ("opacities", 0, np.float32(-1)), "opacity 7": ("opacities", 0, np.float32(7)),
 }
-# The two categories in which the product does NOT do what the reference's kernels do: a NaN opacity, or a NaN conic (from a NaN
-# quaternion component with finite cov2D diagonal), makes the reference's alpha = min(0.99f, NaN) = 0.99 on EVERY pixel of the Gaussian's
-# tile rectangle (forward.cu:358: fminf returns its non-NaN argument) -- an opaque block.  The product draws nothing for such a Gaussian
-# (NaN fails its reach test and its exp expansion's clamp).  Neither is meaningful; the suite pins "finite image, same radii".
-NONFINITE_DEVIATING = ("rot NaN", "opacity NaN")
+# The two categories in which the reference's own output is UNDEFINED: a NaN scale or quaternion component makes the 2-D covariance NaN,
+# the radius `(int)ceil(NaN)` = 0 and the tile rectangle one tile (forward.cu:241-250) -- the scan allots that instance a slot of the key
+# list, but duplicateWithKeys emits nothing for radii <= 0 (rasterizer_impl.cu:85) and the slot keeps whatever the binning buffer held
+# before: the reference composites a stale (tile, Gaussian) pair somewhere (tests/tools/debug_nan.py shows its lists one entry short in the
+# Gaussian's own tile and the strays in tile 0).  The product counts the same instances (num_rendered agrees), draws nothing for them, and
+# reads no uninitialised memory.  Everything else -- sixteen categories, NaN opacities included (alpha = min(0.99f, NaN) = 0.99f over the
+# Gaussian's tiles, forward.cu:364) -- the product does bit for bit as the reference's kernels do.
+NONFINITE_REFERENCE_UNDEFINED = ("scale NaN", "rot NaN")
+NONFINITE_DEVIATING = NONFINITE_REFERENCE_UNDEFINED   # (the name rounds 5's tools use)
 
 
 def poison(cloud, name, ids):

@@ -1810,7 +1810,7 @@ def test_forward_launch_order_history_changes_no_result(lazy_options, scene):
                     lo = x * q + min(x, rem)
                     hi = lo + q + (1 if x < rem else 0)
                     assert np.array_equal(np.sort(on["order_fwd"][lo:hi]), np.arange(lo, hi)), (scene, rep, x)
-                if hit:
+                if hit and scene != "dense_lazy":   # (lazy sort: the render kernel walks every tile's sorted front only -- equal costs, any order)
                     assert not np.array_equal(on["order_fwd"], np.arange(tiles))   # really another order than the image's
                 for k in ("color", "radii", "final_T", "accumulation", "n_contrib", "tile_last"):
                     assert np.array_equal(on[k].view(np.uint32) if on[k].dtype == np.float32 else on[k],

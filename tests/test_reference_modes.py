@@ -100,11 +100,13 @@ def test_call_modes_at_config3_size_beside_the_reference(ref_hip, mode):
 
 def test_geometry_outside_the_reference_domain(ref_hip):
     """NaN / +-Inf / zero / negative means, scales, quaternions and opacities (tests/ref_mode_checks.py: NONFINITE_CATEGORIES), eight
-    Gaussians of 20 000 each: in sixteen of the eighteen categories the product does exactly what the reference's kernels do (radii and
-    accumulation bit-identical, image within 1e-6); in the other two (NONFINITE_DEVIATING: the reference composites alpha = fminf(0.99,
-    NaN) = 0.99 over the Gaussian's whole tile rectangle, the product draws nothing) the radii agree and the image stays finite.  All
-    eighteen at once -- on which the reference's own kernels end in a memory access fault (profiles/r5/nonfinite_inputs_ref.log) -- leave
-    the product with a finite image and no fault (tests/tools/nonfinite_inputs.py prints the table)."""
+    Gaussians of 20 000 each: in every category where the reference's output is DEFINED -- sixteen of eighteen, a NaN opacity included
+    (alpha = fminf(0.99, NaN) = 0.99 over the Gaussian's whole tile rectangle: matched since round 6) -- the product does exactly what the
+    reference's kernels do (radii and accumulation bit-identical, image within 1e-6).  In the other two (NONFINITE_REFERENCE_UNDEFINED: a NaN
+    covariance gives radius 0 with one tile, whose key-list slot the reference never writes and then composites as stale memory) the radii
+    and num_rendered agree and the product's image stays finite.  All eighteen at once -- on which the reference's own kernels end in a
+    memory access fault (profiles/r5/nonfinite_inputs_ref.log) -- leave the product with a finite image and no fault
+    (tests/tools/nonfinite_inputs.py prints the table)."""
     from wg_testlib import run_hip
     W, H, P = 640, 360, 20_000
     cam = S.make_camera(W, H)

@@ -314,15 +314,22 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
             }
         }
         g.depths[idx] = vz;
+        // radius 0 with a tile: only a NaN covariance gets here ((int)NaN = 0 in forward.cu:244-246; finite ones have radius >= 2).  The
+        // reference counts the tile (tiles_touched = 1, so num_rendered agrees) but its duplicateWithKeys emits nothing for radii <= 0
+        // (rasterizer_impl.cu:85) and leaves that list slot UNWRITTEN -- whatever it then composites there is stale memory.  Here the
+        // instance exists and draws nothing: its record is parked with opacity 0 and a zero conic (never reached: wg_alpha.h: strip_mask).
+        const bool drawn = radius_i > 0;
+        conx = drawn ? conx : 0.0f; cony = drawn ? cony : 0.0f; conz = drawn ? conz : 0.0f;
+        const float o_eff = drawn ? opacity * coef : 0.0f;
         float4* rec = g.splats + 3 * (size_t)idx;
         rec[0] = make_float4(pixx, pixy, conx, cony);
         if (two) {   // Two-colour walk: the second set rides in the record's three spare floats
             static_assert(WG_STRIP_EXACT == 1, "the box strip test keeps the splat's extent in r2.zw");
-            rec[1] = make_float4(conz, opacity * coef, c2r, cr);
+            rec[1] = make_float4(conz, o_eff, c2r, cr);
             rec[2] = make_float4(cg, cb, c2g, c2b);
         } else {
-            rec[1] = make_float4(conz, opacity * coef, 0.f, cr);  // .z: spare (the backward kernel parks the Gaussian's id there in LDS)
-            const float2 ext = splat_extent(conx, cony, conz, opacity * coef);  // the box variant of the strip tests (wg_alpha.h)
+            rec[1] = make_float4(conz, o_eff, 0.f, cr);  // .z: spare (the backward kernel parks the Gaussian's id there in LDS)
+            const float2 ext = splat_extent(conx, cony, conz, o_eff);  // the box variant of the strip tests (wg_alpha.h)
             rec[2] = make_float4(cg, cb, ext.x, ext.y);
         }
     }

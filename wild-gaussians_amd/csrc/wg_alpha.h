@@ -95,11 +95,13 @@ __device__ __forceinline__ ExactCoef exact_coef_of(const float4 r0, const float4
 // below -103 (where it returns 0) the clamp keeps ldexp's result a denormal: either way alpha < 1/255 and the pair is skipped.
 // (The clamp is not optional: for |x| >~ 2^23 the split's low part pl is the rounding error of x * log2e, as large as ulp(ph) / 2, and
 //  v_exp_f32 of it would overflow.)
-// A NaN power (a NaN conic or mean in the record) is KEPT, as the reference keeps it: `power > 0` is false, exp(NaN) = NaN, min(0.99f, NaN) =
-// 0.99f -- the pair is blended at alpha 0.99 (forward.cu:358-366).  v_max_f32 would swallow the NaN (it returns the other operand), so the
-// first fused multiply-add below takes the UNCLAMPED argument: for x >= -104 that is the clamped one, bit for bit; for x < -104 it makes pl
-// hugely negative, v_exp_f32 underflows to 0 and the result is 0 instead of a denormal -- alpha < 1/255 and the pair skipped either way --;
-// for a NaN it puts the NaN back.  No instruction is spent on it (rounds 4-5 documented the NaN case as a deviation instead).
+// A NaN power is KEPT, as the reference keeps it: `power > 0` is false, exp(NaN) = NaN, min(0.99f, NaN) = 0.99f -- the pair is blended at
+// alpha 0.99 (forward.cu:358-366; experiments/r6/nan_min_probe.hip shows v_min_f32 doing that on gfx950).  v_max_f32 would swallow the
+// NaN (it returns the other operand), so the first fused multiply-add below takes the UNCLAMPED argument: for x >= -104 that is the clamped
+// one, bit for bit; for x < -104 it makes pl hugely negative, v_exp_f32 underflows to 0 and the result is 0 instead of a denormal -- alpha
+// < 1/255 and the pair skipped either way --; for a NaN it puts the NaN back.  No instruction is spent on it.  (No record the preprocess
+// kernel writes can produce one -- a NaN conic comes with radius 0 and is parked with opacity 0, a NaN mean has no tile -- so this is the
+// reference's per-pair semantics kept for its own sake; a NaN OPACITY is what does reach the walk: strip_mask_exact below.)
 // tests/test_exp_expansion.py holds this function to the compiler's own `expf` (built -ffp-contract=off) over a dense range of arguments:
 // a toolchain whose exp lowering changes fails that test directly, not only the parity tests downstream.
 __device__ __forceinline__ float ref_expf_nonpos(float x) {
@@ -267,9 +269,10 @@ __device__ __forceinline__ uint32_t strip_mask_exact(const float4 r0, const floa
     const bool vis = !(o * 1.001f < (1.0f / 255.0f));  // true for a NaN opacity: the reference blends it at alpha = min(0.99f, NaN) = 0.99f everywhere (forward.cu:364)
     const float AC = A * C;
     const bool definite = A > 0.0f && C > 0.0f && (AC - B * B) > 4e-6f * AC;
-    // A NaN anywhere in the record reaches every strip, whatever the opacity: the reference blends such a pair at alpha = min(0.99f, NaN) =
-    // 0.99f on every pixel of the Gaussian's tile rectangle (forward.cu:358-366; a NaN conic comes with opacity * coef = 0: `0 * exp(NaN)`)
-    const bool any_nan = !(A == A && B == B && C == C && o == o && mx == mx && my == my);
+    // A NaN opacity reaches every strip: the reference blends such a Gaussian at alpha = min(0.99f, NaN) = 0.99f on every pixel of its tile
+    // rectangle (forward.cu:364).  (A NaN CONIC never gets here with an opacity: its radius is (int)NaN = 0, the reference's duplicateWithKeys
+    // emits nothing for it -- rasterizer_impl.cu:85 -- and preprocess.hip parks such a record with opacity 0.)
+    const bool o_nan = !(o == o);
     const float tau2 = 2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(255.0f * o) * 1.002f + 0.002f;
     const float nBC = -B * __builtin_amdgcn_rcpf(C), nBA = -B * __builtin_amdgcn_rcpf(A), B2 = 2.0f * B;
     // the tile's sample box (wave-uniform; +-inf bounds of strips outside the image drop out of the min / max)
@@ -289,7 +292,7 @@ __device__ __forceinline__ uint32_t strip_mask_exact(const float4 r0, const floa
         const float fh = yf * (C * yf + B2 * u) + A * u * u;
         if (fminf(fv, fh) <= thr) m |= 1u << s;
     }
-    return any_nan ? 15u : (vis ? (definite ? m : 15u) : 0u);
+    return o_nan ? 15u : (vis ? (definite ? m : 15u) : 0u);
 }
 // r0, r1, r2: the record as preprocess wrote it (conic unscaled)
 __device__ __forceinline__ uint32_t strip_mask(const float4 r0, const float4 r1, const float4 r2, const StripBounds& sb) {

@@ -683,6 +683,8 @@ def main():
         "library": {"version": _C.version(), "path": os.path.relpath(_C._LIB_PATH, ROOT), "options": args.option,
                     **profile_stamps(), "geometry_reuse": _C.get_option("geometry_reuse"),
                     # speculative forward (rasterizer_impl.cu:284's rendezvous moved behind the call's last launch): how it fared in this process
+                    "near_far_split": {k: _C.get_option(k) for k in ("near_adapt", "near_per_tile", "near_per_tile_now", "near_far_tiles_last")},
+                    "forward_order": _C.get_option("forward_order"),
                     "speculative_forward": {k: _C.get_option(k) for k in ("speculative_forward", "spec_frames", "spec_misses", "forward_polls",
                                                                           "forward_polls_waited", "forward_wait_us_total")}},
     }

@@ -89,6 +89,14 @@ struct Mailbox {
 thread_local Mailbox t_mailbox;
 thread_local uint32_t t_last_instances_per_tile = 0;  // density of this thread's previous frame: the near / far split's "try it" hint
 thread_local uint32_t t_split_backoff = 0;            // frames for which the split is not attempted after one that needed the far phase
+// The split's aimed number of near instances per tile, ADAPTED per host thread (option "near_adapt", default on; a fixed "near_per_tile" wins):
+// every split frame reports how many tiles ran out of near instances (the mailbox's need_far, read a frame late).  Four clean frames in
+// a row lower the aim by 10 %; a frame in which more than one tile in a thousand asked lifts it to a floor an eighth above the level that
+// failed, where it then stays (the floor is relaxed by a tenth every 512 frames).  Never above the fixed default (1.1 x the front target): the adaptation can only shorten what
+// is scattered and sorted -- at 10 M Gaussians / 4K pixels stop ~215 instances deep and 900 near instances per tile were twice what the
+// deepest tile needed.  Results do not depend on it (a tile that runs out gets its far instances: the far phase).
+struct NearAdapt { uint32_t cur = 0, floor = 0, clean = 0, age = 0, last_far = 0; };
+thread_local NearAdapt t_near;
 
 // Speculative forward: what this host thread's recent frames looked like.  A prediction is made only from frames of the same image
 // size and a similar number of Gaussians (training: the model grows slowly, the cameras alternate -- hence the maximum over the last
@@ -716,7 +724,9 @@ static int forward_impl(const wg_forward_args& a) {
     // 1000 359 fps, none of them sending a tile to the far phase; 1.5 x the front target keeps a margin for deeper walks)
     //  With the difference-grid counting: 1230 / 1000 / 900 per tile 365 / 404 / 427 fps there, 1021 / 1103 / 1145 train iter/s on
     //  the dense x3 frame: a near bag that fits the 1024-key network is sorted without a selection pass.)
-    const uint32_t near_per_tile = opt.near_per_tile > 0 ? (uint32_t)opt.near_per_tile : (opt.lazy.target * 11u) / 10u;
+    const uint32_t near_default = (opt.lazy.target * 11u) / 10u;
+    const bool near_adaptive = opt.near_per_tile <= 0 && opt.near_adapt != 0 && opt.near_split < 0;
+    if (near_adaptive && (t_near.cur == 0u || t_near.cur > near_default)) t_near.cur = near_default;
     // Frames whose pixels do not saturate (low opacities: after an opacity reset, early in training) walk their whole lists: every
     // band then asks for its far instances and the split only adds a second, slower scatter.  The last split frame's request mask
     // arrives through the mailbox: the number of tiles that asked.  A few deep tiles are what the far phase is for (its cost is a
@@ -728,8 +738,24 @@ static int forward_impl(const wg_forward_args& a) {
             const uint32_t far_tiles = mb.host->need_far - 1u;
             if ((uint64_t)far_tiles * 50u > (uint64_t)tiles) t_split_backoff = 64;
             mb.host->need_far = 0u;
+            if (near_adaptive) {
+                t_near.last_far = far_tiles;
+                // (a handful of tiles asking is cheap -- the far scatter walks the flagged bands' far Gaussians only -- and says the aim sits right
+                //  at the deepest tiles' need: a failure is more than one tile in a thousand)
+                if ((uint64_t)far_tiles * 1000u > (uint64_t)tiles) {
+                    // (the report is a frame old: the aim may have been lowered once since -- then the next report fails too and lifts it again)
+                    t_near.floor = std::min(near_default, std::max(t_near.floor, t_near.cur + t_near.cur / 8u + 1u));
+                    t_near.cur = t_near.floor;
+                    t_near.clean = 0;
+                } else if (++t_near.clean >= 4u) {
+                    t_near.clean = 0;
+                    t_near.cur = std::max(std::max(t_near.floor, 192u), (t_near.cur * 9u) / 10u);
+                }
+                if (++t_near.age >= 512u) { t_near.age = 0; t_near.floor = (t_near.floor * 9u) / 10u; }
+            }
         }
     }
+    const uint32_t near_per_tile = opt.near_per_tile > 0 ? (uint32_t)opt.near_per_tile : (near_adaptive ? t_near.cur : near_default);
     const bool backoff = opt.near_split < 0 && t_split_backoff > 0;
     if (backoff) t_split_backoff--;
     // Automatic mode attempts it for large scenes and whenever this host thread's previous frame was dense (a performance hint only:
@@ -1231,11 +1257,13 @@ int wg_set_option(const char* name, int value) {
     if (std::strcmp(name, "near_split") == 0) {  // (also clears the calling thread's back-off and density hint: a fresh start)
         o.near_split = value < 0 ? -1 : (value != 0);
         t_split_backoff = 0;
+        t_near = NearAdapt();
         t_last_instances_per_tile = 0;
         if (t_mailbox.host) t_mailbox.host->need_far = 0u;
         return WG_OK;
     }
     if (std::strcmp(name, "near_per_tile") == 0) { o.near_per_tile = value > 0 ? value : 0; return WG_OK; }
+    if (std::strcmp(name, "near_adapt") == 0) { o.near_adapt = value != 0; t_near = NearAdapt(); return WG_OK; }
     if (std::strcmp(name, "box_count") == 0) { o.box_count = value < 0 ? -1 : (value != 0); return WG_OK; }
     if (std::strcmp(name, "depth_codes") == 0) {
         if (value != 0 && value != 1 && (value < 8 || value > 12)) return WG_ERR_INVALID_ARGUMENT;
@@ -1260,6 +1288,8 @@ int wg_get_option(const char* name) {
     if (!name) return -1;
     if (std::strcmp(name, "roctx") == 0) return g_roctx.enabled ? 1 : 0;
     if (std::strcmp(name, "near_split_backoff") == 0) return (int)t_split_backoff;  // read-only, of the calling thread
+    if (std::strcmp(name, "near_per_tile_now") == 0) return (int)t_near.cur;        // read-only: the calling thread's adapted aim (0 = none yet)
+    if (std::strcmp(name, "near_far_tiles_last") == 0) return (int)t_near.last_far;  // read-only: tiles that asked for far instances in the last reported split frame
     // read-only counters of the calling thread since the last wg_set_option("speculative_forward", ...)
     if (std::strcmp(name, "spec_frames") == 0) return (int)std::min<uint64_t>(t_wait.spec_frames, 0x7fffffffu);
     if (std::strcmp(name, "spec_misses") == 0) return (int)std::min<uint64_t>(t_wait.spec_misses, 0x7fffffffu);
@@ -1284,6 +1314,7 @@ int wg_get_option(const char* name) {
     if (std::strcmp(name, "staged_scatter") == 0) return o.staged_scatter;
     if (std::strcmp(name, "near_split") == 0) return o.near_split;
     if (std::strcmp(name, "near_per_tile") == 0) return o.near_per_tile;
+    if (std::strcmp(name, "near_adapt") == 0) return o.near_adapt;
     if (std::strcmp(name, "box_count") == 0) return o.box_count;
     if (std::strcmp(name, "lazy_min_len") == 0) return (int)o.lazy.min_len;
     if (std::strcmp(name, "lazy_target") == 0) return (int)o.lazy.target;

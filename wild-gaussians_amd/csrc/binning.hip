@@ -1185,7 +1185,9 @@ __global__ void __launch_bounds__(256) tile_front_sort_kernel(const uint32_t* __
         len = extract_front(bucket_ids + begin, n, depths, 0ull, n, target, cap, id_mask, sc);
         src = sc.ids;  // plain ids
     }
-    if (len <= 1024) tile_sort_body<4>(skeys, len, src, depths, point_list + begin, id_mask);
+    // (the smallest network that holds the front: a near bag of ~450 instances on the 512-key network keeps all four waves busy)
+    if (len <= 512) tile_sort_body<2>(skeys, len, src, depths, point_list + begin, id_mask);
+    else if (len <= 1024) tile_sort_body<4>(skeys, len, src, depths, point_list + begin, id_mask);
     else tile_sort_body<8>(skeys, len, src, depths, point_list + begin, id_mask);
     if (threadIdx.x == 0) seg_end[tile] = len;
 }

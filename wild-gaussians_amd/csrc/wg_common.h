@@ -262,7 +262,8 @@ struct Options {
     int deterministic_backward = 0;   // 1: per-instance slots + an ordered per-Gaussian sum instead of float atomics (bit-reproducible)
     int near_split = -1;              // near / far split of dense frames: -1 automatic (P >= band_list_min_p or a dense previous frame, and >= SPLIT_DENSE_AVG =
                                       // 1100 instances per tile) / 0 off / 1 whenever possible (tests)
-    int near_per_tile = 0;            // aimed near instances per tile; 0 = 1.1 x lazy.target
+    int near_per_tile = 0;            // aimed near instances per tile; 0 = adapted from 1.1 x lazy.target down (near_adapt) or that value itself
+    int near_adapt = 1;               // 1: the aim follows the frames' far-phase reports per host thread (api.hip: NearAdapt); 0: fixed
     int box_count = -1;               // tile counting through a difference grid: -1 automatic (with the split's "large or dense" rule) / 0 / 1
     bool force_global_sort = false;   // exercise the fallback binning path
     bool use_mailbox = true;          // 0 restores the copy + synchronise read-back

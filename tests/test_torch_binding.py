@@ -123,3 +123,33 @@ def test_wrong_size_tensors_raise_instead_of_reading_out_of_bounds(binding, name
     # and a well-formed call still works afterwards
     img = rast(**base, colors_precomp=col)[0]
     assert torch.isfinite(img).all()
+
+
+def test_binding_follows_the_environment():
+    """WG_BINDING=ctypes|torch selects the binding at import; without it the compiled one is the default when it has been built."""
+    from diff_gaussian_rasterization import _C
+    want = os.environ.get("WG_BINDING") or ("torch" if built and not os.environ.get("WG_RASTERIZER_LIB") else "ctypes")
+    assert _C.binding_name() == want
+
+
+@pytest.mark.gpu
+@needs_binding
+def test_cross_section_of_the_suite_passes_under_the_ctypes_binding():
+    """The ctypes binding (`WG_BINDING=ctypes`: what serves a variant library, and the fallback where the compiled module has not been
+    built) is a supported path, so a cross-section of the GPU suite runs under it INSIDE the driver-run suite:
+    the four parity cases forward and backward, the operator surface, the thirty-case argument sweep, the deterministic mode, and every call
+    mode beyond the reference's surface (two colour sets, two tones, one tone, raw parameters: twelve cases) against the reference's own
+    kernels -- in a subprocess whose import picks the binding from the environment."""
+    import re
+    import subprocess
+    sel = ("binding_follows_the_environment or forward_rgb_parity or backward_gradient_parity or operator_surface_semantics or "
+           "argument_sweep_against_the_oracle or deterministic_backward_mode_is_bit_reproducible or "
+           "(two_colour_sets_in_one_call and (0 or 5 or 11)) or (two_tones_of_one_sh_block and (1 or 6 or 12)) or "
+           "(one_tone_beside and (2 or 7)) or (raw_parameter_mode_beside and 0) or wrong_size_tensors")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu or not gpu", "-p", "no:cacheprovider", "tests/test_parity_gpu.py",
+                        "tests/test_reference_modes.py", "tests/test_torch_binding.py", "-k", sel],
+                       cwd=ROOT, env=dict(os.environ, WG_BINDING="ctypes"), capture_output=True, text=True, timeout=900)
+    tail = r.stdout[-3000:] + r.stderr[-1500:]
+    assert r.returncode == 0, tail
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 40, tail

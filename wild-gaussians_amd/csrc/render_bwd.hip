@@ -289,8 +289,10 @@ render_backward_kernel(
             scale_conic(q0, q1);
             q2.z = 2.0f * q0.z;  // 2 ca, 2 cc: the gradient of the exponent, up to the factor 1 / log2(e) applied after the reduction
             q2.w = 2.0f * q1.x;
-            q1.z = __uint_as_float(id);  // the record's spare float carries the Gaussian id to the reduction (no second LDS array,
-                                         // no LDS round trip on the reduction path)
+            // the record's spare float carries the Gaussian id to the reduction (no second LDS array, no LDS round trip on the reduction
+            // path) -- on the default path as the BYTE OFFSET of its gradient record, so that the ten reducing lanes form their address with
+            // one 32-bit add on top of the uniform base (48 P < 2^32) instead of a 64-bit multiply-add per reduced instance
+            q1.z = __uint_as_float((RECORD && !DUAL && !DET) ? id * (uint32_t)(GRAD_REC_FLOATS * sizeof(float)) : id);
             if (DET) {  // deterministic mode: it carries the instance's SLOT instead -- the three gathers it takes are issued here, with
                         // the record's, by the staging lane, not behind the butterfly by the ten storing lanes (0.536 -> see EXPERIMENTS.md)
                 const ushort4 rc = rects[id];
@@ -426,7 +428,7 @@ render_backward_kernel(
                 }
             } else if (RECORD) {
                 if (DUAL) { if (issue) unsafeAtomicAdd(abase + (size_t)__float_as_uint(r1.z) * astride, total); }
-                else if (issue) unsafeAtomicAdd(abase + (size_t)__float_as_uint(r1.z) * GRAD_REC_FLOATS, total);  // 64-bit: shift-adds, no quarter-rate 32-bit multiply
+                else if (issue) unsafeAtomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(grad_rec) + (size_t)(__float_as_uint(r1.z) + 4u * (uint32_t)vidx)), total);
             } else {
                 if (issue) unsafeAtomicAdd(abase + astride * __float_as_uint(r1.z), total * (oscale ? (vidx == 5 ? fabsf(o) : o) * vscale : vscale));  // 4*P < 2^32
             }

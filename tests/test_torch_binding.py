@@ -20,8 +20,9 @@ needs_binding = pytest.mark.skipif(not built, reason="compiled binding not built
 @pytest.fixture()
 def binding():
     from diff_gaussian_rasterization import _C
+    before = _C.binding_name()
     yield _C
-    _C.use_binding("torch" if built else "ctypes")
+    _C.use_binding(before)   # (what the process was started with: WG_BINDING, or the default)
 
 
 @needs_binding

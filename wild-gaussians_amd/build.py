@@ -115,13 +115,13 @@ def build_exp_probe(force: bool = False) -> str:
 def build_probes(force: bool = False) -> list:
     """Stand-alone measurement / reproducer programs (no product code; test infrastructure): scripts/pmc_calibration.hip (PMC byte counters on
     known byte counts, round 6), tests/native/malloc_async_lost_stores.cpp (the stream-ordered allocator's lost stores, EXPERIMENTS.md R5.10 /
-    R5.12), experiments/r6/nan_min_probe.hip.  Binaries go to build/ (they travel to the GPU box with the tree)."""
+    R5.12), experiments/at_05a7d0c/nan_min_probe.hip.  Binaries go to build/ (they travel to the GPU box with the tree)."""
     root = os.path.dirname(HERE)
     out = []
     os.makedirs(OBJ, exist_ok=True)
     for src, extra in ((os.path.join(root, "scripts", "pmc_calibration.hip"), ["-O3"]),
                        (os.path.join(root, "tests", "native", "malloc_async_lost_stores.cpp"), ["-O2", "-pthread"]),
-                       (os.path.join(root, "experiments", "r6", "nan_min_probe.hip"), ["-O3"])):
+                       (os.path.join(root, "experiments", "at_05a7d0c", "nan_min_probe.hip"), ["-O3"])):
         exe = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0])
         if force or _newer(exe, [src]):
             r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-w"] + extra + [src, "-o", exe], capture_output=True, text=True)

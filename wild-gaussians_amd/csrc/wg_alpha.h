@@ -96,7 +96,7 @@ __device__ __forceinline__ ExactCoef exact_coef_of(const float4 r0, const float4
 // (The clamp is not optional: for |x| >~ 2^23 the split's low part pl is the rounding error of x * log2e, as large as ulp(ph) / 2, and
 //  v_exp_f32 of it would overflow.)
 // A NaN power is KEPT, as the reference keeps it: `power > 0` is false, exp(NaN) = NaN, min(0.99f, NaN) = 0.99f -- the pair is blended at
-// alpha 0.99 (forward.cu:358-366; experiments/r6/nan_min_probe.hip shows v_min_f32 doing that on gfx950).  v_max_f32 would swallow the
+// alpha 0.99 (forward.cu:358-366; experiments/at_05a7d0c/nan_min_probe.hip shows v_min_f32 doing that on gfx950).  v_max_f32 would swallow the
 // NaN (it returns the other operand), so the first fused multiply-add below takes the UNCLAMPED argument: for x >= -104 that is the clamped
 // one, bit for bit; for x < -104 it makes pl hugely negative, v_exp_f32 underflows to 0 and the result is 0 instead of a denormal -- alpha
 // < 1/255 and the pair skipped either way --; for a NaN it puts the NaN back.  No instruction is spent on it.  (No record the preprocess

@@ -327,8 +327,8 @@ def config_legs(device, deg_unused, with_oracle: bool, clouds: dict) -> dict:
     synchronize on both sides), `pins_ok` -- num_rendered and the SHA-256 of radii, n_contrib and final_T equal what the REFERENCE's own
     kernels (-ffp-contract=off build) gave for this frame on an MI355X (tests/golden/ref_hip_fullsize_sha256.json; no reference binary
     needed) --, and for the fwd+bwd legs `grad_worst`: max over the gradient tensors of max|g - g_oracle| / max|g_oracle| against the CPU
-    oracle on the same inputs.  clouds: name -> (cloud, cam, deg), generated by the caller (config 5's 10 M Gaussians take ~50 s of
-    single-threaded numpy: the caller starts that in a thread before its own passes)."""
+    oracle on the same inputs.  clouds: name -> a callable giving (cloud, cam, deg) (config 5's 10 M Gaussians take a while of single-threaded
+    numpy: generated here, one leg at a time, never beside a timed region)."""
     import gc
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import fullsize_frames as FF
@@ -377,7 +377,7 @@ def config_legs(device, deg_unused, with_oracle: bool, clouds: dict) -> dict:
                    "pins_ok": d == pins[name], "num_rendered": int(R_)}
             if d != pins[name]:
                 leg["pins_mismatch"] = [k for k in d if d[k] != pins[name][k]]
-            for _ in range(8):
+            for _ in range(64 if fwd_only else 8):   # (config 5: the near / far split's adaptive aim settles within ~50 frames of a camera)
                 step()
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
@@ -472,24 +472,11 @@ def main():
     W, H, P = args.width, args.height, args.gaussians
     N = W * H
     sh_degree = 3 if args.colors == "sh" else None
-    # the default (headline) run also carries short legs at BASELINE configs 2, 3, 5 (config_legs): their clouds are generated on a host
-    # thread from here on (numpy releases the interpreter lock inside its generators), beside this process's own passes
+    # the default (headline) run also carries short legs at BASELINE configs 2, 3, 5 (config_legs)
     want_legs = (world == 1 and rank == 0 and not args.no_config_legs and not args.forward_only and args.views is None and args.scale_mult == 1.0 and
                  (P, W, H, args.colors) == (1_000_000, 1920, 1080, "sh") and args.streams == 1 and not args.option)
-    leg_clouds, leg_thread = {}, None
-    if want_legs:
-        import threading
-        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-        import fullsize_frames as FF
-
-        def _gen():
-            for nm in ("config2_500k_1080p_sh3", "config3_3M_1600x1200_precomp", "config5_10M_4K_sh3"):
-                try:
-                    leg_clouds[nm] = FF.frame_inputs(nm)
-                except Exception as ex:  # noqa: BLE001
-                    leg_clouds[nm] = ex
-        leg_thread = threading.Thread(target=_gen, daemon=True)
-        leg_thread.start()
+    # (their clouds are generated AFTER the headline's passes, one leg at a time: a generator thread beside the timed region was measured to
+    #  cost it 4 % and single 3 ms steps -- the interpreter lock changes hands in 5 ms slices)
     cloud = S.make_cloud(P, W, H, sh_degree=sh_degree, seed=0, scale_mult=args.scale_mult)
     V_total = args.views if args.views is not None else world
     if V_total < world:
@@ -970,21 +957,16 @@ def main():
             out["render_compute"] = views
     if want_legs:
         t_legs = time.perf_counter()
-        leg_thread.join()
-        waited = time.perf_counter() - t_legs
-
-        def _take(nm):
-            v = leg_clouds.get(nm)
-            if isinstance(v, Exception):
-                raise v
-            return v
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import fullsize_frames as FF
         del cloud, t, means2D
         gc.collect()
         torch.cuda.empty_cache()
-        out["configs"] = config_legs(device, deg, not args.no_cpu_baseline, {nm: (lambda nm=nm: _take(nm)) for nm in list(leg_clouds)})
+        out["configs"] = config_legs(device, deg, not args.no_cpu_baseline,
+                                     {nm: (lambda nm=nm: FF.frame_inputs(nm)) for nm in ("config2_500k_1080p_sh3", "config3_3M_1600x1200_precomp", "config5_10M_4K_sh3")})
         out["configs"]["note"] = ("BASELINE.json configs 2, 3 (operator level: one call, fwd+bwd) and 5 at their quoted sizes, a ~1.2 s timed leg each after the headline's "
                                   "passes; pins_ok = the frame's radii / n_contrib / final_T hash to the reference build's (tests/golden/ref_hip_fullsize_sha256.json); "
-                                  f"host seconds spent waiting for the legs' clouds after the headline passes: {waited:.1f}, legs in all: {time.perf_counter() - t_legs:.1f}")
+                                  f"seconds for the three legs, their clouds' generation included: {time.perf_counter() - t_legs:.1f}")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -8,11 +8,11 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-BENCH="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-camera-sequence $*"
+BENCH="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-camera-sequence --no-config-legs $*"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
 python scripts/rocpd_summary.py $OUT/trace/t_results.db > $OUT/kernel_trace_summary.txt 2>&1
 grep '"metric"' $OUT/trace.log > $OUT/bench_under_trace.json
-PB="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-camera-sequence $*"
+PB="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-camera-sequence --no-config-legs $*"
 i=0
 for CS in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
           "SQ_INSTS_VMEM SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \

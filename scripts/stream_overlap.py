@@ -25,7 +25,11 @@ def main(path):
     busy = sum(r[2] - r[1] for r in wg)
     print(f"kernels {len(wg)}, queues {queues}, window {span / 1e3:.1f} us, sum of kernel durations {busy / 1e3:.1f} us "
           f"(= {busy / span:.3f} x the window: above 1 means kernels of different queues ran side by side)")
-    short = lambda n: n.split("wg::")[-1].split("(")[0].split("<")[0][:28]  # noqa: E731
+    import re
+
+    def short(n):   # "void wg::render_forward_kernel<true>(int, ...)" -> "render_forward_kernel"
+        m = re.search(r"wg::(\w+)", n)
+        return (m.group(1) if m else n)[:34]
     render = [r for r in wg if "render_forward" in r[0] or "render_backward" in r[0]]
     together = defaultdict(float)
     for n, s, e, q in render:

@@ -448,9 +448,13 @@ hipError_t det_scratch_alloc(ScratchBlock** lease, size_t bytes, hipStream_t str
     ScratchBlock* b = nullptr;
     {
         std::lock_guard<std::mutex> l(g_pool_mu);
-        for (int pass = 0; pass < 3 && !b; pass++)   // large enough + same stream; large enough; anything idle (it will be grown)
+        // large enough + same stream; large enough; too small but this stream's own (or never used): it will be grown.  A too-small block
+        // ANOTHER stream used last is left alone -- growing it means hipFree, which waits for the whole device, that stream's work included
+        // (ADVICE r5): a new block is made instead.
+        for (int pass = 0; pass < 3 && !b; pass++)
             for (ScratchBlock* x : g_scratch)
-                if (!x->busy && x->dev == dev && (pass == 2 || x->cap >= bytes) && (pass != 0 || x->last_stream == stream)) { b = x; break; }
+                if (!x->busy && x->dev == dev && (pass == 2 ? (x->last_stream == stream || x->p == nullptr) : x->cap >= bytes) &&
+                    (pass != 0 || x->last_stream == stream)) { b = x; break; }
         if (!b) {
             b = new ScratchBlock{dev, nullptr, 0, nullptr, nullptr, false, false};
             e = hipEventCreateWithFlags(&b->done, hipEventDisableTiming);
@@ -463,8 +467,13 @@ hipError_t det_scratch_alloc(ScratchBlock** lease, size_t bytes, hipStream_t str
     if (b->cap < bytes) {
         if (b->p) e = hipFree(b->p);   // waits for everything in flight on the device: the block's last user included
         b->p = nullptr; b->cap = 0; b->recorded = false;
-        if (e == hipSuccess) e = hipMalloc(&b->p, bytes);
-        if (e == hipSuccess) b->cap = bytes;
+        // headroom: cameras whose instance counts vary would otherwise re-allocate (= stall the device) at every new maximum
+        const size_t want = ((bytes + bytes / 4) + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        if (e == hipSuccess) {
+            e = hipMalloc(&b->p, want);
+            if (e == hipSuccess) b->cap = want;
+            else { (void)hipGetLastError(); e = hipMalloc(&b->p, bytes); if (e == hipSuccess) b->cap = bytes; }   // (no room for the headroom: the exact size)
+        }
     } else if (b->recorded && b->last_stream != stream) {
         e = hipStreamWaitEvent(stream, b->done, 0);
     }
@@ -479,28 +488,38 @@ hipError_t det_scratch_alloc(ScratchBlock** lease, size_t bytes, hipStream_t str
 // behind the call's last launch on `stream`
 hipError_t det_scratch_free(ScratchBlock* b, hipStream_t stream) {
     const hipError_t e = hipEventRecord(b->done, stream);
-    std::lock_guard<std::mutex> l(g_pool_mu);
-    b->last_stream = stream;
-    b->recorded = e == hipSuccess;
-    b->busy = false;
-    if (e != hipSuccess && b->p) {   // no event to order the next user behind this call: do not hand the memory out again
-        (void)hipFree(b->p);
-        b->p = nullptr; b->cap = 0;
+    void* drop = nullptr;
+    {
+        std::lock_guard<std::mutex> l(g_pool_mu);
+        b->last_stream = stream;
+        b->recorded = e == hipSuccess;
+        if (e != hipSuccess && b->p) {   // no event to order the next user behind this call: do not hand the memory out again
+            drop = b->p;
+            b->p = nullptr; b->cap = 0;
+        }
+        b->busy = false;
     }
+    if (drop) (void)hipFree(drop);   // (outside the lock: hipFree waits for the device, other callers must not wait behind it)
     return e;
 }
 // wg_set_option("release_scratch", 1): the blocks no call is holding go back to the system (hipFree waits for the device first)
 int det_scratch_release() {
-    std::lock_guard<std::mutex> l(g_pool_mu);
+    std::vector<std::pair<int, void*>> drop;   // detached under the lock, freed outside it (hipFree waits for the device)
+    {
+        std::lock_guard<std::mutex> l(g_pool_mu);
+        for (ScratchBlock* b : g_scratch)
+            if (!b->busy && b->p) {
+                drop.push_back({b->dev, b->p});
+                b->p = nullptr; b->cap = 0; b->recorded = false;
+            }
+    }
     int rc = WG_OK;
-    for (ScratchBlock* b : g_scratch)
-        if (!b->busy && b->p) {
-            int cur = 0;
-            const bool sw = hipGetDevice(&cur) == hipSuccess && cur != b->dev && hipSetDevice(b->dev) == hipSuccess;
-            if (hipFree(b->p) != hipSuccess) rc = WG_ERR_HIP;
-            if (sw) (void)hipSetDevice(cur);
-            b->p = nullptr; b->cap = 0; b->recorded = false;
-        }
+    for (auto& d : drop) {
+        int cur = 0;
+        const bool sw = hipGetDevice(&cur) == hipSuccess && cur != d.first && hipSetDevice(d.first) == hipSuccess;
+        if (hipFree(d.second) != hipSuccess) rc = WG_ERR_HIP;
+        if (sw) (void)hipSetDevice(cur);
+    }
     return rc;
 }
 

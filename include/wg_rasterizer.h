@@ -221,6 +221,7 @@ typedef struct wg_image_view {
     const uint32_t* split;      /* [2] {depth-code threshold of the split (0xffffffff = off), bands that needed their far instances} */
     const uint32_t* order_fwd;  /* [tiles] launch order of the forward render kernel ("forward_order"; valid when order_key[0] != 0xffffffff) */
     const uint32_t* order_key;  /* [4] {the camera's row in the launch-order table or 0xffffffff = none, tag lo, tag hi, 1 = the row held this camera} */
+    const uint32_t* order_bwd;  /* [tiles] launch order of the backward render kernel (written by the frame's backward call) */
 } wg_image_view;
 int wg_view_geometry(char* geom_buffer, int P, wg_geometry_view* out);
 int wg_view_binning(char* binning_buffer, int R, wg_binning_view* out);

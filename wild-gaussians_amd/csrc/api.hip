@@ -1241,6 +1241,7 @@ int wg_view_image(char* image_buffer, int width, int height, wg_image_view* out)
     out->split = reinterpret_cast<const uint32_t*>(img.split);
     out->order_fwd = img.order_fwd;
     out->order_key = img.order_key;
+    out->order_bwd = img.order_bwd;
     return WG_OK;
 }
 

@@ -105,7 +105,7 @@ class _BinningView(C.Structure):
 
 
 class _ImageView(C.Structure):
-    _fields_ = [(n, _vp) for n in ("final_T", "accumulation", "n_contrib", "ranges", "tile_last", "tile_near", "split", "order_fwd", "order_key")]
+    _fields_ = [(n, _vp) for n in ("final_T", "accumulation", "n_contrib", "ranges", "tile_last", "tile_near", "split", "order_fwd", "order_key", "order_bwd")]
 
 
 _lib.wg_view_geometry.restype = _i
@@ -704,7 +704,8 @@ def view_image(imageBuffer, H, W):
                 tile_near=_from_ptr(v.tile_near, (tiles,), torch.int32, imageBuffer),
                 split=_from_ptr(v.split, (2,), torch.int32, imageBuffer),
                 order_fwd=_from_ptr(v.order_fwd, (tiles,), torch.int32, imageBuffer),
-                order_key=_from_ptr(v.order_key, (4,), torch.int32, imageBuffer))
+                order_key=_from_ptr(v.order_key, (4,), torch.int32, imageBuffer),
+                order_bwd=_from_ptr(v.order_bwd, (tiles,), torch.int32, imageBuffer))
 
 
 _lib.wg_set_option.restype = _i

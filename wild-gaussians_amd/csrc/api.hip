@@ -1395,6 +1395,6 @@ const char* wg_status_string(int status) {
 
 const char* wg_last_hip_error(void) { return g_last_hip_error.c_str(); }
 
-const char* wg_version(void) { return "wg_rasterizer 0.5 (gfx950)"; }
+const char* wg_version(void) { return "wg_rasterizer 0.6 (gfx950)"; }
 
 }  // extern "C"

@@ -2,6 +2,10 @@
 # round 6, final measurements on the round's final sources (run on the GPU box: gpurun -- 'bash scripts/r5/r5_final.sh'): profiles with the
 # lane-utilisation counters, pair counts from the counting build, the bench line of every BASELINE config, config 4's N = 1 point, A/Bs.
 O=gpurun_out/r6final; mkdir -p $O
+(time python -m pytest tests -m gpu -q) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+bash scripts/r6/pmc_calibrate.sh r6final_cal > $O/pmc_calibrate.log 2>&1
+wild-gaussians_amd/build/malloc_async_lost_stores 40 320 0 > $O/malloc_async_lost_stores.txt 2>&1; wild-gaussians_amd/build/malloc_async_lost_stores 40 320 0 malloc >> $O/malloc_async_lost_stores.txt 2>&1
 bash scripts/profile_gpu.sh r6_prof_headline > $O/profile_headline.log 2>&1
 WORKLOAD="10000000 Gaussians, 3840x2160, sh" bash scripts/profile_gpu.sh r6_prof_config5 --gaussians 10000000 --width 3840 --height 2160 --forward-only > $O/profile_config5.log 2>&1
 cp gpurun_out/r6_prof_headline/pmc_traffic.json profiles/pmc_traffic.json; cp gpurun_out/r6_prof_config5/pmc_traffic.json profiles/pmc_traffic_config5.json

@@ -92,7 +92,7 @@ thread_local uint32_t t_split_backoff = 0;            // frames for which the sp
 // The split's aimed number of near instances per tile, ADAPTED per host thread (option "near_adapt", default on; a fixed "near_per_tile" wins):
 // every split frame reports how many tiles ran out of near instances (the mailbox's need_far, read a frame late).  Four clean frames in
 // a row lower the aim by 10 %; a frame in which more than one tile in a thousand asked lifts it to a floor an eighth above the level that
-// failed, where it then stays (the floor is relaxed by a tenth every 512 frames).  Never above the fixed default (1.1 x the front target): the adaptation can only shorten what
+// failed, where it then stays (the floor is relaxed by a twentieth every 2048 frames).  Never above the fixed default (1.1 x the front target): the adaptation can only shorten what
 // is scattered and sorted -- at 10 M Gaussians / 4K pixels stop ~215 instances deep and 900 near instances per tile were twice what the
 // deepest tile needed.  Results do not depend on it (a tile that runs out gets its far instances: the far phase).
 struct NearAdapt { uint32_t cur = 0, floor = 0, clean = 0, age = 0, last_far = 0; };
@@ -163,7 +163,7 @@ Mailbox* get_mailbox() {
                 const MailboxSlot s = g_mailbox_free.back();
                 g_mailbox_free.pop_back();
                 m.host = s.host; m.dev = s.dev; m.seq = s.seq;
-                m.host->need_far = 0u;
+                m.host->far_report = 0ull;
             }
         }
         void* h = nullptr;
@@ -753,24 +753,30 @@ static int forward_impl(const wg_forward_args& a) {
     // attempted for the next 64 frames of this thread (automatic mode only).
     if (opt.near_split < 0) {
         Mailbox& mb = t_mailbox;
-        if (mb.host && mb.host->need_far != 0u) {
-            const uint32_t far_tiles = mb.host->need_far - 1u;
-            if ((uint64_t)far_tiles * 50u > (uint64_t)tiles) t_split_backoff = 64;
-            mb.host->need_far = 0u;
-            if (near_adaptive) {
+        unsigned long long report = 0ull;
+        if (mb.host) report = __atomic_exchange_n(&mb.host->far_report, 0ull, __ATOMIC_RELAXED);   // (take it: a report is acted on once)
+        if (report != 0ull) {
+            const uint32_t word = (uint32_t)report - 1u, far_tiles = word & 0xffffffu, far_bands = word >> 24, report_aim = (uint32_t)(report >> 32);
+            // (a frame that failed at an aim the adaptation had LOWERED says the aim was too low, not that the scene does not saturate: the aim is
+            //  lifted below, the split stays on -- with the back-off a single probing step cost 64 unsplit frames: 536 -> 447 fps over 600 frames)
+            if ((uint64_t)far_tiles * 50u > (uint64_t)tiles && !(near_adaptive && report_aim != 0u && report_aim < near_default)) t_split_backoff = 64;
+            if (near_adaptive && report_aim != 0u) {
                 t_near.last_far = far_tiles;
-                // (a handful of tiles asking is cheap -- the far scatter walks the flagged bands' far Gaussians only -- and says the aim sits right
-                //  at the deepest tiles' need: a failure is more than one tile in a thousand)
-                if ((uint64_t)far_tiles * 1000u > (uint64_t)tiles) {
-                    // (the report is a frame old: the aim may have been lowered once since -- then the next report fails too and lifts it again)
-                    t_near.floor = std::min(near_default, std::max(t_near.floor, t_near.cur + t_near.cur / 8u + 1u));
-                    t_near.cur = t_near.floor;
+                // (a tile or two asking is cheap -- the far scatter walks the far Gaussians of the flagged BANDS only -- and says the aim sits right
+                //  at the deepest tiles' need: a failure is more than two of the eight bands flagged, or more than one tile in a thousand.  With the tile
+                //  count alone a 600-frame run sat below the cliff: thirty tiles in eight bands cost the whole far phase, 536 -> 447 fps.)
+                if (far_bands > 2u || (uint64_t)far_tiles * 1000u > (uint64_t)tiles) {
+                    // the floor goes an eighth above the aim THE FAILING FRAME ran with (the report carries it): reports lag a frame or two behind
+                    // the calls when the caller does not synchronise, and two frames issued at one failing aim used to lift the floor twice
+                    // (386 failed -> 435 -> 490 where 435 sufficed: 1.8 -> 2.0 ms per frame at 10 M Gaussians / 4K until the floor had decayed)
+                    t_near.floor = std::min(near_default, std::max(t_near.floor, report_aim + report_aim / 8u + 1u));
+                    t_near.cur = std::max(t_near.cur, t_near.floor);
                     t_near.clean = 0;
-                } else if (++t_near.clean >= 4u) {
+                } else if (report_aim == t_near.cur && ++t_near.clean >= 4u) {   // (four clean frames AT the current aim)
                     t_near.clean = 0;
                     t_near.cur = std::max(std::max(t_near.floor, 192u), (t_near.cur * 9u) / 10u);
                 }
-                if (++t_near.age >= 512u) { t_near.age = 0; t_near.floor = (t_near.floor * 9u) / 10u; }
+                if (++t_near.age >= 2048u) { t_near.age = 0; t_near.floor = (t_near.floor * 19u) / 20u; }
             }
         }
     }
@@ -1279,7 +1285,7 @@ int wg_set_option(const char* name, int value) {
         t_split_backoff = 0;
         t_near = NearAdapt();
         t_last_instances_per_tile = 0;
-        if (t_mailbox.host) t_mailbox.host->need_far = 0u;
+        if (t_mailbox.host) t_mailbox.host->far_report = 0ull;
         return WG_OK;
     }
     if (std::strcmp(name, "near_per_tile") == 0) { o.near_per_tile = value > 0 ? value : 0; return WG_OK; }
@@ -1309,6 +1315,7 @@ int wg_get_option(const char* name) {
     if (std::strcmp(name, "roctx") == 0) return g_roctx.enabled ? 1 : 0;
     if (std::strcmp(name, "near_split_backoff") == 0) return (int)t_split_backoff;  // read-only, of the calling thread
     if (std::strcmp(name, "near_per_tile_now") == 0) return (int)t_near.cur;        // read-only: the calling thread's adapted aim (0 = none yet)
+    if (std::strcmp(name, "near_floor_now") == 0) return (int)t_near.floor;         // read-only: the floor the adaptation does not go below (scripts/r6/near_trace.py)
     if (std::strcmp(name, "near_far_tiles_last") == 0) return (int)t_near.last_far;  // read-only: tiles that asked for far instances in the last reported split frame
     // read-only counters of the calling thread since the last wg_set_option("speculative_forward", ...)
     if (std::strcmp(name, "spec_frames") == 0) return (int)std::min<uint64_t>(t_wait.spec_frames, 0x7fffffffu);

@@ -1084,6 +1084,7 @@ __global__ void __launch_bounds__(1024) split_pick_kernel(const uint32_t* __rest
         split->near_code = (pick != SPLIT_OFF && pick + 1 < SPLIT_BINS) ? pick : SPLIT_OFF;
         split->need_far = 0u;
         split->far_tiles = 0u;
+        split->aim = near_per_tile;
     }
 }
 

@@ -152,6 +152,20 @@ __device__ unsigned long long g_bwd_probe[4 * 65536];
 #ifndef WG_BWD_DUAL_WAVES
 #define WG_BWD_DUAL_WAVES 0
 #endif
+// WG_BWD_LDS_REDUCE (default path only: RECORD, not DET, not DUAL): the ten per-lane sums of an instance are reduced through LDS behind the
+// butterfly's FIRST stage instead of through all of it.  The xor-32 stage leaves five sums per lane (lanes 0 - 31: values 0, 2, 4, 6, 8,
+// lanes 32 - 63: values 1, 3, 5, 7, 9); every lane parks them as a row of five floats (five ds_write_b32, row stride 20 bytes: 5 is coprime
+// with the 64 banks, no conflict); lane 32 half + 4 m + h then adds column m of its half's rows h, h + 4, ... h + 28 (four ds_read2_b32 -- at
+// a fixed step the forty reading lanes touch forty different banks, lanes with m >= 5 re-read columns 0 - 2, a broadcast) and two
+// quad-permute adds complete the column: 10 + 7 + 2 vector instructions where the rest of the butterfly spent 3 swaps + 3 adds + 4 selects +
+// 5 DPP adds + moves + 9 wait states.  The LDS instructions issue beside the other waves' vector instructions (the kernel is bound by vector
+// issue), and one wave's LDS operations execute in program order: no wait between the writes and the reads, none before the next
+// instance's writes.  Same box, K9 at the headline frame: butterfly 0.4188, all ten sums through LDS (640 floats per instance written, 1024
+// read) 0.4067, this form (320 / 512) 0.3961 ms; with ds_write_b64 rows (stride 24 bytes, halves skewed by 32 banks) 0.3954: the LDS
+// traffic is what the variants differ in, not the instruction count (profiles/r6/ab_k9_reduction_through_lds.txt).
+#ifndef WG_BWD_LDS_REDUCE
+#define WG_BWD_LDS_REDUCE 1
+#endif
 template <bool RECORD, bool DET = false, bool EXACT = false, bool DUAL = false>
 __global__ void __launch_bounds__(64) WG_BWD_OCC
 #if WG_BWD_DUAL_WAVES
@@ -167,8 +181,13 @@ render_backward_kernel(
     float* __restrict__ det_slots, unsigned char* __restrict__ det_flags, const float* __restrict__ dL_dpix2, float* __restrict__ grad_aux) {
     static_assert(!DUAL || RECORD, "the two-colour walk accumulates into the gradient record (or, DET, into fourteen-float slots)");
     constexpr int SLOT_FLOATS = DUAL ? 14 : 10;   // deterministic mode: floats per (tile, Gaussian) slot (thirteen sums, padded to 8-byte multiples)
-    __shared__ float4 lds[BATCH * (DUAL ? 4 : 3)];
     constexpr int RS = DUAL ? 4 : 3;   // float4 per parked record
+    constexpr bool LDSRED = WG_BWD_LDS_REDUCE && RECORD && !DET && !DUAL;
+    // LDSRED: one row of five sums per lane, at the START of the allocation (ds_read2 offsets are 8-bit element counts from the lane's base
+    // address: behind the records every access would first add the array's offset)
+    __shared__ float4 smem[(LDSRED ? 80 : 0) + BATCH * RS];
+    float4* const lds = smem + (LDSRED ? 80 : 0);
+    float* const red = reinterpret_cast<float*>(smem);
 
 #if WG_PROBE
     const unsigned long long probe_t0 = __builtin_amdgcn_s_memrealtime();
@@ -274,6 +293,10 @@ render_backward_kernel(
 #if WG_COUNT_PAIRS
     unsigned long long wgc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    // LDSRED: this lane's read base (row 32 half + h, column m of its half; lanes with m >= 5 repeat columns 0 - 2), kept opaque so that it
+    // stays in a register (rematerialised inside the loop it is three vector instructions per reduced instance)
+    int rd0 = 5 * (32 * (lane >> 5) + (lane & 3)) + (((lane & 31) >> 2) < 5 ? ((lane & 31) >> 2) : ((lane & 31) >> 2) - 5);
+    if (LDSRED) asm volatile("" : "+v"(rd0));
     for (int hi = hi0; hi > 0; hi -= BATCH) {
         // lane l stages the instance at list position hi-1-l (back to front, backward.cu:517)
         const int posl = hi - 1 - lane;
@@ -418,6 +441,29 @@ render_backward_kernel(
 #if WG_COUNT_PAIRS
             { const int c = __popcll(any_m); WG_CNT(c <= 1 ? 6 : c <= 4 ? 7 : c <= 16 ? 8 : 9, 1); }
 #endif
+            if (LDSRED) {
+                const float w0 = pair_x32(acr, acg), w1 = pair_x32(acb, sx), w2 = pair_x32(sy, sab), w3 = pair_x32(sxx, sxy), w4 = pair_x32(syy, sq);
+                float* row = red + 5 * lane;
+                row[0] = w0; row[1] = w1; row[2] = w2; row[3] = w3; row[4] = w4;
+                asm volatile("" ::: "memory");   // (compiler order only: one wave's LDS operations execute in program order)
+                float t[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) t[i] = red[rd0 + 20 * i];
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int d = 1; d < 8; d <<= 1)
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2 * d) t[i] += t[i + d];
+                float tot = t[0];
+                tot += dpp_f<0xB1>(tot);
+                tot += dpp_f<0x4E>(tot);
+                // lane 32 half + 4 m (m < 5) holds value 2 m + half: byte 8 m + 4 half of the record
+                if ((lane & 3) == 0 && (lane & 31) < 20)
+                    unsafeAtomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(grad_rec) + (size_t)(__float_as_uint(r1.z) + (uint32_t)(2 * (lane & 31) + 4 * (lane >> 5)))), tot);
+                asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\tv_mov_b64 %4, 0"
+                             : "=v"(p0), "=v"(p1), "=v"(p2), "=v"(p3), "=v"(p4));
+                continue;
+            }
             const float total = DUAL ? butterfly13(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, ac2r, ac2g, ac2b, lane)
                                      : butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
             if (DET) {

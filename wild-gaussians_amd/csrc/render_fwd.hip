@@ -484,7 +484,9 @@ __global__ void __launch_bounds__(256) render_fixup_kernel(
     // phase 1 runs after every tile's phase 0 (stream order): which bands asked for far instances is final, and goes to the host's
     // mailbox as the hint for later frames (api.hip: a thread whose frames keep needing the far phase stops attempting the split)
     if (phase == 1 && mailbox && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(&mailbox->need_far, 1u + split->far_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mailbox->far_report,
+                           ((unsigned long long)split->aim << 32) | (1u + min(split->far_tiles, 0xffffffu) + ((uint32_t)__popc(split->need_far & 0xffu) << 24)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // tiles that asked (24 bits), in how many of the eight bands (what the far scatter costs), the frame's aim
     const int tile = xcd_tile(blockIdx.x, tiles);
     uint32_t done = tile_state[tile];
     if (done == 0xffffffffu) return;  // workgroup-uniform

@@ -74,7 +74,7 @@ struct SplitState {
     uint32_t near_code;  // instances of Gaussians with depth_code(depth, SPLIT_BITS) <= near_code are near
     uint32_t need_far;   // bit b: set by the first fix-up phase when a tile of XCD band b ran out of near instances
     uint32_t far_tiles;  // how many tiles did
-    uint32_t pad;
+    uint32_t aim;        // the aimed near instances per tile this frame's threshold was picked for (goes back to the host with the far-phase report)
 };
 
 // Host-visible (pinned, mapped, coherent) mailbox the tile scan writes the same two numbers to, followed by a sequence
@@ -87,10 +87,12 @@ struct HostMailbox {
     //   word0 = seq << 32 | num_rendered
     //   word1 = seq << 32 | spec_fail << 31 | split_active << 30 | min(max_tile_count, 2^30 - 1)
     unsigned long long word0, word1;
-    uint32_t need_far;   // written at the END of a split frame (fix-up phase 1): 1 + the number of tiles that needed far instances
-                         // (0 = nothing new).  Read by the host at the start of a LATER frame as a hint only (no waiting: it may be
-                         // a frame old)
-    uint32_t pad[3];
+    // written at the END of a split frame (fix-up phase 1) with ONE 8-byte store: low word = 1 + the number of tiles that needed far instances (24 bits)
+    // + the number of XCD bands with such a tile << 24 (the far scatter walks the far Gaussians of the flagged bands: its cost goes with the
+    // bands); high word = the near aim that frame ran with (SplitState::aim).  0 = nothing new.  Read by the host at the start of a LATER frame
+    // as a hint only (no waiting: it may be a frame or two old -- hence the aim inside the report, not the host's current one)
+    unsigned long long far_report;
+    uint32_t pad[2];
 };
 constexpr uint32_t MAILBOX_MAX_LIST = (1u << 30) - 1u;
 

@@ -566,7 +566,11 @@ def main():
     ref_pairs = None   # the reference walk's pair counts of this frame, from the CPU oracle leg below (or the counting build's record)
     t_train_profiled = None
     if not args.no_profile:
-        train_step()                      # (first call of the process: lazy initialisations stay out of the stage times)
+        # (first calls of the process: lazy initialisations stay out of the stage times, and the device reaches its steady clocks before the
+        #  stage events are read -- without the ramp the driver's 20-step run timed K9 at 0.44 ms where every longer run and rocprof's steady
+        #  launches read 0.40: `roofline.achieved` is a statement about the kernel, not about the first 20 ms of a process)
+        for _ in range(30):
+            train_step()
         torch.cuda.synchronize(device)
         _C.profile_reset()
         _C.profile_enable(True)

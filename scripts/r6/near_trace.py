@@ -50,18 +50,20 @@ with torch.no_grad():
             frame()
             torch.cuda.synchronize(dev)
             sample((time.perf_counter() - t0) * 1e3)
-# run-length encode on (aim, floor, far tiles, back-off > 0, frame time to 0.2 ms)
-out, prev, n, first = [], None, 0, 0
+# run-length encode on the controller's state (aim, floor, far tiles, back-off > 0); a run carries its frames' mean / max time
+out, prev, n, first, acc, mx = [], None, 0, 0, 0.0, 0.0
+def close():
+    out.append({"from": first, "frames": n, "ms_mean": round(acc / n, 2), "ms_max": round(mx, 1), "aim": prev[0], "floor": prev[1], "far_tiles_last": prev[2], "backoff": prev[3]})
 for i, r in enumerate(rows):
-    key = (round(r[0] / 0.2) * 0.2, r[1], r[2], r[3], r[4] > 0)
+    key = (r[1], r[2], r[3], r[4] > 0)
     if key != prev:
         if prev is not None:
-            out.append({"from": first, "frames": n, "ms": round(prev[0], 1), "aim": prev[1], "floor": prev[2], "far_tiles_last": prev[3], "backoff": prev[4]})
-        prev, n, first = key, 0, i
-    n += 1
-out.append({"from": first, "frames": n, "ms": round(prev[0], 1), "aim": prev[1], "floor": prev[2], "far_tiles_last": prev[3], "backoff": prev[4]})
+            close()
+        prev, n, first, acc, mx = key, 0, i, 0.0, 0.0
+    n += 1; acc += r[0]; mx = max(mx, r[0])
+close()
 ms = sorted(r[0] for r in rows)
-print(json.dumps({"frames": frames, "P": P, "W": W, "H": H, "ms_p10_p50_p90": [ms[len(ms) // 10], ms[len(ms) // 2], ms[(9 * len(ms)) // 10]], "mean_ms": round(sum(ms) / len(ms), 3),
-                  "runs": len(out)}))
+print(json.dumps({"frames": len(rows), "P": P, "W": W, "H": H, "ms_p10_p50_p90": [ms[len(ms) // 10], ms[len(ms) // 2], ms[(9 * len(ms)) // 10]], "mean_ms": round(sum(ms) / len(ms), 3),
+                  "runs": len(out), "frames_over_2.2_ms": sum(1 for m in ms if m > 2.2)}))
 for o in out[:400]:
     print(json.dumps(o))

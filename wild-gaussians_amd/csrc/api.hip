@@ -762,14 +762,17 @@ static int forward_impl(const wg_forward_args& a) {
             if ((uint64_t)far_tiles * 50u > (uint64_t)tiles && !(near_adaptive && report_aim != 0u && report_aim < near_default)) t_split_backoff = 64;
             if (near_adaptive && report_aim != 0u) {
                 t_near.last_far = far_tiles;
-                // (a tile or two asking is cheap -- the far scatter walks the far Gaussians of the flagged BANDS only -- and says the aim sits right
-                //  at the deepest tiles' need: a failure is more than two of the eight bands flagged, or more than one tile in a thousand.  With the tile
-                //  count alone a 600-frame run sat below the cliff: thirty tiles in eight bands cost the whole far phase, 536 -> 447 fps.)
-                if (far_bands > 2u || (uint64_t)far_tiles * 1000u > (uint64_t)tiles) {
-                    // the floor goes an eighth above the aim THE FAILING FRAME ran with (the report carries it): reports lag a frame or two behind
-                    // the calls when the caller does not synchronise, and two frames issued at one failing aim used to lift the floor twice
-                    // (386 failed -> 435 -> 490 where 435 sufficed: 1.8 -> 2.0 ms per frame at 10 M Gaussians / 4K until the floor had decayed)
-                    t_near.floor = std::min(near_default, std::max(t_near.floor, report_aim + report_aim / 8u + 1u));
+                // ANY tile that asked is a failure of the aim its frame ran with.  (Rounds of this controller: "more than one tile in a thousand"
+                // let thirty tiles in all eight bands pass as clean while every frame paid the far scatter of every band, 536 -> 447 fps over 600
+                // frames; "at most two bands" still let the aim rest where a few tiles asked in EVERY frame, each paying a far phase: 2.35 instead of
+                // 1.82 ms per frame for 2000 frames at 10 M Gaussians / 4K, profiles/r6/near_trace_*.)  The floor remembers the level, so there is
+                // no saw-tooth: one or two slow frames per probing step, and a probing step only when the floor has decayed (every 2048 frames).
+                if (far_tiles != 0u) {
+                    // the floor goes an eighth above the aim THE FAILING FRAME ran with (the report carries it) -- a sixteenth when only a handful of
+                    // tiles asked (the aim sits right at the deepest tiles' need): reports lag a frame or two behind the calls when the caller does not
+                    // synchronise, and two frames issued at one failing aim used to lift the floor twice (386 failed -> 435 -> 490 where 435 sufficed)
+                    const uint32_t step = ((uint64_t)far_tiles * 1000u > (uint64_t)tiles || far_bands > 2u) ? report_aim / 8u : report_aim / 16u;
+                    t_near.floor = std::min(near_default, std::max(t_near.floor, report_aim + step + 1u));
                     t_near.cur = std::max(t_near.cur, t_near.floor);
                     t_near.clean = 0;
                 } else if (report_aim == t_near.cur && ++t_near.clean >= 4u) {   // (four clean frames AT the current aim)

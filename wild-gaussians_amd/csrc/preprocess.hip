@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
     if (FAST_SH) {
         const float4* src = reinterpret_cast<const float4*>(p.shs) + (size_t)base * 12;
         const int last = min(64, p.P - base) * 12 - 1;
-#define WG_SH_LOAD(i) sr##i = src[min(i * 64 + lane, last)];
+#define WG_SH_LOAD(i) sr##i = stream_load4(&src[min(i * 64 + lane, last)]);
         WG_SH_LOAD(0) WG_SH_LOAD(1) WG_SH_LOAD(2) WG_SH_LOAD(3) WG_SH_LOAD(4) WG_SH_LOAD(5)
         WG_SH_LOAD(6) WG_SH_LOAD(7) WG_SH_LOAD(8) WG_SH_LOAD(9) WG_SH_LOAD(10) WG_SH_LOAD(11)
 #undef WG_SH_LOAD

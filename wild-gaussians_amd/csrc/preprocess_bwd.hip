@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     if (FAST_SH) {  // 64 Gaussians x 12 float4, coalesced
         const float4* src = reinterpret_cast<const float4*>(p.shs) + (size_t)base * 12;
         const int last = min(64, p.P - base) * 12 - 1;
-#define WG_SH_LOAD(i) sr##i = src[min(i * 64 + lane, last)];
+#define WG_SH_LOAD(i) sr##i = stream_load4(&src[min(i * 64 + lane, last)]);
         WG_SH_LOAD(0) WG_SH_LOAD(1) WG_SH_LOAD(2) WG_SH_LOAD(3) WG_SH_LOAD(4) WG_SH_LOAD(5)
         WG_SH_LOAD(6) WG_SH_LOAD(7) WG_SH_LOAD(8) WG_SH_LOAD(9) WG_SH_LOAD(10) WG_SH_LOAD(11)
 #undef WG_SH_LOAD
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             const int f = i * 64 + lane;
-            if (f < nvalid) dst[f] = stage[(f / 12) * SH_PITCH4 + (f % 12)];
+            if (f < nvalid) stream_store4(&dst[f], stage[(f / 12) * SH_PITCH4 + (f % 12)]);
         }
     }
 }

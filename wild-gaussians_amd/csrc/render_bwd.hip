@@ -182,11 +182,12 @@ render_backward_kernel(
     static_assert(!DUAL || RECORD, "the two-colour walk accumulates into the gradient record (or, DET, into fourteen-float slots)");
     constexpr int SLOT_FLOATS = DUAL ? 14 : 10;   // deterministic mode: floats per (tile, Gaussian) slot (thirteen sums, padded to 8-byte multiples)
     constexpr int RS = DUAL ? 4 : 3;   // float4 per parked record
-    constexpr bool LDSRED = WG_BWD_LDS_REDUCE && RECORD && !DET && !DUAL;
-    // LDSRED: one row of five sums per lane, at the START of the allocation (ds_read2 offsets are 8-bit element counts from the lane's base
+    constexpr bool LDSRED = WG_BWD_LDS_REDUCE != 0;
+    constexpr int NS = DUAL ? 7 : 5;   // sums per lane behind the butterfly's first stage (ten values: 5, the two-colour walk's thirteen: 7)
+    // LDSRED: one row of NS sums per lane, at the START of the allocation (ds_read2 offsets are 8-bit element counts from the lane's base
     // address: behind the records every access would first add the array's offset)
-    __shared__ float4 smem[(LDSRED ? 80 : 0) + BATCH * RS];
-    float4* const lds = smem + (LDSRED ? 80 : 0);
+    __shared__ float4 smem[(LDSRED ? 16 * NS : 0) + BATCH * RS];
+    float4* const lds = smem + (LDSRED ? 16 * NS : 0);
     float* const red = reinterpret_cast<float*>(smem);
 
 #if WG_PROBE
@@ -209,7 +210,10 @@ render_backward_kernel(
 
     // which of the ten reduced values this lane owns after butterfly10(), and where it accumulates it:
     //   0,1,2 -> dL_dcolor[3id + k]; 3,4,5 -> dL_dmean2D[3id + k-3]; 6,7,8 -> dL_dconic[4id + {0,1,3}]; 9 -> dL_dopacity[id]
-    const int vidx = DUAL ? 8 * ((lane >> 1) & 1) + 4 * (lane & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1)
+    // (LDSRED: lane 32 half + 4 m holds value 2 m + half, m < NS; value 12 of the two-colour walk comes out in both halves)
+    const int red_m = (lane & 31) >> 2, red_half = lane >> 5;
+    const int vidx = LDSRED ? min(2 * red_m + red_half, DUAL ? 12 : 9)
+                   : DUAL ? 8 * ((lane >> 1) & 1) + 4 * (lane & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1)
                           : ((lane & 2) ? 8 + ((lane >> 5) & 1) : 4 * (lane & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1));
     const bool owner = (lane & 12) == 0;  // lanes with bits 2,3 clear: one lane per value (two spare for value 8/9 copies)
     float* abase;
@@ -221,7 +225,8 @@ render_backward_kernel(
     else if (vidx < 9) { abase = dL_dconic + (vidx == 8 ? 3 : vidx - 6); astride = 4; }
     else { abase = dL_dopacity; astride = 1; }
     // values 8 and 9 (bit1 set) are replicated over bits 0 and 4: let only the bit0 == bit4 == 0 copy issue
-    const bool issue = DUAL ? (owner && vidx <= 12) : (owner && !((lane & 2) && (lane & 17)));
+    const bool issue = LDSRED ? ((lane & 3) == 0 && red_m < NS && !(DUAL && red_m == 6 && red_half == 1))
+                     : DUAL ? (owner && vidx <= 12) : (owner && !((lane & 2) && (lane & 17)));
     // constant factor of this lane's value (see the per-pair sums below); values 3..8 also carry the splat's opacity
     const bool oscale = vidx >= 3 && vidx <= 8;
     constexpr float INV_L = 1.0f / WG_LOG2E;  // u, v above carry a factor -log2(e)
@@ -295,7 +300,7 @@ render_backward_kernel(
 #endif
     // LDSRED: this lane's read base (row 32 half + h, column m of its half; lanes with m >= 5 repeat columns 0 - 2), kept opaque so that it
     // stays in a register (rematerialised inside the loop it is three vector instructions per reduced instance)
-    int rd0 = 5 * (32 * (lane >> 5) + (lane & 3)) + (((lane & 31) >> 2) < 5 ? ((lane & 31) >> 2) : ((lane & 31) >> 2) - 5);
+    int rd0 = NS * (32 * red_half + (lane & 3)) + (red_m < NS ? red_m : red_m - NS);
     if (LDSRED) asm volatile("" : "+v"(rd0));
     for (int hi = hi0; hi > 0; hi -= BATCH) {
         // lane l stages the instance at list position hi-1-l (back to front, backward.cu:517)
@@ -441,31 +446,27 @@ render_backward_kernel(
 #if WG_COUNT_PAIRS
             { const int c = __popcll(any_m); WG_CNT(c <= 1 ? 6 : c <= 4 ? 7 : c <= 16 ? 8 : 9, 1); }
 #endif
+            float total;
             if (LDSRED) {
-                const float w0 = pair_x32(acr, acg), w1 = pair_x32(acb, sx), w2 = pair_x32(sy, sab), w3 = pair_x32(sxx, sxy), w4 = pair_x32(syy, sq);
-                float* row = red + 5 * lane;
-                row[0] = w0; row[1] = w1; row[2] = w2; row[3] = w3; row[4] = w4;
+                float* row = red + NS * lane;
+                row[0] = pair_x32(acr, acg); row[1] = pair_x32(acb, sx); row[2] = pair_x32(sy, sab); row[3] = pair_x32(sxx, sxy); row[4] = pair_x32(syy, sq);
+                if (DUAL) { row[5] = pair_x32(ac2r, ac2g); row[6] = pair_x32(ac2b, ac2b); }
                 asm volatile("" ::: "memory");   // (compiler order only: one wave's LDS operations execute in program order)
                 float t[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) t[i] = red[rd0 + 20 * i];
+                for (int i = 0; i < 8; i++) t[i] = red[rd0 + 4 * NS * i];
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int d = 1; d < 8; d <<= 1)
 #pragma unroll
                     for (int i = 0; i < 8; i += 2 * d) t[i] += t[i + d];
-                float tot = t[0];
-                tot += dpp_f<0xB1>(tot);
-                tot += dpp_f<0x4E>(tot);
-                // lane 32 half + 4 m (m < 5) holds value 2 m + half: byte 8 m + 4 half of the record
-                if ((lane & 3) == 0 && (lane & 31) < 20)
-                    unsafeAtomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(grad_rec) + (size_t)(__float_as_uint(r1.z) + (uint32_t)(2 * (lane & 31) + 4 * (lane >> 5)))), tot);
-                asm volatile("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\tv_mov_b64 %2, 0\n\tv_mov_b64 %3, 0\n\tv_mov_b64 %4, 0"
-                             : "=v"(p0), "=v"(p1), "=v"(p2), "=v"(p3), "=v"(p4));
-                continue;
+                total = t[0];
+                total += dpp_f<0xB1>(total);
+                total += dpp_f<0x4E>(total);
+            } else {
+                total = DUAL ? butterfly13(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, ac2r, ac2g, ac2b, lane)
+                             : butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
             }
-            const float total = DUAL ? butterfly13(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, ac2r, ac2g, ac2b, lane)
-                                     : butterfly10(acr, acg, acb, sx, sy, sab, sxx, sxy, syy, sq, lane);
             if (DET) {
                 if (issue) {
                     const uint32_t slot = __float_as_uint(r1.z);

@@ -70,6 +70,29 @@ constexpr uint32_t SPLIT_BITS = 12, SPLIT_BINS = 1u << SPLIT_BITS, SPLIT_OFF = 0
 // instances per tile from which a frame counts as dense for the split (measured on the bench scene with scaled Gaussians: forcing
 // the split loses 2.5 % at 911 per tile and gains 5 / 7 / 10 % at 1180 / 1400 / 1640)
 constexpr uint32_t SPLIT_DENSE_AVG = 1100;
+// WG_NT_STREAM (a VARIANT build, default off): the per-Gaussian kernels' once-per-frame streams (the SH block in, dL_dsh out) as non-temporal
+// accesses (EXPERIMENTS.md R6.11).
+#ifndef WG_NT_STREAM
+#define WG_NT_STREAM 0
+#endif
+typedef float wg_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 stream_load4(const float4* p) {
+#if WG_NT_STREAM
+    const wg_v4f v = __builtin_nontemporal_load(reinterpret_cast<const wg_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void stream_store4(float4* p, float4 v) {
+#if WG_NT_STREAM
+    wg_v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<wg_v4f*>(p));
+#else
+    *p = v;
+#endif
+}
+
 struct SplitState {
     uint32_t near_code;  // instances of Gaussians with depth_code(depth, SPLIT_BITS) <= near_code are near
     uint32_t need_far;   // bit b: set by the first fix-up phase when a tile of XCD band b ran out of near instances

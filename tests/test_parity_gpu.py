@@ -774,6 +774,62 @@ def test_near_far_split_backs_off_when_pixels_do_not_saturate(lazy_options):
     assert torch.equal(c["color"], ref["color"])
 
 
+def test_non_temporal_sh_streams_change_no_result():
+    """Option "sh_stream": the per-Gaussian kernels read the SH block (and write dL_dsh) with non-temporal accesses -- a cache hint: colour, radii
+    and, in deterministic mode, every gradient are the same bits either way; -1 (default) turns it on up to sh_stream_max_p Gaussians."""
+    from diff_gaussian_rasterization import _C
+    W, H, P = 256, 160, 20000
+    cam, cloud, cot = S.make_camera(W, H), S.make_cloud(P, W, H, sh_degree=3, seed=12), S.make_cotangent(W, H)
+    assert _C.get_option("sh_stream") == -1 and _C.get_option("sh_stream_max_p") >= 1_000_000
+    outs = []
+    try:
+        _C.set_option("deterministic_backward", 1)
+        for mode in (0, 1, -1):
+            _C.set_option("sh_stream", mode)
+            outs.append(run_hip(cloud, cam, sh_degree=3, cotangent=cot))
+        _C.set_option("sh_stream_max_p", 100)           # automatic mode, P above the limit: off
+        outs.append(run_hip(cloud, cam, sh_degree=3, cotangent=cot))
+    finally:
+        _C.set_option("sh_stream", -1); _C.set_option("sh_stream_max_p", 6_000_000); _C.set_option("deterministic_backward", 0)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o["color"], outs[0]["color"])
+        np.testing.assert_array_equal(o["radii"], outs[0]["radii"])
+        for k in outs[0]["grads"]:
+            np.testing.assert_array_equal(o["grads"][k], outs[0]["grads"][k], err_msg=k)
+
+
+def test_near_aim_adapts_and_settles_where_no_tile_asks(lazy_options):
+    """Automatic mode on a dense frame whose pixels saturate ~220 instances deep: the aimed near instances per tile start at 1.1 x the front
+    target and are lowered while the far-phase reports stay clean; a report in which ANY tile asked lifts the floor above the aim THAT frame ran
+    with (the report carries it) and the aim rests there: no tile asks in the settled frames (each asking tile costs its band a far scatter),
+    the aim never exceeds the default, and every frame on the way -- lowered aims, the failing frame, the lifted one -- is the unsplit
+    frame bit for bit."""
+    from diff_gaussian_rasterization import _C
+    W, H, P = 320, 200, 30000
+    cam = S.make_camera(W, H)
+    cloud = S.make_cloud(P, W, H, sh_degree=1, seed=5, scale_mult=11.0)   # ~2500 instances per tile
+    lazy_options(near_split=0)
+    ref = run_hip_native(cloud, cam, sh_degree=1)
+    lazy_options(near_split=-1, band_list_min_p=1, near_adapt=1)         # (setting near_adapt resets this thread's controller)
+    default_aim = (820 * 11) // 10
+    aims, floors, asked = [], [], []
+    for i in range(120):
+        f = run_hip_native(cloud, cam, sh_degree=1)
+        torch.cuda.synchronize()
+        assert f["num_rendered"] == ref["num_rendered"] and torch.equal(f["color"], ref["color"]), i
+        assert torch.equal(f["views"]["image"]["n_contrib"], ref["views"]["image"]["n_contrib"]), i
+        assert int(f["views"]["image"]["split"].cpu().numpy().view(np.uint32)[0]) != 0xffffffff, i   # the split stayed on (no back-off)
+        aims.append(_C.get_option("near_per_tile_now")); floors.append(_C.get_option("near_floor_now")); asked.append(_C.get_option("near_far_tiles_last"))
+    assert aims[0] == default_aim and max(aims) <= default_aim
+    assert min(aims) < default_aim // 2                    # it did come down: pixels stop ~220 deep, the default aims at 902
+    assert max(floors) > 0 and max(asked) > 0              # it found the level at which tiles start asking ...
+    first_fail = next(i for i, fl in enumerate(floors) if fl > 0)
+    assert floors[first_fail] <= aims[first_fail - 1] + aims[first_fail - 1] // 4 + 2   # ... and lifted the floor ONCE above the failing aim, not twice
+    assert _C.get_option("near_split_backoff") == 0
+    assert aims[-1] >= floors[-1] and all(a == 0 for a in asked[-20:])     # settled: nobody asks
+    assert len(set(aims[-20:])) == 1
+
+
 def test_near_far_split_stays_off_on_frames_that_are_not_dense(lazy_options):
     """Automatic mode: attempted from band_list_min_p Gaussians on, but switched off on the device below 1500 instances per tile."""
     W, H, P = 640, 360, 60000

@@ -723,6 +723,7 @@ static int forward_impl(const wg_forward_args& a) {
     fp.means3D = means3D; fp.shs = shs; fp.colors_precomp = colors_precomp; fp.opacities = opacities;
     fp.colors_precomp2 = (out_color2 && P > 0 && !sh_second) ? second->colors_precomp2 : nullptr;
     if (raw != nullptr && P > 0) fp.filter_3D = raw->filter_3D;
+    fp.nt_stream = opt.sh_stream == 1 || (opt.sh_stream < 0 && P <= opt.sh_stream_max_p);
     fp.scales = scales; fp.scale_modifier = scale_modifier; fp.rotations = rotations; fp.cov3D_precomp = cov3D_precomp;
     fp.viewmatrix = viewmatrix; fp.projmatrix = projmatrix; fp.cam_pos = cam_pos;
     fp.tan_fovx = tan_fovx; fp.tan_fovy = tan_fovy;
@@ -1195,6 +1196,7 @@ static int backward_impl(const wg_backward_args& a) {
     bp.kernel_size = kernel_size; bp.radii = radii;
     bp.dL_dcolor2 = dual ? second->dL_dcolor2 : nullptr;
     if (raw != nullptr) { bp.filter_3D = raw->filter_3D; bp.raw_opacities = raw->raw_opacities; }
+    bp.nt_stream = opt.sh_stream == 1 || (opt.sh_stream < 0 && P <= opt.sh_stream_max_p);
     WG_STAGE(WG_STAGE_PREPROCESS_BACKWARD, wg::launch_preprocess_backward(bp, device_tone(tone, tone2, sh_second && dual), geom, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,
                                             dL_dscale, dL_drot, record, stream),
              "preprocess_backward");
@@ -1276,6 +1278,8 @@ int wg_set_option(const char* name, int value) {
     if (std::strcmp(name, "forward_order_slots") == 0) { if (value < 0 || value > (1 << 16)) return WG_ERR_INVALID_ARGUMENT; o.forward_order_slots = value; return WG_OK; }   // (read when a device's table is allocated)
     if (std::strcmp(name, "order_period") == 0) { if (value < 0 || value > 4096) return WG_ERR_INVALID_ARGUMENT; o.order_period = value; return WG_OK; }
     if (std::strcmp(name, "backward_order_period") == 0) { if (value < 0 || value > 4096) return WG_ERR_INVALID_ARGUMENT; o.backward_order_period = value; return WG_OK; }
+    if (std::strcmp(name, "sh_stream") == 0) { o.sh_stream = value < 0 ? -1 : (value != 0); return WG_OK; }
+    if (std::strcmp(name, "sh_stream_max_p") == 0) { if (value < 0) return WG_ERR_INVALID_ARGUMENT; o.sh_stream_max_p = value; return WG_OK; }
     if (std::strcmp(name, "speculative_forward") == 0) {  // (a deferred frame still pending is dropped: its verdict goes unread)
         if (value < 0 || value > 2) return WG_ERR_INVALID_ARGUMENT;
         o.speculative = value; t_spec.clear(); t_wait.clear(); t_deferred.pending = false;
@@ -1292,7 +1296,11 @@ int wg_set_option(const char* name, int value) {
         return WG_OK;
     }
     if (std::strcmp(name, "near_per_tile") == 0) { o.near_per_tile = value > 0 ? value : 0; return WG_OK; }
-    if (std::strcmp(name, "near_adapt") == 0) { o.near_adapt = value != 0; t_near = NearAdapt(); return WG_OK; }
+    if (std::strcmp(name, "near_adapt") == 0) {   // (also resets the calling thread's controller and drops a report still waiting in its mailbox)
+        o.near_adapt = value != 0; t_near = NearAdapt(); t_split_backoff = 0;
+        if (t_mailbox.host) t_mailbox.host->far_report = 0ull;
+        return WG_OK;
+    }
     if (std::strcmp(name, "box_count") == 0) { o.box_count = value < 0 ? -1 : (value != 0); return WG_OK; }
     if (std::strcmp(name, "depth_codes") == 0) {
         if (value != 0 && value != 1 && (value < 8 || value > 12)) return WG_ERR_INVALID_ARGUMENT;
@@ -1334,6 +1342,8 @@ int wg_get_option(const char* name) {
     if (std::strcmp(name, "forward_order_slots") == 0) return o.forward_order_slots;
     if (std::strcmp(name, "order_period") == 0) return o.order_period;
     if (std::strcmp(name, "backward_order_period") == 0) return o.backward_order_period;
+    if (std::strcmp(name, "sh_stream") == 0) return o.sh_stream;
+    if (std::strcmp(name, "sh_stream_max_p") == 0) return o.sh_stream_max_p;
     if (std::strcmp(name, "speculative_forward") == 0) return o.speculative;
     if (std::strcmp(name, "spec_margin_pct") == 0) return o.spec_margin_pct;
     if (std::strcmp(name, "force_global_sort") == 0) return o.force_global_sort ? 1 : 0;

@@ -50,8 +50,9 @@ __device__ __forceinline__ float sh_channel(int deg, const float* sh, float x, f
 // lane stride.  The values, and the order of the arithmetic on them, are unchanged.
 constexpr int SH_PITCH4 = 13;
 
-template <bool FAST_SH, bool PRECOMP, bool TONE>
+template <int SH_MODE, bool PRECOMP, bool TONE>   // SH_MODE: 0 generic layout, 1 coalesced block through LDS, 2 the same with non-temporal loads
 __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometryState g, int* __restrict__ radii_out, ToneArg<TONE> tone) {
+    constexpr bool FAST_SH = SH_MODE != 0, NT = SH_MODE == 2;
     __shared__ float4 stage[FAST_SH ? 64 * SH_PITCH4 : 1];
     const int lane = threadIdx.x;
     const int base = blockIdx.x * 64;
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
     if (FAST_SH) {
         const float4* src = reinterpret_cast<const float4*>(p.shs) + (size_t)base * 12;
         const int last = min(64, p.P - base) * 12 - 1;
-#define WG_SH_LOAD(i) sr##i = stream_load4(&src[min(i * 64 + lane, last)]);
+#define WG_SH_LOAD(i) sr##i = stream_load4<NT>(&src[min(i * 64 + lane, last)]);
         WG_SH_LOAD(0) WG_SH_LOAD(1) WG_SH_LOAD(2) WG_SH_LOAD(3) WG_SH_LOAD(4) WG_SH_LOAD(5)
         WG_SH_LOAD(6) WG_SH_LOAD(7) WG_SH_LOAD(8) WG_SH_LOAD(9) WG_SH_LOAD(10) WG_SH_LOAD(11)
 #undef WG_SH_LOAD
@@ -358,15 +359,17 @@ hipError_t launch_preprocess(const FwdParams& p, const ShTone& tone_in, const Ge
     const bool tone = tone_in.enabled && p.shs != nullptr && p.colors_precomp == nullptr;
 #define WG_LAUNCH(F, C) hipLaunchKernelGGL((preprocess_kernel<F, C, false>), grid, block, 0, stream, p, g, radii_out, NoTone{})
 #define WG_LAUNCH_TONE(F, C) hipLaunchKernelGGL((preprocess_kernel<F, C, true>), grid, block, 0, stream, p, g, radii_out, tone_in)
+#define WG_LAUNCH_FAST(L, C) do { if (p.nt_stream) L(2, C); else L(1, C); } while (0)
     if (tone) {
-        if (fast && !pre) WG_LAUNCH_TONE(true, false);
-        else if (fast) WG_LAUNCH_TONE(true, true);
-        else if (!pre) WG_LAUNCH_TONE(false, false);
-        else WG_LAUNCH_TONE(false, true);
-    } else if (fast && !pre) WG_LAUNCH(true, false);
-    else if (fast) WG_LAUNCH(true, true);
-    else if (!pre) WG_LAUNCH(false, false);
-    else WG_LAUNCH(false, true);
+        if (fast && !pre) WG_LAUNCH_FAST(WG_LAUNCH_TONE, false);
+        else if (fast) WG_LAUNCH_FAST(WG_LAUNCH_TONE, true);
+        else if (!pre) WG_LAUNCH_TONE(0, false);
+        else WG_LAUNCH_TONE(0, true);
+    } else if (fast && !pre) WG_LAUNCH_FAST(WG_LAUNCH, false);
+    else if (fast) WG_LAUNCH_FAST(WG_LAUNCH, true);
+    else if (!pre) WG_LAUNCH(0, false);
+    else WG_LAUNCH(0, true);
+#undef WG_LAUNCH_FAST
 #undef WG_LAUNCH
 #undef WG_LAUNCH_TONE
     return hipGetLastError();

@@ -61,12 +61,13 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
 // 12 KiB SH block second (into registers), and only the SH part of the arithmetic -- placed last -- waits for it.
 // RECORD: the per-tile pass left its raw sums in grad_rec (wg_common.h: GRAD_REC_*); this kernel applies the per-Gaussian factors
 // and WRITES dL_dmean2D / dL_dconic / dL_dopacity / dL_dcolor for every Gaussian.  !RECORD: those four arrive accumulated.
-template <bool FAST_SH, bool HAS_SCALES, bool TONE, bool RECORD>
+template <int SH_MODE, bool HAS_SCALES, bool TONE, bool RECORD>   // SH_MODE: 0 generic layout, 1 coalesced blocks through LDS, 2 the same with non-temporal accesses
 __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     BwdParams p, const float4* __restrict__ splats, const unsigned char* __restrict__ clamped, const float4* __restrict__ grad_rec,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
     float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot, ToneArg<TONE> tone) {
+    constexpr bool FAST_SH = SH_MODE != 0, NT = SH_MODE == 2;
     __shared__ float4 stage[FAST_SH ? 64 * SH_PITCH4 : 1];
     const int lane = threadIdx.x;
     const int base = blockIdx.x * 64;
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
     if (FAST_SH) {  // 64 Gaussians x 12 float4, coalesced
         const float4* src = reinterpret_cast<const float4*>(p.shs) + (size_t)base * 12;
         const int last = min(64, p.P - base) * 12 - 1;
-#define WG_SH_LOAD(i) sr##i = stream_load4(&src[min(i * 64 + lane, last)]);
+#define WG_SH_LOAD(i) sr##i = stream_load4<NT>(&src[min(i * 64 + lane, last)]);
         WG_SH_LOAD(0) WG_SH_LOAD(1) WG_SH_LOAD(2) WG_SH_LOAD(3) WG_SH_LOAD(4) WG_SH_LOAD(5)
         WG_SH_LOAD(6) WG_SH_LOAD(7) WG_SH_LOAD(8) WG_SH_LOAD(9) WG_SH_LOAD(10) WG_SH_LOAD(11)
 #undef WG_SH_LOAD
@@ -303,24 +304,24 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
         float* o = dL_dcov3D + 6 * (size_t)idx;
         o[0] = dcov[0]; o[1] = dcov[1]; o[2] = dcov[2]; o[3] = dcov[3]; o[4] = dcov[4]; o[5] = dcov[5];
         if (RECORD) {
-            dL_dopacity[idx] = write_dLdo ? dLdo_out : dLdo_in;
-            dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = g2abs;
+            stream_store1<NT>(&dL_dopacity[idx], write_dLdo ? dLdo_out : dLdo_in);
+            stream_store1<NT>(&dL_dmean2D[3 * idx], g2x); stream_store1<NT>(&dL_dmean2D[3 * idx + 1], g2y); stream_store1<NT>(&dL_dmean2D[3 * idx + 2], g2abs);
             // the reference's intermediates: only a caller that wants them passes the pointers (wg_rasterizer.h)
-            if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[idx] = dconic;
-            if (dL_dcolor) { dL_dcolor[3 * idx] = dcol0; dL_dcolor[3 * idx + 1] = dcol1; dL_dcolor[3 * idx + 2] = dcol2; }
+            if (dL_dconic) stream_store4<NT && WG_NT_OUT>(&reinterpret_cast<float4*>(dL_dconic)[idx], dconic);
+            if (dL_dcolor) { stream_store1<NT>(&dL_dcolor[3 * idx], dcol0); stream_store1<NT>(&dL_dcolor[3 * idx + 1], dcol1); stream_store1<NT>(&dL_dcolor[3 * idx + 2], dcol2); }
             if (p.dL_dcolor2) {   // two-colour walk (render_bwd.hip: DUAL): the record's floats 10, 11 and grad_aux; zeros for a culled Gaussian
                 const float4 r2 = grad_rec[3 * (size_t)idx + 2];
                 const float* aux = reinterpret_cast<const float*>(grad_rec) + (size_t)p.P * GRAD_REC_FLOATS;
                 p.dL_dcolor2[3 * idx] = r2.z; p.dL_dcolor2[3 * idx + 1] = r2.w; p.dL_dcolor2[3 * idx + 2] = aux[idx];
             }
         } else if (write_dLdo) {
-            dL_dopacity[idx] = dLdo_out;
+            stream_store1<NT>(&dL_dopacity[idx], dLdo_out);
         }
         if (HAS_SCALES) {
-            dL_dscale[3 * idx] = dsc[0];
-            dL_dscale[3 * idx + 1] = dsc[1];
-            dL_dscale[3 * idx + 2] = dsc[2];
-            reinterpret_cast<float4*>(dL_drot)[idx] = dq;
+            stream_store1<NT>(&dL_dscale[3 * idx], dsc[0]);
+            stream_store1<NT>(&dL_dscale[3 * idx + 1], dsc[1]);
+            stream_store1<NT>(&dL_dscale[3 * idx + 2], dsc[2]);
+            stream_store4<NT && WG_NT_OUT>(&reinterpret_cast<float4*>(dL_drot)[idx], dq);
         }
     }
 
@@ -475,9 +476,9 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
 
     // ---- outputs: written for every Gaussian of the range (zeros when culled) ----
     if (in) {
-        dL_dmean3D[3 * idx] = gmx;
-        dL_dmean3D[3 * idx + 1] = gmy;
-        dL_dmean3D[3 * idx + 2] = gmz;
+        stream_store1<NT>(&dL_dmean3D[3 * idx], gmx);
+        stream_store1<NT>(&dL_dmean3D[3 * idx + 1], gmy);
+        stream_store1<NT>(&dL_dmean3D[3 * idx + 2], gmz);
         if (!FAST_SH && p.shs != nullptr && !vis) {
             float* d = dL_dsh + (size_t)idx * p.M * 3;
             for (int k = 0; k < p.M * 3; k++) d[k] = 0.f;
@@ -503,7 +504,7 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             const int f = i * 64 + lane;
-            if (f < nvalid) stream_store4(&dst[f], stage[(f / 12) * SH_PITCH4 + (f % 12)]);
+            if (f < nvalid) stream_store4<NT>(&dst[f], stage[(f / 12) * SH_PITCH4 + (f % 12)]);
         }
     }
 }
@@ -527,10 +528,10 @@ hipError_t launch_preprocess_backward(const BwdParams& p, const ShTone& tone_in,
         else if (record) hipLaunchKernelGGL((preprocess_backward_kernel<F, S, false, true>), grid, block, 0, stream, WG_ARGS, NoTone{});    \
         else hipLaunchKernelGGL((preprocess_backward_kernel<F, S, false, false>), grid, block, 0, stream, WG_ARGS, NoTone{});               \
     } while (0)
-    if (fast && sc) WG_LAUNCH(true, true);
-    else if (fast) WG_LAUNCH(true, false);
-    else if (sc) WG_LAUNCH(false, true);
-    else WG_LAUNCH(false, false);
+    if (fast && sc) { if (p.nt_stream) WG_LAUNCH(2, true); else WG_LAUNCH(1, true); }
+    else if (fast) { if (p.nt_stream) WG_LAUNCH(2, false); else WG_LAUNCH(1, false); }
+    else if (sc) WG_LAUNCH(0, true);
+    else WG_LAUNCH(0, false);
 #undef WG_LAUNCH
 #undef WG_ARGS
     return hipGetLastError();

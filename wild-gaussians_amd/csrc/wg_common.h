@@ -70,27 +70,36 @@ constexpr uint32_t SPLIT_BITS = 12, SPLIT_BINS = 1u << SPLIT_BITS, SPLIT_OFF = 0
 // instances per tile from which a frame counts as dense for the split (measured on the bench scene with scaled Gaussians: forcing
 // the split loses 2.5 % at 911 per tile and gains 5 / 7 / 10 % at 1180 / 1400 / 1640)
 constexpr uint32_t SPLIT_DENSE_AVG = 1100;
-// WG_NT_STREAM (a VARIANT build, default off): the per-Gaussian kernels' once-per-frame streams (the SH block in, dL_dsh out) as non-temporal
-// accesses (EXPERIMENTS.md R6.11).
-#ifndef WG_NT_STREAM
-#define WG_NT_STREAM 0
-#endif
+// The per-Gaussian kernels' once-per-frame streams -- the SH block in, dL_dsh out -- as NON-TEMPORAL accesses (`nt`: no allocation in the caches on
+// the way): at 1 M Gaussians the 192 MB SH block otherwise flushes the records, lists and image state the other kernels re-read out of the L2s /
+// the memory-side cache (preprocess 0.0706 -> 0.0581 ms, preprocess_backward 0.1023 -> 0.0960, the render kernels ~1 % each); at 10 M nothing
+// fits anyway and the hint costs ~2 % (EXPERIMENTS.md R6.11).  A template parameter of the kernels (SH mode 2), chosen per launch (option "sh_stream").
 typedef float wg_v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
 __device__ __forceinline__ float4 stream_load4(const float4* p) {
-#if WG_NT_STREAM
-    const wg_v4f v = __builtin_nontemporal_load(reinterpret_cast<const wg_v4f*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
+    if constexpr (NT) {
+        const wg_v4f v = __builtin_nontemporal_load(reinterpret_cast<const wg_v4f*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
 }
-__device__ __forceinline__ void stream_store4(float4* p, float4 v) {
-#if WG_NT_STREAM
-    wg_v4f t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<wg_v4f*>(p));
-#else
-    *p = v;
+#ifndef WG_NT_OUT
+#define WG_NT_OUT 0   // a VARIANT build: K11's per-Gaussian gradient outputs (84 B per Gaussian) as non-temporal stores too (EXPERIMENTS.md R6.11)
 #endif
+template <bool NT>
+__device__ __forceinline__ void stream_store1(float* p, float v) {
+    if constexpr (NT && WG_NT_OUT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <bool NT>
+__device__ __forceinline__ void stream_store4(float4* p, float4 v) {
+    if constexpr (NT) {
+        wg_v4f t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<wg_v4f*>(p));
+    } else {
+        *p = v;
+    }
 }
 
 struct SplitState {
@@ -214,6 +223,7 @@ struct FwdParams {
     int prefiltered;
     const float* filter_3D = nullptr;   // raw-parameter mode (wg_raw_gaussians): opacities / scales / rotations above are the caller's RAW
                                         // parameters and get_gaussians() (method.py:1060-1086) runs inside the kernel (wg_act.h)
+    bool nt_stream = false;             // the SH block as non-temporal loads (stream_load4 above)
 };
 
 // kernels / stages (each launches on `stream`, returns hipGetLastError())
@@ -296,6 +306,8 @@ struct Options {
     int forward_order_slots = 2048;   //   rows of that table (x 9216 tiles x 4 B = 75 MB of device memory, allocated at the first forward call)
     int order_period = 128;           //   rounds of the snake dealing (the hardware's placement period per XCD; 0 = plain descending order)
     int backward_order_period = 0;    //   the same for the backward kernel's order (0: descending, its tail is dealt dynamically)
+    int sh_stream = -1;               // the SH block in / dL_dsh out as non-temporal accesses: 1 on, 0 off, -1 up to sh_stream_max_p Gaussians
+    int sh_stream_max_p = 6000000;    //   (wg_common.h: stream_load4; a gain while the rest of the frame's state fits the caches, a small loss at 10 M)
 };
 hipError_t launch_tile_sort_lazy(const ImageState& img, const BinningState& b, const GeometryState& g, int tiles, int code_bits,
                                  const LazyConfig& lazy, bool split, const BinStats* guard, hipStream_t stream);
@@ -341,6 +353,7 @@ struct BwdParams {
     float* dL_dcolor2 = nullptr;    // two-colour walk: [P,3], written from the record's floats 10, 11 and grad_aux
     const float* filter_3D = nullptr;      // raw-parameter mode: scales / rotations above are RAW, raw_opacities the raw opacities; dL_dscale /
     const float* raw_opacities = nullptr;  // dL_drot / dL_dopacity come out as the gradients of the RAW parameters
+    bool nt_stream = false;                // the SH block in and dL_dsh out as non-temporal accesses (stream_load4 / stream_store4)
 };
 // record: the four arrays are OUTPUTS computed from g.grad_rec (see GRAD_REC_*); otherwise inputs accumulated by the per-tile pass
 hipError_t launch_preprocess_backward(const BwdParams& p, const ShTone& tone, const GeometryState& g, float* dL_dmean2D,

@@ -377,7 +377,7 @@ def config_legs(device, deg_unused, with_oracle: bool, clouds: dict) -> dict:
                    "pins_ok": d == pins[name], "num_rendered": int(R_)}
             if d != pins[name]:
                 leg["pins_mismatch"] = [k for k in d if d[k] != pins[name][k]]
-            for _ in range(64 if fwd_only else 8):   # (config 5: the near / far split's adaptive aim settles within ~50 frames of a camera)
+            for _ in range(120 if fwd_only else 8):   # (config 5: the near / far split's adaptive aim settles within ~60 unsynchronised frames of a scene)
                 step()
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
@@ -394,6 +394,15 @@ def config_legs(device, deg_unused, with_oracle: bool, clouds: dict) -> dict:
             leg["steps"] = steps
             leg["ms_per_step"] = round(1e3 * dt / steps, 4)
             leg["fps" if fwd_only else "iters_per_s"] = round(steps / dt, 2)
+            # where the leg's time goes: 40 more steps with the library's per-stage events on (outside the timed region above)
+            _C.profile_reset(); _C.profile_enable(True)
+            for _ in range(40):
+                step()
+            torch.cuda.synchronize(device)
+            st_ = _C.profile_read(); _C.profile_enable(False)
+            leg["stages_ms"] = {k: round(v[0] / 40.0, 4) for k, v in st_.items() if v[1] > 0}   # per step (a stage may be several launches)
+            if fwd_only:
+                leg["near_far_split"] = {k: _C.get_option(k) for k in ("near_per_tile_now", "near_floor_now", "near_far_tiles_last", "near_split_backoff")}
             if not fwd_only and with_oracle:
                 from oracle import oracle
                 o = oracle.run_scene(cloud, cam, sh_degree=deg, cotangent=cot_np)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6, final measurements on the round's final sources (run on the GPU box: gpurun -- 'bash scripts/r5/r5_final.sh'): profiles with the
+# round 6, final measurements on the round's final sources (run on the GPU box: gpurun -- 'bash scripts/r6/r6_final.sh'; the butterfly variant build of K9 must exist:
+# WG_BUILD_VARIANT=butterfly WG_EXTRA_FLAGS=-DWG_BWD_LDS_REDUCE=0 python wild-gaussians_amd/build.py): profiles with the
 # lane-utilisation counters, pair counts from the counting build, the bench line of every BASELINE config, config 4's N = 1 point, A/Bs.
 O=gpurun_out/r6final; mkdir -p $O
 (time python -m pytest tests -m gpu -q) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
@@ -25,6 +26,12 @@ python bench.py --gaussians 500000 --no-camera-sequence > $O/bench_config2_500k.
 python bench.py --gaussians 10000000 --width 3840 --height 2160 --forward-only --steps 100 --warmup 10 > $O/bench_config5_10M_4K_forward.json 2> $O/bench_config5.err
 python bench.py --gaussians 3000000 --width 1600 --height 1200 --colors precomp --no-cpu-baseline --no-camera-sequence --steps 200 --warmup 20 > $O/bench_3M_1600x1200.json 2> $O/bench_3M.err
 for m in 2 3 4; do python bench.py --scale-mult $m --no-cpu-baseline --no-camera-sequence --steps 200 --warmup 20 > $O/bench_dense_x$m.json 2> $O/bench_dense_x$m.err; done
+python bench.py --no-cpu-baseline --no-camera-sequence --steps 300 --warmup 30 --option sh_stream=0 > $O/bench_sh_stream_off.json 2> $O/bench_sh_stream_off.err
+python bench.py --gaussians 10000000 --width 3840 --height 2160 --forward-only --no-cpu-baseline --no-camera-sequence --steps 1500 --warmup 20 > $O/bench_config5_1500_steps.json 2> $O/bench_config5_1500.err
+python scripts/r6/near_trace.py 2500 > $O/near_trace_synchronized.txt 2> $O/near_trace_sync.err
+NEAR_TRACE_BENCH_LIKE=1 python scripts/r6/near_trace.py 3500 > $O/near_trace_pipelined.txt 2> $O/near_trace_pipe.err
+python scripts/r6/diag_sh_stream.py > $O/diag_sh_stream_1M.json 2> $O/diag_sh_stream.err
+WG_RASTERIZER_LIB=$PWD/wild-gaussians_amd/build/butterfly/libwg_rasterizer.so python bench.py --no-cpu-baseline --no-camera-sequence --no-config-legs --steps 300 --warmup 30 > $O/bench_k9_butterfly_build.json 2> $O/bench_k9_butterfly.err
 python bench.py --no-cpu-baseline --no-camera-sequence --steps 300 --warmup 30 --option deterministic_backward=1 > $O/bench_deterministic.json 2> $O/bench_det.err
 python bench.py --no-cpu-baseline --no-camera-sequence --steps 300 --warmup 30 --option exact_compositing=0 > $O/bench_exact_off.json 2> $O/bench_exact_off.err
 python scripts/diag_host_wait.py > $O/host_wait_1M_compiled_binding.json 2> $O/hw1.err

@@ -95,7 +95,14 @@ thread_local uint32_t t_split_backoff = 0;            // frames for which the sp
 // failed, where it then stays (the floor is relaxed by a twentieth every 2048 frames).  Never above the fixed default (1.1 x the front target): the adaptation can only shorten what
 // is scattered and sorted -- at 10 M Gaussians / 4K pixels stop ~215 instances deep and 900 near instances per tile were twice what the
 // deepest tile needed.  Results do not depend on it (a tile that runs out gets its far instances: the far phase).
-struct NearAdapt { uint32_t cur = 0, floor = 0, clean = 0, age = 0, last_far = 0; };
+// What it has learnt belongs to one SCENE: a cloud outside [P / 2, 2 P] of the one it learnt from starts it afresh (bench.py's config legs run a
+// 3 M-Gaussian frame and then a 10 M-Gaussian frame on one thread: the first one's floor of 698 sat under the second, 2.03 instead of 1.84 ms per
+// frame).  Not the image size: a training run's cameras may differ in theirs (Photo Tourism) while the depth at which pixels stop is the scene's.
+struct NearAdapt {
+    uint32_t cur = 0, floor = 0, clean = 0, age = 0, last_far = 0;
+    int P = 0;
+    bool same_scene(int P_) const { return P != 0 && (int64_t)P_ * 2 >= (int64_t)P && (int64_t)P_ <= (int64_t)P * 2; }
+};
 thread_local NearAdapt t_near;
 
 // Speculative forward: what this host thread's recent frames looked like.  A prediction is made only from frames of the same image
@@ -746,6 +753,11 @@ static int forward_impl(const wg_forward_args& a) {
     //  the dense x3 frame: a near bag that fits the 1024-key network is sorted without a selection pass.)
     const uint32_t near_default = (opt.lazy.target * 11u) / 10u;
     const bool near_adaptive = opt.near_per_tile <= 0 && opt.near_adapt != 0 && opt.near_split < 0;
+    if (near_adaptive && !t_near.same_scene(P)) {
+        t_near = NearAdapt();
+        t_near.P = P;
+        if (t_mailbox.host) t_mailbox.host->far_report = 0ull;   // (a report of the other scene's last frame)
+    }
     if (near_adaptive && (t_near.cur == 0u || t_near.cur > near_default)) t_near.cur = near_default;
     // Frames whose pixels do not saturate (low opacities: after an opacity reset, early in training) walk their whole lists: every
     // band then asks for its far instances and the split only adds a second, slower scatter.  The last split frame's request mask

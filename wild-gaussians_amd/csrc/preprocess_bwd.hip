@@ -304,24 +304,24 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
         float* o = dL_dcov3D + 6 * (size_t)idx;
         o[0] = dcov[0]; o[1] = dcov[1]; o[2] = dcov[2]; o[3] = dcov[3]; o[4] = dcov[4]; o[5] = dcov[5];
         if (RECORD) {
-            stream_store1<NT>(&dL_dopacity[idx], write_dLdo ? dLdo_out : dLdo_in);
-            stream_store1<NT>(&dL_dmean2D[3 * idx], g2x); stream_store1<NT>(&dL_dmean2D[3 * idx + 1], g2y); stream_store1<NT>(&dL_dmean2D[3 * idx + 2], g2abs);
+            dL_dopacity[idx] = write_dLdo ? dLdo_out : dLdo_in;
+            dL_dmean2D[3 * idx] = g2x; dL_dmean2D[3 * idx + 1] = g2y; dL_dmean2D[3 * idx + 2] = g2abs;
             // the reference's intermediates: only a caller that wants them passes the pointers (wg_rasterizer.h)
-            if (dL_dconic) stream_store4<NT && WG_NT_OUT>(&reinterpret_cast<float4*>(dL_dconic)[idx], dconic);
-            if (dL_dcolor) { stream_store1<NT>(&dL_dcolor[3 * idx], dcol0); stream_store1<NT>(&dL_dcolor[3 * idx + 1], dcol1); stream_store1<NT>(&dL_dcolor[3 * idx + 2], dcol2); }
+            if (dL_dconic) reinterpret_cast<float4*>(dL_dconic)[idx] = dconic;
+            if (dL_dcolor) { dL_dcolor[3 * idx] = dcol0; dL_dcolor[3 * idx + 1] = dcol1; dL_dcolor[3 * idx + 2] = dcol2; }
             if (p.dL_dcolor2) {   // two-colour walk (render_bwd.hip: DUAL): the record's floats 10, 11 and grad_aux; zeros for a culled Gaussian
                 const float4 r2 = grad_rec[3 * (size_t)idx + 2];
                 const float* aux = reinterpret_cast<const float*>(grad_rec) + (size_t)p.P * GRAD_REC_FLOATS;
                 p.dL_dcolor2[3 * idx] = r2.z; p.dL_dcolor2[3 * idx + 1] = r2.w; p.dL_dcolor2[3 * idx + 2] = aux[idx];
             }
         } else if (write_dLdo) {
-            stream_store1<NT>(&dL_dopacity[idx], dLdo_out);
+            dL_dopacity[idx] = dLdo_out;
         }
         if (HAS_SCALES) {
-            stream_store1<NT>(&dL_dscale[3 * idx], dsc[0]);
-            stream_store1<NT>(&dL_dscale[3 * idx + 1], dsc[1]);
-            stream_store1<NT>(&dL_dscale[3 * idx + 2], dsc[2]);
-            stream_store4<NT && WG_NT_OUT>(&reinterpret_cast<float4*>(dL_drot)[idx], dq);
+            dL_dscale[3 * idx] = dsc[0];
+            dL_dscale[3 * idx + 1] = dsc[1];
+            dL_dscale[3 * idx + 2] = dsc[2];
+            reinterpret_cast<float4*>(dL_drot)[idx] = dq;
         }
     }
 
@@ -476,9 +476,9 @@ __global__ void __launch_bounds__(64) preprocess_backward_kernel(
 
     // ---- outputs: written for every Gaussian of the range (zeros when culled) ----
     if (in) {
-        stream_store1<NT>(&dL_dmean3D[3 * idx], gmx);
-        stream_store1<NT>(&dL_dmean3D[3 * idx + 1], gmy);
-        stream_store1<NT>(&dL_dmean3D[3 * idx + 2], gmz);
+        dL_dmean3D[3 * idx] = gmx;
+        dL_dmean3D[3 * idx + 1] = gmy;
+        dL_dmean3D[3 * idx + 2] = gmz;
         if (!FAST_SH && p.shs != nullptr && !vis) {
             float* d = dL_dsh + (size_t)idx * p.M * 3;
             for (int k = 0; k < p.M * 3; k++) d[k] = 0.f;

@@ -84,14 +84,6 @@ __device__ __forceinline__ float4 stream_load4(const float4* p) {
         return *p;
     }
 }
-#ifndef WG_NT_OUT
-#define WG_NT_OUT 0   // a VARIANT build: K11's per-Gaussian gradient outputs (84 B per Gaussian) as non-temporal stores too (EXPERIMENTS.md R6.11)
-#endif
-template <bool NT>
-__device__ __forceinline__ void stream_store1(float* p, float v) {
-    if constexpr (NT && WG_NT_OUT) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
 template <bool NT>
 __device__ __forceinline__ void stream_store4(float4* p, float4 v) {
     if constexpr (NT) {

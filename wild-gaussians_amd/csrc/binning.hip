@@ -268,7 +268,7 @@ __device__ __forceinline__ int band_of_tile(int t, int tiles) {
 // corners beyond the grid dropped -- and two prefix passes over the grid (along x, then along y) turn it into the per-tile counts:
 // four atomics per Gaussian whatever its size (10 M Gaussians at 4K: 211 M instances -> 40 M atomics).  Exact integer arithmetic
 // modulo 2^32, so the packed (total << 16 | near) words come out the same as well: identical histograms.
-template <bool BOX>
+template <bool BOX, bool LISTS>   // LISTS: band_list != nullptr (a template parameter: with the list code behind a run-time branch the list-free frames' count took 4 us longer)
 __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const ushort4* __restrict__ rects, uint32_t* __restrict__ chunk_hist,
                                                          uint16_t* __restrict__ band_list, uint32_t* __restrict__ band_cnt, int gx,
                                                          int tiles, const float* __restrict__ depths, const SplitState* __restrict__ split,
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const us
     int begin, end;
     chunk_bounds(P, chunk, begin, end);
     const int per = (P + BIN_CHUNKS - 1) / BIN_CHUNKS;
-    uint16_t* lists = band_list ? band_list + (size_t)chunk * 8 * per : nullptr;
+    uint16_t* lists = LISTS ? band_list + (size_t)chunk * 8 * per : nullptr;
     // uniform trip counts (for_each_tile is convergent); PF rectangles are requested before the first is used, so a thread
     // pays one memory latency per PF Gaussians instead of one each (culled Gaussians carry an all-zero rectangle)
     for (int base = begin; base < end; base += PF * BIN_THREADS) {
@@ -302,20 +302,29 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const us
         for (int k = 0; k < PF; k++) {
             if (base + k * BIN_THREADS >= end) break;
             const bool valid = r[k].z > r[k].x && r[k].w > r[k].y;
-            if (lists) {  // workgroup-uniform
+            if constexpr (LISTS) {
                 const int b_lo = valid ? band_of_tile(r[k].y * gx + r[k].x, tiles) : 8;
                 const int b_hi = valid ? band_of_tile((r[k].w - 1) * gx + r[k].z - 1, tiles) : -1;
                 const uint32_t local = (uint32_t)(base + k * BIN_THREADS + tid - begin);
+                // the eight bands' appends of this slot in ONE LDS round trip: lane b carries band b's count into a single ds_add_rtn (eight
+                // leader-lane atomics one after the other were eight dependent round trips per Gaussian slot, the kernel's chain at 10 M Gaussians:
+                // scan 0.231 -> 0.212 ms there, 0.094 -> 0.090 at 3 M.  All 64 (slot, band) pairs of a batch in one atomic: 0.237 / 0.101 -- the sixteen
+                // band bounds held across the batch and the ballots taken twice cost more than the seven round trips saved.)
+                uint64_t m[8];
+                uint32_t mine = 0u;
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
-                    const bool in = b >= b_lo && b <= b_hi;
-                    const uint64_t m = __ballot(in);
-                    if (m == 0ull) continue;
-                    const int leader = __builtin_ctzll(m);
-                    uint32_t wbase = 0;
-                    if (lane == leader) wbase = atomicAdd(&bcnt[b], (uint32_t)__builtin_popcountll(m));
-                    wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, leader);
-                    if (in) lists[(size_t)b * per + wbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)local;
+                    m[b] = __ballot(b >= b_lo && b <= b_hi);
+                    if (lane == b) mine = (uint32_t)__builtin_popcountll(m[b]);
+                }
+                uint32_t wbase = 0u;
+                if (lane < 8 && mine != 0u) wbase = atomicAdd(&bcnt[lane], mine);
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    if (m[b] == 0ull) continue;   // wave-uniform
+                    const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)wbase, b);
+                    if (b >= b_lo && b <= b_hi)
+                        lists[(size_t)b * per + bb + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[b] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[b], 0u))] = (uint16_t)local;
                 }
             }
             if (BOX) {
@@ -382,7 +391,7 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const us
     }
     uint32_t* out = chunk_hist + (size_t)chunk * tiles;
     for (int t = tid; t < tiles; t += BIN_THREADS) out[t] = hist[t];
-    if (lists && tid < 8) band_cnt[chunk * 8 + tid] = bcnt[tid];
+    if (LISTS && tid < 8) band_cnt[chunk * 8 + tid] = bcnt[tid];
 }
 
 // Column scan: for each tile, exclusive prefix over the chunks.  Workgroup = 16 waves x 64 tiles; wave w owns a sixteenth of the
@@ -1252,16 +1261,21 @@ static hipError_t ensure_lds(const void* fn, size_t bytes) {
 hipError_t launch_tile_count(int P, const GeometryState& g, const ImageState& img, int gx, int tiles, bool split, bool box, bool fused_scan,
                              hipStream_t stream) {
     const size_t lds = (size_t)tiles * sizeof(uint32_t);
-    hipError_t e = ensure_lds(reinterpret_cast<const void*>(tile_count_kernel<false>), lds);
-    if (e == hipSuccess) e = ensure_lds(reinterpret_cast<const void*>(tile_count_kernel<true>), lds);
-    if (e != hipSuccess) return e;
     const SplitState* sp = split ? img.split : nullptr;
-    if (box && gx <= BIN_THREADS)
-        hipLaunchKernelGGL(tile_count_kernel<true>, dim3(BIN_CHUNKS), dim3(BIN_THREADS), lds, stream, P, g.rects, img.chunk_hist, g.band_list,
-                           g.band_cnt, gx, tiles, g.depths, sp, img.scan_ticket);
-    else
-        hipLaunchKernelGGL(tile_count_kernel<false>, dim3(BIN_CHUNKS), dim3(BIN_THREADS), lds, stream, P, g.rects, img.chunk_hist, g.band_list,
-                           g.band_cnt, gx, tiles, g.depths, sp, img.scan_ticket);
+    const bool bx = box && gx <= BIN_THREADS, ls = g.band_list != nullptr;
+    hipError_t e = hipSuccess;
+#define WG_COUNT(B, L)                                                                                                                         \
+    do {                                                                                                                                       \
+        e = ensure_lds(reinterpret_cast<const void*>(tile_count_kernel<B, L>), lds);                                                           \
+        if (e != hipSuccess) return e;                                                                                                         \
+        hipLaunchKernelGGL((tile_count_kernel<B, L>), dim3(BIN_CHUNKS), dim3(BIN_THREADS), lds, stream, P, g.rects, img.chunk_hist, g.band_list, \
+                           g.band_cnt, gx, tiles, g.depths, sp, img.scan_ticket);                                                              \
+    } while (0)
+    if (bx && ls) WG_COUNT(true, true);
+    else if (bx) WG_COUNT(true, false);
+    else if (ls) WG_COUNT(false, true);
+    else WG_COUNT(false, false);
+#undef WG_COUNT
     e = hipGetLastError();
     if (e != hipSuccess || fused_scan) return e;  // fused: launch_tile_scan runs the column scan too
     hipLaunchKernelGGL(chunk_scan_kernel, dim3((tiles + 63) / 64), dim3(64 * SCAN_WAVES), 0, stream, img.chunk_hist, img.tile_count, tiles,

@@ -58,7 +58,7 @@ GeometryState GeometryState::fromChunk(char*& chunk, size_t P, bool lists) {
     carve(chunk, g.scan_temp, g.scan_temp_bytes);
     lists = lists && band_lists_possible(P);
     carve(chunk, g.band_list, lists ? (size_t)BIN_CHUNKS * 8 * ((Pa + BIN_CHUNKS - 1) / BIN_CHUNKS) : 0);
-    carve(chunk, g.band_cnt, lists ? (size_t)BIN_CHUNKS * 8 : 0);
+    carve(chunk, g.band_cnt, lists ? (size_t)BIN_CHUNKS * 16 : 0);   // per (chunk, band): the near (or, without a split, all) candidates, then the far ones
     if (!lists) g.band_list = nullptr;
     return g;
 }
@@ -274,13 +274,13 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const us
                                                          int tiles, const float* __restrict__ depths, const SplitState* __restrict__ split,
                                                          uint32_t* __restrict__ scan_ticket) {
     extern __shared__ uint32_t hist[];
-    __shared__ uint32_t bcnt[8];
+    __shared__ uint32_t bcnt[16];   // LISTS: per band, the near (without a split: all) candidates listed so far, then the far ones
     const int tid = threadIdx.x, chunk = blockIdx.x, lane = tid & 63;
     if (chunk == 0 && tid == 0) *scan_ticket = 0u;  // the fused column + tile scan's ticket counter (a fresh buffer holds anything)
     const uint32_t near_code = split ? split->near_code : SPLIT_OFF;
     const bool packed = near_code != SPLIT_OFF;  // workgroup-uniform
     for (int t = tid; t < tiles; t += BIN_THREADS) hist[t] = 0;
-    if (tid < 8) bcnt[tid] = 0;
+    if (tid < 16) bcnt[tid] = 0;
     __syncthreads();
     int begin, end;
     chunk_bounds(P, chunk, begin, end);
@@ -310,21 +310,36 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const us
                 // leader-lane atomics one after the other were eight dependent round trips per Gaussian slot, the kernel's chain at 10 M Gaussians:
                 // scan 0.231 -> 0.212 ms there, 0.094 -> 0.090 at 3 M.  All 64 (slot, band) pairs of a batch in one atomic: 0.237 / 0.101 -- the sixteen
                 // band bounds held across the batch and the ballots taken twice cost more than the seven round trips saved.)
-                uint64_t m[8];
+                // With an active split a band's list is kept in two parts: the NEAR Gaussians from the front (what the near scatter reads: about a
+                // tenth of the candidates at 10 M Gaussians / 4K -- every candidate costs it a dependent rectangle + depth load), the far ones from
+                // the back (what the far scatter reads when a tile of the band asks).  A band has room for the whole chunk: the parts cannot meet.
+                const bool nr = (inc[k] & 1u) != 0u;   // (without a split every instance counts 1: one part)
+                uint64_t m[8], mf[8];
                 uint32_t mine = 0u;
+                const uint64_t near_m = __ballot(nr);   // (one ballot for near / far, the parts' masks by scalar AND: not sixteen ballots)
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
-                    m[b] = __ballot(b >= b_lo && b <= b_hi);
+                    const uint64_t all = __ballot(b >= b_lo && b <= b_hi);
+                    m[b] = all & near_m;
+                    mf[b] = all & ~near_m;
                     if (lane == b) mine = (uint32_t)__builtin_popcountll(m[b]);
+                    if (lane == 8 + b) mine = (uint32_t)__builtin_popcountll(mf[b]);
                 }
                 uint32_t wbase = 0u;
-                if (lane < 8 && mine != 0u) wbase = atomicAdd(&bcnt[lane], mine);
+                if (lane < 16 && mine != 0u) wbase = atomicAdd(&bcnt[lane], mine);
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
-                    if (m[b] == 0ull) continue;   // wave-uniform
-                    const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)wbase, b);
-                    if (b >= b_lo && b <= b_hi)
-                        lists[(size_t)b * per + bb + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[b] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[b], 0u))] = (uint16_t)local;
+                    const bool in = b >= b_lo && b <= b_hi;
+                    if (m[b] != 0ull) {   // wave-uniform
+                        const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)wbase, b);
+                        if (in && nr)
+                            lists[(size_t)b * per + bb + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[b] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[b], 0u))] = (uint16_t)local;
+                    }
+                    if (mf[b] != 0ull) {  // wave-uniform
+                        const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 8 + b);
+                        if (in && !nr)
+                            lists[(size_t)b * per + (uint32_t)(per - 1) - (bb + __builtin_amdgcn_mbcnt_hi((uint32_t)(mf[b] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mf[b], 0u)))] = (uint16_t)local;
+                    }
                 }
             }
             if (BOX) {
@@ -391,7 +406,7 @@ __global__ void __launch_bounds__(BIN_THREADS) tile_count_kernel(int P, const us
     }
     uint32_t* out = chunk_hist + (size_t)chunk * tiles;
     for (int t = tid; t < tiles; t += BIN_THREADS) out[t] = hist[t];
-    if (LISTS && tid < 8) band_cnt[chunk * 8 + tid] = bcnt[tid];
+    if (LISTS && tid < 16) band_cnt[chunk * 16 + tid] = bcnt[tid];
 }
 
 // Column scan: for each tile, exclusive prefix over the chunks.  Workgroup = 16 waves x 64 tiles; wave w owns a sixteenth of the
@@ -724,7 +739,7 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, const ushort4*
     chunk_bounds(P, chunk, begin, end);
     const int per = (P + BIN_CHUNKS - 1) / BIN_CHUNKS;
     const uint16_t* list = LISTS ? band_list + ((size_t)chunk * 8 + band) * per : nullptr;
-    const int cn = LISTS ? (int)band_cnt[chunk * 8 + band] : end - begin;
+    const int cn = LISTS ? (int)band_cnt[chunk * 16 + band] : end - begin;   // (with an active split: the near candidates, the front part of the list)
     if (cn == 0) return;
     const uint32_t* hbase = chunk_hist + (size_t)chunk * tiles;
     for (int t = t0 + tid; t < t1; t += 256) cursor[t - t0] = tile_offset[t] + hbase[t];
@@ -926,7 +941,7 @@ __global__ void __launch_bounds__(1024) tile_scatter_staged_kernel(int P, const 
                 int cb, ce;
                 chunk_bounds(P, c, cb, ce);
                 const uint16_t* list = LISTS ? band_list + ((size_t)c * 8 + band) * per : nullptr;
-                const int cn = LISTS ? (int)band_cnt[c * 8 + band] : ce - cb;
+                const int cn = LISTS ? (int)band_cnt[c * 16 + band] : ce - cb;
                 for (int gb0 = 0; gb0 < cn; gb0 += PF * 1024) {
                     ushort4 r[PF];
                     uint32_t entry[PF];
@@ -998,8 +1013,9 @@ __global__ void __launch_bounds__(256) tile_scatter_far_kernel(int P, const usho
     int begin, end;
     chunk_bounds(P, chunk, begin, end);
     const int per = (P + BIN_CHUNKS - 1) / BIN_CHUNKS;
-    const uint16_t* list = LISTS ? band_list + ((size_t)chunk * 8 + band) * per : nullptr;
-    const int cn = LISTS ? (int)band_cnt[chunk * 8 + band] : end - begin;
+    // (the far candidates: the back part of the band's list, tile_count_kernel)
+    const int cn = LISTS ? (int)band_cnt[chunk * 16 + 8 + band] : end - begin;
+    const uint16_t* list = LISTS ? band_list + ((size_t)chunk * 8 + band) * per + (per - cn) : nullptr;
     const int y0 = t0 / gx, y1 = (t1 - 1) / gx;
     for (int base = 0; base < cn; base += 256) {  // uniform trip count: for_each_tile is convergent
         const int i = base + tid;

@@ -1,0 +1,10 @@
+O=gpurun_out/r7y; mkdir -p $O
+python -m pytest tests/test_parity_gpu.py -q -m gpu -x -k "lazy_colour or near or non_temporal" 2>&1 | tail -2
+python bench.py --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+python - $O/bench_driver_cmd.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['stages_ms'])
+for k,v in d['configs'].items():
+    if isinstance(v,dict): print(k, {kk:v.get(kk) for kk in ('iters_per_s','fps','ms_per_step','steps','pins_ok','stages_ms','near_far_split')})
+PY

@@ -774,6 +774,40 @@ def test_near_far_split_backs_off_when_pixels_do_not_saturate(lazy_options):
     assert torch.equal(c["color"], ref["color"])
 
 
+@pytest.mark.parametrize("npt", [30, 400])
+def test_lazy_colour_of_split_frames_changes_no_result(lazy_options, npt):
+    """Option "lazy_colour" (default on): a frame that attempts the near / far split with plain SH colours leaves the colour out of the per-Gaussian
+    kernel, colours the NEAR Gaussians once the threshold is known and the far ones only when a tile asks for its far instances.  Image, radii,
+    image state and -- deterministic mode -- every gradient are the bits of the frame coloured up front; with 30 near instances per tile nearly
+    every tile takes the far phase (the far Gaussians' colours are needed), with 400 hardly any."""
+    from diff_gaussian_rasterization import _C
+    cloud, cam, W, H = _dense_scene()
+    cloud3 = S.make_cloud(30000, W, H, sh_degree=3, seed=5, scale_mult=7.0)   # (degree 3: the 16-coefficient layout of the vector loads)
+    cot = S.make_cotangent(W, H)
+    outs = {}
+    try:
+        _C.set_option("deterministic_backward", 1)
+        for lc in (0, 1):
+            lazy_options(lazy_sort=1, near_split=1, near_per_tile=npt, lazy_min_len=256, lazy_target=100, lazy_cap=256, band_list_min_p=1)
+            _C.set_option("lazy_colour", lc); _C.set_option("lazy_colour_min_p", 1)   # (default: from 4 M Gaussians on)
+            native = run_hip_native(cloud3, cam, sh_degree=3)
+            sp = native["views"]["image"]["split"].cpu().numpy().view(np.uint32)
+            assert sp[0] != 0xffffffff and (npt != 30 or sp[1] != 0)     # split active; far phase taken at 30
+            outs[lc] = (native, run_hip(cloud3, cam, sh_degree=3, cotangent=cot))
+    finally:
+        _C.set_option("lazy_colour", 1); _C.set_option("lazy_colour_min_p", 4_000_000); _C.set_option("deterministic_backward", 0)
+    a, b = outs[0], outs[1]
+    assert torch.equal(a[0]["color"], b[0]["color"]) and torch.equal(a[0]["radii"], b[0]["radii"]) and a[0]["num_rendered"] == b[0]["num_rendered"]
+    for k in ("final_T", "n_contrib", "tile_last", "ranges"):
+        assert torch.equal(a[0]["views"]["image"][k], b[0]["views"]["image"][k]), k
+    np.testing.assert_array_equal(a[1]["color"], b[1]["color"])
+    for k in a[1]["grads"]:
+        np.testing.assert_array_equal(a[1]["grads"][k], b[1]["grads"][k], err_msg=k)
+    lazy_options(near_split=0, lazy_sort=0)
+    full = run_hip(cloud3, cam, sh_degree=3)
+    np.testing.assert_array_equal(full["color"], b[1]["color"])          # ... and of the frame without any split
+
+
 def test_non_temporal_sh_streams_change_no_result():
     """Option "sh_stream": the per-Gaussian kernels read the SH block (and write dL_dsh) with non-temporal accesses -- a cache hint: colour, radii
     and, in deterministic mode, every gradient are the same bits either way; -1 (default) turns it on up to sh_stream_max_p Gaussians."""

@@ -805,6 +805,11 @@ static int forward_impl(const wg_forward_args& a) {
                            wg::GeometryState::band_lists_possible((size_t)P) &&
                            (opt.near_split == 1 || P >= opt.band_list_min_p || t_last_instances_per_tile >= wg::SPLIT_DENSE_AVG) && !backoff;
     bool split_active = false;
+    // Frames that attempt the split with plain SH colours colour their Gaussians LAZILY: the per-Gaussian kernel leaves the colour out (and the
+    // 192-byte SH block unread), the near Gaussians are coloured once the threshold is known, the far ones only if a tile asks for its far
+    // instances (preprocess.hip: GEOM_ONLY, sh_colour_kernel).  Same colours, bit for bit, for every Gaussian the walk can reach.
+    const bool lazy_colour = try_split && opt.lazy_colour != 0 && P >= opt.lazy_colour_min_p && shs != nullptr && colors_precomp == nullptr && tone == nullptr && tone2 == nullptr &&
+                             !sh_second && out_color2 == nullptr;
 
     // ---- what depends on the instance count, as functions of it (used by the speculative and by the classic flow alike) ----
     // Longest per-tile list decides the binning path: full register sort of every tile, lazy front sort when lists are long,
@@ -844,7 +849,8 @@ static int forward_impl(const wg_forward_args& a) {
             WG_STAGE(WG_STAGE_RENDER_FIXUP,
                      wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, out_color2, opt.lazy, try_split, 0, opt.exact_compositing != 0, (wg::HostMailbox*)nullptr, guard, stream),
                      "render_fixup");
-            if (far) {  // both return at once unless some tile ran out of near instances with pixels still accumulating
+            if (far) {  // all return at once unless some tile ran out of near instances with pixels still accumulating
+                if (lazy_colour) WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_sh_colour(fp, geom, img.split, true, stream), "sh_colour_far");
                 WG_STAGE(WG_STAGE_DUPLICATE_KEYS, wg::launch_tile_scatter_far(P, geom, img, bin, gx, tiles, code_bits, guard, stream), "tile_scatter_far");
                 WG_STAGE(WG_STAGE_RENDER_FIXUP,
                          wg::launch_render_fixup(code_bits, width, height, gx, gy, img, bin, geom, subpixel_offset, background, out_color, out_color2, opt.lazy, true, 1, opt.exact_compositing != 0, mbox ? mbox->dev : (wg::HostMailbox*)nullptr, guard, stream),
@@ -869,13 +875,14 @@ static int forward_impl(const wg_forward_args& a) {
                 fo.table = nullptr;
             }
         }
-        WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, device_tone(tone, tone2, sh_second), geom, radii, stream), "preprocess");
+        WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_preprocess(fp, device_tone(tone, tone2, sh_second), geom, radii, lazy_colour, stream), "preprocess");
         wg::SpecLimits spec;   // all zero: the classic flow
         char* spec_chunk = nullptr;
         bool spec_lazy = false;
         if (tiles <= wg::BIN_MAX_TILES) {
             if (try_split)
                 WG_STAGE(WG_STAGE_SCAN, wg::launch_split_threshold(P, geom, img, tiles, opt.near_split == 1, near_per_tile, stream), "split_threshold");
+            if (lazy_colour) WG_STAGE(WG_STAGE_PREPROCESS, wg::launch_sh_colour(fp, geom, img.split, false, stream), "sh_colour_near");
             const bool box = opt.box_count == 1 || (opt.box_count < 0 && (P >= opt.band_list_min_p || t_last_instances_per_tile >= 1500u));
             WG_STAGE(WG_STAGE_SCAN, wg::launch_tile_count(P, geom, img, gx, tiles, try_split, box, opt.fused_scan != 0, stream), "tile_count");
             mbox = (debug || !opt.use_mailbox || fixed) ? nullptr : get_mailbox();
@@ -1290,6 +1297,8 @@ int wg_set_option(const char* name, int value) {
     if (std::strcmp(name, "forward_order_slots") == 0) { if (value < 0 || value > (1 << 16)) return WG_ERR_INVALID_ARGUMENT; o.forward_order_slots = value; return WG_OK; }   // (read when a device's table is allocated)
     if (std::strcmp(name, "order_period") == 0) { if (value < 0 || value > 4096) return WG_ERR_INVALID_ARGUMENT; o.order_period = value; return WG_OK; }
     if (std::strcmp(name, "backward_order_period") == 0) { if (value < 0 || value > 4096) return WG_ERR_INVALID_ARGUMENT; o.backward_order_period = value; return WG_OK; }
+    if (std::strcmp(name, "lazy_colour") == 0) { o.lazy_colour = value != 0; return WG_OK; }
+    if (std::strcmp(name, "lazy_colour_min_p") == 0) { if (value < 0) return WG_ERR_INVALID_ARGUMENT; o.lazy_colour_min_p = value; return WG_OK; }
     if (std::strcmp(name, "sh_stream") == 0) { o.sh_stream = value < 0 ? -1 : (value != 0); return WG_OK; }
     if (std::strcmp(name, "sh_stream_max_p") == 0) { if (value < 0) return WG_ERR_INVALID_ARGUMENT; o.sh_stream_max_p = value; return WG_OK; }
     if (std::strcmp(name, "speculative_forward") == 0) {  // (a deferred frame still pending is dropped: its verdict goes unread)
@@ -1354,6 +1363,8 @@ int wg_get_option(const char* name) {
     if (std::strcmp(name, "forward_order_slots") == 0) return o.forward_order_slots;
     if (std::strcmp(name, "order_period") == 0) return o.order_period;
     if (std::strcmp(name, "backward_order_period") == 0) return o.backward_order_period;
+    if (std::strcmp(name, "lazy_colour") == 0) return o.lazy_colour;
+    if (std::strcmp(name, "lazy_colour_min_p") == 0) return o.lazy_colour_min_p;
     if (std::strcmp(name, "sh_stream") == 0) return o.sh_stream;
     if (std::strcmp(name, "sh_stream_max_p") == 0) return o.sh_stream_max_p;
     if (std::strcmp(name, "speculative_forward") == 0) return o.speculative;

@@ -12,6 +12,7 @@
 #include "wg_common.h"
 #include "wg_alpha.h"
 #include "wg_act.h"
+#include "wg_sort.h"   // depth_code (sh_colour_kernel: near or far?)
 
 #pragma clang fp contract(off)
 
@@ -50,8 +51,13 @@ __device__ __forceinline__ float sh_channel(int deg, const float* sh, float x, f
 // lane stride.  The values, and the order of the arithmetic on them, are unchanged.
 constexpr int SH_PITCH4 = 13;
 
-template <int SH_MODE, bool PRECOMP, bool TONE>   // SH_MODE: 0 generic layout, 1 coalesced block through LDS, 2 the same with non-temporal loads
+// GEOM_ONLY (round 6, frames that attempt the near / far split with plain SH colours): everything but the colour -- the record's colour floats
+// are left zero, the clamp flags cleared and the SH block is not read; sh_colour_kernel below colours the Gaussians whose instances can be
+// walked at all: the NEAR ones before the binning chain, the far ones only when a tile asks for its far instances.  The 192-byte SH block is
+// four fifths of what this kernel reads per Gaussian, and at 10 M Gaussians / 4K nine Gaussians in ten are far.
+template <int SH_MODE, bool PRECOMP, bool TONE, bool GEOM_ONLY = false>   // SH_MODE: 0 generic layout, 1 coalesced block through LDS, 2 the same with non-temporal loads
 __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometryState g, int* __restrict__ radii_out, ToneArg<TONE> tone) {
+    static_assert(!GEOM_ONLY || (SH_MODE == 0 && !TONE), "the geometry-only instantiation loads no SH block");
     constexpr bool FAST_SH = SH_MODE != 0, NT = SH_MODE == 2;
     __shared__ float4 stage[FAST_SH ? 64 * SH_PITCH4 : 1];
     const int lane = threadIdx.x;
@@ -71,7 +77,7 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
     }
     // the camera position only enters through the SH view direction (forward.cu:33): absent (null) with precomputed colours
     float camx = 0.f, camy = 0.f, camz = 0.f;
-    if (p.colors_precomp == nullptr) { camx = p.cam_pos[0]; camy = p.cam_pos[1]; camz = p.cam_pos[2]; }  // wave-uniform, scalar loads
+    if (!GEOM_ONLY && p.colors_precomp == nullptr) { camx = p.cam_pos[0]; camy = p.cam_pos[1]; camz = p.cam_pos[2]; }  // wave-uniform, scalar loads
     // Geometry inputs first, SH block second: the memory counter retires loads in issue order, so whatever the geometry
     // waits for has to be issued ahead of the twelve SH loads for those to stay in flight behind it.
     float px = p.means3D[3 * ld], py = p.means3D[3 * ld + 1], pz = p.means3D[3 * ld + 2];
@@ -227,7 +233,10 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
         float c2r = 0.f, c2g = 0.f, c2b = 0.f;   // second colour set (two-colour walk): precomputed, or the same SH block through a second tone
         bool two = false;                        // wave-uniform
         if constexpr (TONE) two = tone.second != 0;
-        if (p.colors_precomp == nullptr) {
+        if (GEOM_ONLY) {
+            cr = cg = cb = 0.0f;      // (sh_colour_kernel writes the three floats and the clamp flags of the Gaussians it colours)
+            g.clamped[idx] = 0;
+        } else if (p.colors_precomp == nullptr) {
             // computeColorFromSH, forward.cu:20-71
             float dx = px - camx, dy = py - camy, dz = pz - camz;
             const float len = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -342,6 +351,61 @@ __global__ void __launch_bounds__(64) preprocess_kernel(FwdParams p, GeometrySta
     g.tiles_touched[idx] = touched;
 }
 
+// The colour half of a split frame (GEOM_ONLY above): computeColorFromSH (forward.cu:20-71) with the operations, their order and the
+// -ffp-contract=off of preprocess_kernel -- the same bits -- into the three colour floats of the 48-byte record (r1.w, r2.x, r2.y) and `clamped`.
+// FAR = false: the Gaussians at or below the frame's near threshold (every visible one when the device switched the split off); FAR = true: the
+// others, and only when some tile asked for its far instances (split->need_far, set by the first fix-up phase).  One Gaussian per lane, its
+// twelve 16-byte loads at a 192-byte stride: with one lane in ten active a wave touches a tenth of its block's lines (a coalesced block load
+// would fetch all of them for one near Gaussian in 64).
+template <bool FAR, bool VEC>
+__global__ void __launch_bounds__(256) sh_colour_kernel(FwdParams p, GeometryState g, const SplitState* __restrict__ split) {
+    const uint32_t near_code = split->near_code;
+    if (FAR && (split->need_far == 0u || near_code == SPLIT_OFF)) return;   // uniform: nobody asked
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.P || g.tiles_touched[idx] == 0u) return;
+    const bool is_near = near_code == SPLIT_OFF || depth_code(__float_as_uint(g.depths[idx]), SPLIT_BITS) <= near_code;
+    if (is_near == FAR) return;
+    const float camx = p.cam_pos[0], camy = p.cam_pos[1], camz = p.cam_pos[2];
+    const float px = p.means3D[3 * idx], py = p.means3D[3 * idx + 1], pz = p.means3D[3 * idx + 2];
+    float dx = px - camx, dy = py - camy, dz = pz - camz;
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx = dx / len; dy = dy / len; dz = dz / len;
+    float cr, cg, cb;
+    if (VEC) {   // M == 16, 16-byte aligned
+        const float4* src = reinterpret_cast<const float4*>(p.shs) + (size_t)idx * 12;
+        float sh[48];
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            const float4 v = src[q];
+            sh[4 * q] = v.x; sh[4 * q + 1] = v.y; sh[4 * q + 2] = v.z; sh[4 * q + 3] = v.w;
+        }
+        cr = sh_channel(p.D, sh + 0, dx, dy, dz);
+        cg = sh_channel(p.D, sh + 1, dx, dy, dz);
+        cb = sh_channel(p.D, sh + 2, dx, dy, dz);
+    } else {
+        const float* sh = p.shs + (size_t)idx * p.M * 3;
+        cr = sh_channel(p.D, sh + 0, dx, dy, dz);
+        cg = sh_channel(p.D, sh + 1, dx, dy, dz);
+        cb = sh_channel(p.D, sh + 2, dx, dy, dz);
+    }
+    g.clamped[idx] = (unsigned char)((cr < 0 ? 1 : 0) | (cg < 0 ? 2 : 0) | (cb < 0 ? 4 : 0));
+    float* rec = reinterpret_cast<float*>(g.splats + 3 * (size_t)idx);
+    rec[7] = fmaxf(cr, 0.0f);
+    rec[8] = fmaxf(cg, 0.0f);
+    rec[9] = fmaxf(cb, 0.0f);
+}
+
+hipError_t launch_sh_colour(const FwdParams& p, const GeometryState& g, const SplitState* split, bool far, hipStream_t stream) {
+    if (p.P <= 0) return hipSuccess;
+    const bool vec = p.M == 16 && (reinterpret_cast<uintptr_t>(p.shs) % 16 == 0);
+    const dim3 grid((p.P + 255) / 256), block(256);
+    if (far && vec) hipLaunchKernelGGL((sh_colour_kernel<true, true>), grid, block, 0, stream, p, g, split);
+    else if (far) hipLaunchKernelGGL((sh_colour_kernel<true, false>), grid, block, 0, stream, p, g, split);
+    else if (vec) hipLaunchKernelGGL((sh_colour_kernel<false, true>), grid, block, 0, stream, p, g, split);
+    else hipLaunchKernelGGL((sh_colour_kernel<false, false>), grid, block, 0, stream, p, g, split);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D,
                                                            const float* __restrict__ vm, unsigned char* __restrict__ present) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -351,12 +415,18 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* _
     present[idx] = !(vz <= 0.2f);  // auxiliary.h:154
 }
 
-hipError_t launch_preprocess(const FwdParams& p, const ShTone& tone_in, const GeometryState& g, int* radii_out, hipStream_t stream) {
+hipError_t launch_preprocess(const FwdParams& p, const ShTone& tone_in, const GeometryState& g, int* radii_out, bool geom_only, hipStream_t stream) {
     if (p.P <= 0) return hipSuccess;
     const bool fast = p.shs != nullptr && p.colors_precomp == nullptr && p.M == 16 && (reinterpret_cast<uintptr_t>(p.shs) % 16 == 0);
     const bool pre = p.cov3D_precomp != nullptr;
     const dim3 grid((p.P + 63) / 64), block(64);
     const bool tone = tone_in.enabled && p.shs != nullptr && p.colors_precomp == nullptr;
+    if (geom_only) {   // (api.hip asks for it with plain SH colours only; launch_sh_colour supplies the colours)
+        if (tone || p.shs == nullptr || p.colors_precomp != nullptr || p.colors_precomp2 != nullptr) return hipErrorInvalidValue;
+        if (pre) hipLaunchKernelGGL((preprocess_kernel<0, true, false, true>), grid, block, 0, stream, p, g, radii_out, NoTone{});
+        else hipLaunchKernelGGL((preprocess_kernel<0, false, false, true>), grid, block, 0, stream, p, g, radii_out, NoTone{});
+        return hipGetLastError();
+    }
 #define WG_LAUNCH(F, C) hipLaunchKernelGGL((preprocess_kernel<F, C, false>), grid, block, 0, stream, p, g, radii_out, NoTone{})
 #define WG_LAUNCH_TONE(F, C) hipLaunchKernelGGL((preprocess_kernel<F, C, true>), grid, block, 0, stream, p, g, radii_out, tone_in)
 #define WG_LAUNCH_FAST(L, C) do { if (p.nt_stream) L(2, C); else L(1, C); } while (0)

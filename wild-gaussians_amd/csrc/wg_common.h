@@ -219,7 +219,10 @@ struct FwdParams {
 };
 
 // kernels / stages (each launches on `stream`, returns hipGetLastError())
-hipError_t launch_preprocess(const FwdParams& p, const ShTone& tone, const GeometryState& g, int* radii_out, hipStream_t stream);
+hipError_t launch_preprocess(const FwdParams& p, const ShTone& tone, const GeometryState& g, int* radii_out, bool geom_only, hipStream_t stream);
+// the colour half of a split frame (preprocess.hip: GEOM_ONLY): far = false the near Gaussians, far = true the others if some tile asked for them
+struct SplitState;
+hipError_t launch_sh_colour(const FwdParams& p, const GeometryState& g, const SplitState* split, bool far, hipStream_t stream);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, unsigned char* present, hipStream_t stream);
 hipError_t launch_recolor(int P, const GeometryState& src, const GeometryState& dst, const float* colors, int* radii_out, hipStream_t stream);
 hipError_t run_scan(const GeometryState& g, int P, hipStream_t stream);
@@ -298,6 +301,8 @@ struct Options {
     int forward_order_slots = 2048;   //   rows of that table (x 9216 tiles x 4 B = 75 MB of device memory, allocated at the first forward call)
     int order_period = 128;           //   rounds of the snake dealing (the hardware's placement period per XCD; 0 = plain descending order)
     int backward_order_period = 0;    //   the same for the backward kernel's order (0: descending, its tail is dealt dynamically)
+    int lazy_colour = 1;              // frames that attempt the near / far split with plain SH colours: colour the near Gaussians only, the far ones when asked for
+    int lazy_colour_min_p = 4000000;  //   from this many Gaussians on (10 M / 4K: 583 -> 647 fps; 3 M / 1080p fwd+bwd: 719 -> 711 iter/s, 1 M dense: -0.4 %)
     int sh_stream = -1;               // the SH block in / dL_dsh out as non-temporal accesses: 1 on, 0 off, -1 up to sh_stream_max_p Gaussians
     int sh_stream_max_p = 6000000;    //   (wg_common.h: stream_load4; a gain while the rest of the frame's state fits the caches, a small loss at 10 M)
 };

@@ -809,7 +809,7 @@ static int forward_impl(const wg_forward_args& a) {
     // 192-byte SH block unread), the near Gaussians are coloured once the threshold is known, the far ones only if a tile asks for its far
     // instances (preprocess.hip: GEOM_ONLY, sh_colour_kernel).  Same colours, bit for bit, for every Gaussian the walk can reach.
     const bool lazy_colour = try_split && opt.lazy_colour != 0 && P >= opt.lazy_colour_min_p && shs != nullptr && colors_precomp == nullptr && tone == nullptr && tone2 == nullptr &&
-                             !sh_second && out_color2 == nullptr;
+                             !sh_second && out_color2 == nullptr && raw == nullptr;   // (plain SH colours of activated parameters: the combinations the suite holds)
 
     // ---- what depends on the instance count, as functions of it (used by the speculative and by the classic flow alike) ----
     // Longest per-tile list decides the binning path: full register sort of every tile, lazy front sort when lists are long,

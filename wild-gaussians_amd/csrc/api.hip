@@ -90,9 +90,10 @@ thread_local Mailbox t_mailbox;
 thread_local uint32_t t_last_instances_per_tile = 0;  // density of this thread's previous frame: the near / far split's "try it" hint
 thread_local uint32_t t_split_backoff = 0;            // frames for which the split is not attempted after one that needed the far phase
 // The split's aimed number of near instances per tile, ADAPTED per host thread (option "near_adapt", default on; a fixed "near_per_tile" wins):
-// every split frame reports how many tiles ran out of near instances (the mailbox's need_far, read a frame late).  Four clean frames in
-// a row lower the aim by 10 %; a frame in which more than one tile in a thousand asked lifts it to a floor an eighth above the level that
-// failed, where it then stays (the floor is relaxed by a twentieth every 2048 frames).  Never above the fixed default (1.1 x the front target): the adaptation can only shorten what
+// every split frame reports how many tiles ran out of near instances and the aim it ran with (the mailbox's far_report, read a frame or two
+// late).  Four clean reports at the current aim lower it by 10 %; a frame in which ANY tile asked lifts it to a floor an eighth (a sixteenth for a
+// handful of tiles) above the aim THAT frame ran with, where it then stays (the floor is relaxed by a twentieth every 2048 frames).  Never above the
+// fixed default (1.1 x the front target): the adaptation can only shorten what
 // is scattered and sorted -- at 10 M Gaussians / 4K pixels stop ~215 instances deep and 900 near instances per tile were twice what the
 // deepest tile needed.  Results do not depend on it (a tile that runs out gets its far instances: the far phase).
 // What it has learnt belongs to one SCENE: a cloud outside [P / 2, 2 P] of the one it learnt from starts it afresh (bench.py's config legs run a

@@ -774,8 +774,9 @@ def test_near_far_split_backs_off_when_pixels_do_not_saturate(lazy_options):
     assert torch.equal(c["color"], ref["color"])
 
 
+@pytest.mark.parametrize("flow", [1, 0, 2])   # speculative (default), classic, deferred speculation
 @pytest.mark.parametrize("npt", [30, 400])
-def test_lazy_colour_of_split_frames_changes_no_result(lazy_options, npt):
+def test_lazy_colour_of_split_frames_changes_no_result(lazy_options, npt, flow):
     """Option "lazy_colour" (default on): a frame that attempts the near / far split with plain SH colours leaves the colour out of the per-Gaussian
     kernel, colours the NEAR Gaussians once the threshold is known and the far ones only when a tile asks for its far instances.  Image, radii,
     image state and -- deterministic mode -- every gradient are the bits of the frame coloured up front; with 30 near instances per tile nearly
@@ -787,6 +788,7 @@ def test_lazy_colour_of_split_frames_changes_no_result(lazy_options, npt):
     outs = {}
     try:
         _C.set_option("deterministic_backward", 1)
+        _C.set_option("speculative_forward", flow)
         for lc in (0, 1):
             lazy_options(lazy_sort=1, near_split=1, near_per_tile=npt, lazy_min_len=256, lazy_target=100, lazy_cap=256, band_list_min_p=1)
             _C.set_option("lazy_colour", lc); _C.set_option("lazy_colour_min_p", 1)   # (default: from 4 M Gaussians on)
@@ -796,8 +798,10 @@ def test_lazy_colour_of_split_frames_changes_no_result(lazy_options, npt):
             outs[lc] = (native, run_hip(cloud3, cam, sh_degree=3, cotangent=cot))
     finally:
         _C.set_option("lazy_colour", 1); _C.set_option("lazy_colour_min_p", 4_000_000); _C.set_option("deterministic_backward", 0)
+        _C.set_option("speculative_forward", 1)
     a, b = outs[0], outs[1]
-    assert torch.equal(a[0]["color"], b[0]["color"]) and torch.equal(a[0]["radii"], b[0]["radii"]) and a[0]["num_rendered"] == b[0]["num_rendered"]
+    assert torch.equal(a[0]["color"], b[0]["color"]) and torch.equal(a[0]["radii"], b[0]["radii"])
+    assert flow == 2 or a[0]["num_rendered"] == b[0]["num_rendered"]     # (a deferred call returns before its frame's count is known)
     for k in ("final_T", "n_contrib", "tile_last", "ranges"):
         assert torch.equal(a[0]["views"]["image"][k], b[0]["views"]["image"][k]), k
     np.testing.assert_array_equal(a[1]["color"], b[1]["color"])
